@@ -1,0 +1,252 @@
+#!/usr/bin/env python
+"""Benchmark of the W8A16 hot path on MI355X.  Contract: python bench.py --gpus N --steps K --warmup W
+(for N > 1 launched by torch.distributed.run, one rank per GPU); rank 0 prints ONE JSON line.
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): w8a16 GEMV, M=1, N=K=4096.
+A "step" is one w8_a16_gemm call (one pass of the decode hot path over one batch) on the next of NBUF distinct
+(weight, scale) sets -- NBUF*16 MiB >= 512 MiB, so the weights come from HBM, not the 256 MB Infinity Cache.
+  value      whole-job GB/s: algorithmic bytes (K*N + 2*M*K + 2*N + 2*M*N = 16 801 792 B/step) * steps * replicas
+             / wall time of the timed region (inputs resident in HBM, K steps replayed as one HIP graph, barrier +
+             synchronize on both sides, MAX over ranks).  Includes the ~1-2 us dependent-kernel boundary per step.
+  roofline   dominant kernel (gemv_kernel): algorithmic bytes / mean kernel duration, measured live with a HIP
+             event pair around every launch on the launch stream (a second pass over the same K steps).
+  secondary  the other half of the metric: fused dequant-GEMM at M=1024, N=K=4096 in TFLOP/s (MFMA roofline).
+  cpu_baseline  the oracle's scalar C port of the same GEMV on one host core (bounded sample), and beside it
+             (cpu_linear_fp16) the north star's CPU torch.nn.Linear fp16 forward on all host cores.
+Multi-GPU: replicas only (model replicated, no data-path collective); rank 0 fans the activations out with one
+broadcast, results are checked to be bit-identical across replicas.  scaling = "weak".
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_F16_PEAK_TFLOPS = 2500.0  # dense fp16/bf16 MFMA
+
+
+def gemv_bytes(M, N, K):
+    return K * N + 2 * M * K + 2 * N + 2 * M * N
+
+
+def make_weight_sets(ops, nbuf, K, N, dev):
+    """set 0 = nn.Linear default init, seed 1 (the recipe of examples/layers/test_qlinear.py); the others are
+    U(+-1/sqrt(K)) drawn on the GPU.  All quantised by the HIP quantiser on the GPU."""
+    sets = []
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(K, N, bias=False, dtype=torch.float16)
+    w0 = lin.weight.detach().t().contiguous()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    bound = 1.0 / (K ** 0.5)
+    for i in range(nbuf):
+        if i == 0:
+            w = w0.to(dev)
+        else:
+            w = ((torch.rand(K, N, device=dev, generator=g) * 2 - 1) * bound).half()
+        processed, scales = ops.quant_weights(w, torch.int8, False)
+        sets.append((processed, scales))
+        del w
+    return sets, w0, lin
+
+
+def capture_graph(fn, nsteps):
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        fn(0, 3)  # warm the capture stream / lazy init outside capture
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    with torch.cuda.graph(g):
+        fn(0, nsteps)
+    return g
+
+
+def event_pair_kernel_time(fn_one, nsteps):
+    """Mean duration (seconds) between an event recorded right before and right after each launch."""
+    starts = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps)]
+    stops = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps)]
+    for i in range(nsteps):
+        starts[i].record()
+        fn_one(i)
+        stops[i].record()
+    torch.cuda.synchronize()
+    ms = np.array([starts[i].elapsed_time(stops[i]) for i in range(nsteps)])
+    return float(ms.mean()) * 1e-3, float(np.median(ms)) * 1e-3, float(ms.min()) * 1e-3
+
+
+def cpu_gemv_baseline(oracle, x, q, s, budget_s=10.0):
+    """Oracle port (scalar C, one core) of the same GEMV; bounded sample."""
+    t_end = time.perf_counter() + budget_s
+    oracle.w8a16_gemm_f32acc(x, q, s)  # warm
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() < t_end or n < 3:
+        oracle.w8a16_gemm_f32acc(x, q, s)
+        n += 1
+    dt = time.perf_counter() - t0
+    return n, dt
+
+
+def cpu_linear_baseline(lin, x, runs):
+    torch.set_num_threads(os.cpu_count() or 1)
+    with torch.no_grad():
+        for _ in range(3):
+            lin(x)
+        ts = []
+        for _ in range(runs):
+            t0 = time.perf_counter()
+            lin(x)
+            ts.append(time.perf_counter() - t0)
+    return float(np.median(ts))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--nbuf", type=int, default=40, help="distinct weight sets rotated per step (x16 MiB)")
+    ap.add_argument("--gemm-steps", type=int, default=40)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=10.0)
+    args = ap.parse_args()
+
+    from eetq_amd import ops
+    from eetq_amd.utils.replicas import ReplicaGroup
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the W8A16 path has no CPU implementation)")
+    grp = ReplicaGroup()
+    if grp.world_size != args.gpus and grp.rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, grp.world_size), file=sys.stderr)
+    dev = grp.device
+    M, N, K = 1, 4096, 4096
+    steps, warmup, nbuf = args.steps, args.warmup, args.nbuf
+
+    sets, w0_cpu, lin_cpu = make_weight_sets(ops, nbuf, K, N, dev)
+    # identical activations on every replica: rank 0 draws them, RCCL broadcast fans them out
+    torch.manual_seed(1)
+    x = torch.rand(M, K, dtype=torch.float16).to(dev)
+    grp.fan_out(x)
+    outs = [torch.empty(M, N, dtype=torch.float16, device=dev) for _ in range(8)]
+
+    def gemv_steps(first, count):
+        for i in range(first, first + count):
+            w, s = sets[i % nbuf]
+            ops.w8_a16_gemm_(x, w, s, outs[i % len(outs)], M, N, K)
+
+    # ---- parity of this run (rank 0 checks against the oracle; all ranks must agree bit for bit) ----
+    parity = {}
+    y0 = torch.empty(M, N, dtype=torch.float16, device=dev)
+    ops.w8_a16_gemm_(x, sets[0][0], sets[0][1], y0, M, N, K)
+    torch.cuda.synchronize()
+    crcs = grp.gather_checksums(y0)
+    parity["replicas_bit_identical"] = len(set(crcs)) == 1
+    oracle = None
+    if grp.rank == 0:
+        import oracle as _oracle
+        oracle = _oracle
+        q, s = oracle.quantize(w0_cpu.numpy())
+        ref = oracle.w8a16_gemm(x.cpu().numpy(), q, s).astype(np.float32)
+        got = y0.cpu().numpy().astype(np.float32)
+        parity["tier_a_max_abs_err_vs_oracle"] = float(np.abs(got - ref).max())
+        parity["tier_a_ok"] = bool(np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref)))
+        with torch.no_grad():
+            y_lin = lin_cpu(x.cpu()).numpy().astype(np.float32)
+        parity["tier_b_max_abs_err_vs_cpu_linear_fp16"] = float(np.abs(got - y_lin).max())
+        parity["packed_bit_exact"] = bool(np.array_equal(sets[0][0].cpu().numpy(), oracle.gfx950_pack(q)))
+
+    # ---- timed region: W warm-up steps, then exactly K steps (one graph replay) ----
+    gemv_steps(0, warmup)
+    torch.cuda.synchronize()
+    graph = capture_graph(gemv_steps, steps)
+    graph.replay()  # one untimed replay: graph upload
+    torch.cuda.synchronize()
+    seconds = grp.timed(graph.replay)
+    step_bytes = gemv_bytes(M, N, K)
+    value = grp.world_size * steps * step_bytes / seconds / 1e9
+
+    # ---- roofline of the dominant kernel: event pair around every launch, same K steps ----
+    k_mean, k_med, k_min = event_pair_kernel_time(lambda i: gemv_steps(i, 1), steps)
+    achieved = step_bytes / k_mean / 1e9
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("gemv_hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {"kernel": "gemv_kernel<1,16,4>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": step_bytes, "kernel_us_mean": round(k_mean * 1e6, 3),
+                "kernel_us_median": round(k_med * 1e6, 3), "kernel_us_min": round(k_min * 1e6, 3)}
+
+    # ---- secondary: fused dequant-GEMM, M = 1024 ----
+    Mg = 1024
+    torch.manual_seed(2)
+    xg = torch.rand(Mg, K, dtype=torch.float16).to(dev)
+    yg = [torch.empty(Mg, N, dtype=torch.float16, device=dev) for _ in range(2)]
+
+    def gemm_steps(first, count):
+        for i in range(first, first + count):
+            w, s = sets[i % nbuf]
+            ops.w8_a16_gemm_(xg, w, s, yg[i % 2], Mg, N, K)
+
+    gemm_steps(0, 5)
+    torch.cuda.synchronize()
+    ggraph = capture_graph(gemm_steps, args.gemm_steps)
+    ggraph.replay()
+    torch.cuda.synchronize()
+    gsec = grp.timed(ggraph.replay)
+    flops = 2.0 * Mg * N * K
+    g_mean, g_med, g_min = event_pair_kernel_time(lambda i: gemm_steps(i, 1), args.gemm_steps)
+    gemm = {"metric": "dequant-GEMM TFLOPS @ M=1024, N=K=4096", "value": round(grp.world_size * args.gemm_steps * flops / gsec / 1e12, 2),
+            "unit": "TFLOP/s", "steps": args.gemm_steps, "ms_per_step": round(gsec * 1e3 / args.gemm_steps, 5),
+            "roofline": {"kernel": "gemm_mfma_kernel", "bound": "mfma", "achieved": round(flops / g_mean / 1e12, 2),
+                         "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / g_mean / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                         "kernel_us_mean": round(g_mean * 1e6, 2), "kernel_us_min": round(g_min * 1e6, 2), "traffic": None}}
+
+    # ---- CPU baselines (rank 0, N = 1 only; bounded) ----
+    cpu_baseline = None
+    cpu_linear = None
+    if grp.rank == 0 and grp.world_size == 1 and not args.no_cpu_baseline:
+        q, s = oracle.quantize(w0_cpu.numpy())
+        n_it, dt = cpu_gemv_baseline(oracle, x.cpu().numpy(), q, s, args.cpu_budget)
+        cpu_baseline = {"value": round(n_it * step_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                        "sample": "%d calls of oracle_w8a16_gemm_f32acc (scalar C restatement) at M=1, N=K=4096 in %.1f s"
+                                  % (n_it, dt), "ms_per_call": round(dt / n_it * 1e3, 3)}
+        ms1 = cpu_linear_baseline(lin_cpu, x.cpu(), 10) * 1e3
+        ms1024 = cpu_linear_baseline(lin_cpu, xg.cpu(), 5) * 1e3
+        cpu_linear = {"what": "torch.nn.Linear(4096, 4096).half() forward on host CPU (north-star baseline)",
+                      "cores": os.cpu_count(), "torch_threads": torch.get_num_threads(),
+                      "m1_ms": round(ms1, 3), "m1_gbps_fp16_weights": round(2.0 * K * N / (ms1 * 1e-3) / 1e9, 2),
+                      "m1024_ms": round(ms1024, 3), "m1024_gflops": round(flops / (ms1024 * 1e-3) / 1e9, 1)}
+
+    if grp.rank == 0:
+        line = {
+            "metric": "w8a16 GEMV GB/s @ M=1 and dequant-GEMM TFLOPS @ M=1024, N=K=4096",
+            "value": round(value, 1), "unit": "GB/s", "n_gpus": grp.world_size, "steps": steps, "warmup": warmup,
+            "ms_per_step": round(seconds * 1e3 / steps, 6), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "w8a16 GEMV M=1, N=K=4096 (BASELINE configs[1]); %d distinct weight sets rotated (%d MiB)"
+                                   % (nbuf, nbuf * K * N // (1 << 20)), "M": M, "N": N, "K": K,
+                       "parallelism": "replicas x%d (no data-path collective)" % grp.world_size,
+                       "launch": "HIP graph of %d dependent launches" % steps},
+            "roofline": roofline, "secondary": gemm, "cpu_baseline": cpu_baseline, "cpu_linear_fp16": cpu_linear,
+            "parity": parity,
+        }
+        print(json.dumps(line))
+    grp.close()
+
+
+if __name__ == "__main__":
+    main()

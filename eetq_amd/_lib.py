@@ -1,0 +1,101 @@
+"""Loader for ``libeetq_amd.so`` (the C ABI declared in ``include/eetq_amd.h``).
+
+The product path has no CPU fallback: if the shared library is missing and cannot be built with hipcc,
+importing :mod:`eetq_amd.ops` raises.  The library is kept in-tree (``eetq_amd/libeetq_amd.so``).
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libeetq_amd.so")
+CSRC_DIR = os.path.join(_HERE, "csrc")
+
+EETQ_OK = 0
+DTYPE_F16, DTYPE_F32 = 0, 1
+LAYOUT_ROW_MAJOR, LAYOUT_GFX950, LAYOUT_SM80 = 0, 1, 2
+PATH_AUTO, PATH_GEMV, PATH_MFMA, PATH_SKINNY = 0, 1, 2, 3
+
+_lib = None
+
+
+def _sources_newer_than_lib():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for name in os.listdir(CSRC_DIR):
+        if name.endswith((".hip", ".hpp", "Makefile")) and os.path.getmtime(os.path.join(CSRC_DIR, name)) > t:
+            return True
+    hdr = os.path.join(_HERE, "..", "include", "eetq_amd.h")
+    return os.path.exists(hdr) and os.path.getmtime(hdr) > t
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into ``eetq_amd/libeetq_amd.so`` (hipcc cross-compiles w/o a GPU)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        raise RuntimeError("eetq_amd: hipcc not found; cannot build libeetq_amd.so")
+    if force or _sources_newer_than_lib():
+        cmd = ["make", "-C", CSRC_DIR, "-j8", "HIPCC=" + hipcc] + (["-B"] if force else [])
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if verbose or res.returncode != 0:
+            print(res.stdout)
+        if res.returncode != 0:
+            raise RuntimeError("eetq_amd: building libeetq_amd.so failed:\n" + res.stdout[-4000:])
+    return LIB_PATH
+
+
+def _declare(L):
+    vp, sz, i32, f32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_float
+    sigs = {
+        "eetq_quantize_i8": [vp, i32, sz, sz, vp, vp, i32, vp, vp, vp],
+        "eetq_quantize_i8_host": [vp, i32, sz, sz, vp, vp, i32, vp],
+        "eetq_pack_i8": [vp, sz, sz, vp, i32, vp],
+        "eetq_unpack_i8": [vp, sz, sz, vp, i32, vp],
+        "eetq_pack_i8_host": [vp, sz, sz, vp, i32],
+        "eetq_unpack_i8_host": [vp, sz, sz, vp, i32],
+        "eetq_w8a16_gemm": [vp, vp, vp, vp, i32, i32, i32, vp],
+        "eetq_w8a16_gemm_ex": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "eetq_rmsnorm_f16": [vp, vp, vp, f32, i32, i32, vp],
+        "eetq_rotary_neox_f16": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(L, name)
+        fn.argtypes = args
+        fn.restype = i32
+    L.eetq_last_error.restype = ctypes.c_char_p
+    L.eetq_last_error.argtypes = []
+    L.eetq_version.restype = ctypes.c_char_p
+    L.eetq_version.argtypes = []
+    L.eetq_device_supported.restype = i32
+    L.eetq_device_supported.argtypes = []
+    return L
+
+
+EXPORTED_SYMBOLS = (
+    "eetq_quantize_i8", "eetq_quantize_i8_host", "eetq_pack_i8", "eetq_unpack_i8", "eetq_pack_i8_host",
+    "eetq_unpack_i8_host", "eetq_w8a16_gemm", "eetq_w8a16_gemm_ex", "eetq_rmsnorm_f16",
+    "eetq_rotary_neox_f16", "eetq_last_error", "eetq_version", "eetq_device_supported",
+)
+
+
+def lib():
+    """Return the loaded library, building it first when the sources are newer (dev machines only)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH) or (os.path.isdir(CSRC_DIR) and shutil.which("hipcc")
+                                            and _sources_newer_than_lib()):
+            build()
+        try:
+            _lib = _declare(ctypes.CDLL(LIB_PATH))
+        except OSError as e:  # no fallback on purpose
+            raise RuntimeError("eetq_amd: cannot load %s (%s). The HIP extension is required." % (LIB_PATH, e))
+    return _lib
+
+
+def check(status):
+    """Non-zero status -> RuntimeError (what the reference's C++ exceptions become through pybind)."""
+    if status != EETQ_OK:
+        msg = lib().eetq_last_error()
+        raise RuntimeError(msg.decode() if msg else "eetq_amd: error %d" % status)

@@ -1,0 +1,208 @@
+// extern "C" boundary of libeetq_amd.so (declarations + reference citations: include/eetq_amd.h).
+// Stateless apart from (a) the thread-local last-error string and (b) a per-device scratch buffer for the
+// quantiser's column maxima (N floats), so the reference's "no workspace argument" signature is kept.
+#include <mutex>
+#include <string>
+
+#include "common.hpp"
+
+namespace eetq {
+
+namespace {
+thread_local std::string g_last_error;
+
+struct Scratch {
+    float* ptr   = nullptr;
+    size_t elems = 0;
+};
+std::mutex g_scratch_mutex;
+Scratch    g_scratch[64];
+}  // namespace
+
+void set_error(const std::string& msg) { g_last_error = msg; }
+
+int fail(int code, const std::string& msg)
+{
+    set_error(msg);
+    return code;
+}
+
+int check_hip(hipError_t e, const char* what)
+{
+    if (e == hipSuccess) return EETQ_OK;
+    (void)hipGetLastError();  // clear the sticky launch error
+    return fail(EETQ_ERR_HIP, std::string("[eetq_amd] HIP error: ") + hipGetErrorString(e) + " in " + what);
+}
+
+static int colmax_scratch(size_t n, float** out)
+{
+    int dev = 0;
+    EETQ_TRY_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    Scratch&                    s = g_scratch[dev & 63];
+    if (s.elems < n) {
+        if (s.ptr) EETQ_TRY_HIP(hipFree(s.ptr));
+        s.ptr   = nullptr;
+        s.elems = 0;
+        size_t want = n < 65536 ? 65536 : n;
+        EETQ_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&s.ptr), want * sizeof(float)));
+        s.elems = want;
+    }
+    *out = s.ptr;
+    return EETQ_OK;
+}
+
+static int check_gemm_args(const void* x, const void* w, const void* s, const void* y, int M, int N, int K)
+{
+    EETQ_REQUIRE(x && w && s && y, "null pointer");
+    EETQ_REQUIRE(M >= 1 && N >= 1 && K >= 1, "invalid GEMM shape");
+    // the reference throws "Temp assertion: k must be multiple of threadblockK" (fpA_intB_gemm_template.h:139-142)
+    EETQ_REQUIRE(K % 64 == 0, "k must be a multiple of 64");
+    EETQ_REQUIRE(N % 16 == 0, "n must be a multiple of 16");
+    EETQ_REQUIRE(((uintptr_t)x | (uintptr_t)w | (uintptr_t)y) % 16 == 0 && (uintptr_t)s % 2 == 0,
+                 "x, weight and y must be 16-byte aligned");
+    return EETQ_OK;
+}
+
+// RAII device buffer for the blocking host-pointer variants
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf()
+    {
+        if (p) (void)hipFree(p);
+    }
+    int alloc(size_t bytes) { return check_hip(hipMalloc(&p, bytes ? bytes : 1), "hipMalloc"); }
+};
+
+}  // namespace eetq
+
+using namespace eetq;
+
+extern "C" {
+
+const char* eetq_last_error(void) { return g_last_error.c_str(); }
+
+const char* eetq_version(void) { return "eetq_amd 0.1.0 gfx950"; }
+
+int eetq_device_supported(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    return std::string(prop.gcnArchName).rfind("gfx950", 0) == 0 ? 1 : 0;
+}
+
+int eetq_quantize_i8(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
+                     void* scales, float* workspace, void* stream)
+{
+    if (!workspace) {
+        int st = colmax_scratch(N, &workspace);
+        if (st != EETQ_OK) return st;
+    }
+    return launch_quantize(w, w_dtype, K, N, q_raw, q_packed, layout, scales, workspace,
+                           static_cast<hipStream_t>(stream));
+}
+
+int eetq_pack_i8(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, void* stream)
+{
+    return launch_pack(q_raw, K, N, q_packed, layout, static_cast<hipStream_t>(stream));
+}
+
+int eetq_unpack_i8(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, void* stream)
+{
+    return launch_unpack(q_packed, K, N, q_raw, layout, static_cast<hipStream_t>(stream));
+}
+
+int eetq_quantize_i8_host(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
+                          int layout, void* scales)
+{
+    EETQ_REQUIRE(w && scales, "null pointer");
+    EETQ_REQUIRE(w_dtype == EETQ_DTYPE_F16 || w_dtype == EETQ_DTYPE_F32,
+                 "Invalid datatype. Weight must be FP16 or FP32");
+    EETQ_REQUIRE(K > 0 && N > 0, "weight should not be empty tensor");
+    const size_t esz = w_dtype == EETQ_DTYPE_F16 ? 2 : 4;
+    DevBuf       dw, draw, dpk, dsc, dmax;
+    int          st;
+    if ((st = dw.alloc(K * N * esz)) || (st = dsc.alloc(N * esz)) || (st = dmax.alloc(N * sizeof(float)))) return st;
+    if (q_raw && (st = draw.alloc(K * N))) return st;
+    if (q_packed && (st = dpk.alloc(K * N))) return st;
+    EETQ_TRY_HIP(hipMemcpy(dw.p, w, K * N * esz, hipMemcpyHostToDevice));
+    st = launch_quantize(dw.p, w_dtype, K, N, static_cast<int8_t*>(draw.p), static_cast<int8_t*>(dpk.p), layout,
+                         dsc.p, static_cast<float*>(dmax.p), nullptr);
+    if (st != EETQ_OK) return st;
+    EETQ_TRY_HIP(hipStreamSynchronize(nullptr));
+    if (q_raw) EETQ_TRY_HIP(hipMemcpy(q_raw, draw.p, K * N, hipMemcpyDeviceToHost));
+    if (q_packed) EETQ_TRY_HIP(hipMemcpy(q_packed, dpk.p, K * N, hipMemcpyDeviceToHost));
+    EETQ_TRY_HIP(hipMemcpy(scales, dsc.p, N * esz, hipMemcpyDeviceToHost));
+    return EETQ_OK;
+}
+
+static int relayout_host(const int8_t* src, size_t K, size_t N, int8_t* dst, int layout, bool pack)
+{
+    EETQ_REQUIRE(src && dst, "null pointer");
+    EETQ_REQUIRE(K > 0 && N > 0, "weight should not be empty tensor");
+    DevBuf a, b;
+    int    st;
+    if ((st = a.alloc(K * N)) || (st = b.alloc(K * N))) return st;
+    EETQ_TRY_HIP(hipMemcpy(a.p, src, K * N, hipMemcpyHostToDevice));
+    st = pack ? launch_pack(static_cast<int8_t*>(a.p), K, N, static_cast<int8_t*>(b.p), layout, nullptr)
+              : launch_unpack(static_cast<int8_t*>(a.p), K, N, static_cast<int8_t*>(b.p), layout, nullptr);
+    if (st != EETQ_OK) return st;
+    EETQ_TRY_HIP(hipStreamSynchronize(nullptr));
+    EETQ_TRY_HIP(hipMemcpy(dst, b.p, K * N, hipMemcpyDeviceToHost));
+    return EETQ_OK;
+}
+
+int eetq_pack_i8_host(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout)
+{
+    return relayout_host(q_raw, K, N, q_packed, layout, true);
+}
+
+int eetq_unpack_i8_host(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout)
+{
+    return relayout_host(q_packed, K, N, q_raw, layout, false);
+}
+
+int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N, int K,
+                       int path, void* stream)
+{
+    int st = check_gemm_args(x, w_packed, scales, y, M, N, K);
+    if (st != EETQ_OK) return st;
+    const f16*     xp = static_cast<const f16*>(x);
+    const uint8_t* wp = reinterpret_cast<const uint8_t*>(w_packed);
+    const f16*     sp = static_cast<const f16*>(scales);
+    f16*           yp = static_cast<f16*>(y);
+    hipStream_t    s  = static_cast<hipStream_t>(stream);
+    switch (path) {
+        case EETQ_PATH_AUTO:
+            // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
+            if (M <= kGemvMaxM) return launch_gemv(xp, wp, sp, yp, M, N, K, s);
+            return launch_gemm_mfma(xp, wp, sp, yp, M, N, K, s);
+        case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, yp, M, N, K, s);
+        case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, yp, M, N, K, s);
+        default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] unknown or unimplemented GEMM path");
+    }
+}
+
+int eetq_w8a16_gemm(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N, int K,
+                    void* stream)
+{
+    return eetq_w8a16_gemm_ex(x, w_packed, scales, y, M, N, K, EETQ_PATH_AUTO, stream);
+}
+
+int eetq_rmsnorm_f16(const void* x, const void* gamma, void* out, float eps, int rows, int cols, void* stream)
+{
+    return launch_rmsnorm(static_cast<const f16*>(x), static_cast<const f16*>(gamma), static_cast<f16*>(out), eps,
+                          rows, cols, static_cast<hipStream_t>(stream));
+}
+
+int eetq_rotary_neox_f16(const int64_t* positions, void* query, void* key, const void* cos_sin_cache, int tokens,
+                         int heads, int head_size, int rot_dim, void* stream)
+{
+    return launch_rotary(positions, static_cast<f16*>(query), static_cast<f16*>(key),
+                         static_cast<const f16*>(cos_sin_cache), tokens, heads, head_size, rot_dim,
+                         static_cast<hipStream_t>(stream));
+}
+
+}  // extern "C"

@@ -1,0 +1,90 @@
+// Shared device/host helpers for the gfx950 kernels.  gfx950 only: wave64, no other targets.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/eetq_amd.h"
+
+namespace eetq {
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32;
+typedef u32 u32x2 __attribute__((ext_vector_type(2)));
+typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;
+// native layout constants (DESIGN.md "HBM layout")
+constexpr int kTileN     = 16;    // output columns per tile
+constexpr int kTileK     = 64;    // k per tile
+constexpr int kTileBytes = 1024;  // one wave-wide 16 B/lane load
+
+// ---- status / error plumbing (abi.hip owns the storage) -------------------------------------------
+void set_error(const std::string& msg);
+int  fail(int code, const std::string& msg);
+int  check_hip(hipError_t e, const char* what);
+
+#define EETQ_TRY_HIP(expr)                                   \
+    do {                                                     \
+        int _st = ::eetq::check_hip((expr), #expr);          \
+        if (_st != EETQ_OK) return _st;                      \
+    } while (0)
+
+#define EETQ_REQUIRE(cond, msg)                                                          \
+    do {                                                                                 \
+        if (!(cond)) return ::eetq::fail(EETQ_ERR_INVALID, std::string("[eetq_amd] ") + msg); \
+    } while (0)
+
+// ---- device helpers ----------------------------------------------------------------------------------
+__device__ __forceinline__ f16x2 as_f16x2(u32 v) { return __builtin_bit_cast(f16x2, v); }
+__device__ __forceinline__ u32 as_u32(f16x2 v) { return __builtin_bit_cast(u32, v); }
+
+// One dword of the native layout holds uint8 (q+128) for k-locals [0,2,1,3] (bytes 0..3).
+// v_perm_b32 builds 0x64bb64bb = fp16 pair (1024+b_lo, 1024+b_hi); subtracting 1152 gives the exact
+// integer q (reference: interleaved_numeric_conversion.h:53-85 does the same with prmt + sub.f16x2);
+// the product with the fp16 scale is rounded once to fp16 (mma_tensorop_dequantizer.h:259-274).
+// v_perm_b32 byte selectors: 0-3 pick bytes of src1, 4-7 bytes of src0.
+__device__ __forceinline__ void dequant_dword(u32 w, f16x2 scale2, f16x2& k01, f16x2& k23)
+{
+    const u32   c64  = 0x64646464u;
+    const u32   lo   = __builtin_amdgcn_perm(w, c64, 0x00060004u);  // bytes [w.b0, 0x64, w.b2, 0x64]
+    const u32   hi   = __builtin_amdgcn_perm(w, c64, 0x00070005u);  // bytes [w.b1, 0x64, w.b3, 0x64]
+    const f16x2 bias = {(f16)1152.0f, (f16)1152.0f};
+    k01              = (as_f16x2(lo) - bias) * scale2;
+    k23              = (as_f16x2(hi) - bias) * scale2;
+}
+
+// 16 bytes of one column (k-locals 0..15 in natural order after dequant) -> 8 fp16 pairs.
+__device__ __forceinline__ void dequant_16(const u32x4& w, f16x2 scale2, f16x2 (&out)[8])
+{
+    dequant_dword(w.x, scale2, out[0], out[1]);
+    dequant_dword(w.y, scale2, out[2], out[3]);
+    dequant_dword(w.z, scale2, out[4], out[5]);
+    dequant_dword(w.w, scale2, out[6], out[7]);
+}
+
+__device__ __forceinline__ float wave_xor_add(float v, int mask)
+{
+    return v + __shfl_xor(v, mask, 64);
+}
+
+// ---- kernel launchers (one per .hip file) ------------------------------------------------------------
+int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
+                    int layout, void* scales, float* colmax, hipStream_t stream);
+int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
+int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
+int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, f16* y, int M, int N, int K,
+                hipStream_t stream);
+int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, f16* y, int M, int N, int K,
+                     hipStream_t stream);
+int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows, int cols, hipStream_t stream);
+int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int heads, int head_size,
+                  int rot_dim, hipStream_t stream);
+
+constexpr int kGemvMaxM = 4;
+
+}  // namespace eetq

@@ -1,0 +1,124 @@
+// Side ops of the EETQ operator surface, plain HIP (HBM/L2-bound elementwise + row reduction).
+//   rmsnorm : replaces generalT5LayerNorm (/root/reference/csrc/layernorm_kernels/layernorm.cu:25-51) and its
+//             launcher (:54-77, :98-113): out = clamp_fp16((x * rsqrt(mean(x^2) + eps)) * gamma), fp32 math,
+//             clamp to +-(65504-1000) (reduction.cuh:78-82).
+//   rotary  : replaces rotary_embedding_neox_kernel (/root/reference/csrc/embedding_kernels/
+//             pos_encoding_kernels.cu:12-53) for fp16: in-place NeoX rotation, fp16 arithmetic with a
+//             rounding after every multiply/add exactly like the half operators there.
+#include "common.hpp"
+
+namespace eetq {
+
+namespace {
+
+constexpr float kHalfClamp = 65504.f - 1000.f;
+
+__device__ __forceinline__ float clamp_for_half(float v)
+{
+    return v > 0.f ? fminf(v, kHalfClamp) : fmaxf(v, -kHalfClamp);
+}
+
+template <int THREADS>
+__device__ __forceinline__ float block_sum(float v, float* red)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < THREADS / 64; ++i) s += red[i];
+    return s;
+}
+
+// one workgroup per row; 8 fp16 (16 B) per lane per step when cols % 8 == 0
+template <int THREADS, bool VEC>
+__global__ __launch_bounds__(THREADS) void rmsnorm_kernel(const f16* __restrict__ x, const f16* __restrict__ gamma,
+                                                          f16* __restrict__ out, float eps, int cols)
+{
+    __shared__ float red[THREADS / 64];
+    const f16* xr = x + (size_t)blockIdx.x * cols;
+    f16*       orow = out + (size_t)blockIdx.x * cols;
+    float      ss = 0.f;
+    if constexpr (VEC) {
+        for (int i = threadIdx.x * 8; i < cols; i += THREADS * 8) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) ss += (float)v[j] * (float)v[j];
+        }
+    } else {
+        for (int i = threadIdx.x; i < cols; i += THREADS) ss += (float)xr[i] * (float)xr[i];
+    }
+    const float var = block_sum<THREADS>(ss, red);
+    const float s   = rsqrtf(var / (float)cols + eps);
+    if constexpr (VEC) {
+        for (int i = threadIdx.x * 8; i < cols; i += THREADS * 8) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(xr + i);
+            const f16x8 g = *reinterpret_cast<const f16x8*>(gamma + i);
+            f16x8       o;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = (f16)clamp_for_half(((float)v[j] * s) * (float)g[j]);
+            *reinterpret_cast<f16x8*>(orow + i) = o;
+        }
+    } else {
+        for (int i = threadIdx.x; i < cols; i += THREADS)
+            orow[i] = (f16)clamp_for_half(((float)xr[i] * s) * (float)gamma[i]);
+    }
+}
+
+__global__ void rotary_neox_kernel(const int64_t* __restrict__ positions, f16* __restrict__ query,
+                                   f16* __restrict__ key, const f16* __restrict__ cache, int rot_dim, int stride,
+                                   int heads, int head_size)
+{
+#pragma clang fp contract(off)
+    const int     token = blockIdx.x;
+    const int64_t pos   = positions[token];
+    const f16*    cp    = cache + pos * rot_dim;
+    const int     embed = rot_dim / 2;
+    const int     n     = heads * embed;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int    head = i / embed;
+        const int    off  = i - head * embed;
+        const size_t base = (size_t)token * stride + (size_t)head * head_size;
+        const f16    c = cp[off], s = cp[embed + off];
+        const f16    qx = query[base + off], qy = query[base + embed + off];
+        const f16    qxc = qx * c, qys = qy * s, qyc = qy * c, qxs = qx * s;
+        query[base + off]         = qxc - qys;
+        query[base + embed + off] = qyc + qxs;
+        const f16 kx = key[base + off], ky = key[base + embed + off];
+        const f16 kxc = kx * c, kys = ky * s, kyc = ky * c, kxs = kx * s;
+        key[base + off]         = kxc - kys;
+        key[base + embed + off] = kyc + kxs;
+    }
+}
+
+}  // namespace
+
+int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows, int cols, hipStream_t stream)
+{
+    EETQ_REQUIRE(x && gamma && out, "null pointer");
+    EETQ_REQUIRE(rows >= 0 && cols > 0, "invalid shape");
+    if (rows == 0) return EETQ_OK;
+    if (cols % 8 == 0)
+        rmsnorm_kernel<256, true><<<rows, 256, 0, stream>>>(x, gamma, out, eps, cols);
+    else
+        rmsnorm_kernel<256, false><<<rows, 256, 0, stream>>>(x, gamma, out, eps, cols);
+    return check_hip(hipGetLastError(), "rmsnorm_kernel launch");
+}
+
+int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int heads, int head_size,
+                  int rot_dim, hipStream_t stream)
+{
+    EETQ_REQUIRE(pos && q && k && cache, "null pointer");
+    EETQ_REQUIRE(tokens >= 0 && heads > 0 && head_size > 0 && rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size,
+                 "invalid rotary shape");
+    if (tokens == 0) return EETQ_OK;
+    int threads = heads * rot_dim / 2;
+    threads     = threads < 512 ? threads : 512;
+    threads     = (threads + 63) / 64 * 64;
+    rotary_neox_kernel<<<tokens, threads, 0, stream>>>(pos, q, k, cache, rot_dim, heads * head_size, heads, head_size);
+    return check_hip(hipGetLastError(), "rotary_neox_kernel launch");
+}
+
+}  // namespace eetq

@@ -1,0 +1,317 @@
+// Per-channel symmetric int8 quantiser and weight re-layout kernels (plain HIP, HBM-bound byte work).
+//
+// Reference behaviour restated (paths relative to /root/reference):
+//   quantise  csrc/cutlass_kernels/cutlass_preprocessors.cc:581-678  (ft::symmetric_quantize)
+//   sm80 pack csrc/cutlass_kernels/cutlass_preprocessors.cc:497-534  (preprocess_weights_for_mixed_gemm)
+// The reference runs these single-threaded on the CPU (three strided K x N passes + four re-layout
+// passes); here every pass is one coalesced sweep: a 64(k) x 64(n) tile is read row-wise, transposed
+// through LDS and written in the destination layout with 16-byte stores.
+#include "common.hpp"
+
+namespace eetq {
+
+namespace {
+
+constexpr int kQT     = 64;       // tile edge
+constexpr int kQPitch = kQT + 16; // LDS row pitch in bytes (keeps 16-B alignment, breaks power-of-2 stride)
+
+__constant__ int kPerm16[16] = {0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15};
+
+// ---- pass 1: per-column max |w| -----------------------------------------------------------------------
+// std::max(a, |w|) with a starting at 0.f ignores NaN (a < NaN is false), see :619-628.  |w| >= 0, so
+// the IEEE bit pattern orders like an unsigned integer and atomicMax on the bits is exact.
+template <typename T, int V>
+__global__ __launch_bounds__(256) void colmax_kernel(const T* __restrict__ w, size_t K, size_t N,
+                                                     u32* __restrict__ colmax_bits, int rows_per_block)
+{
+    const size_t col0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * V;
+    if (col0 >= N) return;
+    const size_t k_begin = (size_t)blockIdx.y * rows_per_block;
+    size_t       k_end   = k_begin + rows_per_block;
+    if (k_end > K) k_end = K;
+    float m[V];
+#pragma unroll
+    for (int i = 0; i < V; ++i) m[i] = 0.f;
+    for (size_t k = k_begin; k < k_end; ++k) {
+        T v[V];
+        *reinterpret_cast<u32x4*>(v) = *reinterpret_cast<const u32x4*>(w + k * N + col0);
+#pragma unroll
+        for (int i = 0; i < V; ++i) {
+            const float a = __builtin_fabsf((float)v[i]);
+            m[i]          = (m[i] < a) ? a : m[i];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < V; ++i) atomicMax(colmax_bits + col0 + i, __builtin_bit_cast(u32, m[i]));
+}
+
+// ---- element quantiser ----------------------------------------------------------------------------------
+// :644-648  q = int8(max(-128.f, min(127.f, round(w / s)))) with std::min/std::max NaN behaviour and C
+// round() (half away from zero).  IEEE fp32 division (no reciprocal), subnormals kept.
+__device__ __forceinline__ int8_t quantize_elt(float w, float s)
+{
+    const float scaled = __builtin_roundf(w / s);
+    const float hi     = (scaled < 127.f) ? scaled : 127.f;  // std::min(127.f, scaled)
+    const float lo     = (-128.f < hi) ? hi : -128.f;        // std::max(-128.f, hi)
+    return (int8_t)(int)lo;
+}
+
+template <typename T>
+struct SrcTraits;
+template <>
+struct SrcTraits<f16> {
+    static constexpr bool kQuantize = true;
+};
+template <>
+struct SrcTraits<float> {
+    static constexpr bool kQuantize = true;
+};
+template <>
+struct SrcTraits<int8_t> {
+    static constexpr bool kQuantize = false;
+};
+
+// Load 16 consecutive columns of one row and produce 16 int8.
+template <typename T>
+__device__ __forceinline__ u32x4 load_quantize_16(const T* __restrict__ src, const float* __restrict__ colmax)
+{
+    union {
+        int8_t b[16];
+        u32x4  v;
+    } out;
+    if constexpr (!SrcTraits<T>::kQuantize) {
+        out.v = *reinterpret_cast<const u32x4*>(src);
+    } else {
+        T v[16];
+        constexpr int kVecs = (int)(sizeof(T) * 16 / 16);
+#pragma unroll
+        for (int i = 0; i < kVecs; ++i)
+            reinterpret_cast<u32x4*>(v)[i] = reinterpret_cast<const u32x4*>(src)[i];
+        float s[16];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            reinterpret_cast<f32x4*>(s)[i] = reinterpret_cast<const f32x4*>(colmax)[i];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) out.b[i] = quantize_elt((float)v[i], s[i] * (1.f / 128.f));
+    }
+    return out.v;
+}
+
+// ---- pass 2: quantise (or copy) one 64x64 tile and emit it in the requested layouts -----------------------
+// grid = (ceil(N/64), K/64), block = 256.  Thread t loads row r = t/4, columns seg*16..+15 (seg = t%4).
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void tile_pack_kernel(const T* __restrict__ src, size_t K, size_t N,
+                                                        const float* __restrict__ colmax,
+                                                        int8_t* __restrict__ q_raw, uint8_t* __restrict__ q_packed,
+                                                        void* __restrict__ scales, int scales_f32)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kQT][kQPitch];
+    const int    t   = threadIdx.x;
+    const size_t n0  = (size_t)blockIdx.x * kQT;
+    const size_t kt  = blockIdx.y;
+    const size_t k0  = kt * kQT;
+    const int    r   = t >> 2;
+    const int    seg = t & 3;
+    const size_t nc  = n0 + (size_t)seg * 16;
+
+    if (nc < N) {
+        const u32x4 q = load_quantize_16<T>(src + (k0 + r) * N + nc, colmax ? colmax + nc : nullptr);
+        *reinterpret_cast<u32x4*>(&tile[r][seg * 16]) = q;
+        if (q_raw) *reinterpret_cast<u32x4*>(q_raw + (k0 + r) * N + nc) = q;
+    }
+    if constexpr (SrcTraits<T>::kQuantize) {
+        // scales: written once per column by the first row of tiles (:633-634 scale = T(colmax * 2^-7))
+        if (kt == 0 && t < kQT && n0 + t < N && scales) {
+            const float s32 = colmax[n0 + t] * (1.f / 128.f);
+            if (scales_f32)
+                reinterpret_cast<float*>(scales)[n0 + t] = s32;
+            else
+                reinterpret_cast<f16*>(scales)[n0 + t] = (f16)s32;
+        }
+    }
+    if (!q_packed) return;
+    __syncthreads();
+
+    if constexpr (LAYOUT == EETQ_LAYOUT_GFX950) {
+        // 4 tiles of 16 columns; thread = (chunk, lane); lane = g*16 + c holds k-locals 16g..16g+15 of column c
+        const int chunk = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
+        if (n0 + (size_t)chunk * 16 < N) {
+            u32 d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 b0 = tile[16 * g + 4 * i + 0][chunk * 16 + c];
+                const u32 b1 = tile[16 * g + 4 * i + 2][chunk * 16 + c];  // bytes 1<->2 swapped
+                const u32 b2 = tile[16 * g + 4 * i + 1][chunk * 16 + c];
+                const u32 b3 = tile[16 * g + 4 * i + 3][chunk * 16 + c];
+                d[i]         = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ 0x80808080u;  // +128
+            }
+            const size_t ntile = (n0 >> 4) + chunk;
+            uint8_t*     dst   = q_packed + (ntile * (K >> 6) + kt) * (size_t)kTileBytes + (size_t)lane * 16;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{d[0], d[1], d[2], d[3]};
+        }
+    } else if constexpr (LAYOUT == EETQ_LAYOUT_SM80) {
+        // closed form of P1..P4: for column pair cp and 64-row tile kt the 128 output
+        // bytes are [even column k 0..63][odd column k 0..63] with rows permuted inside 16 and bytes 1<->2
+        // of each dword swapped, +128.
+        const int pair = t >> 3, sg = t & 7, half = sg >> 2, kk = (sg & 3) * 16;
+        u32       d[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const u32 b0 = tile[kk + kPerm16[4 * i + 0]][2 * pair + half];
+            const u32 b1 = tile[kk + kPerm16[4 * i + 2]][2 * pair + half];
+            const u32 b2 = tile[kk + kPerm16[4 * i + 1]][2 * pair + half];
+            const u32 b3 = tile[kk + kPerm16[4 * i + 3]][2 * pair + half];
+            d[i]         = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ 0x80808080u;
+        }
+        uint8_t* dst = q_packed + ((n0 >> 1) + pair) * (2 * K) + kt * 128 + (size_t)half * 64 + kk;
+        *reinterpret_cast<u32x4*>(dst) = u32x4{d[0], d[1], d[2], d[3]};
+    }
+}
+
+// ---- inverse: packed layout -> raw row-major ----------------------------------------------------------------
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void tile_unpack_kernel(const uint8_t* __restrict__ q_packed, size_t K, size_t N,
+                                                          int8_t* __restrict__ q_raw)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kQT][kQPitch];
+    const int    t  = threadIdx.x;
+    const size_t n0 = (size_t)blockIdx.x * kQT;
+    const size_t kt = blockIdx.y;
+    const size_t k0 = kt * kQT;
+
+    if constexpr (LAYOUT == EETQ_LAYOUT_GFX950) {
+        const int chunk = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
+        if (n0 + (size_t)chunk * 16 < N) {
+            const size_t   ntile = (n0 >> 4) + chunk;
+            const uint8_t* s     = q_packed + (ntile * (K >> 6) + kt) * (size_t)kTileBytes + (size_t)lane * 16;
+            const u32x4    v     = *reinterpret_cast<const u32x4*>(s);
+            const u32      d[4]  = {v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                tile[16 * g + 4 * i + 0][chunk * 16 + c] = (uint8_t)(d[i]);
+                tile[16 * g + 4 * i + 2][chunk * 16 + c] = (uint8_t)(d[i] >> 8);
+                tile[16 * g + 4 * i + 1][chunk * 16 + c] = (uint8_t)(d[i] >> 16);
+                tile[16 * g + 4 * i + 3][chunk * 16 + c] = (uint8_t)(d[i] >> 24);
+            }
+        }
+    } else {
+        const int      pair = t >> 3, sg = t & 7, half = sg >> 2, kk = (sg & 3) * 16;
+        const uint8_t* s    = q_packed + ((n0 >> 1) + pair) * (2 * K) + kt * 128 + (size_t)half * 64 + kk;
+        const u32x4    v    = *reinterpret_cast<const u32x4*>(s);
+        const u32      d[4] = {v.x ^ 0x80808080u, v.y ^ 0x80808080u, v.z ^ 0x80808080u, v.w ^ 0x80808080u};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            tile[kk + kPerm16[4 * i + 0]][2 * pair + half] = (uint8_t)(d[i]);
+            tile[kk + kPerm16[4 * i + 2]][2 * pair + half] = (uint8_t)(d[i] >> 8);
+            tile[kk + kPerm16[4 * i + 1]][2 * pair + half] = (uint8_t)(d[i] >> 16);
+            tile[kk + kPerm16[4 * i + 3]][2 * pair + half] = (uint8_t)(d[i] >> 24);
+        }
+    }
+    __syncthreads();
+    const int    r = t >> 2, seg = t & 3;
+    const size_t nc = n0 + (size_t)seg * 16;
+    if (nc < N)
+        *reinterpret_cast<u32x4*>(q_raw + (k0 + r) * N + nc) = *reinterpret_cast<const u32x4*>(&tile[r][seg * 16]);
+}
+
+int check_layout_shape(size_t K, size_t N, int layout)
+{
+    EETQ_REQUIRE(K > 0 && N > 0, "weight should not be empty tensor");
+    EETQ_REQUIRE(K % 64 == 0, "the number of rows (K) of the quantized matrix must be a multiple of 64");
+    EETQ_REQUIRE(N % 16 == 0, "the number of columns (N) must be a multiple of 16");
+    if (layout == EETQ_LAYOUT_SM80)
+        EETQ_REQUIRE(N % 64 == 0, "The number of columns must be a multiple of 64 (sm80 layout)");
+    EETQ_REQUIRE(layout == EETQ_LAYOUT_GFX950 || layout == EETQ_LAYOUT_SM80 || layout == EETQ_LAYOUT_ROW_MAJOR,
+                 "unknown weight layout");
+    return EETQ_OK;
+}
+
+template <typename T>
+int launch_tile_pack(const T* src, size_t K, size_t N, const float* colmax, int8_t* q_raw, int8_t* q_packed,
+                     int layout, void* scales, int scales_f32, hipStream_t stream)
+{
+    dim3     grid((unsigned)((N + kQT - 1) / kQT), (unsigned)(K / kQT));
+    uint8_t* p = reinterpret_cast<uint8_t*>(q_packed);
+    if (layout == EETQ_LAYOUT_SM80 && p)
+        tile_pack_kernel<T, EETQ_LAYOUT_SM80><<<grid, 256, 0, stream>>>(src, K, N, colmax, q_raw, p, scales, scales_f32);
+    else
+        tile_pack_kernel<T, EETQ_LAYOUT_GFX950><<<grid, 256, 0, stream>>>(src, K, N, colmax, q_raw, p, scales,
+                                                                         scales_f32);
+    return check_hip(hipGetLastError(), "tile_pack_kernel launch");
+}
+
+}  // namespace
+
+int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
+                    void* scales, float* colmax, hipStream_t stream)
+{
+    int st = check_layout_shape(K, N, q_packed ? layout : EETQ_LAYOUT_ROW_MAJOR);
+    if (st != EETQ_OK) return st;
+    EETQ_REQUIRE(w && scales && colmax, "null pointer");
+    EETQ_REQUIRE(w_dtype == EETQ_DTYPE_F16 || w_dtype == EETQ_DTYPE_F32,
+                 "Invalid datatype. Weight must be FP16 or FP32");
+    // ROW_MAJOR "packed" output is just the raw tensor again
+    int8_t* raw_out    = q_raw;
+    int8_t* packed_out = q_packed;
+    int8_t* raw_copy   = nullptr;
+    if (layout == EETQ_LAYOUT_ROW_MAJOR) {
+        if (!raw_out)
+            raw_out = q_packed;
+        else if (q_packed && q_packed != raw_out)
+            raw_copy = q_packed;
+        packed_out = nullptr;
+    }
+    EETQ_TRY_HIP(hipMemsetAsync(colmax, 0, N * sizeof(float), stream));
+    const int rows_per_block = 128;
+    if (w_dtype == EETQ_DTYPE_F16) {
+        dim3 grid((unsigned)((N / 8 + 255) / 256), (unsigned)((K + rows_per_block - 1) / rows_per_block));
+        colmax_kernel<f16, 8><<<grid, 256, 0, stream>>>(static_cast<const f16*>(w), K, N,
+                                                        reinterpret_cast<u32*>(colmax), rows_per_block);
+    } else {
+        dim3 grid((unsigned)((N / 4 + 255) / 256), (unsigned)((K + rows_per_block - 1) / rows_per_block));
+        colmax_kernel<float, 4><<<grid, 256, 0, stream>>>(static_cast<const float*>(w), K, N,
+                                                          reinterpret_cast<u32*>(colmax), rows_per_block);
+    }
+    EETQ_TRY_HIP(hipGetLastError());
+    if (w_dtype == EETQ_DTYPE_F16)
+        st = launch_tile_pack<f16>(static_cast<const f16*>(w), K, N, colmax, raw_out, packed_out, layout, scales, 0,
+                                   stream);
+    else
+        st = launch_tile_pack<float>(static_cast<const float*>(w), K, N, colmax, raw_out, packed_out, layout, scales,
+                                     1, stream);
+    if (st != EETQ_OK) return st;
+    if (raw_copy) EETQ_TRY_HIP(hipMemcpyAsync(raw_copy, raw_out, K * N, hipMemcpyDeviceToDevice, stream));
+    return EETQ_OK;
+}
+
+int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream)
+{
+    int st = check_layout_shape(K, N, layout);
+    if (st != EETQ_OK) return st;
+    EETQ_REQUIRE(q_raw && q_packed && q_raw != q_packed, "null or aliased pointer");
+    if (layout == EETQ_LAYOUT_ROW_MAJOR) {
+        EETQ_TRY_HIP(hipMemcpyAsync(q_packed, q_raw, K * N, hipMemcpyDeviceToDevice, stream));
+        return EETQ_OK;
+    }
+    return launch_tile_pack<int8_t>(q_raw, K, N, nullptr, nullptr, q_packed, layout, nullptr, 0, stream);
+}
+
+int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream)
+{
+    int st = check_layout_shape(K, N, layout);
+    if (st != EETQ_OK) return st;
+    EETQ_REQUIRE(q_raw && q_packed && q_raw != q_packed, "null or aliased pointer");
+    if (layout == EETQ_LAYOUT_ROW_MAJOR) {
+        EETQ_TRY_HIP(hipMemcpyAsync(q_raw, q_packed, K * N, hipMemcpyDeviceToDevice, stream));
+        return EETQ_OK;
+    }
+    dim3           grid((unsigned)((N + kQT - 1) / kQT), (unsigned)(K / kQT));
+    const uint8_t* p = reinterpret_cast<const uint8_t*>(q_packed);
+    if (layout == EETQ_LAYOUT_SM80)
+        tile_unpack_kernel<EETQ_LAYOUT_SM80><<<grid, 256, 0, stream>>>(p, K, N, q_raw);
+    else
+        tile_unpack_kernel<EETQ_LAYOUT_GFX950><<<grid, 256, 0, stream>>>(p, K, N, q_raw);
+    return check_hip(hipGetLastError(), "tile_unpack_kernel launch");
+}
+
+}  // namespace eetq

@@ -1,0 +1,121 @@
+"""Quantised linear modules over the W8A16 operators.
+
+Host-side mirror of /root/reference/python/eetq/modules/qlinear.py: ``quantize_and_preprocess_weights``
+(:14-24), ``W8A16Linear`` (:27-62), ``EetqLinearMMFunction`` (:64-94) and ``EetqLinear`` (:96-124) keep
+their names, constructor arguments, buffer names/shapes/dtypes and forward semantics so state dicts and
+callers (transformers' EETQ integration, TGI) are interchangeable.  ``W8A16LoraLinear`` (:127-186) is dead
+code in the reference (never constructed successfully) and is not carried over.
+"""
+import torch
+import torch.nn as nn
+from torch.autograd import Function
+
+from ..ops import preprocess_weights, quant_weights, w8_a16_gemm
+
+__all__ = ["quantize_and_preprocess_weights", "W8A16Linear", "EetqLinearMMFunction", "EetqLinear"]
+
+
+def quantize_and_preprocess_weights(weight, scales=None):
+    """nn.Linear weight [out, in] -> (processed int8 [in, out], scales [out]).
+
+    fp16 weights are quantised (per output channel, symmetric); int8 weights (e.g. bitsandbytes) are only
+    re-laid-out and need caller-provided ``scales``.  Anything else raises ValueError, like the reference.
+    Unlike the reference (which always round-trips through host memory, qlinear.py:16), a weight that
+    already lives on the GPU is quantised in place on that GPU.
+    """
+    kn = torch.t(weight).contiguous()  # [K = in_features, N = out_features]
+    if weight.dtype == torch.int8:
+        assert scales is not None, "int8 weights need their scales"
+        return preprocess_weights(kn), scales
+    if weight.dtype == torch.float16:
+        processed, scales = quant_weights(kn, torch.int8, False)
+        return processed, scales
+    raise ValueError("Unsupported data type: {}".format(weight.dtype))
+
+
+def _bias_add(out, bias):
+    return out if bias is None else out + bias
+
+
+class W8A16Linear(nn.Module):
+    """Inference-only linear layer: int8 weight ``qweight`` [in, out], fp16 ``weight_scales`` [out]."""
+
+    def __init__(self, in_features, out_features, bias=True, dev="cuda:0"):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.register_buffer("qweight", torch.zeros((in_features, out_features), dtype=torch.int8, device=dev))
+        self.register_buffer("weight_scales", torch.zeros((out_features,), dtype=torch.float16, device=dev))
+        if bias:
+            self.register_buffer("bias", torch.zeros((out_features,), dtype=torch.float16, device=dev))
+        else:
+            self.bias = None
+
+    @classmethod
+    def from_torch(cls, linear, scales=None, init_only=False):
+        dev = linear.weight.device
+        mod = cls(linear.in_features, linear.out_features, bias=linear.bias is not None, dev=dev)
+        if init_only:  # buffers only; weights arrive later through load_state_dict
+            return mod
+        if linear.bias is not None:
+            mod.bias = linear.bias.clone().half()
+        qweight, scales = quantize_and_preprocess_weights(linear.weight, scales)
+        mod.qweight = qweight.to(dev)
+        mod.weight_scales = scales.half().to(dev)
+        return mod
+
+    @torch.no_grad()
+    def forward(self, input):
+        return _bias_add(w8_a16_gemm(input, self.qweight, self.weight_scales), self.bias)
+
+    def extra_repr(self):
+        return "in_features={}, out_features={}, bias={}".format(self.in_features, self.out_features,
+                                                                 self.bias is not None)
+
+
+class EetqLinearMMFunction(Function):
+    """Autograd wrapper: forward = fused dequant GEMM; backward dequantises W by multiplying an identity
+    (exact: every output element is a single product) and returns grad_input only."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scales, bias=None):
+        ctx.save_for_backward(x, weight, scales, bias)
+        return _bias_add(w8_a16_gemm(x, weight, scales), bias)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, weight, scales, _bias = ctx.saved_tensors
+        grad_input = None
+        if ctx.needs_input_grad[0]:
+            eye = torch.eye(weight.shape[0], device=weight.device, dtype=x.dtype)
+            w_deq = w8_a16_gemm(eye, weight, scales)  # fp16 [K, N] == fp16(q * s)
+            grad_input = grad_output.squeeze(0).matmul(w_deq.transpose(0, 1)).unsqueeze(0)
+        return grad_input, None, None, None
+
+
+class EetqLinear(nn.Module):
+    """The module shape transformers/TGI instantiate: buffer ``weight`` int8 [in, out], ``weight_scales``
+    registered later via :meth:`register_scale`, optional fp16 ``bias``."""
+
+    def __init__(self, in_features, out_features, bias=True, device="cuda:0"):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.register_buffer("weight", torch.zeros((in_features, out_features), dtype=torch.int8, device=device))
+        if bias:
+            self.register_buffer("bias", torch.zeros((out_features,), dtype=torch.float16, device=device))
+        else:
+            self.bias = None
+
+    def register(self, buffer_name, tensor):
+        self.register_buffer(buffer_name, tensor)
+
+    def register_scale(self, device):
+        n = self.weight.shape[-1]
+        self.register_buffer("weight_scales", torch.zeros((n,), dtype=torch.float16, device=device))
+
+    def forward(self, input):
+        if self.training:
+            return EetqLinearMMFunction.apply(input, self.weight, self.weight_scales, self.bias)
+        with torch.no_grad():
+            return EetqLinearMMFunction.apply(input, self.weight, self.weight_scales, self.bias)

@@ -1,0 +1,217 @@
+"""The reference's native operator surface, re-hosted on libeetq_amd.so.
+
+Mirrors the pybind module ``EETQ`` (/root/reference/csrc/eetpy.cpp:7-19): same function names, argument
+order, defaults and error type (RuntimeError).  torch is used for tensors, device memory and the current
+stream only; all arithmetic happens in the HIP kernels behind the C ABI (include/eetq_amd.h).  There is
+no CPU fallback: without the shared library or without a GPU these functions raise.
+
+Differences from the reference, all supersets or documented:
+  * ``quant_weights`` / ``preprocess_weights`` also accept GPU tensors (results stay on that GPU); CPU tensors
+    in -> CPU tensors out exactly like the reference (fpA_intB_gemm_wrapper.cu:33,113), staged through the GPU.
+  * the processed layout is this library's gfx950 layout (the reference's is a function of the CUDA SM
+    version, cutlass_preprocessors.cc:113-128); ``layout="sm80"`` reproduces the reference's sm75..sm89 bytes.
+  * int4 (quint4x2) is not implemented (north star is W8A16) -> RuntimeError.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import (DTYPE_F16, DTYPE_F32, LAYOUT_GFX950, LAYOUT_ROW_MAJOR, LAYOUT_SM80, PATH_AUTO, PATH_GEMV,
+                   PATH_MFMA, check)
+
+__all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_",
+           "layernorm_forward", "rotary_embedding_neox", "convert_layout"]
+
+_LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
+            LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
+_PATHS = {"auto": PATH_AUTO, "gemv": PATH_GEMV, "mfma": PATH_MFMA}
+
+
+def _layout_id(layout):
+    try:
+        return _LAYOUTS[layout]
+    except KeyError:
+        raise RuntimeError("unknown weight layout %r (expected 'gfx950', 'sm80' or 'row_major')" % (layout,))
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("eetq_amd: no HIP device available; the W8A16 path has no CPU implementation")
+
+
+def _stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _work_device(t):
+    if t.is_cuda:
+        return t.device
+    _require_gpu()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def quant_weights(origin_weight, quant_type, return_unprocessed_quantized_tensor=False, layout="gfx950"):
+    """Per-column symmetric int8 quantisation of a [K, N] fp16/fp32 weight.
+
+    Reference: symmetric_quantize_last_axis_of_tensor, fpA_intB_gemm_wrapper.cu:28-107.  Returns
+    ``[processed_int8 [K, N], scales [N]]`` or, with the flag, ``[raw_int8, processed_int8, scales]``
+    (scales have the dtype of the weight).  raw int8 and scales are bit-exact with the reference.
+    """
+    weight = origin_weight
+    if not isinstance(weight, torch.Tensor):
+        raise RuntimeError("quant_weights(): origin_weight must be a torch.Tensor")
+    if not weight.is_contiguous():
+        raise RuntimeError("weight must be contiguous")
+    if weight.numel() == 0:
+        raise RuntimeError("weight should not be empty tensor")
+    if weight.dim() not in (2, 3):
+        raise RuntimeError("Invalid dim. The dim of weight should be 2 or 3")
+    if weight.dtype not in (torch.float16, torch.float32):
+        raise RuntimeError("Invalid datatype. Weight must be FP16 or FP32")
+    if quant_type == torch.quint4x2:
+        raise RuntimeError("eetq_amd: int4 (quint4x2) weight-only quantization is not implemented (W8A16 only)")
+    if quant_type != torch.int8:
+        raise RuntimeError("Must be int4 or int8 quantization")
+    if weight.dim() == 3:
+        # the reference quantises a 3-D stack and then fails in preprocess_weights_for_mixed_gemm
+        # (cutlass_preprocessors.cc:504): same observable behaviour
+        raise RuntimeError("[FT][ERROR] Shape must be 2-D")
+    lay = _layout_id(layout)
+    K, N = weight.shape
+    dev = _work_device(weight)
+    with torch.cuda.device(dev):
+        w_dev = weight if weight.is_cuda else weight.to(dev, non_blocking=False)
+        raw = torch.empty((K, N), dtype=torch.int8, device=dev) if return_unprocessed_quantized_tensor else None
+        processed = torch.empty((K, N), dtype=torch.int8, device=dev)
+        scales = torch.empty((N,), dtype=weight.dtype, device=dev)
+        colmax = torch.empty((N,), dtype=torch.float32, device=dev)
+        check(_lib.lib().eetq_quantize_i8(
+            _ptr(w_dev), DTYPE_F16 if weight.dtype == torch.float16 else DTYPE_F32, K, N,
+            _ptr(raw) if raw is not None else None, _ptr(processed), lay, _ptr(scales), _ptr(colmax),
+            _stream_ptr()))
+        if not weight.is_cuda:
+            processed, scales = processed.cpu(), scales.cpu()
+            raw = raw.cpu() if raw is not None else None
+    if return_unprocessed_quantized_tensor:
+        return [raw, processed, scales]
+    return [processed, scales]
+
+
+def _relayout(src, layout, pack):
+    if not isinstance(src, torch.Tensor) or src.dtype != torch.int8:
+        raise RuntimeError("expected an int8 tensor")
+    if src.dim() < 2:
+        raise RuntimeError("Shape must be 2-D")
+    if not src.is_contiguous():
+        src = src.contiguous()
+    lay = _layout_id(layout)
+    K, N = src.shape[-2], src.shape[-1]
+    if src.dim() != 2:
+        raise RuntimeError("[FT][ERROR] Shape must be 2-D")
+    dev = _work_device(src)
+    with torch.cuda.device(dev):
+        s_dev = src if src.is_cuda else src.to(dev)
+        out = torch.empty_like(s_dev)
+        fn = _lib.lib().eetq_pack_i8 if pack else _lib.lib().eetq_unpack_i8
+        check(fn(_ptr(s_dev), K, N, _ptr(out), lay, _stream_ptr()))
+        return out if src.is_cuda else out.cpu()
+
+
+def preprocess_weights(origin_weight, is_int4=False, layout="gfx950"):
+    """Row-major int8 [K, N] -> processed layout (same shape, re-ordered bytes).
+
+    Reference: preprocess_weights_cuda, fpA_intB_gemm_wrapper.cu:109-128.
+    """
+    if is_int4:
+        raise RuntimeError("eetq_amd: int4 weights are not implemented (W8A16 only)")
+    return _relayout(origin_weight, layout, pack=True)
+
+
+def unprocess_weights(processed_weight, layout="gfx950"):
+    """Inverse of :func:`preprocess_weights` (no reference counterpart; needed for checkpoint interop)."""
+    return _relayout(processed_weight, layout, pack=False)
+
+
+def convert_layout(weight, src_layout, dst_layout):
+    """Re-encode a processed int8 weight, e.g. an NVIDIA-written EETQ checkpoint ('sm80') -> 'gfx950'."""
+    return preprocess_weights(unprocess_weights(weight, src_layout), False, dst_layout)
+
+
+def _gemm_launch(input, weight, scale, output, m, n, k, path):
+    if input.dtype != torch.float16:
+        raise RuntimeError("w8_a16_gemm: input must be float16 (got %s)" % input.dtype)
+    if not input.is_cuda:
+        raise RuntimeError("input must be a CUDA tensor")
+    if weight.dtype != torch.int8 or scale.dtype != torch.float16:
+        raise RuntimeError("w8_a16_gemm: weight must be int8 and scale float16")
+    if weight.device != input.device or scale.device != input.device or output.device != input.device:
+        raise RuntimeError("w8_a16_gemm: input, weight, scale and output must be on the same device")
+    if not weight.is_contiguous() or not scale.is_contiguous() or not output.is_contiguous():
+        raise RuntimeError("w8_a16_gemm: weight, scale and output must be contiguous")
+    x = input if input.is_contiguous() else input.contiguous()
+    with torch.cuda.device(input.device):
+        check(_lib.lib().eetq_w8a16_gemm_ex(_ptr(x), _ptr(weight), _ptr(scale), _ptr(output), m, n, k, path,
+                                            _stream_ptr()))
+    return output
+
+
+def w8_a16_gemm(input, weight, scale, path="auto"):
+    """``y = input @ dequant(weight, scale)``: fp16 [..., K] x int8 [K, N] (processed) -> fp16 [..., N].
+
+    Reference: w8_a16_gemm_forward_cuda, fpA_intB_gemm_wrapper.cu:130-173 (fresh output tensor, current
+    stream, asynchronous).  ``path`` ("auto" | "gemv" | "mfma") is a testing hook.
+    """
+    k = input.shape[-1]
+    n = weight.shape[-1]
+    if weight.shape[-2] != k:
+        raise RuntimeError("w8_a16_gemm: weight is [%d, %d] but input has K=%d" % (weight.shape[-2], n, k))
+    m = input.numel() // k if k else 0
+    output = torch.empty(tuple(input.shape[:-1]) + (n,), dtype=input.dtype, device=input.device)
+    if m == 0:
+        return output
+    return _gemm_launch(input, weight, scale, output, m, n, k, _PATHS[path])
+
+
+def w8_a16_gemm_(input, weight, scale, output, m, n, k):
+    """In-place variant writing into ``output`` (reference: w8_a16_gemm_forward_cuda_, :176-202)."""
+    return _gemm_launch(input, weight, scale, output, int(m), int(n), int(k), PATH_AUTO)
+
+
+def layernorm_forward(input, gamma, out, eps):
+    """T5/RMS layernorm into ``out`` (reference: layernorm_forward_cuda, layernorm.cu:98-113). Returns None."""
+    if input.dtype != torch.float16 or gamma.dtype != torch.float16 or out.dtype != torch.float16:
+        raise RuntimeError("layernorm_forward: expected scalar type Half")
+    if not (input.is_cuda and gamma.is_cuda and out.is_cuda):
+        raise RuntimeError("layernorm_forward: tensors must be CUDA tensors")
+    if not (input.is_contiguous() and gamma.is_contiguous() and out.is_contiguous()):
+        raise RuntimeError("layernorm_forward: tensors must be contiguous")
+    cols = input.shape[-1]
+    rows = input.numel() // cols if cols else 0
+    if gamma.numel() != cols or out.numel() != input.numel():
+        raise RuntimeError("layernorm_forward: shape mismatch")
+    with torch.cuda.device(input.device):
+        check(_lib.lib().eetq_rmsnorm_f16(_ptr(input), _ptr(gamma), _ptr(out), float(eps), rows, cols, _stream_ptr()))
+    return None
+
+
+def rotary_embedding_neox(positions, query, key, head_size, cos_sin_cache):
+    """In-place NeoX rotary embedding of query/key (reference: pos_encoding_kernels.cu:55-87). fp16 only."""
+    if query.dtype != torch.float16 or key.dtype != torch.float16 or cos_sin_cache.dtype != torch.float16:
+        raise RuntimeError("eetq_amd: rotary_embedding_neox is implemented for float16 only")
+    if positions.dtype != torch.int64:
+        raise RuntimeError("rotary_embedding_neox: positions must be int64")
+    if not (query.is_contiguous() and key.is_contiguous() and cos_sin_cache.is_contiguous()
+            and positions.is_contiguous()):
+        raise RuntimeError("rotary_embedding_neox: tensors must be contiguous")
+    tokens = query.shape[0] * query.shape[1]
+    rot_dim = cos_sin_cache.shape[1]
+    heads = query.shape[-2]
+    with torch.cuda.device(query.device):
+        check(_lib.lib().eetq_rotary_neox_f16(_ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), tokens,
+                                              heads, int(head_size), rot_dim, _stream_ptr()))
+    return None

@@ -1,0 +1,86 @@
+"""Replica fan-out for multi-GPU runs: one process per GPU, model replicated, no data-path collective.
+
+The reference has no communication layer at all (zero NCCL call sites); BASELINE.json's
+north star asks for "RCCL over xGMI used only to fan out identical prompts".  So the only collectives are
+  * one ``broadcast`` of the input batch (prompts / activations) from rank 0,
+  * one ``all_gather`` of a per-rank checksum + one ``all_reduce(MAX)`` of the timed-region duration,
+all latency-bound and outside the kernels.  Backend "nccl" (= RCCL on ROCm) on GPUs, "gloo" on CPU (tests).
+"""
+import os
+import time
+import zlib
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["ReplicaGroup"]
+
+
+class ReplicaGroup:
+    def __init__(self, backend=None, device=None):
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        use_cuda = torch.cuda.is_available() if device is None else torch.device(device).type == "cuda"
+        if device is None:
+            device = torch.device("cuda", self.local_rank) if use_cuda else torch.device("cpu")
+        self.device = torch.device(device)
+        if self.device.type == "cuda":
+            torch.cuda.set_device(self.device)
+        self.backend = backend or ("nccl" if self.device.type == "cuda" else "gloo")
+        self._own_pg = False
+        if self.world_size > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            kw = {}
+            if self.backend == "nccl":
+                kw["device_id"] = self.device
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world_size, **kw)
+            self._own_pg = True
+
+    # ---- collectives (no-ops for a single replica) ----
+    def fan_out(self, tensor, src=0):
+        """Every replica receives rank ``src``'s tensor (identical prompts / activations)."""
+        if self.world_size > 1:
+            dist.broadcast(tensor, src=src)
+        return tensor
+
+    def barrier(self):
+        if self.world_size > 1:
+            dist.barrier()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
+    def max_over_ranks(self, seconds):
+        if self.world_size == 1:
+            return float(seconds)
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def timed(self, fn):
+        """barrier + sync, run fn(), sync + barrier; returns the MAX wall time over all replicas (seconds)."""
+        self.barrier()
+        t0 = time.perf_counter()
+        fn()
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        t1 = time.perf_counter()
+        local = t1 - t0
+        self.barrier()
+        return self.max_over_ranks(local)
+
+    def gather_checksums(self, tensor):
+        """CRC32 of every replica's result bytes (list of world_size ints): replicas must agree bit for bit."""
+        crc = zlib.crc32(tensor.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()) & 0xFFFFFFFF
+        if self.world_size == 1:
+            return [crc]
+        t = torch.tensor([crc], dtype=torch.int64, device=self.device if self.backend == "nccl" else "cpu")
+        out = [torch.zeros_like(t) for _ in range(self.world_size)]
+        dist.all_gather(out, t)
+        return [int(o.item()) for o in out]
+
+    def close(self):
+        if self._own_pg and dist.is_initialized():
+            dist.destroy_process_group()
+            self._own_pg = False

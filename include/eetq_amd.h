@@ -1,0 +1,114 @@
+/*
+ * eetq_amd.h -- C ABI of libeetq_amd.so: the MI355X (gfx950) implementation of EETQ's W8A16 hot path.
+ *
+ * Every entry point replaces one function of the reference's native boundary (the pybind module
+ * `EETQ`, /root/reference/csrc/eetpy.cpp:7-19); the reference interface each one stands in for is cited
+ * on the declaration.  Plain pointers and sizes only -- no torch types.  All device pointers refer to
+ * the *current* HIP device; `stream` is a hipStream_t passed as void* (NULL = the null stream).  Calls
+ * are asynchronous with respect to the host unless stated otherwise.
+ *
+ * Return value: 0 (EETQ_OK) on success, a negative EETQ_ERR_* code otherwise; the message for the most
+ * recent failure on the calling thread is available from eetq_last_error().  The Python host layer
+ * (eetq_amd/ops.py) turns a non-zero status into RuntimeError, which is what the reference's C++
+ * exceptions become through pybind (csrc/utils/cuda_utils.h:40-60).
+ */
+#ifndef EETQ_AMD_H_
+#define EETQ_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    EETQ_OK              = 0,
+    EETQ_ERR_INVALID     = -1, /* bad argument (null pointer, unsupported shape, unknown enum) */
+    EETQ_ERR_HIP         = -2, /* a HIP runtime call or kernel launch failed */
+    EETQ_ERR_UNSUPPORTED = -3  /* valid request this build does not implement */
+};
+
+/* Element type of the weight handed to the quantiser and of the scales it returns
+ * (reference: symmetric_quantize<half,half> / <float,float>, fpA_intB_gemm_wrapper.cu:78-95). */
+enum { EETQ_DTYPE_F16 = 0, EETQ_DTYPE_F32 = 1 };
+
+/* Byte layout of an int8 [K][N]-shaped weight tensor.
+ *   ROW_MAJOR : raw two's-complement int8, element (k,n) at k*N+n -- the reference's "unprocessed" tensor.
+ *   GFX950    : this library's native layout (DESIGN.md "HBM layout"): 1 KiB tiles of 16 columns x 64 k,
+ *               uint8 = q+128, k-contiguous per column, dword bytes 1<->2 swapped.  What
+ *               eetq_w8a16_gemm consumes.  Requires K % 64 == 0, N % 16 == 0.
+ *   SM80      : the reference's processed layout for sm75..sm89 (cutlass_preprocessors.cc:497-534;
+ *               ColumnMajorTileInterleave<64,2> + row permute + bias/byte swizzle), i.e. the bytes found
+ *               in EETQ checkpoints written on NVIDIA GPUs.  Requires K % 64 == 0, N % 64 == 0. */
+enum { EETQ_LAYOUT_ROW_MAJOR = 0, EETQ_LAYOUT_GFX950 = 1, EETQ_LAYOUT_SM80 = 2 };
+
+/* Kernel selection for eetq_w8a16_gemm_ex (tests and tuning).  AUTO is what eetq_w8a16_gemm uses. */
+enum { EETQ_PATH_AUTO = 0, EETQ_PATH_GEMV = 1, EETQ_PATH_MFMA = 2, EETQ_PATH_SKINNY = 3 };
+
+/* ---- quantise --------------------------------------------------------------------------------------
+ * Replaces EETQ.quant_weights -> symmetric_quantize_last_axis_of_tensor
+ * (csrc/cutlass_kernels/fpA_intB_gemm_wrapper.cu:28-107) -> ft::symmetric_quantize
+ * (csrc/cutlass_kernels/cutlass_preprocessors.cc:581-678).
+ * Per column n of the row-major [K][N] weight: s32 = max_k|w| * 2^-7 (fp32); scales[n] = (dtype)s32;
+ * q = int8(clamp(round_half_away(w / s32), -128, 127)); bit-exact with the reference, including q = 127
+ * for an all-zero column.  q_raw (ROW_MAJOR) and q_packed (in `layout`) may each be NULL.
+ * All pointers are DEVICE pointers.  `scales` has dtype `w_dtype` and N elements.
+ * `workspace` must provide N floats (device); pass NULL to let the library use an internal buffer
+ * (allocated once per device and grown on demand). */
+int eetq_quantize_i8(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
+                     int layout, void* scales, float* workspace, void* stream);
+
+/* Same operation on HOST buffers (what the reference's CPU function receives): uploads w, runs the HIP
+ * kernels, downloads the results and synchronises.  Blocking. */
+int eetq_quantize_i8_host(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
+                          int layout, void* scales);
+
+/* ---- pack / unpack ---------------------------------------------------------------------------------
+ * Replaces EETQ.preprocess_weights -> preprocess_weights_cuda (fpA_intB_gemm_wrapper.cu:109-128) ->
+ * ft::preprocess_weights_for_mixed_gemm (cutlass_preprocessors.cc:497-534).
+ * eetq_pack_i8: ROW_MAJOR int8 [K][N] -> `layout`.  eetq_unpack_i8: `layout` -> ROW_MAJOR (the reference has
+ * no inverse; needed to load NVIDIA-written checkpoints).  Device pointers; src != dst. */
+int eetq_pack_i8(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, void* stream);
+int eetq_unpack_i8(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, void* stream);
+/* Host-buffer variants (blocking), mirroring the CPU-tensor contract of preprocess_weights. */
+int eetq_pack_i8_host(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout);
+int eetq_unpack_i8_host(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout);
+
+/* ---- fused dequant + GEMM --------------------------------------------------------------------------
+ * Replaces EETQ.w8_a16_gemm / w8_a16_gemm_ -> w8_a16_gemm_forward_cuda(_)
+ * (fpA_intB_gemm_wrapper.cu:130-202), i.e. weight_only_batched_gemv_launcher
+ * (csrc/weightOnlyBatchedGemv/kernelLauncher.cu:122-232) for small M and ft::gemm_fp16_int
+ * (csrc/cutlass_kernels/fpA_intB_gemm.cu:21-33) otherwise.
+ *   y[m][n] = fp16( sum_k fp32(x[m][k]) * fp32( fp16( q[k][n] * scales[n] ) ) ),  fp32 accumulation.
+ * x: fp16 [M][K] row-major; w_packed: GFX950 layout of the [K][N] int8 weight; scales: fp16 [N];
+ * y: fp16 [M][N] row-major.  Device pointers, 16-byte aligned.  Requires K % 64 == 0, N % 16 == 0, M >= 1. */
+int eetq_w8a16_gemm(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N, int K,
+                    void* stream);
+/* As above with an explicit kernel path (EETQ_PATH_*); returns EETQ_ERR_UNSUPPORTED when the path cannot
+ * run the shape (e.g. GEMV with M > 8). */
+int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N,
+                       int K, int path, void* stream);
+
+/* ---- side ops --------------------------------------------------------------------------------------
+ * Replaces EETQ.layernorm_forward -> layernorm_forward_cuda (csrc/layernorm_kernels/layernorm.cu:98-113):
+ * T5/RMS norm, out = clamp_fp16( x * rsqrt(mean(x^2) + eps) * gamma ), fp32 math, fp16 I/O.
+ * Launches on `stream` (the reference uses the default stream, layernorm.cu:76). */
+int eetq_rmsnorm_f16(const void* x, const void* gamma, void* out, float eps, int rows, int cols, void* stream);
+
+/* Replaces EETQ.rotary_embedding_neox (csrc/embedding_kernels/pos_encoding_kernels.cu:55-87) for fp16:
+ * in-place NeoX rotation of q and k ([tokens][heads][head_size]) by cos_sin_cache[positions[t]]
+ * ([max_pos][rot_dim], cos half then sin half), every product/sum rounded to fp16 like the reference. */
+int eetq_rotary_neox_f16(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
+                         int tokens, int heads, int head_size, int rot_dim, void* stream);
+
+/* ---- misc ------------------------------------------------------------------------------------------ */
+const char* eetq_last_error(void);   /* thread-local, never NULL */
+const char* eetq_version(void);      /* "eetq_amd <version> gfx950" */
+/* 1 if the current HIP device is a gfx950; 0 otherwise (kernels are built for gfx950 only). */
+int eetq_device_supported(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EETQ_AMD_H_ */

@@ -1,0 +1,416 @@
+/*
+ * eetq_oracle.c -- CPU restatement of the EETQ W8A16 hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the checker for the HIP kernels in eetq_amd/csrc.  Only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it; the product path
+ * (everything under eetq_amd) never links, imports or calls anything in oracle/.
+ *
+ * Every function restates one piece of the reference (paths relative to /root/reference):
+ *   oracle_quantize_*        csrc/cutlass_kernels/cutlass_preprocessors.cc:581-678
+ *   oracle_sm80_*            csrc/cutlass_kernels/cutlass_preprocessors.cc:137-195 (P1 row permute),
+ *                            :201-335 (P2 transpose), :432-495 (P3 column interleave),
+ *                            :337-358 (P4 +128 bias and byte swizzle), driver :497-534
+ *   oracle_w8a16_gemm        numerics contract of the un-runnable CUDA kernels:
+ *                            cutlass_extensions/.../interleaved_numeric_conversion.h:53-85 (exact
+ *                            int8->fp16), gemm/warp/mma_tensorop_dequantizer.h:259-274 (fp16
+ *                            multiply by the per-column scale), default_fpA_intB_traits.h:110 (fp32
+ *                            accumulate), epilogue_helpers.h:73-80 (fp16 store, alpha=1 beta=0)
+ *   oracle_rmsnorm_f16       csrc/layernorm_kernels/layernorm.cu:25-51, reduction.cuh:78-82
+ *   oracle_rotary_neox_f16   csrc/embedding_kernels/pos_encoding_kernels.cu:12-53
+ *
+ * PINNING STATUS.  The reference C++ for quantise/pack cannot be compiled in this image without
+ * writing stand-in CUTLASS / CUDA headers (csrc/cutlass is an empty, un-vendored submodule), so there
+ * is no oracle/_ref build.  The reference ships no golden vectors either.  The oracle is pinned
+ * against the only assertions the reference's own scripts make for this path:
+ *   - examples/layers/test_qlinear.py:20-36  (atol=1e-2 vs torch fp16 nn.Linear, seed 1, 128x1024x4096)
+ *   - examples/layers/test_w8a16_gemm.py:33-41 (preprocess_weights(raw) == processed from quant_weights)
+ * and against the CPU torch.nn.Linear fp16 forward that BASELINE.json names as config[0]; see
+ * tests/test_oracle.py.  Bit-level behaviour of quantise/pack beyond that is restated from the source
+ * lines cited above: for those bytes, parity is "restated, unpinned by a reference build".
+ */
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ fp16 <-> fp32 (IEEE, RNE) */
+
+static inline float h2f(uint16_t h)
+{
+    uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    uint32_t exp  = (h >> 10) & 0x1fu;
+    uint32_t man  = h & 0x3ffu;
+    uint32_t bits;
+    if (exp == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else { /* subnormal: normalise */
+            int e = -1;
+            do { man <<= 1; ++e; } while (!(man & 0x400u));
+            man &= 0x3ffu;
+            bits = sign | ((uint32_t)(127 - 15 - e) << 23) | (man << 13);
+        }
+    } else if (exp == 31) {
+        bits = sign | 0x7f800000u | (man << 13);
+    } else {
+        bits = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    }
+    float f;
+    memcpy(&f, &bits, 4);
+    return f;
+}
+
+static inline uint16_t f2h(float f)
+{
+    uint32_t x;
+    memcpy(&x, &f, 4);
+    uint16_t sign = (uint16_t)((x >> 16) & 0x8000u);
+    uint32_t ax   = x & 0x7fffffffu;
+    if (ax >= 0x7f800000u) { /* inf / nan */
+        return (uint16_t)(sign | 0x7c00u | ((ax > 0x7f800000u) ? (0x200u | ((ax >> 13) & 0x3ffu)) : 0u));
+    }
+    if (ax >= 0x477ff000u) { /* >= 65520 rounds to inf */
+        return (uint16_t)(sign | 0x7c00u);
+    }
+    if (ax < 0x33000001u) { /* < 2^-25 (or == 2^-25 ties to even -> 0) */
+        return sign;
+    }
+    int32_t  e = (int32_t)(ax >> 23) - 127;
+    uint32_t m = (ax & 0x7fffffu) | 0x800000u; /* 24-bit significand */
+    uint32_t shift;
+    uint32_t hexp;
+    if (e < -14) { /* subnormal half */
+        shift = (uint32_t)(13 + (-14 - e));
+        hexp  = 0;
+    } else {
+        shift = 13;
+        hexp  = (uint32_t)(e + 15);
+    }
+    uint32_t q    = m >> shift;
+    uint32_t rem  = m & ((1u << shift) - 1u);
+    uint32_t half = 1u << (shift - 1);
+    if (rem > half || (rem == half && (q & 1u))) {
+        ++q;
+    }
+    uint32_t out;
+    if (hexp == 0) {
+        out = q; /* may carry into exponent 1: correct */
+    } else {
+        out = ((hexp - 1) << 10) + q; /* q includes the hidden bit: (hexp<<10) + (q - 0x400) */
+    }
+    return (uint16_t)(sign | out);
+}
+
+uint16_t oracle_f32_to_f16(float f) { return f2h(f); }
+float    oracle_f16_to_f32(uint16_t h) { return h2f(h); }
+
+/* ------------------------------------------------------------------ quantise (Q2) */
+
+/* cutlass_preprocessors.cc:619-628: per-column max of |w| in fp32, starting from 0.f, using
+ * std::max(a, b) == (a < b) ? b : a  -- a NaN element never replaces the running max. */
+static inline float ref_max(float a, float b) { return (a < b) ? b : a; }
+/* std::min(a, b) == (b < a) ? b : a */
+static inline float ref_min(float a, float b) { return (b < a) ? b : a; }
+
+static void quantize_core(const float* (*row_loader)(const void*, size_t, size_t, float*), const void* w,
+                          size_t K, size_t N, int8_t* q_raw, float* col_scale_f32)
+{
+    float* rowbuf = (float*)malloc(N * sizeof(float));
+    for (size_t j = 0; j < N; ++j) col_scale_f32[j] = 0.f;
+    for (size_t i = 0; i < K; ++i) {
+        const float* r = row_loader(w, i, N, rowbuf);
+        for (size_t j = 0; j < N; ++j) col_scale_f32[j] = ref_max(col_scale_f32[j], fabsf(r[j]));
+    }
+    /* :610 quant_range_scale = 1.f / float(1 << 7); :633 per_col_max[jj] *= quant_range_scale */
+    const float quant_range_scale = 1.f / 128.f;
+    for (size_t j = 0; j < N; ++j) col_scale_f32[j] *= quant_range_scale;
+    /* :638-648 q = int8(max(-128, min(127, round(w / col_scale)))), C round() = half away from zero.
+     * 0/0 = NaN -> round(NaN) = NaN -> min(127, NaN) = 127 -> q = 127 for an all-zero column. */
+    for (size_t i = 0; i < K; ++i) {
+        const float* r = row_loader(w, i, N, rowbuf);
+        for (size_t j = 0; j < N; ++j) {
+            const float scaled  = roundf(r[j] / col_scale_f32[j]);
+            const float clipped = ref_max(-128.f, ref_min(127.f, scaled));
+            q_raw[i * N + j]    = (int8_t)clipped;
+        }
+    }
+    free(rowbuf);
+}
+
+static const float* load_row_f16(const void* w, size_t i, size_t N, float* buf)
+{
+    const uint16_t* p = (const uint16_t*)w + i * N;
+    for (size_t j = 0; j < N; ++j) buf[j] = h2f(p[j]);
+    return buf;
+}
+
+static const float* load_row_f32(const void* w, size_t i, size_t N, float* buf)
+{
+    (void)buf;
+    return (const float*)w + i * N;
+}
+
+/* symmetric_quantize<half,half>: w fp16 [K][N] row-major -> q_raw int8 [K][N], scales fp16 [N]
+ * (stored scale = half(fp32 scale), :634). */
+void oracle_quantize_f16(const uint16_t* w, size_t K, size_t N, int8_t* q_raw, uint16_t* scales)
+{
+    float* s32 = (float*)malloc(N * sizeof(float));
+    quantize_core(load_row_f16, w, K, N, q_raw, s32);
+    for (size_t j = 0; j < N; ++j) scales[j] = f2h(s32[j]);
+    free(s32);
+}
+
+/* symmetric_quantize<float,float>: scales stay fp32. */
+void oracle_quantize_f32(const float* w, size_t K, size_t N, int8_t* q_raw, float* scales)
+{
+    quantize_core(load_row_f32, w, K, N, q_raw, scales);
+}
+
+/* ------------------------------------------------------------------ sm>=75 processed layout (P1..P4) */
+
+/* P1, cutlass_preprocessors.cc:137-195 (int8: B_ROWS_PER_MMA = 16, ELTS_PER_REG = 4):
+ * within every 16 rows, write row t <- read row 8*((t%4)/2) + t%2 + 2*(t/4). */
+static void sm80_permute_rows(int8_t* dst, const int8_t* src, size_t K, size_t N)
+{
+    for (size_t base = 0; base < K; base += 16) {
+        for (size_t t = 0; t < 16; ++t) {
+            const size_t rr = 8 * ((t % 4) / 2) + t % 2 + 2 * (t / 4);
+            memcpy(dst + (base + t) * N, src + (base + rr) * N, N);
+        }
+    }
+}
+
+/* P2, :201-335: [K][N] row-major -> [N][K] (column-major of the original). */
+static void sm80_transpose(int8_t* dst, const int8_t* src, size_t K, size_t N)
+{
+    for (size_t k = 0; k < K; ++k)
+        for (size_t n = 0; n < N; ++n) dst[n * K + k] = src[k * N + n];
+}
+
+/* P3, :432-495 with rows_per_column_tile = 64, columns_interleaved = 2 (mixed_gemm_B_layout.h:59-71):
+ * operates on the column-major tensor in uint32 units (4 k-values).  num_vec_rows = K/4,
+ * vec_rows_per_tile = 16.  For read column c, vec row v (base b = v - v%16):
+ *   write row = 2*b + 16*(c%2) + v%16, in output "column" c/2 whose length is 2*num_vec_rows. */
+static void sm80_interleave_columns(int8_t* dst, const int8_t* src, size_t K, size_t N)
+{
+    const uint32_t* in  = (const uint32_t*)src;
+    uint32_t*       out = (uint32_t*)dst;
+    const size_t    nvr = K / 4;
+    for (size_t c = 0; c < N; ++c) {
+        for (size_t v = 0; v < nvr; ++v) {
+            const size_t b  = v - v % 16;
+            const size_t wr = 2 * b + 16 * (c % 2) + v % 16;
+            out[(c / 2) * nvr * 2 + wr] = in[c * nvr + v];
+        }
+    }
+}
+
+/* P4, :337-358: +128 then swap bytes 1 and 2 of every aligned 4. */
+static void sm80_bias_and_swizzle(int8_t* buf, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) buf[i] = (int8_t)((int)buf[i] + 128);
+    for (size_t b = 0; b + 3 < n; b += 4) {
+        int8_t t   = buf[b + 1];
+        buf[b + 1] = buf[b + 2];
+        buf[b + 2] = t;
+    }
+}
+
+/* preprocess_weights_for_mixed_gemm for arch in [75, 90), int8 (:497-534).  Requires K%64==0, N%64==0
+ * (the reference checks N%64 at :455 and silently needs K%64). Returns 0 on success, -1 on bad shape. */
+int oracle_sm80_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* out)
+{
+    if (K == 0 || N == 0 || K % 64 || N % 64) return -1;
+    int8_t* a = (int8_t*)malloc(K * N);
+    int8_t* b = (int8_t*)malloc(K * N);
+    sm80_permute_rows(a, q_raw, K, N);
+    sm80_transpose(b, a, K, N);
+    sm80_interleave_columns(a, b, K, N);
+    sm80_bias_and_swizzle(a, K * N);
+    memcpy(out, a, K * N);
+    free(a);
+    free(b);
+    return 0;
+}
+
+/* Closed form of the same mapping: used as a cross-check of the 4-step
+ * restatement and as the spec of the inverse. */
+static const int kPerm16[16] = {0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14, 15};
+
+static inline size_t sm80_offset(size_t k_written, size_t n, size_t K)
+{
+    /* position, before the P4 byte swap, of the element that sits at (row k_written, col n) after P1 */
+    size_t p = (n >> 1) * 2 * K + (k_written >> 6) * 128 + (n & 1) * 64 + (k_written & 63);
+    static const size_t swz[4] = {0, 2, 1, 3};
+    return (p & ~(size_t)3) + swz[p & 3];
+}
+
+int oracle_sm80_pack_closed_form(const int8_t* q_raw, size_t K, size_t N, int8_t* out)
+{
+    if (K == 0 || N == 0 || K % 64 || N % 64) return -1;
+    for (size_t k = 0; k < K; ++k) {
+        const size_t src_k = (k & ~(size_t)15) + (size_t)kPerm16[k & 15];
+        for (size_t n = 0; n < N; ++n)
+            out[sm80_offset(k, n, K)] = (int8_t)((int)q_raw[src_k * N + n] + 128);
+    }
+    return 0;
+}
+
+int oracle_sm80_unpack(const int8_t* packed, size_t K, size_t N, int8_t* q_raw)
+{
+    if (K == 0 || N == 0 || K % 64 || N % 64) return -1;
+    for (size_t k = 0; k < K; ++k) {
+        const size_t src_k = (k & ~(size_t)15) + (size_t)kPerm16[k & 15];
+        for (size_t n = 0; n < N; ++n)
+            q_raw[src_k * N + n] = (int8_t)((int)(uint8_t)packed[sm80_offset(k, n, K)] - 128);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------ gfx950 native layout (this repo's)
+ * Not a reference algorithm: this is the CPU statement of the layout the HIP pack kernel must produce
+ * (DESIGN.md "HBM layout").  Tile = 16 output columns x 64 k = 1 KiB, tiles ordered [n/16][k/64];
+ * inside a tile 64 "lanes" of 16 bytes, lane = ((k>>4)&3)*16 + (n&15); inside a lane the 16 k-values
+ * are stored as uint8 (q+128) with bytes 1 and 2 of every dword swapped. */
+static inline size_t gfx950_offset(size_t k, size_t n, size_t K)
+{
+    static const size_t swz[4] = {0, 2, 1, 3};
+    const size_t tile = (n >> 4) * (K >> 6) + (k >> 6);
+    const size_t lane = ((k >> 4) & 3) * 16 + (n & 15);
+    const size_t j    = k & 15;
+    return tile * 1024 + lane * 16 + (j & ~(size_t)3) + swz[j & 3];
+}
+
+int oracle_gfx950_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* out)
+{
+    if (K == 0 || N == 0 || K % 64 || N % 16) return -1;
+    for (size_t k = 0; k < K; ++k)
+        for (size_t n = 0; n < N; ++n) out[gfx950_offset(k, n, K)] = (int8_t)((int)q_raw[k * N + n] + 128);
+    return 0;
+}
+
+int oracle_gfx950_unpack(const int8_t* packed, size_t K, size_t N, int8_t* q_raw)
+{
+    if (K == 0 || N == 0 || K % 64 || N % 16) return -1;
+    for (size_t k = 0; k < K; ++k)
+        for (size_t n = 0; n < N; ++n)
+            q_raw[k * N + n] = (int8_t)((int)(uint8_t)packed[gfx950_offset(k, n, K)] - 128);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ W8A16 GEMM contract
+ * y[m][n] = fp16( sum_k fp32(x[m][k]) * fp32( fp16( q[k][n] * s[n] ) ) ), summation order free.
+ * The oracle accumulates in double (the exact value the fp32 orders scatter around) and rounds once to
+ * fp32 then fp16.  q_raw is the UNPROCESSED row-major [K][N] int8. */
+void oracle_w8a16_gemm(const uint16_t* x, const int8_t* q_raw, const uint16_t* scales, uint16_t* y, size_t M,
+                       size_t N, size_t K)
+{
+    float*  wdq = (float*)malloc(K * sizeof(float));
+    double* acc = (double*)malloc(M * sizeof(double));
+    for (size_t n = 0; n < N; ++n) {
+        const float s = h2f(scales[n]);
+        /* fp16(q*s): q is exact in fp16, the product is rounded once (v_pk_mul_f16 / hmul2 semantics) */
+        for (size_t k = 0; k < K; ++k) wdq[k] = h2f(f2h((float)q_raw[k * N + n] * s));
+        for (size_t m = 0; m < M; ++m) acc[m] = 0.0;
+        for (size_t m = 0; m < M; ++m) {
+            const uint16_t* xr = x + m * K;
+            double          a  = 0.0;
+            for (size_t k = 0; k < K; ++k) a += (double)h2f(xr[k]) * (double)wdq[k];
+            acc[m] = a;
+        }
+        for (size_t m = 0; m < M; ++m) y[m * N + n] = f2h((float)acc[m]);
+    }
+    free(wdq);
+    free(acc);
+}
+
+/* Same contract with strict left-to-right fp32 accumulation (one legal order): used to size the
+ * tolerance band that "summation order free" implies, and as the timed cpu_baseline port. */
+void oracle_w8a16_gemm_f32acc(const uint16_t* x, const int8_t* q_raw, const uint16_t* scales, uint16_t* y,
+                              size_t M, size_t N, size_t K)
+{
+    float* xf = (float*)malloc(M * K * sizeof(float));
+    for (size_t i = 0; i < M * K; ++i) xf[i] = h2f(x[i]);
+    float* acc = (float*)calloc(M * N, sizeof(float));
+    float* wrow = (float*)malloc(N * sizeof(float));
+    float* sf = (float*)malloc(N * sizeof(float));
+    for (size_t n = 0; n < N; ++n) sf[n] = h2f(scales[n]);
+    for (size_t k = 0; k < K; ++k) {
+        for (size_t n = 0; n < N; ++n) wrow[n] = h2f(f2h((float)q_raw[k * N + n] * sf[n]));
+        for (size_t m = 0; m < M; ++m) {
+            const float xv = xf[m * K + k];
+            float*      a  = acc + m * N;
+            for (size_t n = 0; n < N; ++n) a[n] += xv * wrow[n];
+        }
+    }
+    for (size_t i = 0; i < M * N; ++i) y[i] = f2h(acc[i]);
+    free(xf);
+    free(acc);
+    free(wrow);
+    free(sf);
+}
+
+/* Dequantised weight fp16(q*s) as fp16 [K][N]: what EetqLinearMMFunction.backward obtains by
+ * multiplying an identity (python/eetq/modules/qlinear.py:83-86). */
+void oracle_dequant(const int8_t* q_raw, const uint16_t* scales, uint16_t* w, size_t K, size_t N)
+{
+    for (size_t k = 0; k < K; ++k)
+        for (size_t n = 0; n < N; ++n) w[k * N + n] = f2h((float)q_raw[k * N + n] * h2f(scales[n]));
+}
+
+/* ------------------------------------------------------------------ T5 / RMS layernorm (N1)
+ * layernorm.cu:35-50: var = sum(x^2) (fp32); s = rsqrtf(var / n + eps); out = clamp((x * s) * gamma),
+ * clamp to +-(65504 - 1000) (reduction.cuh:78-82), then fp32 -> fp16 RNE.  The sum is accumulated in
+ * double here (the CUDA kernel's tree order is not reproducible); rsqrt is computed as 1/sqrt in double
+ * and rounded to fp32. */
+void oracle_rmsnorm_f16(const uint16_t* x, const uint16_t* gamma, uint16_t* out, float eps, size_t rows,
+                        size_t cols)
+{
+    const float lim = 65504.f - 1000.f;
+    for (size_t r = 0; r < rows; ++r) {
+        const uint16_t* xr  = x + r * cols;
+        double          var = 0.0;
+        for (size_t c = 0; c < cols; ++c) {
+            const float v = h2f(xr[c]);
+            var += (double)v * (double)v;
+        }
+        const float mean = (float)var / (float)cols + eps;
+        const float s    = (float)(1.0 / sqrt((double)mean));
+        for (size_t c = 0; c < cols; ++c) {
+            float v = (h2f(xr[c]) * s) * h2f(gamma[c]);
+            v       = (v > 0.f) ? fminf(v, lim) : fmaxf(v, -lim);
+            out[r * cols + c] = f2h(v);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ NeoX rotary (next row f-2)
+ * pos_encoding_kernels.cu:12-53 for scalar_t = half: every product/sum is an fp16 operation
+ * (q_x * cos - q_y * sin evaluated as half ops: two roundings for the products, one for the sub).
+ * q,k: [tokens][heads][head_size] in place; cache: [max_pos][rot_dim] = cos | sin halves. */
+static inline uint16_t hmul(uint16_t a, uint16_t b) { return f2h(h2f(a) * h2f(b)); }
+static inline uint16_t hsub(uint16_t a, uint16_t b) { return f2h(h2f(a) - h2f(b)); }
+static inline uint16_t hadd(uint16_t a, uint16_t b) { return f2h(h2f(a) + h2f(b)); }
+
+void oracle_rotary_neox_f16(const int64_t* positions, uint16_t* q, uint16_t* k, const uint16_t* cache,
+                            size_t tokens, size_t heads, size_t head_size, size_t rot_dim)
+{
+    const size_t embed = rot_dim / 2;
+    for (size_t t = 0; t < tokens; ++t) {
+        const uint16_t* c = cache + (size_t)positions[t] * rot_dim;
+        for (size_t h = 0; h < heads; ++h) {
+            uint16_t* qh = q + (t * heads + h) * head_size;
+            uint16_t* kh = k + (t * heads + h) * head_size;
+            for (size_t i = 0; i < embed; ++i) {
+                const uint16_t cs = c[i], sn = c[embed + i];
+                const uint16_t qx = qh[i], qy = qh[embed + i];
+                qh[i]         = hsub(hmul(qx, cs), hmul(qy, sn));
+                qh[embed + i] = hadd(hmul(qy, cs), hmul(qx, sn));
+                const uint16_t kx = kh[i], ky = kh[embed + i];
+                kh[i]         = hsub(hmul(kx, cs), hmul(ky, sn));
+                kh[embed + i] = hadd(hmul(ky, cs), hmul(kx, sn));
+            }
+        }
+    }
+}

@@ -1,0 +1,64 @@
+"""The C ABI: the shared library loads on a GPU-less host, exports every symbol declared in include/eetq_amd.h,
+and rejects bad arguments with a status + message (no kernels are launched here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from eetq_amd import _lib
+    return _lib.lib()
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "eetq_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(eetq_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    from eetq_amd import _lib
+    names = _declared_functions()
+    assert len(names) >= 13
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(raw, n), "include/eetq_amd.h declares %s but the library does not export it" % n
+    assert set(names) == set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_version_and_error_string(lib):
+    assert lib.eetq_version().decode().startswith("eetq_amd ")
+    assert isinstance(lib.eetq_last_error(), bytes)
+
+
+def test_argument_validation_without_gpu(lib):
+    # null pointers / bad shapes are rejected before any HIP call
+    assert lib.eetq_w8a16_gemm(None, None, None, None, 1, 64, 64, None) == -1
+    assert b"null pointer" in lib.eetq_last_error()
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.eetq_w8a16_gemm(p, p, p, p, 1, 64, 100, None) == -1
+    assert b"multiple of 64" in lib.eetq_last_error()
+    assert lib.eetq_w8a16_gemm(p, p, p, p, 1, 24, 64, None) == -1
+    assert lib.eetq_w8a16_gemm(p, p, p, p, 0, 64, 64, None) == -1
+    assert lib.eetq_pack_i8(p, 64, 24, p, 1, None) == -1           # N % 16
+    assert lib.eetq_pack_i8(p, 32, 64, p, 1, None) == -1           # K % 64
+    assert lib.eetq_pack_i8(None, 64, 64, p, 1, None) == -1
+    assert lib.eetq_rmsnorm_f16(None, p, p, 1e-6, 1, 64, None) == -1
+    assert lib.eetq_rotary_neox_f16(p, p, p, p, 1, 1, 64, 63, None) == -1   # odd rot_dim
+
+
+def test_no_oracle_in_product():
+    """The product path must never import or link the oracle (it is test infrastructure)."""
+    pkg = os.path.join(ROOT, "eetq_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".cpp", "Makefile")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
+                assert "eetq_oracle" not in text and "liboracle" not in text, f

@@ -1,0 +1,351 @@
+"""Parity of the HIP path (through the C ABI, via eetq_amd.ops) against the oracle.  Needs an MI355X.
+
+Bars: quantise / pack / unpack -> bit-exact.  GEMM/GEMV -> tier-A tolerance vs the oracle contract
+(|err| <= 1e-3 * max|y| + 2e-3 * |y|) and the reference's own atol = 1e-2 vs CPU torch
+float16 nn.Linear.  Full BASELINE sizes are covered by size-independent properties (identity -> exact dequant,
+pack/unpack round trip, GEMV-vs-MFMA cross check, torch fp32 reference)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import eetq_amd.ops as _ops
+    from eetq_amd import _lib
+    assert _lib.lib().eetq_device_supported() == 1, "kernels are built for gfx950 only"
+    return _ops
+
+
+def _tier_a(y, ref):
+    y = y.astype(np.float32)
+    ref = ref.astype(np.float32)
+    tol = 1e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref)
+    return np.abs(y - ref) <= tol
+
+
+def _rand_case(K, N, M, seed, wscale=0.02):
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal((K, N)) * wscale).astype(np.float16)
+    x = rng.random((M, K)).astype(np.float16)
+    return w, x
+
+
+# ---------------------------------------------------------------- quantise / pack: bit-exact
+
+@pytest.mark.parametrize("name", ["quant_edge_f16_k128_n64", "quant_rand_f16_k192_n256", "quant_rand_f32_k64_n64"])
+def test_quant_weights_golden(ops, golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    w = torch.from_numpy(g["w"])
+    raw, processed, scales = ops.quant_weights(w, torch.int8, True)
+    assert raw.device.type == "cpu" and processed.shape == w.shape and scales.dtype == w.dtype
+    assert np.array_equal(raw.numpy(), g["q"])
+    assert scales.numpy().tobytes() == g["s"].tobytes()
+    assert np.array_equal(processed.numpy(), g["gfx950"])
+    p2, s2 = ops.quant_weights(w, torch.int8, False)
+    assert np.array_equal(p2.numpy(), g["gfx950"]) and s2.numpy().tobytes() == g["s"].tobytes()
+    p3, _ = ops.quant_weights(w, torch.int8, False, layout="sm80")
+    assert np.array_equal(p3.numpy(), g["sm80"])
+    # examples/layers/test_w8a16_gemm.py:33-41: preprocess(raw) == processed
+    assert np.array_equal(ops.preprocess_weights(raw).numpy(), g["gfx950"])
+    assert np.array_equal(ops.preprocess_weights(raw, False, "sm80").numpy(), g["sm80"])
+
+
+@pytest.mark.parametrize("K,N,dtype", [(64, 16, np.float16), (64, 48, np.float32), (256, 128, np.float16),
+                                       (1024, 4096, np.float16), (4096, 4096, np.float16), (4096, 11008, np.float16),
+                                       (512, 1040, np.float32)])
+def test_quantize_bit_exact_vs_oracle(ops, oracle, K, N, dtype):
+    rng = np.random.default_rng(K * 7 + N)
+    w = (rng.standard_normal((K, N)) * 0.02).astype(dtype)
+    w[:, N // 2] = 0
+    w[3, 1] = 0.5
+    raw, processed, scales = ops.quant_weights(torch.from_numpy(w).to(DEV), torch.int8, True)
+    assert raw.is_cuda and processed.is_cuda and scales.is_cuda
+    q, s = oracle.quantize(w)
+    assert np.array_equal(raw.cpu().numpy(), q)
+    assert scales.cpu().numpy().tobytes() == s.tobytes()
+    assert np.array_equal(processed.cpu().numpy(), oracle.gfx950_pack(q))
+
+
+def test_quantize_default_init_4096(ops, oracle):
+    """The distribution of the headline configs: nn.Linear default init, seed 1."""
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(4096, 4096, bias=False, dtype=torch.float16)
+    w = lin.weight.detach().t().contiguous()
+    processed, scales = ops.quant_weights(w, torch.int8, False)
+    q, s = oracle.quantize(w.numpy())
+    assert scales.numpy().tobytes() == s.tobytes()
+    assert np.array_equal(processed.numpy(), oracle.gfx950_pack(q))
+
+
+@pytest.mark.parametrize("layout", ["gfx950", "sm80"])
+@pytest.mark.parametrize("K,N", [(64, 64), (192, 256), (4096, 4096), (11008, 4096)])
+def test_pack_unpack_roundtrip_and_oracle(ops, oracle, layout, K, N):
+    rng = np.random.default_rng(K + N)
+    q = rng.integers(-128, 128, (K, N), dtype=np.int8)
+    packed = ops.preprocess_weights(torch.from_numpy(q).to(DEV), False, layout)
+    ref = oracle.gfx950_pack(q) if layout == "gfx950" else oracle.sm80_pack(q)
+    assert np.array_equal(packed.cpu().numpy(), ref)
+    back = ops.unprocess_weights(packed, layout)
+    assert np.array_equal(back.cpu().numpy(), q)
+    if layout == "sm80":  # NVIDIA-written checkpoint bytes -> native layout
+        native = ops.convert_layout(packed, "sm80", "gfx950")
+        assert np.array_equal(native.cpu().numpy(), oracle.gfx950_pack(q))
+
+
+def test_shape_errors(ops):
+    with pytest.raises(RuntimeError):
+        ops.quant_weights(torch.zeros(32, 64, dtype=torch.float16), torch.int8)        # K % 64
+    with pytest.raises(RuntimeError):
+        ops.quant_weights(torch.zeros(64, 24, dtype=torch.float16), torch.int8)        # N % 16
+    with pytest.raises(RuntimeError):
+        ops.preprocess_weights(torch.zeros(64, 32, dtype=torch.int8), False, "sm80")   # N % 64 for sm80
+    with pytest.raises(RuntimeError):
+        ops.quant_weights(torch.zeros(2, 64, 64, dtype=torch.float16), torch.int8)     # 3-D: reference throws too
+    x = torch.zeros(1, 100, dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.w8_a16_gemm(x, torch.zeros(100, 64, dtype=torch.int8, device=DEV), torch.ones(64, dtype=torch.float16, device=DEV))
+
+
+# ---------------------------------------------------------------- GEMV / GEMM vs the oracle contract
+
+def _run_gemm(ops, oracle, w, x, path="auto"):
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    y = ops.w8_a16_gemm(torch.from_numpy(x).to(DEV), processed, scales, path=path)
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), q, s
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("K,N", [(64, 16), (128, 48), (1024, 256), (4096, 512), (11008, 64), (1088, 32)])
+def test_gemv_vs_oracle(ops, oracle, M, K, N):
+    w, x = _rand_case(K, N, M, seed=K + N + M)
+    y, q, s = _run_gemm(ops, oracle, w, x, path="gemv")
+    ref = oracle.w8a16_gemm(x, q, s)
+    ok = _tier_a(y, ref)
+    assert ok.all(), "max err %g at %s" % (np.abs(y.astype(np.float32) - ref.astype(np.float32)).max(),
+                                          np.argwhere(~ok)[:4])
+
+
+@pytest.mark.parametrize("M,K,N", [(5, 64, 16), (8, 256, 128), (17, 128, 144), (64, 1024, 256), (128, 512, 128),
+                                   (130, 192, 272), (300, 2048, 384), (8, 4096, 4096), (64, 4096, 1024)])
+def test_mfma_gemm_vs_oracle(ops, oracle, M, K, N):
+    w, x = _rand_case(K, N, M, seed=K + N + M)
+    x[:, ::7] *= -1  # signed activations
+    y, q, s = _run_gemm(ops, oracle, w, x, path="mfma")
+    ref = oracle.w8a16_gemm(x, q, s)
+    ok = _tier_a(y, ref)
+    assert ok.all(), "max err %g at %s" % (np.abs(y.astype(np.float32) - ref.astype(np.float32)).max(),
+                                          np.argwhere(~ok)[:4])
+
+
+def test_mfma_transpose_detecting(ops, oracle):
+    """Asymmetric, structured inputs: catches swapped rows/cols or a wrong k mapping (guide rule 16)."""
+    K, N, M = 128, 128, 128
+    q = np.zeros((K, N), np.int8)
+    for k in range(K):
+        for n in range(N):
+            q[k, n] = ((3 * k + 5 * n) % 255) - 127
+    s = (np.arange(N) % 7 + 1).astype(np.float16) / 256
+    x = ((np.arange(M)[:, None] * 2 + np.arange(K)[None, :]) % 13 - 6).astype(np.float16) / 8
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    for path in ("mfma",):
+        y = ops.w8_a16_gemm(torch.from_numpy(x).to(DEV), processed, torch.from_numpy(s).to(DEV), path=path).cpu().numpy()
+        ref = oracle.w8a16_gemm(x, q, s)
+        assert _tier_a(y, ref).all()
+    y = ops.w8_a16_gemm(torch.from_numpy(x[:3]).to(DEV), processed, torch.from_numpy(s).to(DEV), path="gemv").cpu().numpy()
+    assert _tier_a(y, oracle.w8a16_gemm(x[:3], q, s)).all()
+
+
+@pytest.mark.parametrize("K,N", [(128, 64), (4096, 4096)])
+def test_identity_gemm_is_exact_dequant(ops, oracle, K, N):
+    """Size-independent property at full size (python/eetq/modules/qlinear.py:83-86): eye(K) @ W == fp16(q*s),
+    bit-exact, for every byte value that occurs -- exercises M = K (4096) through the MFMA path."""
+    rng = np.random.default_rng(K)
+    w = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
+    q, s = oracle.quantize(w)
+    if K >= 256:
+        q[:256, 0] = np.arange(-128, 128, dtype=np.int8)  # every byte value
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    eye = torch.eye(K, dtype=torch.float16, device=DEV)
+    y = ops.w8_a16_gemm(eye, processed, torch.from_numpy(s).to(DEV)).cpu().numpy()
+    assert np.array_equal(y, oracle.dequant(q, s))
+    # and one row at a time through the GEMV path
+    y1 = ops.w8_a16_gemm(eye[5:6].contiguous(), processed, torch.from_numpy(s).to(DEV)).cpu().numpy()
+    assert np.array_equal(y1[0], oracle.dequant(q, s)[5])
+
+
+@pytest.mark.parametrize("M", [1, 4, 8, 64, 1024])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 11008), (11008, 4096)])
+def test_llama7b_shapes_vs_torch_fp32(ops, oracle, M, K, N):
+    """BASELINE.json configs[3]: Llama-2-7B shapes.  The oracle is too slow at M=1024, so the comparator is a
+    torch fp32 matmul on the GPU over the oracle-dequantised weight (same contract, fp32 accumulate), plus an
+    oracle check of 4 sampled rows."""
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(K, N, bias=False, dtype=torch.float16)
+    w = lin.weight.detach().t().contiguous()
+    x = torch.rand(M, K, dtype=torch.float16)
+    processed, scales = ops.quant_weights(w, torch.int8, False)
+    y = ops.w8_a16_gemm(x.to(DEV), processed.to(DEV), scales.to(DEV))
+    q, s = oracle.quantize(w.numpy())
+    wdq = torch.from_numpy(oracle.dequant(q, s)).to(DEV)
+    ref = (x.to(DEV).float() @ wdq.float()).cpu().numpy()
+    assert _tier_a(y.cpu().numpy(), ref).all()
+    rows = sorted(set([0, M // 3, M // 2, M - 1]))
+    ref_rows = oracle.w8a16_gemm(x.numpy()[rows], q, s)
+    assert _tier_a(y.cpu().numpy()[rows], ref_rows).all()
+    # reference's own bar vs fp16 nn.Linear on the original weights (atol 1e-2 at K=1024, scaled by sqrt(K/1024))
+    with torch.no_grad():
+        y_lin = lin(x[rows]).numpy().astype(np.float32)
+    assert np.abs(y.cpu().numpy()[rows].astype(np.float32) - y_lin).max() <= 1e-2 * np.sqrt(K / 1024.0)
+
+
+def test_gemv_and_mfma_agree(ops, oracle):
+    w, x = _rand_case(4096, 4096, 4, seed=99)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    a = ops.w8_a16_gemm(xd, processed, scales, path="gemv").float()
+    b = ops.w8_a16_gemm(xd, processed, scales, path="mfma").float()
+    assert (a - b).abs().max().item() <= 2e-3 * a.abs().max().item()
+
+
+def test_reference_test_qlinear_recipe_on_gpu(ops, golden_dir):
+    """examples/layers/test_qlinear.py:19-36 end to end: W8A16Linear.from_torch + forward vs fp16 nn.Linear, atol 1e-2."""
+    from eetq_amd.modules.qlinear import W8A16Linear
+    man = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["linear"][1]
+    torch.manual_seed(1)
+    lin = torch.nn.Linear(1024, 4096, bias=False, dtype=torch.float16)
+    qlin = W8A16Linear.from_torch(lin.to(DEV))
+    x = torch.rand(128, 1024, dtype=torch.float16)
+    out = qlin(x.to(DEV)).cpu()
+    gold = torch.from_numpy(np.load(os.path.join(golden_dir, man["file"]))["y"])
+    assert torch.allclose(out[:: man["row_step"]], gold, atol=1e-2)
+
+
+def test_3d_input_and_inplace_variant(ops, oracle):
+    w, x = _rand_case(256, 128, 12, seed=5)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    x3 = torch.from_numpy(x).to(DEV).reshape(3, 4, 256)
+    y3 = ops.w8_a16_gemm(x3, processed, scales)
+    assert y3.shape == (3, 4, 128)
+    out = torch.empty(12, 128, dtype=torch.float16, device=DEV)
+    ret = ops.w8_a16_gemm_(x3, processed, scales, out, 12, 128, 256)
+    assert ret.data_ptr() == out.data_ptr()
+    assert torch.equal(out, y3.reshape(12, 128))
+    assert _tier_a(out.cpu().numpy(), oracle.w8a16_gemm(x, q, s)).all()
+
+
+def test_non_default_stream(ops, oracle):
+    w, x = _rand_case(1024, 256, 2, seed=8)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    st = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(st):
+        y = ops.w8_a16_gemm(xd, processed, scales)
+    st.synchronize()
+    assert _tier_a(y.cpu().numpy(), oracle.w8a16_gemm(x, q, s)).all()
+
+
+# ---------------------------------------------------------------- side ops
+
+@pytest.mark.parametrize("shape", [(2, 3, 4096), (1, 1, 5120), (4, 7, 520), (1, 5, 100)])
+def test_layernorm_forward(ops, oracle, shape):
+    torch.manual_seed(shape[-1])
+    x = (torch.randn(*shape) * 3).half()
+    g = (torch.rand(shape[-1]) + 0.5).half()
+    out = torch.empty_like(x, device=DEV)
+    assert ops.layernorm_forward(x.to(DEV), g.to(DEV), out, 1e-6) is None
+    ref = oracle.rmsnorm_f16(x.numpy(), g.numpy(), 1e-6).astype(np.float32)
+    got = out.cpu().numpy().astype(np.float32)
+    assert np.allclose(got, ref, rtol=2e-3, atol=2e-3)     # fp32 reduction order differs; <= 1-2 fp16 ulp
+    ones = torch.full((1, 1, 64), 3.0, dtype=torch.float16, device=DEV)
+    gam = torch.tensor([65000.0, -65000.0] * 32, dtype=torch.float16, device=DEV)
+    out = torch.empty_like(ones)
+    ops.layernorm_forward(ones, gam, out, 0.0)
+    assert np.array_equal(out.cpu().numpy(), oracle.rmsnorm_f16(ones.cpu().numpy(), gam.cpu().numpy(), 0.0))
+
+
+@pytest.mark.parametrize("heads,hs,rot", [(4, 64, 64), (40, 128, 128), (8, 64, 32)])
+def test_rotary_embedding_neox(ops, oracle, heads, hs, rot):
+    torch.manual_seed(heads)
+    b, t = 2, 5
+    q = torch.randn(b, t, 1, heads, hs).half()
+    k = torch.randn(b, t, 1, heads, hs).half()
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2).float() / rot))
+    fr = torch.einsum("i,j->ij", torch.arange(64).float(), inv)
+    cache = torch.cat([fr.cos(), fr.sin()], -1).half()
+    pos = torch.randint(0, 64, (b, t))
+    qd, kd = q.to(DEV), k.to(DEV)
+    assert ops.rotary_embedding_neox(pos.to(DEV), qd, kd, hs, cache.to(DEV)) is None
+    qo, ko = oracle.rotary_neox_f16(pos.numpy(), q.numpy().reshape(b * t, heads, hs), k.numpy().reshape(b * t, heads, hs),
+                                    cache.numpy(), hs)
+    assert np.array_equal(qd.cpu().numpy().reshape(b * t, heads, hs), qo)   # fp16 op-for-op: bit-exact
+    assert np.array_equal(kd.cpu().numpy().reshape(b * t, heads, hs), ko)
+
+
+# ---------------------------------------------------------------- modules / eet_quantize
+
+def test_eetq_linear_forward_backward(ops, oracle):
+    from eetq_amd.modules.qlinear import EetqLinear
+    K, N = 256, 128
+    w, x = _rand_case(K, N, 6, seed=21)
+    q, s = oracle.quantize(w)
+    mod = EetqLinear(K, N, bias=True, device=DEV)
+    mod.register_scale(DEV)
+    mod.weight.copy_(torch.from_numpy(oracle.gfx950_pack(q)))
+    mod.weight_scales.copy_(torch.from_numpy(s))
+    mod.bias.copy_(torch.linspace(-1, 1, N).half())
+    xin = torch.from_numpy(x).to(DEV).reshape(1, 6, K).requires_grad_(True)
+    mod.train()
+    y = mod(xin)
+    ref = oracle.w8a16_gemm(x, q, s).astype(np.float32) + mod.bias.float().cpu().numpy()
+    assert np.allclose(y.detach().cpu().numpy().reshape(6, N).astype(np.float32), ref, atol=4e-3, rtol=4e-3)
+    gy = torch.ones_like(y)
+    y.backward(gy)
+    wdq = torch.from_numpy(oracle.dequant(q, s)).float()
+    gref = (torch.ones(6, N) @ wdq.t()).numpy()
+    assert np.allclose(xin.grad.cpu().numpy().reshape(6, K).astype(np.float32), gref, atol=2e-2, rtol=1e-2)
+    mod.eval()
+    assert torch.equal(mod(xin.detach()), y.detach())
+
+
+def test_eet_quantize_tiny_model(ops):
+    from eetq_amd.modules.qlinear import W8A16Linear
+    from eetq_amd.utils.quantizer import eet_quantize
+    torch.manual_seed(0)
+
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([torch.nn.Linear(128, 256, bias=True), torch.nn.Linear(256, 128, bias=False)])
+            self.lm_head = torch.nn.Linear(128, 64, bias=False)
+
+        def forward(self, x):
+            return self.lm_head(self.layers[1](torch.relu(self.layers[0](x))))
+
+    model = Tiny().half().to(DEV)
+    x = torch.rand(3, 128, dtype=torch.float16, device=DEV)
+    with torch.no_grad():
+        ref = model(x)
+    eet_quantize(model)
+    assert isinstance(model.layers[0], W8A16Linear) and isinstance(model.layers[1], W8A16Linear)
+    assert isinstance(model.lm_head, torch.nn.Linear)
+    assert set(model.layers[0].state_dict().keys()) == {"qweight", "weight_scales", "bias"}
+    out = model(x)
+    assert torch.allclose(out, ref, atol=2e-2, rtol=2e-2)
