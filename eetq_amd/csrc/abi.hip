@@ -3,6 +3,7 @@
 // quantiser's column maxima (N floats), so the reference's "no workspace argument" signature is kept.
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "common.hpp"
 
@@ -18,6 +19,26 @@ struct Scratch {
 std::mutex g_scratch_mutex;
 Scratch    g_scratch[64];
 }  // namespace
+
+// ---- optional per-dispatch timing (bench.py): every kernel launched on this thread between eetq_prof_begin and
+// eetq_prof_end gets a start/stop event pair attached to its dispatch packet (begin/end timestamps of the kernel
+// itself, the same clock rocprofv3 --kernel-trace reports).
+namespace {
+thread_local std::vector<hipEvent_t> g_prof_events;  // 2 per launch
+thread_local size_t                  g_prof_used  = 0;
+thread_local bool                    g_prof_armed = false;
+}  // namespace
+
+ProfEvents next_prof_events()
+{
+    ProfEvents ev;
+    if (g_prof_armed && g_prof_used + 2 <= g_prof_events.size()) {
+        ev.start = g_prof_events[g_prof_used];
+        ev.stop  = g_prof_events[g_prof_used + 1];
+        g_prof_used += 2;
+    }
+    return ev;
+}
 
 void set_error(const std::string& msg) { g_last_error = msg; }
 
@@ -83,6 +104,34 @@ extern "C" {
 const char* eetq_last_error(void) { return g_last_error.c_str(); }
 
 const char* eetq_version(void) { return "eetq_amd 0.1.0 gfx950"; }
+
+int eetq_prof_begin(int max_launches)
+{
+    EETQ_REQUIRE(max_launches > 0 && max_launches <= (1 << 20), "invalid launch count");
+    while (g_prof_events.size() < (size_t)max_launches * 2) {
+        hipEvent_t e;
+        EETQ_TRY_HIP(hipEventCreate(&e));
+        g_prof_events.push_back(e);
+    }
+    g_prof_used  = 0;
+    g_prof_armed = true;
+    return EETQ_OK;
+}
+
+int eetq_prof_end(float* durations_us, int capacity, int* count)
+{
+    g_prof_armed = false;
+    EETQ_TRY_HIP(hipDeviceSynchronize());
+    const int n = (int)(g_prof_used / 2);
+    if (count) *count = n;
+    for (int i = 0; i < n && i < capacity && durations_us; ++i) {
+        float ms = 0.f;
+        EETQ_TRY_HIP(hipEventElapsedTime(&ms, g_prof_events[2 * i], g_prof_events[2 * i + 1]));
+        durations_us[i] = ms * 1000.f;
+    }
+    g_prof_used = 0;
+    return EETQ_OK;
+}
 
 int eetq_device_supported(void)
 {

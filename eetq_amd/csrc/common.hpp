@@ -1,5 +1,6 @@
 // Shared device/host helpers for the gfx950 kernels.  gfx950 only: wave64, no other targets.
 #pragma once
+#include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
@@ -70,6 +71,22 @@ __device__ __forceinline__ void dequant_16(const u32x4& w, f16x2 scale2, f16x2 (
 __device__ __forceinline__ float wave_xor_add(float v, int mask)
 {
     return v + __shfl_xor(v, mask, 64);
+}
+
+// ---- launch helper: optionally attaches per-dispatch begin/end timestamps (eetq_prof_begin/_end) ---------
+struct ProfEvents {
+    hipEvent_t start = nullptr, stop = nullptr;
+};
+ProfEvents next_prof_events();  // {nullptr, nullptr} unless profiling is armed on this thread
+
+template <typename Kern, typename... Args>
+inline void launch_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStream_t stream, Args... args)
+{
+    const ProfEvents ev = next_prof_events();
+    if (ev.start)
+        hipExtLaunchKernelGGL(kern, grid, block, (unsigned)smem, stream, ev.start, ev.stop, 0, args...);
+    else
+        hipLaunchKernelGGL(kern, grid, block, (unsigned)smem, stream, args...);
 }
 
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------

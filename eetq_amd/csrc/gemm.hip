@@ -235,7 +235,7 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, f16* y, 
         attr_set_mask |= 1ull << (dev & 63);
     }
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    gemm_mfma_kernel<<<tiles, THREADS, SMEM_BYTES, stream>>>(x, w, scales, y, M, N, K);
+    launch_kernel(gemm_mfma_kernel, dim3(tiles), dim3(THREADS), SMEM_BYTES, stream, x, w, scales, y, M, N, K);
     return check_hip(hipGetLastError(), "gemm_mfma_kernel launch");
 }
 

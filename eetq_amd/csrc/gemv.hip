@@ -14,104 +14,57 @@
 //   * lane (g = lane>>4, c = lane&15) gets 16 consecutive k of column c: dequantised in registers (v_perm +
 //     v_pk_add_f16 + v_pk_mul_f16, exact q then fp16(q*s)) and accumulated with v_dot2c_f32_f16;
 //   * reduction: DPP/bpermute across the 4 k-groups of a wave, then across waves through 1 KiB of LDS.
-#include "common.hpp"
+#include "gemv_kernel.hpp"
 
 namespace eetq {
 
 namespace {
 
-template <int M>
-__device__ __forceinline__ void gemv_consume(const u32x4& wv, f16x2 scale2, const f16* __restrict__ xrow, int K,
-                                             float (&acc)[M])
+using gemv::gemv_kernel;
+
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int OCC>
+int launch_inst(const f16* x, const uint8_t* w, const f16* scales, f16* y, int N, int K, hipStream_t stream)
 {
-    f16x2 wq[8];
-    dequant_16(wv, scale2, wq);
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const u32x4 xa   = *reinterpret_cast<const u32x4*>(xrow + (size_t)m * K);
-        const u32x4 xb   = *reinterpret_cast<const u32x4*>(xrow + (size_t)m * K + 8);
-        const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
-#pragma unroll
-        for (int i = 0; i < 8; ++i) acc[m] = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc[m], false);
+    auto         kern = gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC>;
+    const size_t smem = gemv::gemv_smem_bytes(M, K, WAVES, XREG);
+    if (smem > 64 * 1024) {  // opt in to > 64 KiB dynamic LDS (host-side attribute, cheap)
+        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem));
     }
+    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K);
+    return check_hip(hipGetLastError(), "gemv_kernel launch");
 }
 
-template <int M, int WAVES, int UNROLL>
-__global__ __launch_bounds__(WAVES * 64) void gemv_kernel(const f16* __restrict__ x, const uint8_t* __restrict__ w,
-                                                          const f16* __restrict__ scales, f16* __restrict__ y,
-                                                          int N, int K)
+// LDS-staged activations: pick the number of 16-byte x loads per thread at compile time (no conditional loads)
+template <int M, int WAVES, int D, bool EXACT, int OCC>
+int launch_lds(const f16* x, const uint8_t* w, const f16* scales, f16* y, int N, int K, hipStream_t stream)
 {
-    __shared__ float red[WAVES][M][16];
-    const int ntile = blockIdx.x;
-    const int wave  = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane  = threadIdx.x & 63;
-    const int g = lane >> 4, c = lane & 15;
-    const int KT = K >> 6;
-
-    const u32x4* wp = reinterpret_cast<const u32x4*>(w + (size_t)ntile * KT * kTileBytes) + lane;
-    const f16*   xg = x + 16 * g;  // this lane's 16-k window inside a 64-k tile
-
-    float acc[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = 0.f;
-
-    // The scale is needed before the first dot product (contract: fp16(q*s) first) but must not delay the
-    // weight stream: its load is queued here, its first use is pinned *after* the weight loads are issued.
-    u32 sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
-
-    int kt = wave;
-    // main loop: UNROLL tiles in flight per wave
-    for (; kt + (UNROLL - 1) * WAVES < KT; kt += UNROLL * WAVES) {
-        u32x4 wv[UNROLL];
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) wv[u] = __builtin_nontemporal_load(wp + (size_t)(kt + u * WAVES) * 64);
-        asm volatile("" : "+v"(sraw)::"memory");  // weight loads stay at the head of the memory queue
-        const f16x2 scale2 = as_f16x2(sraw | (sraw << 16));
-#pragma unroll
-        for (int u = 0; u < UNROLL; ++u) gemv_consume<M>(wv[u], scale2, xg + (size_t)(kt + u * WAVES) * 64, K, acc);
-    }
-    // tail: one tile at a time
-    for (; kt < KT; kt += WAVES) {
-        const u32x4 wv = __builtin_nontemporal_load(wp + (size_t)kt * 64);
-        asm volatile("" : "+v"(sraw)::"memory");
-        const f16x2 scale2 = as_f16x2(sraw | (sraw << 16));
-        gemv_consume<M>(wv, scale2, xg + (size_t)kt * 64, K, acc);
-    }
-
-    // reduce the 4 k-groups (lanes c, c+16, c+32, c+48)
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        acc[m] = wave_xor_add(acc[m], 16);
-        acc[m] = wave_xor_add(acc[m], 32);
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int m = 0; m < M; ++m) red[wave][m][lane] = acc[m];
-    }
-    __syncthreads();
-    if (threadIdx.x < M * 16) {
-        const int m = threadIdx.x >> 4, cc = threadIdx.x & 15;
-        float     s = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < WAVES; ++wv) s += red[wv][m][cc];
-        y[(size_t)m * N + ntile * 16 + cc] = (f16)s;
-    }
+    const int xvecs = M * K / 8, threads = WAVES * 64;
+    const int need  = (xvecs + threads - 1) / threads;
+    if (gemv::gemv_smem_bytes(M, K, WAVES, false) > 160 * 1024 || need > 8)
+        return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] GEMV: M*K too large for LDS staging");
+    if (need <= 1) return launch_inst<M, WAVES, D, EXACT, false, 1, OCC>(x, w, scales, y, N, K, stream);
+    if (need <= 2) return launch_inst<M, WAVES, D, EXACT, false, 2, OCC>(x, w, scales, y, N, K, stream);
+    if (need <= 4) return launch_inst<M, WAVES, D, EXACT, false, 4, OCC>(x, w, scales, y, N, K, stream);
+    return launch_inst<M, WAVES, D, EXACT, false, 8, OCC>(x, w, scales, y, N, K, stream);
 }
 
 template <int M>
 int launch_m(const f16* x, const uint8_t* w, const f16* scales, f16* y, int N, int K, hipStream_t stream)
 {
-    const int ntiles = N / kTileN;
-    const int KT     = K / kTileK;
-    // 16 waves x 4 tiles in flight = 64 KiB per workgroup; shorter K uses fewer waves so every wave has work
-    if (KT >= 64) {
-        gemv_kernel<M, 16, 4><<<ntiles, 16 * 64, 0, stream>>>(x, w, scales, y, N, K);
-    } else if (KT >= 16) {
-        gemv_kernel<M, 8, 2><<<ntiles, 8 * 64, 0, stream>>>(x, w, scales, y, N, K);
-    } else {
-        gemv_kernel<M, 4, 1><<<ntiles, 4 * 64, 0, stream>>>(x, w, scales, y, N, K);
+    const int KT = K / kTileK;
+    // Tuned on MI355X with tools/kbench (profiles/r01_kbench_gemv.txt):
+    if (KT == 64) {  // K = 4096: 16 waves x 4 tiles, straight-line; <= 64 VGPRs so two workgroups fit a CU
+        if constexpr (M <= 2)
+            return launch_inst<M, 16, 4, true, true, 1, 8>(x, w, scales, y, N, K, stream);
+        else
+            return launch_lds<M, 16, 4, true, 4>(x, w, scales, y, N, K, stream);
     }
-    return check_hip(hipGetLastError(), "gemv_kernel launch");
+    // generic K: every wave must own >= D tiles; D = 2 in flight per wave won at K = 11008
+    if (KT >= 32) return launch_lds<M, 16, 2, false, (M == 1 ? 8 : 4)>(x, w, scales, y, N, K, stream);
+    if (KT >= 16) return launch_lds<M, 8, 2, false, 2>(x, w, scales, y, N, K, stream);
+    if (KT >= 4) return launch_lds<M, 4, 1, false, 1>(x, w, scales, y, N, K, stream);
+    return launch_lds<M, 1, 1, false, 1>(x, w, scales, y, N, K, stream);
 }
 
 }  // namespace

@@ -1,0 +1,201 @@
+// Kernel templates of the W8A16 decode GEMV (included by gemv.hip and by tools/kbench.hip).
+#pragma once
+#include "common.hpp"
+
+namespace eetq {
+namespace gemv {
+
+template <bool NT>
+__device__ __forceinline__ u32x4 load_w(const u32x4* p)
+{
+    if constexpr (NT)
+        return __builtin_nontemporal_load(p);
+    else
+        return *p;
+}
+
+// xor-16 / xor-32 butterfly sums with the gfx950 lane-swap instructions (VALU, no LDS round trip).
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second;
+// v_permlane32_swap exchanges the upper half of the first with the lower half of the second.  Feeding the same
+// value twice yields (a', b') with a' + b' = v[lane] + v[lane ^ 16] (resp. ^ 32) in every lane.
+__device__ __forceinline__ float sum_xor16(float v)
+{
+    const u32 u = __builtin_bit_cast(u32, v);
+    auto      r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (u32)r[0]) + __builtin_bit_cast(float, (u32)r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v)
+{
+    const u32 u = __builtin_bit_cast(u32, v);
+    auto      r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (u32)r[0]) + __builtin_bit_cast(float, (u32)r[1]);
+}
+
+// One 1 KiB tile: this lane's 16 k of column c against the matching 16 activations of every batch row.
+// xs = this lane's window of the LDS copy of x (row m at xs + m*K halfs).
+template <int M>
+__device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, const f16* xs, int K, float (&acc)[M])
+{
+    f16x2 wq[8];
+    dequant_16(wv, scale2, wq);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        const u32x4 xa    = *reinterpret_cast<const u32x4*>(xs + m * K);
+        const u32x4 xb    = *reinterpret_cast<const u32x4*>(xs + m * K + 8);
+        const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[m] = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc[m], false);
+    }
+}
+
+// grid.x = N/16 (one workgroup per 16-column tile row = one contiguous K*16-byte stream), block = WAVES*64.
+// Wave w takes tiles w, w+WAVES, ...; D tiles (16 B/lane each) are kept in flight per wave.
+//
+// No load in this kernel sits behind a branch: hipcc answers a conditional load with s_waitcnt vmcnt(0) at
+// every join, which serialises the stream.  Instead the launch picks a shape-specialised instantiation:
+//   EXACT : K/64 == WAVES*D, every wave owns exactly D tiles -> straight-line code, no loop.
+//   else  : every wave owns >= D tiles; software-pipelined loop with unconditional refills, then a clamped
+//           (possibly redundant, L2-resident) tail batch whose *use* is predicated.
+//   XREG  : (EXACT only) activations go straight to registers, issued ahead of the weight stream so they
+//           retire at L2 latency; no LDS, no barrier before the math.
+//   else  : activations are staged once per workgroup in LDS (XV 16-byte loads per thread, clamped).
+// Dynamic LDS: [M*K fp16 activations unless XREG] + WAVES*M*16 floats (cross-wave reduction).
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int N,
+    int K)
+{
+    static_assert(!XREG || EXACT, "register-resident activations need the exact-fit shape");
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    f16*   xs  = reinterpret_cast<f16*>(smem);
+    float* red = reinterpret_cast<float*>(smem + (XREG ? 0 : (size_t)M * K * 2));
+
+    const int tid   = threadIdx.x;
+    const int ntile = blockIdx.x;
+    const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane  = tid & 63;
+    const int g = lane >> 4, c = lane & 15;
+    const int KT = K >> 6;
+
+    // Memory queue order matters (returns are in order): the tiny scale + activation loads go first so they
+    // retire at L2 latency while the weight stream is already queued right behind them.
+    u32 sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
+
+    u32x4 xr[XREG ? M * D * 2 : 1];  // XREG: this lane's 16 activations for each of its D tiles, per batch row
+    u32x4 xv[XREG ? 1 : XV];
+    if constexpr (XREG) {
+#pragma unroll
+        for (int m = 0; m < M; ++m)
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                const u32x4* p       = reinterpret_cast<const u32x4*>(x + (size_t)m * K + (wave + d * WAVES) * 64 + 16 * g);
+                xr[(m * D + d) * 2]     = p[0];
+                xr[(m * D + d) * 2 + 1] = p[1];
+            }
+    } else {
+        const int    xvecs = (M * K) >> 3;  // 16-byte vectors of x
+        const u32x4* xg    = reinterpret_cast<const u32x4*>(x);
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * WAVES * 64;
+            xv[i]       = xg[v < xvecs ? v : xvecs - 1];
+        }
+    }
+
+    const u32x4* wp     = reinterpret_cast<const u32x4*>(w + (size_t)ntile * KT * kTileBytes) + wave * 64 + lane;
+    const size_t stride = (size_t)WAVES * 64;  // u32x4 elements between consecutive tiles of this wave
+    u32x4        buf[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) buf[d] = load_w<true>(wp + d * stride);
+
+    if constexpr (!XREG) {
+        const int xvecs = (M * K) >> 3;
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * WAVES * 64;
+            if (v < xvecs) reinterpret_cast<u32x4*>(xs)[v] = xv[i];  // store (not load) behind the branch
+        }
+    }
+    asm volatile("" : "+v"(sraw));
+    const f16x2 scale2 = as_f16x2(sraw | (sraw << 16));
+    if constexpr (!XREG) __syncthreads();
+
+    float acc[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = 0.f;
+
+    if constexpr (XREG) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            f16x2 wq[8];
+            dequant_16(buf[d], scale2, wq);
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                const u32x4 xa = xr[(m * D + d) * 2], xb = xr[(m * D + d) * 2 + 1];
+                const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) acc[m] = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc[m], false);
+            }
+        }
+    } else {
+        const f16* xl = xs + wave * 64 + 16 * g;  // + 64*WAVES halfs per tile step
+        if constexpr (EXACT) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) consume_tile<M>(buf[d], scale2, xl + (size_t)d * 64 * WAVES, K, acc);
+        } else {
+            const int n = (KT - wave + WAVES - 1) / WAVES;  // tiles of this wave (>= D by launch contract)
+            int       i = 0;
+            for (; i + 2 * D <= n; i += D) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) {
+                    consume_tile<M>(buf[d], scale2, xl + (size_t)(i + d) * 64 * WAVES, K, acc);
+                    buf[d] = load_w<true>(wp + (size_t)(i + d + D) * stride);
+                }
+            }
+            // buf holds tiles i..i+D-1; r = n-(i+D) in [0, D) tiles remain: fetch them with clamped indices
+            const int r = n - (i + D);
+            u32x4     tail[D > 1 ? D - 1 : 1];
+#pragma unroll
+            for (int d = 0; d < D - 1; ++d) {
+                const int t = i + D + d;
+                tail[d]     = load_w<true>(wp + (size_t)(t < n ? t : n - 1) * stride);
+            }
+#pragma unroll
+            for (int d = 0; d < D; ++d) consume_tile<M>(buf[d], scale2, xl + (size_t)(i + d) * 64 * WAVES, K, acc);
+#pragma unroll
+            for (int d = 0; d < D - 1; ++d)
+                if (d < r) consume_tile<M>(tail[d], scale2, xl + (size_t)(i + D + d) * 64 * WAVES, K, acc);
+        }
+    }
+
+    // ---- reduction: 4 k-groups of the wave (lanes c, c+16, c+32, c+48), then across waves via LDS ----
+#pragma unroll
+    for (int m = 0; m < M; ++m) acc[m] = sum_xor32(sum_xor16(acc[m]));
+    if (lane < 16) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) red[(wave * M + m) * 16 + lane] = acc[m];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        // lane (g, c) sums waves g, g+4, ...; the butterfly adds the 4 groups
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < (WAVES + 3) / 4; ++wv) {
+                const int ww = g + 4 * wv;
+                if (ww < WAVES) s += red[(ww * M + m) * 16 + c];
+            }
+            s = sum_xor32(sum_xor16(s));
+            if (lane < 16) y[(size_t)m * N + ntile * 16 + c] = (f16)s;
+        }
+    }
+}
+
+inline size_t gemv_smem_bytes(int M, int K, int waves, bool xreg)
+{
+    return (xreg ? 0 : (size_t)M * K * 2) + (size_t)waves * M * 16 * 4;
+}
+
+}  // namespace gemv
+}  // namespace eetq

@@ -102,6 +102,14 @@ int eetq_rmsnorm_f16(const void* x, const void* gamma, void* out, float eps, int
 int eetq_rotary_neox_f16(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
                          int tokens, int heads, int head_size, int rot_dim, void* stream);
 
+/* ---- profiling hook (no reference counterpart; used by bench.py) -------------------------------------
+ * Between eetq_prof_begin(n) and eetq_prof_end() every kernel this library launches from the calling thread
+ * carries a start/stop event pair on its dispatch packet; eetq_prof_end synchronises the device and returns
+ * the kernel durations in microseconds, in launch order (*count = launches recorded, <= n).  Not capturable
+ * into a HIP graph. */
+int eetq_prof_begin(int max_launches);
+int eetq_prof_end(float* durations_us, int capacity, int* count);
+
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* eetq_last_error(void);   /* thread-local, never NULL */
 const char* eetq_version(void);      /* "eetq_amd <version> gfx950" */
