@@ -226,10 +226,14 @@ int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales
     switch (path) {
         case EETQ_PATH_AUTO:
             // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
-            if (M <= kGemvMaxM) return launch_gemv(xp, wp, sp, yp, M, N, K, s);
+            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 16 -> MFMA stream kernel (same weight
+            // stream, activations in LDS) when they fit; otherwise the LDS-tiled MFMA GEMM.
+            if (M == 1) return launch_gemv(xp, wp, sp, yp, M, N, K, s);
+            if (skinny_supported(M, N, K)) return launch_skinny(xp, wp, sp, yp, M, N, K, s);
             return launch_gemm_mfma(xp, wp, sp, yp, M, N, K, s);
         case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, yp, M, N, K, s);
         case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, yp, M, N, K, s);
+        case EETQ_PATH_SKINNY: return launch_skinny(xp, wp, sp, yp, M, N, K, s);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] unknown or unimplemented GEMM path");
     }
 }

@@ -25,7 +25,7 @@ __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_g
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
-_PATHS = {"auto": PATH_AUTO, "gemv": PATH_GEMV, "mfma": PATH_MFMA}
+_PATHS = {"auto": PATH_AUTO, "gemv": PATH_GEMV, "mfma": PATH_MFMA, "skinny": _lib.PATH_SKINNY}
 
 
 def _layout_id(layout):

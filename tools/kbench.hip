@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "../eetq_amd/csrc/gemv_kernel.hpp"
+#include "../eetq_amd/csrc/skinny_kernel.hpp"
 
 namespace eetq {  // stubs for the error plumbing declared in common.hpp (unused by the kernels)
 void set_error(const std::string&) {}
@@ -160,6 +161,31 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
            name, N, K, M, st.mean, st.med, st.mn, st.p90, bytes / st.med / 1e3, g, bytes / g / 1e3);
 }
 
+template <int WAVES, int D, bool EXACT, int XV, int OCC>
+static void bench_skinny(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
+                         const eetq::f16* scales, eetq::f16* y)
+{
+    const int    grid  = N / 16;
+    const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
+    auto         kern  = eetq::skinny::skinny_kernel<WAVES, D, EXACT, XV, OCC>;
+    const size_t smem  = eetq::skinny::skinny_smem_bytes(M, K, WAVES);
+    if (smem > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    auto st = time_dispatch(
+        [&](int i, hipEvent_t a, hipEvent_t b) {
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, 0, a, b, 0, x,
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K);
+        },
+        400);
+    double g = time_graph(
+        [&](int i, hipStream_t s) {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, s, x,
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K);
+        },
+        400);
+    printf("%-30s N=%5d K=%5d M=%2d | disp mean %6.2f med %6.2f min %6.2f p90 %6.2f us -> %6.0f GB/s(med) | graph %6.2f us/step -> %6.0f GB/s\n",
+           name, N, K, M, st.mean, st.med, st.mn, st.p90, bytes / st.med / 1e3, g, bytes / g / 1e3);
+}
+
 int main(int argc, char** argv)
 {
     const char* what = argc > 1 ? argv[1] : "all";
@@ -183,10 +209,10 @@ int main(int argc, char** argv)
         CK(hipMemcpy(p, host.data(), WBIG, hipMemcpyHostToDevice));
     }
     eetq::f16 *x, *scales, *y;
-    CK(hipMalloc(&x, 8 * 11008 * 2));
+    CK(hipMalloc(&x, 16 * 11008 * 2));
     CK(hipMalloc(&scales, 11008 * 2));
-    CK(hipMalloc(&y, 8 * 11008 * 2));
-    std::vector<uint16_t> hx(8 * 11008, 0x3800), hs(11008, 0x1c00);  // x = 0.5, s = 2^-8
+    CK(hipMalloc(&y, 16 * 11008 * 2));
+    std::vector<uint16_t> hx(16 * 11008, 0x3800), hs(11008, 0x1c00);  // x = 0.5, s = 2^-8
     for (size_t i = 0; i < hx.size(); ++i) hx[i] = 0x3000 + (rand() & 0x7ff);
     CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
     CK(hipMemcpy(scales, hs.data(), hs.size() * 2, hipMemcpyHostToDevice));
@@ -230,6 +256,18 @@ int main(int argc, char** argv)
         bench_gemv<1, 16, 2, false, false, 2, 8>("M1 loop lds 16x2 o8", 4096, 11008, bufs_big, x, scales, y);
         bench_gemv<1, 16, 8, false, false, 2, 4>("M1 loop lds 16x8 o4", 4096, 11008, bufs_big, x, scales, y);
         bench_gemv<4, 16, 4, false, false, 8, 4>("M4 loop lds 16x4 o4", 4096, 11008, bufs_big, x, scales, y);
+    }
+    if (!strcmp(what, "all") || !strcmp(what, "skinny")) {
+        printf("--- skinny MFMA stream kernel ---\n");
+        bench_skinny<16, 4, true, 1, 4>("skinny exact 16x4 o4", 1, 4096, 4096, bufs, x, scales, y);
+        bench_skinny<16, 4, true, 1, 4>("skinny exact 16x4 o4", 2, 4096, 4096, bufs, x, scales, y);
+        bench_skinny<16, 4, true, 2, 4>("skinny exact 16x4 o4", 4, 4096, 4096, bufs, x, scales, y);
+        bench_skinny<16, 4, true, 4, 4>("skinny exact 16x4 o4", 8, 4096, 4096, bufs, x, scales, y);
+        bench_skinny<16, 4, true, 8, 4>("skinny exact 16x4 o4", 16, 4096, 4096, bufs, x, scales, y);
+        bench_skinny<16, 4, true, 4, 8>("skinny exact 16x4 o8", 8, 4096, 4096, bufs, x, scales, y);
+        bench_skinny<16, 4, true, 4, 4>("skinny exact 16x4 N=11008", 8, 11008, 4096, bufs_big, x, scales, y);
+        bench_skinny<16, 2, false, 8, 4>("skinny loop 16x2 K=11008 M4", 4, 4096, 11008, bufs_big, x, scales, y);
+        bench_skinny<16, 4, false, 8, 4>("skinny loop 16x4 K=11008 M4", 4, 4096, 11008, bufs_big, x, scales, y);
     }
     return 0;
 }
