@@ -16,6 +16,7 @@
 
 #include "../eetq_amd/csrc/gemv_kernel.hpp"
 #include "../eetq_amd/csrc/skinny_kernel.hpp"
+#include "../eetq_amd/csrc/gemm_kernel.hpp"
 
 namespace eetq {  // stubs for the error plumbing declared in common.hpp (unused by the kernels)
 void set_error(const std::string&) {}
@@ -186,6 +187,31 @@ static void bench_skinny(const char* name, int M, int N, int K, const std::vecto
            name, N, K, M, st.mean, st.med, st.mn, st.p90, bytes / st.med / 1e3, g, bytes / g / 1e3);
 }
 
+template <int SCHED>
+static void bench_gemm(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
+                       const eetq::f16* scales, eetq::f16* y)
+{
+    using namespace eetq::gemm;
+    auto kern = gemm_mfma_kernel<SCHED>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    const int    tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const double flops = 2.0 * M * N * K;
+    auto         st    = time_dispatch(
+        [&](int i, hipEvent_t a, hipEvent_t b) {
+            hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS), SMEM_BYTES, 0, a, b, 0, x,
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K);
+        },
+        60, 10);
+    double g = time_graph(
+        [&](int i, hipStream_t s) {
+            hipLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS), SMEM_BYTES, s, x, (const uint8_t*)bufs[i % bufs.size()],
+                               scales, y, M, N, K);
+        },
+        40);
+    printf("%-22s M=%5d N=%5d K=%5d | disp mean %7.2f med %7.2f min %7.2f us -> %7.1f TF(med) | graph %7.2f us/step -> %7.1f TF\n",
+           name, M, N, K, st.mean, st.med, st.mn, flops / st.med / 1e6, g, flops / g / 1e6);
+}
+
 int main(int argc, char** argv)
 {
     const char* what = argc > 1 ? argv[1] : "all";
@@ -256,6 +282,25 @@ int main(int argc, char** argv)
         bench_gemv<1, 16, 2, false, false, 2, 8>("M1 loop lds 16x2 o8", 4096, 11008, bufs_big, x, scales, y);
         bench_gemv<1, 16, 8, false, false, 2, 4>("M1 loop lds 16x8 o4", 4096, 11008, bufs_big, x, scales, y);
         bench_gemv<4, 16, 4, false, false, 8, 4>("M4 loop lds 16x4 o4", 4096, 11008, bufs_big, x, scales, y);
+    }
+    if (!strcmp(what, "all") || !strcmp(what, "gemm")) {
+        printf("--- MFMA dequant-GEMM ---\n");
+        eetq::f16 *xg, *yg;
+        CK(hipMalloc(&xg, 8192ull * 4096 * 2));
+        CK(hipMalloc(&yg, 8192ull * 11008 * 2));
+        {
+            std::vector<uint16_t> h(8192ull * 4096);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));  // +-[0.125, 0.5)
+            CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        bench_gemm<0>("gemm sched0 (compiler)", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<1>("gemm sched1 (sgb)", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<2>("gemm sched2 (manual)", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<2>("gemm sched2 (manual)", 4096, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<2>("gemm sched2 (manual)", 8192, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<2>("gemm sched2 (manual)", 1024, 11008, 4096, bufs_big, xg, scales, yg);
+        bench_gemm<2>("gemm sched2 (manual)", 64, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<2>("gemm sched2 (manual)", 128, 4096, 4096, bufs, xg, scales, yg);
     }
     if (!strcmp(what, "all") || !strcmp(what, "skinny")) {
         printf("--- skinny MFMA stream kernel ---\n");
