@@ -37,10 +37,17 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, f16* y, 
     if (!(attr_set_mask >> (dev & 63) & 1ull)) {
         EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mfma_kernel<2>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_mfma8_kernel<0>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8_BYTES));
         attr_set_mask |= 1ull << (dev & 63);
     }
+    EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31),
+                 "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    launch_kernel(gemm_mfma_kernel<2>, dim3(tiles), dim3(THREADS), SMEM_BYTES, stream, x, w, scales, y, M, N, K);
+    if (K / BK >= STAGES8 - 1)  // 8 waves (two K halves per step, 6-stage DMA ring): needs >= 5 K steps
+        launch_kernel(gemm_mfma8_kernel<0>, dim3(tiles), dim3(THREADS8), SMEM8_BYTES, stream, x, w, scales, y, M, N, K);
+    else
+        launch_kernel(gemm_mfma_kernel<2>, dim3(tiles), dim3(THREADS), SMEM_BYTES, stream, x, w, scales, y, M, N, K);
     return check_hip(hipGetLastError(), "gemm_mfma_kernel launch");
 }
 

@@ -308,5 +308,248 @@ __global__ __launch_bounds__(THREADS) void gemm_mfma_kernel(const f16* __restric
     }
 }
 
+
+// =====================================================================================================================
+// 8-wave variant: same 128 x 128 x 64 workgroup tile, but the two 32-deep halves of every K step go to two wave
+// groups (waves 0-3: k-locals 0..31, waves 4-7: 32..63; each wave still owns 128 rows x 32 columns).  Two waves per
+// SIMD: while one wave's MFMAs occupy the matrix pipe the other issues its LDS reads / dequant VALU / DMA, which a
+// single in-order wave per SIMD cannot hide (PMC on the 4-wave kernel: 22 % issue stalls + 24 % s_waitcnt/barrier).
+// The two groups' fp32 partial sums are added once at the end through LDS.  S8-stage DMA ring, one barrier per K step.
+constexpr int THREADS8 = 512;
+constexpr int STAGES8  = 6;
+constexpr int SMEM8_BYTES = STAGES8 * STAGE_BYTES;  // 144 KiB (also covers the 64 KiB end-of-kernel reduction)
+constexpr int DMA8_PER_WAVE = 3;                    // 16 A + 8 B pieces of 1 KiB per stage over 8 waves
+
+// ABLATE (kbench only): 1 = no DMA in the loop, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier
+template <int ABLATE = 0>
+__global__ __launch_bounds__(THREADS8, 2) void gemm_mfma8_kernel(const f16* __restrict__ x, const uint8_t* __restrict__ w,
+                                                                 const f16* __restrict__ scales, f16* __restrict__ y,
+                                                                 int M, int N, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int grp  = wave >> 2;  // which 32-deep half of each K step
+    const int wn   = wave & 3;   // which 32-column slice of the tile
+    const int KT   = K >> 6;
+
+    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_n = (N + BN - 1) / BN;
+    const int T       = tiles_m * tiles_n;
+    int       tile;
+    {
+        const int b = blockIdx.x, q = T >> 3, r = T & 7, xcd = b & 7, idx = b >> 3;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int m0 = (tile % tiles_m) * BM;
+    const int n0 = (tile / tiles_m) * BN;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, (int)((size_t)M * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(w), 0, (int)((size_t)N * K), 0x00020000);
+    // DMA pieces of this wave: A pieces 2*wave, 2*wave+1 (8 rows x 128 B each), B piece wave (one 16-column tile)
+    int a_voff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row  = (wave * 2 + i) * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((row >> 1) & 7);
+        int       gm   = m0 + row;
+        gm             = gm < M ? gm : M - 1;
+        a_voff[i]      = (gm * K + slot * 8) * 2;
+    }
+    int b_voff;
+    {
+        const int n_tiles_total = N >> 4;
+        int       nt            = (n0 >> 4) + wave;
+        nt                      = nt < n_tiles_total ? nt : n_tiles_total - 1;
+        b_voff                  = nt * KT * kTileBytes + lane * 16;
+    }
+    auto dma_piece = [&](int i, int stage, int kt) {  // i = 0, 1: A pieces; 2: B piece
+        uint8_t* sa = smem + stage * STAGE_BYTES;
+        if (i < 2)
+            dma16(x_rsrc, a_voff[i], kt * BK * 2, sa + (wave * 2 + i) * 1024);
+        else
+            dma16(w_rsrc, b_voff, kt * kTileBytes, sa + A_STAGE_BYTES + wave * 1024);
+    };
+
+    const int fn = lane & 31, fh = lane >> 5;
+    const int b_off     = A_STAGE_BYTES + (wn * 2 + (fn >> 4)) * 1024 + (fn & 15) * 16 + fh * 256 + grp * 512;
+    const int a_key     = (fn >> 1) & 7;
+    const int a_row_off = fn * 128;
+    const int a_slot0   = ((4 * grp + 2 * fh + 0) ^ a_key) << 4;
+    const int a_slot1   = ((4 * grp + 2 * fh + 1) ^ a_key) << 4;
+
+    const int   ncol_c = (n0 + wn * 32 + fn) < N ? (n0 + wn * 32 + fn) : N - 1;
+    const f16   sc     = scales[ncol_c];
+    const f16x2 scale2 = {sc, sc};
+
+    f32x16 acc[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
+
+    struct Frags {
+        u32x4 wq;
+        f16x8 xa[2][4];
+    };
+    typedef f16x8 WFrag[2];
+
+    // One K step of one wave: 8 MFMAs on (wcur, fcur); in their shadow the LDS reads of the next K step's fragments
+    // (READ), the dequant of the freshly read weights, and this wave's 3 DMA pieces of stage kt+STAGES8-1 (DMA).
+    auto step = [&](const WFrag& wcur, const Frags& fcur, auto read_tag, int nstage, Frags& fnext, WFrag& wnext,
+                    auto dma_tag, int dma_stage, int dma_kt) {
+        constexpr bool READ = decltype(read_tag)::value;
+        constexpr bool DMA  = decltype(dma_tag)::value;
+        const uint8_t* sa   = smem + nstage * STAGE_BYTES;
+        f16x2          wd[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = i >> 2, mt = i & 3;
+            if constexpr (!(ABLATE & 8))
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[e], fcur.xa[e][mt], acc[mt], 0, 0, 0);
+            else
+                asm volatile("" ::"v"(wcur[e]), "v"(fcur.xa[e][mt]));
+            if constexpr (READ && !(ABLATE & 4)) {
+                if (i == 0) fnext.wq = *reinterpret_cast<const u32x4*>(sa + b_off);
+                if (i < 4) {
+                    const int ne = i >> 1;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int nmt     = 2 * (i & 1) + j;
+                        fnext.xa[ne][nmt] = *reinterpret_cast<const f16x8*>(sa + nmt * 32 * 128 + a_row_off +
+                                                                            (ne ? a_slot1 : a_slot0));
+                    }
+                } else if constexpr (!(ABLATE & 2)) {
+                    const int d   = i - 4;
+                    const u32 wdw = d == 0 ? fnext.wq.x : d == 1 ? fnext.wq.y : d == 2 ? fnext.wq.z : fnext.wq.w;
+                    dequant_dword(wdw, scale2, wd[2 * d], wd[2 * d + 1]);
+                    asm volatile("" : "+v"(wd[2 * d]), "+v"(wd[2 * d + 1]));  // pin the VALU ops to this MFMA's shadow
+                }
+            }
+            if constexpr (DMA && !(ABLATE & 1)) {
+                if (i < DMA8_PER_WAVE) dma_piece(i, dma_stage, dma_kt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (READ && !(ABLATE & 4)) {
+            if constexpr (!(ABLATE & 2)) {
+                wnext[0] = make_frag(wd[0], wd[1], wd[2], wd[3]);
+                wnext[1] = make_frag(wd[4], wd[5], wd[6], wd[7]);
+            } else {
+                wnext[0] = __builtin_bit_cast(f16x8, fnext.wq);
+                wnext[1] = __builtin_bit_cast(f16x8, fnext.wq);
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): free (reads are >= 4 MFMAs old), keeps hipcc's counts exact
+        } else if constexpr (READ) {
+            wnext[0] = wcur[0];
+            wnext[1] = wcur[1];
+            fnext    = fcur;
+        }
+    };
+
+    // ---- prologue: STAGES8-1 stages in flight; stage 0 -> fragments ----
+    asm volatile("" ::"v"(scale2));
+#pragma unroll
+    for (int s = 0; s < STAGES8 - 1; ++s) {  // KT >= STAGES8 - 1 by launch contract
+#pragma unroll
+        for (int i = 0; i < DMA8_PER_WAVE; ++i) dma_piece(i, s, s);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES8 - 2) * DMA8_PER_WAVE) : "memory");  // stage 0 landed
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;
+    WFrag w0, w1;
+    {
+        f0.wq = *reinterpret_cast<const u32x4*>(smem + b_off);
+#pragma unroll
+        for (int e = 0; e < 2; ++e)
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                f0.xa[e][mt] = *reinterpret_cast<const f16x8*>(smem + mt * 32 * 128 + a_row_off + (e ? a_slot1 : a_slot0));
+        f16x2 wd[8];
+        dequant_16(f0.wq, scale2, wd);
+        w0[0] = make_frag(wd[0], wd[1], wd[2], wd[3]);
+        w0[1] = make_frag(wd[4], wd[5], wd[6], wd[7]);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+    }
+
+    // REM = K steps after this one, clamped to STAGES8-1.  REM >= STAGES8-1: steady state (DMA for stage kt+STAGES8-1).
+    int  stage = 0;
+    auto k_step = [&](int kt, auto rem_tag, const WFrag& wcur, const Frags& fcur, WFrag& wnext, Frags& fnext) {
+        constexpr int REM  = decltype(rem_tag)::value;
+        const int     next = stage + 1 == STAGES8 ? 0 : stage + 1;
+        if constexpr (REM >= 1) {
+            // stage kt+1 must have landed in LDS (all waves' pieces); younger stages stay in flight
+            constexpr int younger = (REM - 1) < (STAGES8 - 3) ? (REM - 1) : (STAGES8 - 3);
+            if constexpr (!(ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger * DMA8_PER_WAVE) : "memory");
+            if constexpr (!(ABLATE & 16)) __builtin_amdgcn_s_barrier();
+            int dst = stage + STAGES8 - 1;
+            dst     = dst >= STAGES8 ? dst - STAGES8 : dst;
+            step(wcur, fcur, std::true_type{}, next, fnext, wnext, std::integral_constant<bool, (REM >= STAGES8 - 1)>{},
+                 dst, kt + STAGES8 - 1);
+        } else {
+            step(wcur, fcur, std::false_type{}, 0, fnext, wnext, std::false_type{}, 0, 0);
+        }
+        stage = next;
+    };
+    using Steady = std::integral_constant<int, STAGES8 - 1>;
+    // Main loop: two K steps per iteration so the two fragment sets alternate without register copies.  It stops
+    // 6 (KT even) or 5 (KT odd) steps before the end, so the drain below is fully static: no run-time choice of
+    // fragment set or of REM (both would push the fragment registers through scratch).  Needs KT >= 5.
+    const int tail = (KT & 1) ? 5 : 6;
+    int       kt   = 0;
+    for (; kt < KT - tail; kt += 2) {
+        k_step(kt, Steady{}, w0, f0, w1, f1);
+        k_step(kt + 1, Steady{}, w1, f1, w0, f0);
+    }
+    if (tail == 6) {
+        k_step(kt, std::integral_constant<int, 5>{}, w0, f0, w1, f1);
+        k_step(kt + 1, std::integral_constant<int, 4>{}, w1, f1, w0, f0);
+        k_step(kt + 2, std::integral_constant<int, 3>{}, w0, f0, w1, f1);
+        k_step(kt + 3, std::integral_constant<int, 2>{}, w1, f1, w0, f0);
+        k_step(kt + 4, std::integral_constant<int, 1>{}, w0, f0, w1, f1);
+        k_step(kt + 5, std::integral_constant<int, 0>{}, w1, f1, w0, f0);
+    } else {
+        k_step(kt, std::integral_constant<int, 4>{}, w0, f0, w1, f1);
+        k_step(kt + 1, std::integral_constant<int, 3>{}, w1, f1, w0, f0);
+        k_step(kt + 2, std::integral_constant<int, 2>{}, w0, f0, w1, f1);
+        k_step(kt + 3, std::integral_constant<int, 1>{}, w1, f1, w0, f0);
+        k_step(kt + 4, std::integral_constant<int, 0>{}, w0, f0, w1, f1);
+    }
+
+    // ---- combine the two K halves: group 1 parks its accumulators in LDS, group 0 adds and stores ----
+    __builtin_amdgcn_s_barrier();  // every wave is done with the stage ring
+    float* red = reinterpret_cast<float*>(smem) + (size_t)wn * 64 * 64;  // [reg 0..63][lane]
+    if (grp == 1) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(mt * 16 + r) * 64 + lane] = acc[mt][r];
+    }
+    __syncthreads();
+    if (grp == 0) {
+        const int nbase = n0 + wn * 32 + 4 * fh;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] += red[(mt * 16 + r) * 64 + lane];
+            const int m = m0 + mt * 32 + fn;
+            if (m < M) {
+                f16* yrow = y + (size_t)m * N + nbase;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    if (nbase + 8 * q < N) {
+                        const f16x2 lo = {(f16)acc[mt][4 * q + 0], (f16)acc[mt][4 * q + 1]};
+                        const f16x2 hi = {(f16)acc[mt][4 * q + 2], (f16)acc[mt][4 * q + 3]};
+                        *reinterpret_cast<u32x2*>(yrow + 8 * q) = u32x2{as_u32(lo), as_u32(hi)};
+                    }
+                }
+            }
+        }
+    }
+}
+
 }  // namespace gemm
 }  // namespace eetq
