@@ -9,7 +9,8 @@ A "step" is one w8_a16_gemm call (one pass of the decode hot path over one batch
              / wall time of the timed region (inputs resident in HBM, K steps replayed as one HIP graph, barrier +
              synchronize on both sides, MAX over ranks).  Includes the ~1-2 us dependent-kernel boundary per step.
   roofline   dominant kernel (gemv_kernel): algorithmic bytes / mean kernel duration, measured live with a HIP
-             event pair around every launch on the launch stream (a second pass over the same K steps).
+             start/stop event pair attached to every dispatch (hipExtLaunchKernelGGL via eetq_prof_begin/_end) on the
+             launch stream, in a second pass over the same K steps; read_only_floor = the same for a load-only kernel.
   secondary  the other half of the metric: fused dequant-GEMM at M=1024, N=K=4096 in TFLOP/s (MFMA roofline).
   cpu_baseline  the oracle's scalar C port of the same GEMV on one host core (bounded sample), and beside it
              (cpu_linear_fp16) the north star's CPU torch.nn.Linear fp16 forward on all host cores.
@@ -71,17 +72,21 @@ def capture_graph(fn, nsteps):
     return g
 
 
-def event_pair_kernel_time(fn_one, nsteps):
-    """Mean duration (seconds) between an event recorded right before and right after each launch."""
-    starts = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps)]
-    stops = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps)]
-    for i in range(nsteps):
-        starts[i].record()
-        fn_one(i)
-        stops[i].record()
-    torch.cuda.synchronize()
-    ms = np.array([starts[i].elapsed_time(stops[i]) for i in range(nsteps)])
-    return float(ms.mean()) * 1e-3, float(np.median(ms)) * 1e-3, float(ms.min()) * 1e-3
+def dispatch_kernel_time(run, nlaunches):
+    """Mean/median/min kernel duration (seconds) of `nlaunches` launches issued by run(): every launch carries a HIP
+    start/stop event pair on its dispatch packet (eetq_prof_begin/_end -> hipExtLaunchKernelGGL), i.e. the kernel's own
+    begin/end timestamps -- the quantity rocprofv3 --kernel-trace reports -- on the stream the kernel is launched on."""
+    import ctypes
+    from eetq_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.eetq_prof_begin(nlaunches))
+    run()
+    buf = (ctypes.c_float * nlaunches)()
+    cnt = ctypes.c_int(0)
+    _lib.check(L.eetq_prof_end(buf, nlaunches, ctypes.byref(cnt)))
+    us = np.array(buf[:cnt.value], dtype=np.float64)
+    assert cnt.value == nlaunches, (cnt.value, nlaunches)
+    return float(us.mean()) * 1e-6, float(np.median(us)) * 1e-6, float(us.min()) * 1e-6
 
 
 def cpu_gemv_baseline(oracle, x, q, s, budget_s=10.0):
@@ -115,7 +120,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--nbuf", type=int, default=40, help="distinct weight sets rotated per step (x16 MiB)")
-    ap.add_argument("--gemm-steps", type=int, default=40)
+    ap.add_argument("--gemm-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
@@ -176,8 +181,23 @@ def main():
     value = grp.world_size * steps * step_bytes / seconds / 1e9
 
     # ---- roofline of the dominant kernel: event pair around every launch, same K steps ----
-    k_mean, k_med, k_min = event_pair_kernel_time(lambda i: gemv_steps(i, 1), steps)
+    gemv_steps(0, 20)
+    torch.cuda.synchronize()
+    k_mean, k_med, k_min = dispatch_kernel_time(lambda: gemv_steps(0, steps), steps)
     achieved = step_bytes / k_mean / 1e9
+    # the floor: a kernel that only reads the same 16 MiB (same load pattern), timed the same way
+    import ctypes
+    from eetq_amd import _lib
+    sink = torch.zeros(16, dtype=torch.int32, device=dev)
+    stream_ptr = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def read_only():
+        for i in range(steps):
+            _lib.check(_lib.lib().eetq_diag_stream_read(ctypes.c_void_p(sets[i % nbuf][0].data_ptr()), K * N,
+                                                        ctypes.c_void_p(sink.data_ptr()), stream_ptr))
+    read_only()
+    torch.cuda.synchronize()
+    f_mean, f_med, f_min = dispatch_kernel_time(read_only, steps)
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(tpath):
@@ -185,10 +205,13 @@ def main():
             traffic = json.load(open(tpath)).get("gemv_hbm_bytes_per_launch")
         except Exception:
             traffic = None
-    roofline = {"kernel": "gemv_kernel<1,16,4>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+    roofline = {"kernel": "gemv_kernel<M=1,16 waves x 4 tiles,exact,xreg>", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": step_bytes, "kernel_us_mean": round(k_mean * 1e6, 3),
-                "kernel_us_median": round(k_med * 1e6, 3), "kernel_us_min": round(k_min * 1e6, 3)}
+                "kernel_us_median": round(k_med * 1e6, 3), "kernel_us_min": round(k_min * 1e6, 3),
+                "read_only_floor": {"what": "kernel that only loads the same 16 MiB (16 B/lane nt loads), same timing method",
+                                    "kernel_us_mean": round(f_mean * 1e6, 3), "gbps": round(K * N / f_mean / 1e9, 1),
+                                    "frac_of_peak": round(K * N / f_mean / 1e9 / HBM_PEAK_GBPS, 4)}}
 
     # ---- secondary: fused dequant-GEMM, M = 1024 ----
     Mg = 1024
@@ -201,17 +224,17 @@ def main():
             w, s = sets[i % nbuf]
             ops.w8_a16_gemm_(xg, w, s, yg[i % 2], Mg, N, K)
 
-    gemm_steps(0, 5)
+    gemm_steps(0, 60)  # warm-up: lets the clocks settle under MFMA load
     torch.cuda.synchronize()
     ggraph = capture_graph(gemm_steps, args.gemm_steps)
     ggraph.replay()
     torch.cuda.synchronize()
     gsec = grp.timed(ggraph.replay)
     flops = 2.0 * Mg * N * K
-    g_mean, g_med, g_min = event_pair_kernel_time(lambda i: gemm_steps(i, 1), args.gemm_steps)
+    g_mean, g_med, g_min = dispatch_kernel_time(lambda: gemm_steps(0, args.gemm_steps), args.gemm_steps)
     gemm = {"metric": "dequant-GEMM TFLOPS @ M=1024, N=K=4096", "value": round(grp.world_size * args.gemm_steps * flops / gsec / 1e12, 2),
             "unit": "TFLOP/s", "steps": args.gemm_steps, "ms_per_step": round(gsec * 1e3 / args.gemm_steps, 5),
-            "roofline": {"kernel": "gemm_mfma_kernel", "bound": "mfma", "achieved": round(flops / g_mean / 1e12, 2),
+            "roofline": {"kernel": "gemm_mfma8_kernel", "bound": "mfma", "achieved": round(flops / g_mean / 1e12, 2),
                          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / g_mean / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
                          "kernel_us_mean": round(g_mean * 1e6, 2), "kernel_us_min": round(g_min * 1e6, 2), "traffic": None}}
 

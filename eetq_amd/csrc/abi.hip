@@ -133,6 +133,11 @@ int eetq_prof_end(float* durations_us, int capacity, int* count)
     return EETQ_OK;
 }
 
+int eetq_diag_stream_read(const void* p, size_t bytes, void* sink, void* stream)
+{
+    return launch_stream_read(p, bytes, static_cast<unsigned*>(sink), static_cast<hipStream_t>(stream));
+}
+
 int eetq_device_supported(void)
 {
     int dev = 0;

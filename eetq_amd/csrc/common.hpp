@@ -106,6 +106,8 @@ int  launch_skinny(const f16* x, const uint8_t* w, const f16* scales, f16* y, in
                    hipStream_t stream);
 bool skinny_supported(int M, int N, int K);
 
+int  launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t stream);
+
 constexpr int kGemvMaxM   = 4;
 constexpr int kSkinnyMaxM = 16;
 

@@ -1,0 +1,30 @@
+// Diagnostic kernel (bench.py only): read `bytes` once with the same access pattern as the GEMV weight stream
+// (16 B/lane, non-temporal, 4 loads in flight per lane) and do nothing else.  Its duration is the floor any kernel
+// that must read that many bytes from HBM can reach on this chip: the yardstick next to roofline.frac.
+#include "gemv_kernel.hpp"
+
+namespace eetq {
+
+namespace {
+__global__ __launch_bounds__(1024) void stream_read_kernel(const u32x4* __restrict__ p, unsigned* __restrict__ sink)
+{
+    const u32x4* q = p + (size_t)blockIdx.x * 4096 + threadIdx.x;
+    u32x4        v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = gemv::load_w<true>(q + i * 1024);
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    if (acc == 0x9e3779b9u) sink[0] = acc;  // practically never true: keeps the loads alive
+}
+}  // namespace
+
+int launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t stream)
+{
+    EETQ_REQUIRE(p && sink && bytes >= 65536 && bytes % 65536 == 0, "stream_read: bytes must be a multiple of 64 KiB");
+    launch_kernel(stream_read_kernel, dim3((unsigned)(bytes / 65536)), dim3(1024), 0, stream,
+                  static_cast<const u32x4*>(p), sink);
+    return check_hip(hipGetLastError(), "stream_read_kernel launch");
+}
+
+}  // namespace eetq

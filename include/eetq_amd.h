@@ -109,6 +109,9 @@ int eetq_rotary_neox_f16(const int64_t* positions, void* query, void* key, const
  * into a HIP graph. */
 int eetq_prof_begin(int max_launches);
 int eetq_prof_end(float* durations_us, int capacity, int* count);
+/* Diagnostic: a kernel that only reads `bytes` (multiple of 64 KiB) from p with the GEMV's load pattern; its
+ * duration is the read floor for that many bytes on this chip.  `sink` = 4 writable device bytes. */
+int eetq_diag_stream_read(const void* p, size_t bytes, void* sink, void* stream);
 
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* eetq_last_error(void);   /* thread-local, never NULL */
