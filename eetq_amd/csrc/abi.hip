@@ -231,14 +231,16 @@ int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales
     switch (path) {
         case EETQ_PATH_AUTO:
             // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
-            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 16 -> MFMA stream kernel (same weight
-            // stream, activations in LDS) when they fit; otherwise the LDS-tiled MFMA GEMM.
+            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 64 -> MFMA stream kernel (same weight
+            // stream, activations straight from L2 into MFMA operands); larger M -> LDS-tiled MFMA GEMM.
             if (M == 1) return launch_gemv(xp, wp, sp, yp, M, N, K, s);
-            if (skinny_supported(M, N, K)) return launch_skinny(xp, wp, sp, yp, M, N, K, s);
+            // (for 32 < M <= 64 the activation re-reads of the stream kernel grow with N/16 workgroups: wide N
+            // goes to the tiled kernel; measured crossover in profiles/r01_sweep.json)
+            if (M <= 32 || (M <= kStreamMaxM && N <= 6144)) return launch_streamk(xp, wp, sp, yp, M, N, K, s);
             return launch_gemm_mfma(xp, wp, sp, yp, M, N, K, s);
         case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, yp, M, N, K, s);
         case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, yp, M, N, K, s);
-        case EETQ_PATH_SKINNY: return launch_skinny(xp, wp, sp, yp, M, N, K, s);
+        case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, yp, M, N, K, s);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] unknown or unimplemented GEMM path");
     }
 }

@@ -102,13 +102,12 @@ int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows
 int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int heads, int head_size,
                   int rot_dim, hipStream_t stream);
 
-int  launch_skinny(const f16* x, const uint8_t* w, const f16* scales, f16* y, int M, int N, int K,
-                   hipStream_t stream);
-bool skinny_supported(int M, int N, int K);
-
 int  launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t stream);
 
+int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, f16* y, int M, int N, int K,
+                    hipStream_t stream);
+
 constexpr int kGemvMaxM   = 4;
-constexpr int kSkinnyMaxM = 16;
+constexpr int kStreamMaxM = 64;
 
 }  // namespace eetq

@@ -1,0 +1,144 @@
+// Kernel template of the medium-batch (M <= 128) W8A16 "stream" GEMM with register-resident activations.
+//
+// Same HBM-bound weight stream as the GEMV kernel (waves of a workgroup split K, 16 B/lane tile loads go
+// straight to registers and are MFMA B operands as they are), but the activation fragments are loaded straight from
+// global memory (they live in L2: M*K*2 bytes, re-read by every workgroup) instead of being staged in LDS, so M*K is
+// not limited by the 160 KiB LDS.  One workgroup owns NT adjacent 16-column tile rows so each activation fragment is
+// reused by NT weight tiles; MT = ceil(M/16) row tiles of v_mfma_f32_16x16x32_f16.
+// Included by streamk.hip and tools/kbench.hip.
+#pragma once
+#include "common.hpp"
+#include "gemv_kernel.hpp"
+
+namespace eetq {
+namespace streamk {
+
+// grid.x = N / (16*NT); block = WAVES*64; wave w takes k tiles w, w+WAVES, ... (each >= D tiles by launch contract).
+// Dynamic LDS: WAVES * MT*NT*256 floats (cross-wave reduction only).
+template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel(
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
+    int N, int K)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    float* red = reinterpret_cast<float*>(smem);
+
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int g = lane >> 4, c = lane & 15;
+    const int KT     = K >> 6;
+    const int ntile0 = blockIdx.x * NT;
+
+    u32 sraw[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sraw[t] = reinterpret_cast<const uint16_t*>(scales)[(ntile0 + t) * 16 + c];
+
+    // per-lane activation row pointers: row 16*mt + c (clamped: rows >= M compute garbage that is never stored)
+    const u32x4* xrow[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        int r    = 16 * mt + c;
+        r        = r < M ? r : M - 1;
+        xrow[mt] = reinterpret_cast<const u32x4*>(x + (size_t)r * K + 16 * g);  // + 8 u32x4 per k tile
+    }
+    const u32x4* wp[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        wp[t] = reinterpret_cast<const u32x4*>(w + (size_t)(ntile0 + t) * KT * kTileBytes) + lane;  // + 64 per k tile
+
+    struct Stage {
+        u32x4 wq[NT];
+        u32x4 xa[MT][2];
+    };
+    auto load_stage = [&](int kt, Stage& s) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) s.wq[t] = gemv::load_w<true>(wp[t] + (size_t)kt * 64);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            s.xa[mt][0] = xrow[mt][(size_t)kt * 8];
+            s.xa[mt][1] = xrow[mt][(size_t)kt * 8 + 1];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[mt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f16x2 scale2[NT];
+    auto  consume = [&](const Stage& s) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f16x2 wq[8];
+            dequant_16(s.wq[t], scale2[t], wq);
+            const f16x8 b0 = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
+            const f16x8 b1 = {wq[4].x, wq[4].y, wq[5].x, wq[5].y, wq[6].x, wq[6].y, wq[7].x, wq[7].y};
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s.xa[mt][0]), b0,
+                                                                    acc[mt][t], 0, 0, 0);
+                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s.xa[mt][1]), b1,
+                                                                    acc[mt][t], 0, 0, 0);
+            }
+        }
+    };
+
+    // ---- software-pipelined K loop over this wave's tiles: no load behind a branch (see gemv_kernel.hpp) ----
+    const int n = (KT - wave + WAVES - 1) / WAVES;  // >= D
+    Stage     st[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) load_stage(wave + d * WAVES, st[d]);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        asm volatile("" : "+v"(sraw[t]));
+        scale2[t] = as_f16x2(sraw[t] | (sraw[t] << 16));
+    }
+    int i = 0;
+    for (; i + 2 * D <= n; i += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            consume(st[d]);
+            load_stage(wave + (i + d + D) * WAVES, st[d]);
+        }
+    }
+    const int r = n - (i + D);  // 0 <= r < D tiles remain beyond the D already loaded
+    Stage     tail[D > 1 ? D - 1 : 1];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+        const int t = i + D + d;
+        load_stage(wave + (t < n ? t : n - 1) * WAVES, tail[d]);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) consume(st[d]);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (d < r) consume(tail[d]);
+
+    // ---- cross-wave reduction: acc[mt][t][j] = partial y[16*mt + 4g + j][16*(ntile0+t) + c] ----
+    constexpr int kPerWave = MT * NT * 256;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                red[wave * kPerWave + ((mt * NT + t) * 16 + 4 * g + j) * 16 + c] = acc[mt][t][j];
+    __syncthreads();
+    for (int o = tid; o < kPerWave; o += WAVES * 64) {
+        const int cc = o & 15, rr = (o >> 4) & 15, tt = (o >> 8) % NT, mt = (o >> 8) / NT;
+        const int m = 16 * mt + rr;
+        if (m < M) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < WAVES; ++wv) s += red[wv * kPerWave + o];
+            y[(size_t)m * N + (ntile0 + tt) * 16 + cc] = (f16)s;
+        }
+    }
+}
+
+inline size_t streamk_smem_bytes(int mt, int nt, int waves) { return (size_t)waves * mt * nt * 256 * 4; }
+
+}  // namespace streamk
+}  // namespace eetq

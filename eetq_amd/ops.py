@@ -25,7 +25,7 @@ __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_g
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
-_PATHS = {"auto": PATH_AUTO, "gemv": PATH_GEMV, "mfma": PATH_MFMA, "skinny": _lib.PATH_SKINNY}
+_PATHS = {"auto": PATH_AUTO, "gemv": PATH_GEMV, "mfma": PATH_MFMA, "stream": _lib.PATH_STREAM}
 
 
 def _layout_id(layout):
@@ -164,7 +164,7 @@ def w8_a16_gemm(input, weight, scale, path="auto"):
     """``y = input @ dequant(weight, scale)``: fp16 [..., K] x int8 [K, N] (processed) -> fp16 [..., N].
 
     Reference: w8_a16_gemm_forward_cuda, fpA_intB_gemm_wrapper.cu:130-173 (fresh output tensor, current
-    stream, asynchronous).  ``path`` ("auto" | "gemv" | "mfma") is a testing hook.
+    stream, asynchronous).  ``path`` ("auto" | "gemv" | "stream" | "mfma") is a testing hook.
     """
     k = input.shape[-1]
     n = weight.shape[-1]

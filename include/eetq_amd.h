@@ -44,7 +44,7 @@ enum { EETQ_DTYPE_F16 = 0, EETQ_DTYPE_F32 = 1 };
 enum { EETQ_LAYOUT_ROW_MAJOR = 0, EETQ_LAYOUT_GFX950 = 1, EETQ_LAYOUT_SM80 = 2 };
 
 /* Kernel selection for eetq_w8a16_gemm_ex (tests and tuning).  AUTO is what eetq_w8a16_gemm uses. */
-enum { EETQ_PATH_AUTO = 0, EETQ_PATH_GEMV = 1, EETQ_PATH_MFMA = 2, EETQ_PATH_SKINNY = 3 };
+enum { EETQ_PATH_AUTO = 0, EETQ_PATH_GEMV = 1 /* M <= 4 */, EETQ_PATH_MFMA = 2 /* LDS-tiled */, EETQ_PATH_STREAM = 3 /* M <= 64 */ };
 
 /* ---- quantise --------------------------------------------------------------------------------------
  * Replaces EETQ.quant_weights -> symmetric_quantize_last_axis_of_tensor
@@ -86,7 +86,7 @@ int eetq_unpack_i8_host(const int8_t* q_packed, size_t K, size_t N, int8_t* q_ra
 int eetq_w8a16_gemm(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N, int K,
                     void* stream);
 /* As above with an explicit kernel path (EETQ_PATH_*); returns EETQ_ERR_UNSUPPORTED when the path cannot
- * run the shape (e.g. GEMV with M > 8). */
+ * run the shape (e.g. GEMV with M > 4, STREAM with M > 64). */
 int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N,
                        int K, int path, void* stream);
 

@@ -136,17 +136,12 @@ def test_gemv_vs_oracle(ops, oracle, M, K, N):
                                           np.argwhere(~ok)[:4])
 
 
-@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 15, 16])
+@pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 15, 16, 17, 31, 33, 48, 64])
 @pytest.mark.parametrize("K,N", [(64, 16), (128, 48), (1024, 256), (4096, 512), (11008, 64), (2048, 32), (2112, 16)])
-def test_skinny_mfma_vs_oracle(ops, oracle, M, K, N):
-    w, x = _rand_case(K, N, M, seed=3 * K + N + M)
-    x[:, ::5] *= -1
-    if M * (2 * K + 16) + 16 * 1024 > 144 * 1024:
-        with pytest.raises(RuntimeError):   # activations do not fit LDS: explicit path refuses, AUTO falls back
-            _run_gemm(ops, oracle, w, x, path="skinny")
-        y, q, s = _run_gemm(ops, oracle, w, x, path="auto")
-    else:
-        y, q, s = _run_gemm(ops, oracle, w, x, path="skinny")
+def test_stream_mfma_vs_oracle(ops, oracle, M, K, N):
+    w, x = _rand_case(K, N, M, seed=5 * K + N + M)
+    x[:, ::3] *= -1
+    y, q, s = _run_gemm(ops, oracle, w, x, path="stream")
     ref = oracle.w8a16_gemm(x, q, s)
     ok = _tier_a(y, ref)
     assert ok.all(), "max err %g at %s" % (np.abs(y.astype(np.float32) - ref.astype(np.float32)).max(),

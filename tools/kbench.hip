@@ -15,8 +15,8 @@
 #include <vector>
 
 #include "../eetq_amd/csrc/gemv_kernel.hpp"
-#include "../eetq_amd/csrc/skinny_kernel.hpp"
 #include "../eetq_amd/csrc/gemm_kernel.hpp"
+#include "../eetq_amd/csrc/streamk_kernel.hpp"
 
 namespace eetq {  // stubs for the error plumbing declared in common.hpp (unused by the kernels)
 void set_error(const std::string&) {}
@@ -162,31 +162,6 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
            name, N, K, M, st.mean, st.med, st.mn, st.p90, bytes / st.med / 1e3, g, bytes / g / 1e3);
 }
 
-template <int WAVES, int D, bool EXACT, int XV, int OCC>
-static void bench_skinny(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
-                         const eetq::f16* scales, eetq::f16* y)
-{
-    const int    grid  = N / 16;
-    const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
-    auto         kern  = eetq::skinny::skinny_kernel<WAVES, D, EXACT, XV, OCC>;
-    const size_t smem  = eetq::skinny::skinny_smem_bytes(M, K, WAVES);
-    if (smem > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-    auto st = time_dispatch(
-        [&](int i, hipEvent_t a, hipEvent_t b) {
-            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K);
-        },
-        400);
-    double g = time_graph(
-        [&](int i, hipStream_t s) {
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, s, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K);
-        },
-        400);
-    printf("%-30s N=%5d K=%5d M=%2d | disp mean %6.2f med %6.2f min %6.2f p90 %6.2f us -> %6.0f GB/s(med) | graph %6.2f us/step -> %6.0f GB/s\n",
-           name, N, K, M, st.mean, st.med, st.mn, st.p90, bytes / st.med / 1e3, g, bytes / g / 1e3);
-}
-
 template <int ABLATE>
 static void bench_gemm8(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
                         const eetq::f16* scales, eetq::f16* y)
@@ -235,6 +210,25 @@ static void bench_gemm(const char* name, int M, int N, int K, const std::vector<
         40);
     printf("%-22s M=%5d N=%5d K=%5d | disp mean %7.2f med %7.2f min %7.2f us -> %7.1f TF(med) | graph %7.2f us/step -> %7.1f TF\n",
            name, M, N, K, st.mean, st.med, st.mn, flops / st.med / 1e6, g, flops / g / 1e6);
+}
+
+template <int MT, int NT, int WAVES, int D, int OCC>
+static void bench_streamk(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
+                          const eetq::f16* scales, eetq::f16* y)
+{
+    const int    grid  = N / (16 * NT);
+    const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
+    auto         kern  = eetq::streamk::streamk_kernel<MT, NT, WAVES, D, OCC>;
+    const size_t smem  = eetq::streamk::streamk_smem_bytes(MT, NT, WAVES);
+    if (smem > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    auto st = time_dispatch(
+        [&](int i, hipEvent_t a, hipEvent_t b) {
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, 0, a, b, 0, x,
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K);
+        },
+        200);
+    printf("%-30s N=%5d K=%5d M=%3d | disp mean %6.2f med %6.2f min %6.2f us -> %6.0f GB/s(med) %7.1f TF\n", name, N, K, M,
+           st.mean, st.med, st.mn, bytes / st.med / 1e3, 2.0 * M * N * K / st.med / 1e6);
 }
 
 int main(int argc, char** argv)
@@ -361,17 +355,34 @@ int main(int argc, char** argv)
                                (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096);
         CK(hipDeviceSynchronize());
     }
-    if (!strcmp(what, "all") || !strcmp(what, "skinny")) {
-        printf("--- skinny MFMA stream kernel ---\n");
-        bench_skinny<16, 4, true, 1, 4>("skinny exact 16x4 o4", 1, 4096, 4096, bufs, x, scales, y);
-        bench_skinny<16, 4, true, 1, 4>("skinny exact 16x4 o4", 2, 4096, 4096, bufs, x, scales, y);
-        bench_skinny<16, 4, true, 2, 4>("skinny exact 16x4 o4", 4, 4096, 4096, bufs, x, scales, y);
-        bench_skinny<16, 4, true, 4, 4>("skinny exact 16x4 o4", 8, 4096, 4096, bufs, x, scales, y);
-        bench_skinny<16, 4, true, 8, 4>("skinny exact 16x4 o4", 16, 4096, 4096, bufs, x, scales, y);
-        bench_skinny<16, 4, true, 4, 8>("skinny exact 16x4 o8", 8, 4096, 4096, bufs, x, scales, y);
-        bench_skinny<16, 4, true, 4, 4>("skinny exact 16x4 N=11008", 8, 11008, 4096, bufs_big, x, scales, y);
-        bench_skinny<16, 2, false, 8, 4>("skinny loop 16x2 K=11008 M4", 4, 4096, 11008, bufs_big, x, scales, y);
-        bench_skinny<16, 4, false, 8, 4>("skinny loop 16x4 K=11008 M4", 4, 4096, 11008, bufs_big, x, scales, y);
+    if (!strcmp(what, "all") || !strcmp(what, "streamk")) {
+        printf("--- stream MFMA kernel with register-resident activations ---\n");
+        eetq::f16* xs;
+        CK(hipMalloc(&xs, 128ull * 13824 * 2));
+        {
+            std::vector<uint16_t> h(128ull * 13824);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
+            CK(hipMemcpy(xs, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        eetq::f16* ys;
+        CK(hipMalloc(&ys, 128ull * 11008 * 2));
+        bench_streamk<1, 1, 16, 2, 4>("MT1 NT1 16x2", 8, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<1, 2, 16, 2, 4>("MT1 NT2 16x2", 8, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<1, 1, 16, 2, 4>("MT1 NT1 16x2", 16, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<1, 1, 16, 2, 4>("MT1 NT1 16x2 K=11008", 8, 4096, 11008, bufs_big, xs, scales, ys);
+        bench_streamk<1, 2, 16, 2, 4>("MT1 NT2 16x2 K=11008", 8, 4096, 11008, bufs_big, xs, scales, ys);
+        bench_streamk<1, 1, 16, 4, 4>("MT1 NT1 16x4 K=11008", 8, 4096, 11008, bufs_big, xs, scales, ys);
+        bench_streamk<1, 1, 16, 2, 4>("MT1 NT1 16x2 N=11008", 8, 11008, 4096, bufs_big, xs, scales, ys);
+        bench_streamk<2, 1, 16, 2, 4>("MT2 NT1 16x2", 32, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<2, 2, 16, 2, 4>("MT2 NT2 16x2", 32, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<4, 1, 16, 2, 4>("MT4 NT1 16x2", 64, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<4, 2, 16, 2, 4>("MT4 NT2 16x2", 64, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<4, 2, 16, 1, 4>("MT4 NT2 16x1", 64, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<4, 2, 8, 2, 2>("MT4 NT2 8x2", 64, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<4, 2, 16, 2, 4>("MT4 NT2 16x2 N=11008", 64, 11008, 4096, bufs_big, xs, scales, ys);
+        bench_streamk<4, 2, 16, 2, 4>("MT4 NT2 16x2 K=11008", 64, 4096, 11008, bufs_big, xs, scales, ys);
+        bench_streamk<8, 1, 16, 1, 4>("MT8 NT1 16x1", 128, 4096, 4096, bufs, xs, scales, ys);
+        bench_streamk<8, 1, 16, 2, 4>("MT8 NT1 16x2", 128, 4096, 4096, bufs, xs, scales, ys);
     }
     return 0;
 }
