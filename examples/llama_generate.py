@@ -1,0 +1,186 @@
+#!/usr/bin/env python
+"""BASELINE.json configs[4]: Llama-2-13B-shaped model, eet_quantize(model), greedy generate prompt=1024 new=50,
+replicated on 1/2/4/8 MI355X (one process per GPU: torchrun --nproc-per-node N examples/llama_generate.py).
+
+No checkpoints are available offline, so the model is a random-init LlamaForCausalLM with the 13B shapes (hidden 5120,
+intermediate 13824, 40 layers, 40 heads, vocab 32000), fp16, fixed seed -- the same recipe the reference's
+examples/models/llama_transformers_example.py:22-90 applies to a real checkpoint (load fp16 -> quantise -> warm-up
+generate -> one timed generate with synchronize on both sides).  Prints one JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from eetq_amd.utils.quantizer import eet_quantize  # noqa: E402
+from eetq_amd.utils.replicas import ReplicaGroup  # noqa: E402
+
+
+def build_model(args, dev):
+    from transformers import LlamaConfig, LlamaForCausalLM
+    cfg = LlamaConfig(hidden_size=args.hidden, intermediate_size=args.inter, num_hidden_layers=args.layers,
+                      num_attention_heads=args.heads, num_key_value_heads=args.heads, vocab_size=32000,
+                      max_position_embeddings=4096)
+    torch.manual_seed(0)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float16)
+    try:
+        with torch.device(dev):
+            model = LlamaForCausalLM(cfg)
+    finally:
+        torch.set_default_dtype(old)
+    return model.eval()
+
+
+class GraphDecoder:
+    """Greedy decode with a static KV cache: the single-token forward is captured ONCE as a HIP graph (token id and
+    position live in static device tensors) and replayed per generated token; prefill stays eager."""
+
+    def __init__(self, model, batch, max_len):
+        from transformers import StaticCache
+        self.model = model
+        dev = next(model.parameters()).device
+        try:
+            self.cache = StaticCache(config=model.config, max_cache_len=max_len)
+        except TypeError:
+            self.cache = StaticCache(config=model.config, max_batch_size=batch, max_cache_len=max_len, device=dev,
+                                     dtype=torch.float16)
+        self.s_tok = torch.zeros(batch, 1, dtype=torch.long, device=dev)
+        self.s_pos = torch.zeros(1, dtype=torch.long, device=dev)
+        # the cache tensors are allocated lazily by the first forward: run one tiny prefill before capturing
+        model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._step()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.s_out = self._step()
+
+    def _step(self):
+        lg = self.model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True).logits
+        return lg[:, -1].argmax(-1, keepdim=True)
+
+    def generate(self, prompt, new_tokens):
+        B, P = prompt.shape
+        self.cache.reset()
+        out = self.model(prompt, past_key_values=self.cache, cache_position=torch.arange(P, device=prompt.device),
+                         use_cache=True)
+        tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        generated = [tok]
+        self.s_tok.copy_(tok)
+        self.s_pos.fill_(P)
+        for _ in range(new_tokens - 1):
+            self.graph.replay()
+            self.s_tok.copy_(self.s_out)
+            self.s_pos += 1
+            generated.append(self.s_out.clone())
+        return torch.cat([prompt] + generated, dim=1)
+
+
+def fuse_rmsnorm(model):
+    """Route every LlamaRMSNorm through the library's T5/RMS layernorm op (the reference's layernorm_forward,
+    csrc/layernorm_kernels/layernorm.cu): one kernel instead of ~6 elementwise launches per norm."""
+    import types
+
+    from eetq_amd.ops import layernorm_forward
+
+    def forward(self, hidden_states):
+        x = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
+        out = torch.empty_like(x)
+        layernorm_forward(x, self.weight, out, self.variance_epsilon)
+        return out
+
+    n = 0
+    for m in model.modules():
+        if type(m).__name__ == "LlamaRMSNorm":
+            m.forward = types.MethodType(forward, m)
+            n += 1
+    return n
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--prompt", type=int, default=1024)
+    ap.add_argument("--new", type=int, default=50)
+    ap.add_argument("--hidden", type=int, default=5120)
+    ap.add_argument("--inter", type=int, default=13824)
+    ap.add_argument("--layers", type=int, default=40)
+    ap.add_argument("--heads", type=int, default=40)
+    ap.add_argument("--no-quant", action="store_true", help="fp16 nn.Linear baseline (rocBLAS) for comparison")
+    ap.add_argument("--fuse-norm", action="store_true", help="LlamaRMSNorm -> eetq layernorm_forward kernel")
+    ap.add_argument("--graph", action="store_true",
+                    help="greedy decode with a static KV cache and ONE captured HIP graph per token (launch-bound "
+                         "inner loop -> hipGraph) instead of transformers' eager generate()")
+    args = ap.parse_args()
+
+    grp = ReplicaGroup()
+    dev = grp.device
+    t0 = time.perf_counter()
+    model = build_model(args, dev)
+    t_build = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    if not args.no_quant:
+        eet_quantize(model)
+    if args.fuse_norm:
+        fuse_rmsnorm(model)
+    torch.cuda.synchronize()
+    t_quant = time.perf_counter() - t0
+
+    # identical prompts on every replica (rank 0 draws them, one broadcast)
+    g = torch.Generator().manual_seed(1)
+    prompt = torch.randint(0, 32000, (args.batch, args.prompt), generator=g).to(dev)
+    grp.fan_out(prompt)
+    kw = dict(max_new_tokens=args.new, min_new_tokens=args.new, do_sample=False, pad_token_id=0)
+
+    with torch.no_grad():
+        out = model.generate(prompt[:, :64], max_new_tokens=4, min_new_tokens=4, do_sample=False, pad_token_id=0)  # warm-up
+        torch.cuda.synchronize()
+        # prefill-only timing (one forward over the prompt)
+        grp.barrier()
+        t0 = time.perf_counter()
+        model(prompt)
+        torch.cuda.synchronize()
+        t_prefill = time.perf_counter() - t0
+        holder = {}
+
+        decoder = GraphDecoder(model, args.batch, args.prompt + args.new + 8) if args.graph else None
+        if decoder is not None:
+            decoder.generate(prompt[:, :64], 4)  # warm-up
+            torch.cuda.synchronize()
+
+        def run():
+            if args.graph:
+                holder["out"] = decoder.generate(prompt, args.new)
+            else:
+                holder["out"] = model.generate(prompt, **kw)
+        secs = grp.timed(run)
+    out = holder["out"]
+    crcs = grp.gather_checksums(out[:, args.prompt:].to(torch.int32))
+    if grp.rank == 0:
+        new_tokens = args.batch * args.new
+        line = {"config": "Llama-2-13B shapes, random init fp16, %s, prompt=%d new=%d batch=%d, %s" %
+                          ("fp16 nn.Linear" if args.no_quant else "eet_quantize (W8A16)", args.prompt, args.new, args.batch,
+                           ("hipGraph decode" if args.graph else "transformers eager generate") +
+                           (", fused rmsnorm" if args.fuse_norm else "")),
+                "n_gpus": grp.world_size, "end_to_end_s": round(secs, 4), "prefill_s": round(t_prefill, 4),
+                "tokens_per_s_per_replica": round(new_tokens / secs, 2),
+                "tokens_per_s_aggregate": round(grp.world_size * new_tokens / secs, 2),
+                "decode_tokens_per_s_per_replica": round(new_tokens / max(secs - t_prefill, 1e-9), 2),
+                "replicas_identical_tokens": len(set(crcs)) == 1, "build_s": round(t_build, 1),
+                "quantize_s": round(t_quant, 2),
+                "max_mem_GB": round(torch.cuda.max_memory_allocated() / 1e9, 2)}
+        print(json.dumps(line))
+    grp.close()
+
+
+if __name__ == "__main__":
+    main()
