@@ -218,14 +218,16 @@ int eetq_unpack_i8_host(const int8_t* q_packed, size_t K, size_t N, int8_t* q_ra
     return relayout_host(q_packed, K, N, q_raw, layout, false);
 }
 
-int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N, int K,
-                       int path, void* stream)
+static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scales, const void* bias, void* y, int M,
+                         int N, int K, int path, void* stream)
 {
     int st = check_gemm_args(x, w_packed, scales, y, M, N, K);
     if (st != EETQ_OK) return st;
+    EETQ_REQUIRE(!bias || (uintptr_t)bias % 8 == 0, "bias must be 8-byte aligned");
     const f16*     xp = static_cast<const f16*>(x);
     const uint8_t* wp = reinterpret_cast<const uint8_t*>(w_packed);
     const f16*     sp = static_cast<const f16*>(scales);
+    const f16*     bp = static_cast<const f16*>(bias);
     f16*           yp = static_cast<f16*>(y);
     hipStream_t    s  = static_cast<hipStream_t>(stream);
     switch (path) {
@@ -233,22 +235,34 @@ int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales
             // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
             // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 64 -> MFMA stream kernel (same weight
             // stream, activations straight from L2 into MFMA operands); larger M -> LDS-tiled MFMA GEMM.
-            if (M == 1) return launch_gemv(xp, wp, sp, yp, M, N, K, s);
             // (for 32 < M <= 64 the activation re-reads of the stream kernel grow with N/16 workgroups: wide N
             // goes to the tiled kernel; measured crossover in profiles/r01_sweep.json)
-            if (M <= 32 || (M <= kStreamMaxM && N <= 6144)) return launch_streamk(xp, wp, sp, yp, M, N, K, s);
-            return launch_gemm_mfma(xp, wp, sp, yp, M, N, K, s);
-        case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, yp, M, N, K, s);
-        case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, yp, M, N, K, s);
-        case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, yp, M, N, K, s);
+            if (M == 1) return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
+            if (M <= 32 || (M <= kStreamMaxM && N <= 6144)) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
+            return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
+        case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
+        case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
+        case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] unknown or unimplemented GEMM path");
     }
+}
+
+int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N, int K,
+                       int path, void* stream)
+{
+    return gemm_dispatch(x, w_packed, scales, nullptr, y, M, N, K, path, stream);
 }
 
 int eetq_w8a16_gemm(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N, int K,
                     void* stream)
 {
-    return eetq_w8a16_gemm_ex(x, w_packed, scales, y, M, N, K, EETQ_PATH_AUTO, stream);
+    return gemm_dispatch(x, w_packed, scales, nullptr, y, M, N, K, EETQ_PATH_AUTO, stream);
+}
+
+int eetq_w8a16_gemm_bias(const void* x, const int8_t* w_packed, const void* scales, const void* bias, void* y, int M,
+                         int N, int K, int path, void* stream)
+{
+    return gemm_dispatch(x, w_packed, scales, bias, y, M, N, K, path, stream);
 }
 
 int eetq_rmsnorm_f16(const void* x, const void* gamma, void* out, float eps, int rows, int cols, void* stream)

@@ -94,9 +94,9 @@ int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_ra
                     int layout, void* scales, float* colmax, hipStream_t stream);
 int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
 int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
-int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, f16* y, int M, int N, int K,
+int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
                 hipStream_t stream);
-int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, f16* y, int M, int N, int K,
+int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
                      hipStream_t stream);
 int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows, int cols, hipStream_t stream);
 int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int heads, int head_size,
@@ -104,7 +104,7 @@ int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int toke
 
 int  launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t stream);
 
-int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, f16* y, int M, int N, int K,
+int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
                     hipStream_t stream);
 
 constexpr int kGemvMaxM   = 4;

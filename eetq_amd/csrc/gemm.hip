@@ -27,7 +27,7 @@ namespace eetq {
 
 using namespace gemm;
 
-int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, f16* y, int M, int N, int K,
+int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
                      hipStream_t stream)
 {
     // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device
@@ -45,9 +45,9 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, f16* y, 
                  "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     if (K / BK >= STAGES8 - 1)  // 8 waves (two K halves per step, 6-stage DMA ring): needs >= 5 K steps
-        launch_kernel(gemm_mfma8_kernel<0>, dim3(tiles), dim3(THREADS8), SMEM8_BYTES, stream, x, w, scales, y, M, N, K);
+        launch_kernel(gemm_mfma8_kernel<0>, dim3(tiles), dim3(THREADS8), SMEM8_BYTES, stream, x, w, scales, bias, y, M, N, K);
     else
-        launch_kernel(gemm_mfma_kernel<2>, dim3(tiles), dim3(THREADS), SMEM_BYTES, stream, x, w, scales, y, M, N, K);
+        launch_kernel(gemm_mfma_kernel<2>, dim3(tiles), dim3(THREADS), SMEM_BYTES, stream, x, w, scales, bias, y, M, N, K);
     return check_hip(hipGetLastError(), "gemm_mfma_kernel launch");
 }
 

@@ -35,8 +35,8 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 
 template <int SCHED>
 __global__ __launch_bounds__(THREADS) void gemm_mfma_kernel(const f16* __restrict__ x, const uint8_t* __restrict__ w,
-                                                            const f16* __restrict__ scales, f16* __restrict__ y,
-                                                            int M, int N, int K)
+                                                            const f16* __restrict__ scales, const f16* __restrict__ bias,
+                                                            f16* __restrict__ y, int M, int N, int K)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid  = threadIdx.x;
@@ -299,8 +299,13 @@ __global__ __launch_bounds__(THREADS) void gemm_mfma_kernel(const f16* __restric
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 if (nbase + 8 * q < N) {  // N % 16 == 0: a group of 4 columns is all-in or all-out
-                    const f16x2 lo = {(f16)acc[mt][4 * q + 0], (f16)acc[mt][4 * q + 1]};
-                    const f16x2 hi = {(f16)acc[mt][4 * q + 2], (f16)acc[mt][4 * q + 3]};
+                    f16x2 lo = {(f16)acc[mt][4 * q + 0], (f16)acc[mt][4 * q + 1]};
+                    f16x2 hi = {(f16)acc[mt][4 * q + 2], (f16)acc[mt][4 * q + 3]};
+                    if (bias) {  // fp16 add after the fp16 rounding: bit-identical to the reference's separate `+ bias`
+                        const u32x2 b = *reinterpret_cast<const u32x2*>(bias + nbase + 8 * q);
+                        lo            = lo + as_f16x2(b.x);
+                        hi            = hi + as_f16x2(b.y);
+                    }
                     *reinterpret_cast<u32x2*>(yrow + 8 * q) = u32x2{as_u32(lo), as_u32(hi)};
                 }
             }
@@ -323,8 +328,8 @@ constexpr int DMA8_PER_WAVE = 3;                    // 16 A + 8 B pieces of 1 Ki
 // ABLATE (kbench only): 1 = no DMA in the loop, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier
 template <int ABLATE = 0>
 __global__ __launch_bounds__(THREADS8, 2) void gemm_mfma8_kernel(const f16* __restrict__ x, const uint8_t* __restrict__ w,
-                                                                 const f16* __restrict__ scales, f16* __restrict__ y,
-                                                                 int M, int N, int K)
+                                                                 const f16* __restrict__ scales, const f16* __restrict__ bias,
+                                                                 f16* __restrict__ y, int M, int N, int K)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid  = threadIdx.x;
@@ -541,8 +546,13 @@ __global__ __launch_bounds__(THREADS8, 2) void gemm_mfma8_kernel(const f16* __re
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     if (nbase + 8 * q < N) {
-                        const f16x2 lo = {(f16)acc[mt][4 * q + 0], (f16)acc[mt][4 * q + 1]};
-                        const f16x2 hi = {(f16)acc[mt][4 * q + 2], (f16)acc[mt][4 * q + 3]};
+                        f16x2 lo = {(f16)acc[mt][4 * q + 0], (f16)acc[mt][4 * q + 1]};
+                        f16x2 hi = {(f16)acc[mt][4 * q + 2], (f16)acc[mt][4 * q + 3]};
+                        if (bias) {  // fp16 add after the fp16 rounding: bit-identical to the reference's separate `+ bias`
+                            const u32x2 b = *reinterpret_cast<const u32x2*>(bias + nbase + 8 * q);
+                            lo            = lo + as_f16x2(b.x);
+                            hi            = hi + as_f16x2(b.y);
+                        }
                         *reinterpret_cast<u32x2*>(yrow + 8 * q) = u32x2{as_u32(lo), as_u32(hi)};
                     }
                 }

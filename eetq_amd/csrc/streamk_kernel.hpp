@@ -17,8 +17,8 @@ namespace streamk {
 // Dynamic LDS: WAVES * MT*NT*256 floats (cross-wave reduction only).
 template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel(
-    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
-    int N, int K)
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
+    const f16* __restrict__ bias, f16* __restrict__ y, int M, int N, int K)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* red = reinterpret_cast<float*>(smem);
@@ -133,7 +133,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
             float s = 0.f;
 #pragma unroll
             for (int wv = 0; wv < WAVES; ++wv) s += red[wv * kPerWave + o];
-            y[(size_t)m * N + (ntile0 + tt) * 16 + cc] = (f16)s;
+            f16 v = (f16)s;
+            if (bias) v = v + bias[(ntile0 + tt) * 16 + cc];
+            y[(size_t)m * N + (ntile0 + tt) * 16 + cc] = v;
         }
     }
 }

@@ -33,10 +33,6 @@ def quantize_and_preprocess_weights(weight, scales=None):
     raise ValueError("Unsupported data type: {}".format(weight.dtype))
 
 
-def _bias_add(out, bias):
-    return out if bias is None else out + bias
-
-
 class W8A16Linear(nn.Module):
     """Inference-only linear layer: int8 weight ``qweight`` [in, out], fp16 ``weight_scales`` [out]."""
 
@@ -66,7 +62,8 @@ class W8A16Linear(nn.Module):
 
     @torch.no_grad()
     def forward(self, input):
-        return _bias_add(w8_a16_gemm(input, self.qweight, self.weight_scales), self.bias)
+        # bias is fused into the kernel epilogue: same bits as the reference's `output + self.bias` (qlinear.py:61)
+        return w8_a16_gemm(input, self.qweight, self.weight_scales, bias=self.bias)
 
     def extra_repr(self):
         return "in_features={}, out_features={}, bias={}".format(self.in_features, self.out_features,
@@ -80,7 +77,7 @@ class EetqLinearMMFunction(Function):
     @staticmethod
     def forward(ctx, x, weight, scales, bias=None):
         ctx.save_for_backward(x, weight, scales, bias)
-        return _bias_add(w8_a16_gemm(x, weight, scales), bias)
+        return w8_a16_gemm(x, weight, scales, bias=bias)
 
     @staticmethod
     def backward(ctx, grad_output):

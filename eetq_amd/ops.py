@@ -142,7 +142,7 @@ def convert_layout(weight, src_layout, dst_layout):
     return preprocess_weights(unprocess_weights(weight, src_layout), False, dst_layout)
 
 
-def _gemm_launch(input, weight, scale, output, m, n, k, path):
+def _gemm_launch(input, weight, scale, output, m, n, k, path, bias=None):
     if input.dtype != torch.float16:
         raise RuntimeError("w8_a16_gemm: input must be float16 (got %s)" % input.dtype)
     if not input.is_cuda:
@@ -154,17 +154,25 @@ def _gemm_launch(input, weight, scale, output, m, n, k, path):
     if not weight.is_contiguous() or not scale.is_contiguous() or not output.is_contiguous():
         raise RuntimeError("w8_a16_gemm: weight, scale and output must be contiguous")
     x = input if input.is_contiguous() else input.contiguous()
+    if bias is not None:
+        if bias.dtype != torch.float16 or bias.device != input.device or bias.numel() != n or not bias.is_contiguous():
+            raise RuntimeError("w8_a16_gemm: bias must be a contiguous float16 [N] tensor on the input's device")
     with torch.cuda.device(input.device):
-        check(_lib.lib().eetq_w8a16_gemm_ex(_ptr(x), _ptr(weight), _ptr(scale), _ptr(output), m, n, k, path,
-                                            _stream_ptr()))
+        if bias is None:
+            check(_lib.lib().eetq_w8a16_gemm_ex(_ptr(x), _ptr(weight), _ptr(scale), _ptr(output), m, n, k, path,
+                                                _stream_ptr()))
+        else:
+            check(_lib.lib().eetq_w8a16_gemm_bias(_ptr(x), _ptr(weight), _ptr(scale), _ptr(bias), _ptr(output), m, n, k,
+                                                  path, _stream_ptr()))
     return output
 
 
-def w8_a16_gemm(input, weight, scale, path="auto"):
-    """``y = input @ dequant(weight, scale)``: fp16 [..., K] x int8 [K, N] (processed) -> fp16 [..., N].
+def w8_a16_gemm(input, weight, scale, path="auto", bias=None):
+    """``y = input @ dequant(weight, scale) (+ bias)``: fp16 [..., K] x int8 [K, N] (processed) -> fp16 [..., N].
 
     Reference: w8_a16_gemm_forward_cuda, fpA_intB_gemm_wrapper.cu:130-173 (fresh output tensor, current
-    stream, asynchronous).  ``path`` ("auto" | "gemv" | "stream" | "mfma") is a testing hook.
+    stream, asynchronous).  ``path`` ("auto" | "gemv" | "stream" | "mfma") is a testing hook.  ``bias`` (extension,
+    SURVEY 8f row 3) fuses the reference's separate ``output + bias`` into the kernel epilogue, bit-identically.
     """
     k = input.shape[-1]
     n = weight.shape[-1]
@@ -174,7 +182,7 @@ def w8_a16_gemm(input, weight, scale, path="auto"):
     output = torch.empty(tuple(input.shape[:-1]) + (n,), dtype=input.dtype, device=input.device)
     if m == 0:
         return output
-    return _gemm_launch(input, weight, scale, output, m, n, k, _PATHS[path])
+    return _gemm_launch(input, weight, scale, output, m, n, k, _PATHS[path], bias)
 
 
 def w8_a16_gemm_(input, weight, scale, output, m, n, k):

@@ -90,6 +90,12 @@ int eetq_w8a16_gemm(const void* x, const int8_t* w_packed, const void* scales, v
 int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N,
                        int K, int path, void* stream);
 
+/* Fused bias epilogue: y = fp16(gemm) + bias, the fp16 add done after the fp16 rounding so the
+ * result is bit-identical to the reference's separate `output + bias` (python/eetq/modules/qlinear.py:61), without the
+ * extra elementwise kernel.  bias: fp16 [N], 8-byte aligned, or NULL.  `path` as in eetq_w8a16_gemm_ex. */
+int eetq_w8a16_gemm_bias(const void* x, const int8_t* w_packed, const void* scales, const void* bias, void* y, int M,
+                         int N, int K, int path, void* stream);
+
 /* ---- side ops --------------------------------------------------------------------------------------
  * Replaces EETQ.layernorm_forward -> layernorm_forward_cuda (csrc/layernorm_kernels/layernorm.cu:98-113):
  * T5/RMS norm, out = clamp_fp16( x * rsqrt(mean(x^2) + eps) * gamma ), fp32 math, fp16 I/O.

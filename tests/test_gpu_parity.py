@@ -337,6 +337,39 @@ def test_eetq_linear_forward_backward(ops, oracle):
     assert torch.equal(mod(xin.detach()), y.detach())
 
 
+@pytest.mark.parametrize("M", [1, 3, 8, 40, 200])
+def test_fused_bias_is_bit_identical_to_separate_add(ops, oracle, M):
+    """the kernel-epilogue bias must give the same bits as the reference's `output + bias`."""
+    K, N = 512, 272
+    w, x = _rand_case(K, N, M, seed=77 + M)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    bias = (torch.randn(N) * 0.5).half().to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    fused = ops.w8_a16_gemm(xd, processed, scales, bias=bias)
+    separate = ops.w8_a16_gemm(xd, processed, scales) + bias
+    assert torch.equal(fused, separate)
+    ref = oracle.w8a16_gemm(x, q, s).astype(np.float32) + bias.float().cpu().numpy()
+    assert np.allclose(fused.float().cpu().numpy(), ref, atol=3e-3, rtol=3e-3)
+
+
+def test_fuse_w8a16_linears_qkv(ops):
+    """one launch over concatenated output channels == the three separate launches, bit for bit."""
+    from eetq_amd.modules.qlinear import W8A16Linear
+    from eetq_amd.utils.fuse import fuse_w8a16_linears
+    torch.manual_seed(3)
+    K = 256
+    lins = [torch.nn.Linear(K, n, bias=True).half().to(DEV) for n in (128, 64, 48)]
+    parts = [W8A16Linear.from_torch(l) for l in lins]
+    fused = fuse_w8a16_linears(parts)
+    for M in (1, 5, 70):
+        x = torch.rand(M, K, dtype=torch.float16, device=DEV) - 0.5
+        outs = fused(x)
+        for o, p in zip(outs, parts):
+            assert torch.equal(o, p(x))
+
+
 def test_eet_quantize_tiny_model(ops):
     from eetq_amd.modules.qlinear import W8A16Linear
     from eetq_amd.utils.quantizer import eet_quantize
