@@ -106,6 +106,36 @@ def fuse_rmsnorm(model):
     return n
 
 
+class _SharedInputProj(torch.nn.Module):
+    """Stand-in for q/k/v_proj (or gate/up_proj): the first sibling runs ONE fused W8A16 GEMM over the concatenated
+    output channels and parks the parts; the others hand out their part.  Keeps the stock transformers block intact."""
+
+    def __init__(self, fused, index, box):
+        super().__init__()
+        self.fused, self.index, self.box = (fused if index == 0 else None), index, box
+
+    def forward(self, x):
+        if self.index == 0:
+            self.box[:] = self.fused(x)
+        return self.box[self.index]
+
+
+def fuse_projections(model):
+    """q/k/v and gate/up share their input: 7 -> 4 GEMM launches per decoder layer (eetq_amd.utils.fuse)."""
+    from eetq_amd.utils.fuse import fuse_w8a16_linears
+    n = 0
+    for layer in model.model.layers:
+        att, mlp = layer.self_attn, layer.mlp
+        for owner, names in ((att, ("q_proj", "k_proj", "v_proj")), (mlp, ("gate_proj", "up_proj"))):
+            fused = fuse_w8a16_linears([getattr(owner, nm) for nm in names])
+            box = [None] * len(names)
+            for i, nm in enumerate(names):
+                setattr(owner, nm, _SharedInputProj(fused, i, box))
+            n += 1
+    torch.cuda.empty_cache()
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=1)
@@ -117,6 +147,7 @@ def main():
     ap.add_argument("--heads", type=int, default=40)
     ap.add_argument("--no-quant", action="store_true", help="fp16 nn.Linear baseline (rocBLAS) for comparison")
     ap.add_argument("--fuse-norm", action="store_true", help="LlamaRMSNorm -> eetq layernorm_forward kernel")
+    ap.add_argument("--fuse-proj", action="store_true", help="one W8A16 launch for q/k/v and one for gate/up")
     ap.add_argument("--graph", action="store_true",
                     help="greedy decode with a static KV cache and ONE captured HIP graph per token (launch-bound "
                          "inner loop -> hipGraph) instead of transformers' eager generate()")
@@ -132,6 +163,8 @@ def main():
         eet_quantize(model)
     if args.fuse_norm:
         fuse_rmsnorm(model)
+    if args.fuse_proj and not args.no_quant:
+        fuse_projections(model)
     torch.cuda.synchronize()
     t_quant = time.perf_counter() - t0
 
@@ -170,7 +203,7 @@ def main():
         line = {"config": "Llama-2-13B shapes, random init fp16, %s, prompt=%d new=%d batch=%d, %s" %
                           ("fp16 nn.Linear" if args.no_quant else "eet_quantize (W8A16)", args.prompt, args.new, args.batch,
                            ("hipGraph decode" if args.graph else "transformers eager generate") +
-                           (", fused rmsnorm" if args.fuse_norm else "")),
+                           (", fused rmsnorm" if args.fuse_norm else "") + (", fused qkv + gate/up" if args.fuse_proj else "")),
                 "n_gpus": grp.world_size, "end_to_end_s": round(secs, 4), "prefill_s": round(t_prefill, 4),
                 "tokens_per_s_per_replica": round(new_tokens / secs, 2),
                 "tokens_per_s_aggregate": round(grp.world_size * new_tokens / secs, 2),
