@@ -325,7 +325,8 @@ constexpr int STAGES8  = 6;
 constexpr int SMEM8_BYTES = STAGES8 * STAGE_BYTES;  // 144 KiB (also covers the 64 KiB end-of-kernel reduction)
 constexpr int DMA8_PER_WAVE = 3;                    // 16 A + 8 B pieces of 1 KiB per stage over 8 waves
 
-// ABLATE (kbench only): 1 = no DMA in the loop, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier
+// ABLATE (kbench only): 1 = no DMA in the loop, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier,
+// 32 = static s_setprio 1 for the second wave group, 64 = s_setprio 1 around every MFMA
 template <int ABLATE = 0>
 __global__ __launch_bounds__(THREADS8, 2) void gemm_mfma8_kernel(const f16* __restrict__ x, const uint8_t* __restrict__ w,
                                                                  const f16* __restrict__ scales, const f16* __restrict__ bias,
@@ -413,10 +414,12 @@ __global__ __launch_bounds__(THREADS8, 2) void gemm_mfma8_kernel(const f16* __re
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int e = i >> 2, mt = i & 3;
+            if constexpr (ABLATE & 64) __builtin_amdgcn_s_setprio(1);
             if constexpr (!(ABLATE & 8))
                 acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[e], fcur.xa[e][mt], acc[mt], 0, 0, 0);
             else
                 asm volatile("" ::"v"(wcur[e]), "v"(fcur.xa[e][mt]));
+            if constexpr (ABLATE & 64) __builtin_amdgcn_s_setprio(0);
             if constexpr (READ && !(ABLATE & 4)) {
                 if (i == 0) fnext.wq = *reinterpret_cast<const u32x4*>(sa + b_off);
                 if (i < 4) {
@@ -455,6 +458,9 @@ __global__ __launch_bounds__(THREADS8, 2) void gemm_mfma8_kernel(const f16* __re
         }
     };
 
+    if constexpr (ABLATE & 32) {
+        if (grp == 1) __builtin_amdgcn_s_setprio(1);
+    }
     // ---- prologue: STAGES8-1 stages in flight; stage 0 -> fragments ----
     asm volatile("" ::"v"(scale2));
 #pragma unroll

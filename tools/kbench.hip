@@ -316,6 +316,9 @@ int main(int argc, char** argv)
         bench_gemm<1>("gemm sched1 (sgb)", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm<2>("gemm sched2 (manual)", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm8<0>("gemm8 (8 waves)", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm8<32>("gemm8 +prio grp1", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm8<64>("gemm8 +prio mfma", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm8<0>("gemm8 (8 waves) again", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm8<1>("gemm8 -dma", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm8<2>("gemm8 -dequant", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm8<4>("gemm8 -ldsread", 1024, 4096, 4096, bufs, xg, scales, yg);
