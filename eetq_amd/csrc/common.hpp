@@ -68,11 +68,6 @@ __device__ __forceinline__ void dequant_16(const u32x4& w, f16x2 scale2, f16x2 (
     dequant_dword(w.w, scale2, out[6], out[7]);
 }
 
-__device__ __forceinline__ float wave_xor_add(float v, int mask)
-{
-    return v + __shfl_xor(v, mask, 64);
-}
-
 // ---- launch helper: optionally attaches per-dispatch begin/end timestamps (eetq_prof_begin/_end) ---------
 struct ProfEvents {
     hipEvent_t start = nullptr, stop = nullptr;

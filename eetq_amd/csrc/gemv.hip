@@ -1,19 +1,11 @@
-// W8A16 batched GEMV for decode (M = 1..kGemvMaxM), wave64 reduction, no MFMA, no LDS staging.
+// W8A16 decode GEMV launcher (M = 1 in AUTO dispatch; the kernel also serves M <= 4 on request), kernels in
+// gemv_kernel.hpp: wave64 dot2 + lane-swap reduction, no MFMA.
 //
-// Replaces the reference's weight_only_batched_gemv (csrc/weightOnlyBatchedGemv/kernel.h:294-468, launched
-// from kernelLauncher.cu:165-192 for m <= 4).  Same math up to summation order, except that partial sums are
-// kept in fp32 throughout (the CUDA kernel accumulates 32 products per thread in fp16, kernel.h:325-329):
+// Replaces the reference's weight_only_batched_gemv (csrc/weightOnlyBatchedGemv/kernel.h:294-468, launched from
+// kernelLauncher.cu:165-192 for m <= 4).  Same math up to summation order, except that partial sums are kept in
+// fp32 throughout (the CUDA kernel accumulates 32 products per thread in fp16, kernel.h:325-329):
 //   y[m][n] = fp16( sum_k fp32(x[m][k]) * fp32(fp16(q[k][n] * s[n])) )
-//
-// HBM-bound: K*N weight bytes are read exactly once; everything else is KBs.  Design (DESIGN.md "GEMV"):
-//   * one workgroup owns one 16-column tile row of the native layout, which is K/64 contiguous 1 KiB tiles
-//     = one contiguous K*16-byte stream; its waves take tiles round-robin;
-//   * every load is a whole-tile 16 B/lane global_load_dwordx4 with the non-temporal hint (weights are
-//     streamed once); UNROLL tiles are issued before the first is consumed so a 16-wave workgroup has
-//     64 KiB in flight per CU;
-//   * lane (g = lane>>4, c = lane&15) gets 16 consecutive k of column c: dequantised in registers (v_perm +
-//     v_pk_add_f16 + v_pk_mul_f16, exact q then fp16(q*s)) and accumulated with v_dot2c_f32_f16;
-//   * reduction: DPP/bpermute across the 4 k-groups of a wave, then across waves through 1 KiB of LDS.
+// Design notes (HBM-bound, K*N weight bytes read exactly once): DESIGN.md section 4.1 and gemv_kernel.hpp.
 #include "gemv_kernel.hpp"
 
 namespace eetq {

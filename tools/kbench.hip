@@ -369,6 +369,56 @@ int main(int argc, char** argv)
         }
         eetq::f16* ys;
         CK(hipMalloc(&ys, 128ull * 11008 * 2));
+        uint8_t* huge;
+        CK(hipMalloc(&huge, 4096ull * 22016 * 12));
+        std::vector<uint8_t*> bufs_huge;
+        for (int i = 0; i < 12; ++i) bufs_huge.push_back(huge + (size_t)i * 4096 * 22016);
+        CK(hipMemset(huge, 0x5a, 4096ull * 22016 * 12));
+        for (int M : {4, 8}) {
+            printf("M=%d\n", M);
+            bench_streamk<1, 1, 16, 2, 4>("MT1 16x2 o4 (shipping)", M, 4096, 4096, bufs, xs, scales, ys);
+            bench_streamk<1, 1, 16, 4, 4>("MT1 16x4 o4", M, 4096, 4096, bufs, xs, scales, ys);
+            bench_streamk<1, 1, 16, 2, 8>("MT1 16x2 o8", M, 4096, 4096, bufs, xs, scales, ys);
+            bench_streamk<1, 1, 16, 4, 8>("MT1 16x4 o8", M, 4096, 4096, bufs, xs, scales, ys);
+            bench_streamk<1, 1, 8, 4, 4>("MT1 8x4 o4", M, 4096, 4096, bufs, xs, scales, ys);
+            bench_streamk<1, 1, 16, 2, 4>("MT1 16x2 o4 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 1, 16, 4, 4>("MT1 16x4 o4 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 1, 16, 2, 8>("MT1 16x2 o8 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 1, 16, 4, 8>("MT1 16x4 o8 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 1, 8, 4, 8>("MT1 8x4 o8 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+        }
+    }
+    if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
+        eetq::f16 *xg, *yg;
+        CK(hipMalloc(&xg, 1024ull * 4096 * 2));
+        CK(hipMalloc(&yg, 1024ull * 4096 * 2));
+        std::vector<uint16_t> h(1024ull * 4096);
+        for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
+        CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        using namespace eetq::gemm;
+        auto kern = gemm_mfma8_kernel<0>;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8_BYTES));
+        for (int i = 0; i < 20; ++i)
+            hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM8_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
+                               (const eetq::f16*)nullptr, yg, 1024, 4096, 4096);
+        CK(hipDeviceSynchronize());
+        auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
+        for (int i = 0; i < 20; ++i)
+            hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
+                               (const uint8_t*)bufs[i % bufs.size()], scales, (const eetq::f16*)nullptr, y, 4096, 4096);
+        CK(hipDeviceSynchronize());
+    }
+    if (!strcmp(what, "all") || !strcmp(what, "streamk")) {
+        printf("--- stream MFMA kernel with register-resident activations ---\n");
+        eetq::f16* xs;
+        CK(hipMalloc(&xs, 128ull * 13824 * 2));
+        {
+            std::vector<uint16_t> h(128ull * 13824);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
+            CK(hipMemcpy(xs, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        eetq::f16* ys;
+        CK(hipMalloc(&ys, 128ull * 11008 * 2));
         bench_streamk<1, 1, 16, 2, 4>("MT1 NT1 16x2", 8, 4096, 4096, bufs, xs, scales, ys);
         bench_streamk<1, 2, 16, 2, 4>("MT1 NT2 16x2", 8, 4096, 4096, bufs, xs, scales, ys);
         bench_streamk<1, 1, 16, 2, 4>("MT1 NT1 16x2", 16, 4096, 4096, bufs, xs, scales, ys);
