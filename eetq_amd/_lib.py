@@ -84,10 +84,22 @@ EXPORTED_SYMBOLS = (
 )
 
 
+def _share_hip_runtime_with_torch():
+    """torch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7).  If it is already loaded, our NEEDED
+    entry resolves to it and both sides share ONE HIP runtime (streams, events and graph capture are then the same
+    objects).  Loaded in the other order the process would hold two runtimes -- torch's and /opt/rocm's -- and torch
+    stream handles would be meaningless to our launches.  So: import torch first whenever it is installed."""
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+
+
 def lib():
     """Return the loaded library, building it first when the sources are newer (dev machines only)."""
     global _lib
     if _lib is None:
+        _share_hip_runtime_with_torch()
         if not os.path.exists(LIB_PATH) or (os.path.isdir(CSRC_DIR) and shutil.which("hipcc")
                                             and _sources_newer_than_lib()):
             build()

@@ -21,14 +21,19 @@ def _declared_functions():
     return sorted(set(re.findall(r"\b(eetq_[a-z0-9_]+)\s*\(", text)))
 
 
-def test_header_symbols_are_exported():
+def test_header_symbols_are_exported(lib):
     from eetq_amd import _lib
     names = _declared_functions()
     assert len(names) >= 13
-    raw = ctypes.CDLL(_lib.LIB_PATH)
     for n in names:
-        assert hasattr(raw, n), "include/eetq_amd.h declares %s but the library does not export it" % n
+        assert hasattr(lib, n), "include/eetq_amd.h declares %s but the library does not export it" % n
     assert set(names) == set(_lib.EXPORTED_SYMBOLS)
+
+
+def test_single_hip_runtime_in_process(lib):
+    """torch bundles its own libamdhip64; the loader must end up with exactly one HIP runtime mapped."""
+    mapped = {line.split()[-1] for line in open("/proc/self/maps") if "libamdhip64" in line}
+    assert len(mapped) == 1, mapped
 
 
 def test_version_and_error_string(lib):
