@@ -162,49 +162,25 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
            name, N, K, M, st.mean, st.med, st.mn, st.p90, bytes / st.med / 1e3, g, bytes / g / 1e3);
 }
 
-template <int ABLATE>
+template <int ABLATE, int J = 1>
 static void bench_gemm8(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
                         const eetq::f16* scales, eetq::f16* y)
 {
     using namespace eetq::gemm;
-    auto kern = gemm_mfma8_kernel<ABLATE>;
-    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8_BYTES));
-    const int    tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    const double flops = 2.0 * M * N * K;
-    auto         st    = time_dispatch(
-        [&](int i, hipEvent_t a, hipEvent_t b) {
-            hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS8), SMEM8_BYTES, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, (const eetq::f16*)nullptr, y, M, N, K);
-        },
-        60, 10);
-    double g = time_graph(
-        [&](int i, hipStream_t s) {
-            hipLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS8), SMEM8_BYTES, s, x, (const uint8_t*)bufs[i % bufs.size()],
-                               scales, (const eetq::f16*)nullptr, y, M, N, K);
-        },
-        40);
-    printf("%-22s M=%5d N=%5d K=%5d | disp mean %7.2f med %7.2f min %7.2f us -> %7.1f TF(med) | graph %7.2f us/step -> %7.1f TF\n",
-           name, M, N, K, st.mean, st.med, st.mn, flops / st.med / 1e6, g, flops / g / 1e6);
-}
-
-template <int SCHED>
-static void bench_gemm(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
-                       const eetq::f16* scales, eetq::f16* y)
-{
-    using namespace eetq::gemm;
-    auto kern = gemm_mfma_kernel<SCHED>;
+    auto kern = gemm_tile_kernel<ABLATE, J>;
+    constexpr int THREADS8 = 512 / J;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     const int    tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const double flops = 2.0 * M * N * K;
     auto         st    = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
-            hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS), SMEM_BYTES, 0, a, b, 0, x,
+            hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS8), SMEM_BYTES, 0, a, b, 0, x,
                                   (const uint8_t*)bufs[i % bufs.size()], scales, (const eetq::f16*)nullptr, y, M, N, K);
         },
         60, 10);
     double g = time_graph(
         [&](int i, hipStream_t s) {
-            hipLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS), SMEM_BYTES, s, x, (const uint8_t*)bufs[i % bufs.size()],
+            hipLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS8), SMEM_BYTES, s, x, (const uint8_t*)bufs[i % bufs.size()],
                                scales, (const eetq::f16*)nullptr, y, M, N, K);
         },
         40);
@@ -312,13 +288,12 @@ int main(int argc, char** argv)
             for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));  // +-[0.125, 0.5)
             CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         }
-        bench_gemm<0>("gemm sched0 (compiler)", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm<1>("gemm sched1 (sgb)", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm<2>("gemm sched2 (manual)", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm8<0>("gemm8 (8 waves)", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<32>("gemm8 +prio grp1", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<64>("gemm8 +prio mfma", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm8<0, 2>("gemm J=2 (4 wide waves)", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm8<0>("gemm8 (8 waves) again", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm8<0, 2>("gemm J=2 again", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm8<0, 2>("gemm J=2", 4096, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm8<0, 2>("gemm J=2", 1024, 11008, 4096, bufs_big, xg, scales, yg);
         bench_gemm8<1>("gemm8 -dma", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm8<2>("gemm8 -dequant", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm8<4>("gemm8 -ldsread", 1024, 4096, 4096, bufs, xg, scales, yg);
@@ -332,11 +307,6 @@ int main(int argc, char** argv)
         bench_gemm8<0>("gemm8 (8 waves)", 8192, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm8<0>("gemm8 (8 waves)", 1024, 11008, 4096, bufs_big, xg, scales, yg);
         bench_gemm8<0>("gemm8 (8 waves)", 64, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm<2>("gemm sched2 (manual)", 4096, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm<2>("gemm sched2 (manual)", 8192, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm<2>("gemm sched2 (manual)", 1024, 11008, 4096, bufs_big, xg, scales, yg);
-        bench_gemm<2>("gemm sched2 (manual)", 64, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm<2>("gemm sched2 (manual)", 128, 4096, 4096, bufs, xg, scales, yg);
     }
     if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
         eetq::f16 *xg, *yg;
@@ -346,10 +316,11 @@ int main(int argc, char** argv)
         for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
         CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         using namespace eetq::gemm;
-        auto kern = gemm_mfma8_kernel<0>;
-        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8_BYTES));
+        auto kern = gemm_tile_kernel<0, 1>;
+        constexpr int THREADS8 = 512;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         for (int i = 0; i < 20; ++i)
-            hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM8_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
+            hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
                                (const eetq::f16*)nullptr, yg, 1024, 4096, 4096);
         CK(hipDeviceSynchronize());
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
@@ -396,10 +367,11 @@ int main(int argc, char** argv)
         for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
         CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         using namespace eetq::gemm;
-        auto kern = gemm_mfma8_kernel<0>;
-        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM8_BYTES));
+        auto kern = gemm_tile_kernel<0, 1>;
+        constexpr int THREADS8 = 512;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         for (int i = 0; i < 20; ++i)
-            hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM8_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
+            hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
                                (const eetq::f16*)nullptr, yg, 1024, 4096, 4096);
         CK(hipDeviceSynchronize());
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
