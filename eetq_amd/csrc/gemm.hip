@@ -49,12 +49,21 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, const f1
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         attr_set_mask |= 1ull << (dev & 63);
     }
-    EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31),
-                 "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
-    // J = 2: four wide waves (2 K halves x 2 column halves of 64), measured 2 % ahead of the 8-wave J = 1 form
-    launch_kernel(gemm_tile_kernel<0, 2>, dim3(tiles), dim3(256), SMEM_BYTES, stream, x, w, scales, bias, y, M, N, K);
-    return check_hip(hipGetLastError(), "gemm_tile_kernel launch");
+    // the LDS-DMA path addresses its operands with 32-bit buffer offsets
+    EETQ_REQUIRE((size_t)N * K < (1ull << 31), "weight larger than 2 GiB is not supported by the buffer-addressed DMA path");
+    // activations: split M into row chunks below 2 GiB (a multiple of the 128-row tile), one launch per chunk
+    const size_t row_bytes  = (size_t)K * 2;
+    const int    max_rows   = (int)((((1ull << 31) - 1) / row_bytes) / BM * BM);
+    EETQ_REQUIRE(max_rows >= BM, "K too large for the buffer-addressed DMA path");
+    for (int m = 0; m < M; m += max_rows) {
+        const int rows  = M - m < max_rows ? M - m : max_rows;
+        const int tiles = ((rows + BM - 1) / BM) * ((N + BN - 1) / BN);
+        // J = 2: four wide waves (2 K halves x 2 column halves of 64), measured 2 % ahead of the 8-wave J = 1 form
+        launch_kernel(gemm_tile_kernel<0, 2>, dim3(tiles), dim3(256), SMEM_BYTES, stream, x + (size_t)m * K, w, scales, bias,
+                      y + (size_t)m * N, rows, N, K);
+        EETQ_TRY_HIP(hipGetLastError());
+    }
+    return EETQ_OK;
 }
 
 }  // namespace eetq

@@ -370,6 +370,30 @@ def test_fuse_w8a16_linears_qkv(ops):
             assert torch.equal(o, p(x))
 
 
+def test_eet_quantize_hf_llama_tiny(ops):
+    """Config 5 plumbing at toy scale: a transformers LlamaForCausalLM goes through eet_quantize and still generates
+    the same greedy tokens as its fp16 self (lm_head stays fp16, every other nn.Linear becomes W8A16Linear)."""
+    transformers = pytest.importorskip("transformers")
+    from eetq_amd.modules.qlinear import W8A16Linear
+    from eetq_amd.utils.quantizer import eet_quantize
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=4, vocab_size=512, max_position_embeddings=128)
+    torch.manual_seed(0)
+    model = transformers.LlamaForCausalLM(cfg).half().to(DEV).eval()
+    prompt = torch.randint(0, 512, (2, 16), device=DEV)
+    with torch.no_grad():
+        ref_logits = model(prompt).logits.float()
+    eet_quantize(model)
+    n_q = sum(isinstance(m, W8A16Linear) for m in model.modules())
+    assert n_q == 2 * 7 and isinstance(model.lm_head, torch.nn.Linear)
+    with torch.no_grad():
+        logits = model(prompt).logits.float()
+    # int8 per-channel quantisation error on a random-init toy model: logits stay close, relative to their spread
+    assert (logits - ref_logits).abs().max().item() < 0.05 * ref_logits.abs().max().item() + 0.05
+    out = model.generate(prompt, max_new_tokens=4, do_sample=False, pad_token_id=0)
+    assert out.shape == (2, 20)
+
+
 def test_eet_quantize_tiny_model(ops):
     from eetq_amd.modules.qlinear import W8A16Linear
     from eetq_amd.utils.quantizer import eet_quantize
