@@ -15,7 +15,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 EETQ_OK = 0
 DTYPE_F16, DTYPE_F32 = 0, 1
 LAYOUT_ROW_MAJOR, LAYOUT_GFX950, LAYOUT_SM80 = 0, 1, 2
-PATH_AUTO, PATH_GEMV, PATH_MFMA, PATH_STREAM = 0, 1, 2, 3
+PATH_AUTO, PATH_GEMV, PATH_MFMA, PATH_STREAM, PATH_MID = 0, 1, 2, 3, 4
 
 _lib = None
 

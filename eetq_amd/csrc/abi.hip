@@ -233,16 +233,18 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
     switch (path) {
         case EETQ_PATH_AUTO:
             // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
-            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 64 -> MFMA stream kernel (same weight
-            // stream, activations straight from L2 into MFMA operands); larger M -> LDS-tiled MFMA GEMM.
-            // (for 32 < M <= 64 the activation re-reads of the stream kernel grow with N/16 workgroups: wide N
-            // goes to the tiled kernel; measured crossover in profiles/r01_sweep.json)
+            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 16 -> MFMA stream kernel (same weight stream,
+            // activations straight from L2 into MFMA operands); 17 <= M <= 128 -> medium-batch LDS tile (32 columns,
+            // 256-deep K steps); larger M -> 128 x 128 LDS-tiled MFMA GEMM.  Crossovers measured: profiles/r01_sweep.json.
             if (M == 1) return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
-            if (M <= 32 || (M <= kStreamMaxM && N <= 6144)) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
+            if (M <= 16) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
+            if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31))
+                return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
             return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
+        case EETQ_PATH_MID: return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] unknown or unimplemented GEMM path");
     }
 }

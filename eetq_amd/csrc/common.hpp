@@ -104,5 +104,8 @@ int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, const f16
 
 constexpr int kGemvMaxM   = 4;
 constexpr int kStreamMaxM = 64;
+constexpr int kMidMaxM    = 128;
+int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+                    hipStream_t stream);
 
 }  // namespace eetq

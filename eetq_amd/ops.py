@@ -25,7 +25,7 @@ __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_g
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
-_PATHS = {"auto": PATH_AUTO, "gemv": PATH_GEMV, "mfma": PATH_MFMA, "stream": _lib.PATH_STREAM}
+_PATHS = {"auto": PATH_AUTO, "gemv": PATH_GEMV, "mfma": PATH_MFMA, "stream": _lib.PATH_STREAM, "mid": _lib.PATH_MID}
 
 
 def _layout_id(layout):

@@ -44,7 +44,8 @@ enum { EETQ_DTYPE_F16 = 0, EETQ_DTYPE_F32 = 1 };
 enum { EETQ_LAYOUT_ROW_MAJOR = 0, EETQ_LAYOUT_GFX950 = 1, EETQ_LAYOUT_SM80 = 2 };
 
 /* Kernel selection for eetq_w8a16_gemm_ex (tests and tuning).  AUTO is what eetq_w8a16_gemm uses. */
-enum { EETQ_PATH_AUTO = 0, EETQ_PATH_GEMV = 1 /* M <= 4 */, EETQ_PATH_MFMA = 2 /* LDS-tiled */, EETQ_PATH_STREAM = 3 /* M <= 64 */ };
+enum { EETQ_PATH_AUTO = 0, EETQ_PATH_GEMV = 1 /* M <= 4 */, EETQ_PATH_MFMA = 2 /* LDS-tiled */, EETQ_PATH_STREAM = 3 /* M <= 64; AUTO uses it for 2..16 */,
+       EETQ_PATH_MID = 4 /* M <= 128: 32-column tiles, 256-deep K steps */ };
 
 /* ---- quantise --------------------------------------------------------------------------------------
  * Replaces EETQ.quant_weights -> symmetric_quantize_last_axis_of_tensor

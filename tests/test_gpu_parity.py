@@ -148,6 +148,19 @@ def test_stream_mfma_vs_oracle(ops, oracle, M, K, N):
                                           np.argwhere(~ok)[:4])
 
 
+@pytest.mark.parametrize("M", [1, 7, 32, 33, 48, 64, 65, 100, 128])
+@pytest.mark.parametrize("K,N", [(64, 16), (128, 80), (1024, 256), (4096, 512), (11008, 64), (2048, 48), (2112, 144),
+                                 (320, 32)])
+def test_mid_tile_vs_oracle(ops, oracle, M, K, N):
+    w, x = _rand_case(K, N, M, seed=11 * K + N + M)
+    x[:, ::3] *= -1
+    y, q, s = _run_gemm(ops, oracle, w, x, path="mid")
+    ref = oracle.w8a16_gemm(x, q, s)
+    ok = _tier_a(y, ref)
+    assert ok.all(), "max err %g at %s" % (np.abs(y.astype(np.float32) - ref.astype(np.float32)).max(),
+                                          np.argwhere(~ok)[:4])
+
+
 @pytest.mark.parametrize("M,K,N", [(5, 64, 16), (8, 256, 128), (17, 128, 144), (64, 1024, 256), (128, 512, 128),
                                    (130, 192, 272), (300, 2048, 384), (8, 4096, 4096), (64, 4096, 1024)])
 def test_mfma_gemm_vs_oracle(ops, oracle, M, K, N):

@@ -17,6 +17,7 @@
 #include "../eetq_amd/csrc/gemv_kernel.hpp"
 #include "../eetq_amd/csrc/gemm_kernel.hpp"
 #include "../eetq_amd/csrc/streamk_kernel.hpp"
+#include "../eetq_amd/csrc/gemm_mid_kernel.hpp"
 
 namespace eetq {  // stubs for the error plumbing declared in common.hpp (unused by the kernels)
 void set_error(const std::string&) {}
@@ -207,6 +208,26 @@ static void bench_streamk(const char* name, int M, int N, int K, const std::vect
            st.mean, st.med, st.mn, bytes / st.med / 1e3, 2.0 * M * N * K / st.med / 1e6);
 }
 
+template <int MT, int STAGES>
+static void bench_mid(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
+                      const eetq::f16* scales, eetq::f16* y)
+{
+    using namespace eetq::gemm_mid;
+    using C   = Cfg<MT, STAGES>;
+    auto kern = gemm_mid_kernel<MT, STAGES>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::kSmem));
+    const int    tiles = ((N + kBN - 1) / kBN) * ((M + C::kRows - 1) / C::kRows);
+    const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
+    auto st = time_dispatch(
+        [&](int i, hipEvent_t a, hipEvent_t b) {
+            hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(kThreads), C::kSmem, 0, a, b, 0, x,
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, (const eetq::f16*)nullptr, y, M, N, K);
+        },
+        200);
+    printf("%-22s N=%5d K=%5d M=%3d | disp mean %6.2f med %6.2f min %6.2f us -> %6.0f GB/s(med) %7.1f TF\n", name, N, K, M,
+           st.mean, st.med, st.mn, bytes / st.med / 1e3, 2.0 * M * N * K / st.med / 1e6);
+}
+
 int main(int argc, char** argv)
 {
     const char* what = argc > 1 ? argv[1] : "all";
@@ -329,6 +350,25 @@ int main(int argc, char** argv)
                                (const uint8_t*)bufs[i % bufs.size()], scales, (const eetq::f16*)nullptr, y, 4096, 4096);
         CK(hipDeviceSynchronize());
     }
+    if (!strcmp(what, "all") || !strcmp(what, "mid")) {
+        printf("--- medium-batch tile kernel (32-column tiles, 256-deep K steps) ---\n");
+        eetq::f16 *xs, *ys;
+        CK(hipMalloc(&xs, 128ull * 13824 * 2));
+        CK(hipMalloc(&ys, 128ull * 13824 * 2));
+        {
+            std::vector<uint16_t> h(128ull * 13824);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
+            CK(hipMemcpy(xs, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        bench_mid<1, 3>("mid MT1 S3", 32, 4096, 4096, bufs, xs, scales, ys);
+        bench_mid<2, 3>("mid MT2 S3", 64, 4096, 4096, bufs, xs, scales, ys);
+        bench_mid<3, 2>("mid MT3 S2", 96, 4096, 4096, bufs, xs, scales, ys);
+        bench_mid<4, 2>("mid MT4 S2", 128, 4096, 4096, bufs, xs, scales, ys);
+        bench_mid<2, 2>("mid MT2 S2 N=11008", 64, 11008, 4096, bufs_big, xs, scales, ys);
+        bench_mid<2, 3>("mid MT2 S3 K=11008", 64, 4096, 11008, bufs_big, xs, scales, ys);
+        bench_mid<4, 2>("mid MT4 S2 N=11008", 128, 11008, 4096, bufs_big, xs, scales, ys);
+        bench_mid<1, 2>("mid MT1 S2 N=11008", 32, 11008, 4096, bufs_big, xs, scales, ys);
+    }
     if (!strcmp(what, "all") || !strcmp(what, "streamk")) {
         printf("--- stream MFMA kernel with register-resident activations ---\n");
         eetq::f16* xs;
@@ -379,6 +419,25 @@ int main(int argc, char** argv)
             hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
                                (const uint8_t*)bufs[i % bufs.size()], scales, (const eetq::f16*)nullptr, y, 4096, 4096);
         CK(hipDeviceSynchronize());
+    }
+    if (!strcmp(what, "all") || !strcmp(what, "mid")) {
+        printf("--- medium-batch tile kernel (32-column tiles, 256-deep K steps) ---\n");
+        eetq::f16 *xs, *ys;
+        CK(hipMalloc(&xs, 128ull * 13824 * 2));
+        CK(hipMalloc(&ys, 128ull * 13824 * 2));
+        {
+            std::vector<uint16_t> h(128ull * 13824);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
+            CK(hipMemcpy(xs, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        bench_mid<1, 3>("mid MT1 S3", 32, 4096, 4096, bufs, xs, scales, ys);
+        bench_mid<2, 3>("mid MT2 S3", 64, 4096, 4096, bufs, xs, scales, ys);
+        bench_mid<3, 2>("mid MT3 S2", 96, 4096, 4096, bufs, xs, scales, ys);
+        bench_mid<4, 2>("mid MT4 S2", 128, 4096, 4096, bufs, xs, scales, ys);
+        bench_mid<2, 2>("mid MT2 S2 N=11008", 64, 11008, 4096, bufs_big, xs, scales, ys);
+        bench_mid<2, 3>("mid MT2 S3 K=11008", 64, 4096, 11008, bufs_big, xs, scales, ys);
+        bench_mid<4, 2>("mid MT4 S2 N=11008", 128, 11008, 4096, bufs_big, xs, scales, ys);
+        bench_mid<1, 2>("mid MT1 S2 N=11008", 32, 11008, 4096, bufs_big, xs, scales, ys);
     }
     if (!strcmp(what, "all") || !strcmp(what, "streamk")) {
         printf("--- stream MFMA kernel with register-resident activations ---\n");
