@@ -240,7 +240,7 @@ def main():
             gemm_traffic = None
     gemm = {"metric": "dequant-GEMM TFLOPS @ M=1024, N=K=4096", "value": round(grp.world_size * args.gemm_steps * flops / gsec / 1e12, 2),
             "unit": "TFLOP/s", "steps": args.gemm_steps, "ms_per_step": round(gsec * 1e3 / args.gemm_steps, 5),
-            "roofline": {"kernel": "gemm_mfma8_kernel", "bound": "mfma", "achieved": round(flops / g_mean / 1e12, 2),
+            "roofline": {"kernel": "gemm_tile_kernel", "bound": "mfma", "achieved": round(flops / g_mean / 1e12, 2),
                          "peak": MFMA_F16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(flops / g_mean / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
                          "kernel_us_mean": round(g_mean * 1e6, 2), "kernel_us_min": round(g_min * 1e6, 2), "traffic": gemm_traffic,
                          "algorithmic_flops_per_launch": flops}}

@@ -17,10 +17,10 @@
 //     (LDS-DMA, no VGPR round trip), 6-stage ring, one s_barrier per K step, counted vmcnt;
 //   * A's LDS image is XOR-swizzled through the *source* address (key (row>>1)&7 on the 16-byte slot): ds_read_b128 of
 //     32 rows at one k offset is conflict-free; B's LDS image is the lane-linear global tile, conflict-free as is;
-//   * LDS -> register fragment reads and the dequant of the next K step are hand-placed in the shadow of the current
-//     step's MFMAs (sched_barrier-pinned issue order);
-//   * blockIdx -> tile mapping gives each XCD (own L2) a contiguous run of tiles, M fastest, so a weight panel is
-//     fetched from HBM by one XCD only.
+//   * LDS -> register fragment reads, the dequant of the next K step and the DMA of stage kt+5 are hand-placed in the
+//     shadow of the current step's MFMAs (sched_barrier-pinned issue order, see gemm_kernel.hpp);
+//   * blockIdx -> tile mapping gives each XCD (own L2) a contiguous run of tiles ordered in groups of 4 row tiles: the
+//     32 workgroups resident on an XCD cover 4 row tiles x 8 column tiles, the smallest fabric footprint per K step.
 #include "gemm_kernel.hpp"
 
 namespace eetq {
@@ -45,7 +45,7 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, const f1
     int                       dev           = 0;
     EETQ_TRY_HIP(hipGetDevice(&dev));
     if (!(attr_set_mask >> (dev & 63) & 1ull)) {
-        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<0, 2>),
+        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<0>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         attr_set_mask |= 1ull << (dev & 63);
     }
@@ -58,8 +58,7 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, const f1
     for (int m = 0; m < M; m += max_rows) {
         const int rows  = M - m < max_rows ? M - m : max_rows;
         const int tiles = ((rows + BM - 1) / BM) * ((N + BN - 1) / BN);
-        // J = 2: four wide waves (2 K halves x 2 column halves of 64), measured 2 % ahead of the 8-wave J = 1 form
-        launch_kernel(gemm_tile_kernel<0, 2>, dim3(tiles), dim3(256), SMEM_BYTES, stream, x + (size_t)m * K, w, scales, bias,
+        launch_kernel(gemm_tile_kernel<0>, dim3(tiles), dim3(256), SMEM_BYTES, stream, x + (size_t)m * K, w, scales, bias,
                       y + (size_t)m * N, rows, N, K);
         EETQ_TRY_HIP(hipGetLastError());
     }

@@ -27,34 +27,53 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, int
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_base, 16, voff, soff, 0, 0);
 }
 
+// Same with an instruction offset IMM (<= 4095): the hardware adds it to the LDS address AND to the buffer offset, so
+// pieces of one wave that are 1 KiB apart in LDS share one M0 value (their voff is pre-compensated by -IMM).
+template <int IMM>
+__device__ __forceinline__ void dma16_imm(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, uint8_t* lds_wave_base)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void*)lds_wave_base, 16, voff, soff, IMM, 0);
+}
+
+// 16-byte LDS read at an integer LDS address (the dynamic-LDS base is folded into the per-lane constants once)
+typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+__device__ __forceinline__ u32x4 lds_read16(int addr) { return *(lds_cu32x4*)(uintptr_t)(uint32_t)addr; }
+
 __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 {
     return f16x8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
 }
 
-// Workgroup tile 128 x 128 x 64.  The two 32-deep halves of every K step go to two wave groups; a wave owns 128 rows x
-// (32*J) columns of one K half.
-//   J = 1: 8 waves (2 groups x 4 column slices of 32), two waves per SIMD.
-//   J = 2: 4 waves (2 groups x 2 column slices of 64), one wave per SIMD, 128 fp32 accumulators per lane: every
-//          activation fragment read from LDS feeds two MFMAs, so the LDS read traffic of the A operand halves
-//          (72 -> 40 KiB per K step).  LDS reads + DMA writes were ~63 % of the LDS peak with J = 1.
-// The two groups' fp32 partial sums are added once at the end through LDS.  6-stage DMA ring, one barrier per K step.
-// ABLATE (kbench only): 1 = no DMA in the loop, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier
-template <int ABLATE, int J>
-__global__ __launch_bounds__(512 / J, J == 1 ? 2 : 1) void gemm_tile_kernel(
+// Workgroup tile 128 x 128 x 64, 4 waves = 2 K halves x 2 column halves: a wave owns 128 rows x 64 columns of one
+// 32-deep half of every K step (16 x v_mfma_f32_32x32x16_f16 per step, 128 fp32 accumulators per lane, one wave per
+// SIMD).  Every dequantised weight fragment feeds 4 MFMAs (row repeat), every activation fragment 2 (column repeat).
+// The two K halves' partial sums are added once at the end through LDS.  6-stage LDS-DMA ring, one barrier per K step.
+//
+// Where each instruction sits (one wave per SIMD hides roughly five single-issue instructions under one 32-cycle MFMA,
+// so the ~85 non-MFMA instructions of a K step are spread over its 16 MFMA gaps and pinned there with sched_barrier):
+//   * gap 0: the two weight reads; gaps 1..9: the eight activation fragment reads of the NEXT step;
+//   * gaps 4..15: the 48 int8->fp16 VALU ops as micro-ops, one kind (perm / -1152 / *scale) on four half-dwords per gap:
+//     four independent ops per gap, dependent ops a gap apart;
+//   * gaps 0,1,3,5,8,11: this wave's six LDS-DMA pieces of stage kt+5, spread over the step rather than bursting after
+//     the barrier (the CU's one address/data path needs ~430 cycles for a stage's 24 pieces);
+//   * every wave moves 4 activation + 2 weight pieces, so descriptors and source offsets are static per piece, and the
+//     pieces of one kind share one M0 (the instruction offset advances the LDS address and the buffer offset together);
+//   * gaps 12..15: ring offsets and LDS read addresses of the next step.
+// An earlier schedule (all reads in gaps 0..3, DMA in gaps 0..5, dequant 6 ops per gap in gaps 4..11, bookkeeping after
+// the last MFMA) ran 3 % slower; see profiles/r01_kbench_ablation_gemm.txt.
+// ABLATE (kbench only): 1 = no DMA, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier
+template <int ABLATE>
+__global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, const f16* __restrict__ bias,
     f16* __restrict__ y, int M, int N, int K)
 {
-    constexpr int NWAVES  = 8 / J;            // 2 K groups x (4 / J) column slices
-    constexpr int WN_COLS = 32 * J;           // columns per wave
-    constexpr int PIECES  = 24 / NWAVES;      // 16 A + 8 B LDS-DMA pieces of 1 KiB per stage, split over the waves
-    constexpr int NMFMA   = 8 * J;            // MFMAs per wave per K step
+    constexpr int J = 2, WN_COLS = 64, PIECES = 6, NMFMA = 16;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int grp  = wave / (NWAVES / 2);  // which 32-deep half of each K step
-    const int wn   = wave % (NWAVES / 2);  // which column slice of the tile
+    const int grp  = wave >> 1;  // which 32-deep half of each K step
+    const int wn   = wave & 1;   // which 64-column half of the tile
     const int KT   = K >> 6;
 
     const int tiles_m = (M + BM - 1) / BM;
@@ -65,50 +84,54 @@ __global__ __launch_bounds__(512 / J, J == 1 ? 2 : 1) void gemm_tile_kernel(
         const int b = blockIdx.x, q = T >> 3, r = T & 7, xcd = b & 7, idx = b >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int m0 = (tile % tiles_m) * BM;
-    const int n0 = (tile / tiles_m) * BN;
+    // tile order: row tiles in chunks of kGroupM, inside a chunk column-major.  The 32 workgroups resident on an
+    // XCD at a time are consecutive tiles = 4 row tiles x 8 column tiles: the footprint its L2 fetches over the fabric
+    // per K step (4 x 16 KiB activations + 8 x 8 KiB weights) is the smallest any 32-tile set has -- 64 MB per launch
+    // at M = 1024, N = K = 4096 instead of 84 MB for whole columns of row tiles.
+    constexpr int kGroupM = 4;
+    const int chunk   = tile / (kGroupM * tiles_n);
+    const int in_ch   = tile - chunk * (kGroupM * tiles_n);
+    const int ch_rows = tiles_m - chunk * kGroupM < kGroupM ? tiles_m - chunk * kGroupM : kGroupM;
+    const int m0 = (chunk * kGroupM + in_ch % ch_rows) * BM;
+    const int n0 = (in_ch / ch_rows) * BN;
 
-    const __amdgpu_buffer_rsrc_t x_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, (int)((size_t)M * K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(w), 0, (int)((size_t)N * K), 0x00020000);
-    // DMA pieces of this wave: global piece p = wave*PIECES + i; p < 16: A rows 8p..8p+7 (128 B each), else B tile p-16
-    int  dma_voff[PIECES];
+    // descriptors start kShift bytes below the operands: a piece's voff is pre-compensated by -(its instruction
+    // offset), and must stay non-negative for the hardware's range check
+    constexpr int kShift = 4096;
+    const __amdgpu_buffer_rsrc_t x_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<uint8_t*>(const_cast<f16*>(x)) - kShift, 0, (int)((size_t)M * K * 2) + kShift, 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t*>(w) - kShift, 0, (int)((size_t)N * K) + kShift, 0x00020000);
+    // DMA pieces of this wave: i < 4: activation piece 4*wave + i (rows 8p..8p+7, 128 B each); i >= 4: weight tile
+    // 2*wave + i - 4 of the stage's 8
+    int       dma_voff[PIECES];
     const int n_tiles_total = N >> 4;
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) {
-        const int p = wave * PIECES + i;
-        if (p < 16) {
-            const int row  = p * 8 + (lane >> 3);
-            const int slot = (lane & 7) ^ ((row >> 1) & 7);
-            int       gm   = m0 + row;
-            gm             = gm < M ? gm : M - 1;
-            dma_voff[i]    = (gm * K + slot * 8) * 2;
-        } else {
-            int nt      = (n0 >> 4) + (p - 16);
-            nt          = nt < n_tiles_total ? nt : n_tiles_total - 1;
-            dma_voff[i] = nt * KT * kTileBytes + lane * 16;
-        }
+    for (int i = 0; i < 4; ++i) {
+        const int p    = wave * 4 + i;
+        const int row  = p * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((row >> 1) & 7);
+        int       gm   = m0 + row;
+        gm             = gm < M ? gm : M - 1;
+        dma_voff[i]    = (gm * K + slot * 8) * 2 + kShift - i * 1024;
     }
-    auto dma_piece = [&](int i, int stage, int kt) {
-        const int p  = wave * PIECES + i;
-        uint8_t*  sa = smem + stage * STAGE_BYTES;
-        if (p < 16)
-            dma16(x_rsrc, dma_voff[i], kt * BK * 2, sa + p * 1024);
-        else
-            dma16(w_rsrc, dma_voff[i], kt * kTileBytes, sa + A_STAGE_BYTES + (p - 16) * 1024);
-    };
+#pragma unroll
+    for (int i = 4; i < PIECES; ++i) {
+        int nt      = (n0 >> 4) + wave * 2 + (i - 4);
+        nt          = nt < n_tiles_total ? nt : n_tiles_total - 1;
+        dma_voff[i] = nt * KT * kTileBytes + lane * 16 + kShift - (i - 4) * 1024;
+    }
+    const int dma_lds_a = wave * 4 * 1024;                    // + i * 1024
+    const int dma_lds_b = A_STAGE_BYTES + wave * 2 * 1024;    // + (i - 4) * 1024
 
     const int fn = lane & 31, fh = lane >> 5;
-    // weights of column block j: tile column wn*WN_COLS + 32j + fn -> chunk (col>>4), slot (2*grp+fh)*16 + (col&15)
-    int b_off[J];
-#pragma unroll
-    for (int j = 0; j < J; ++j)
-        b_off[j] = A_STAGE_BYTES + ((wn * WN_COLS + 32 * j + fn) >> 4) * 1024 + (fn & 15) * 16 + fh * 256 + grp * 512;
-    const int a_key     = (fn >> 1) & 7;
-    const int a_row_off = fn * 128;
-    const int a_slot0   = ((4 * grp + 2 * fh + 0) ^ a_key) << 4;
-    const int a_slot1   = ((4 * grp + 2 * fh + 1) ^ a_key) << 4;
+    const int a_key = (fn >> 1) & 7;
+    // per-lane constants of the LDS fragment reads (added to the stage offset)
+    const int lds0 = (int)(uint32_t)(uintptr_t)(lds_void*)smem;
+    const int c_a0 = lds0 + fn * 128 + (((4 * grp + 2 * fh + 0) ^ a_key) << 4);
+    const int c_a1 = lds0 + fn * 128 + (((4 * grp + 2 * fh + 1) ^ a_key) << 4);
+    const int c_b0 = lds0 + A_STAGE_BYTES + ((wn * WN_COLS + fn) >> 4) * 1024 + (fn & 15) * 16 + fh * 256 + grp * 512;
+    const int c_b1 = c_b0 + 2048;
 
     f16x2 scale2[J];
 #pragma unroll
@@ -134,149 +157,196 @@ __global__ __launch_bounds__(512 / J, J == 1 ? 2 : 1) void gemm_tile_kernel(
         f16x8 f[J][2];
     };
 
-    // One K step of one wave: NMFMA MFMAs on (wcur, fcur); in their shadow the LDS reads of the next K step's fragments
-    // (READ), the dequant of the freshly read weights, and this wave's DMA pieces of stage kt+STAGES-1 (DMA).
-    // Issue order (sched_barrier-pinned): slot i = MFMA i, then
-    //   i = 0: weight reads;  i < 4: two activation reads;  i < PIECES: one DMA piece;  4 <= i < 4+4J: one dword of dequant.
-    auto step = [&](const WFrag& wcur, const Frags& fcur, auto read_tag, int nstage, Frags& fnext, WFrag& wnext,
-                    auto dma_tag, int dma_stage, int dma_kt) {
+    // ring state of the step about to run (wave-uniform): rd = LDS offset of the stage whose fragments it reads
+    // (stage kt+1), wr = LDS offset its DMA fills (stage kt+5), ka / kb = source offsets of that stage
+    int rd = STAGE_BYTES, wr = (STAGES - 1) * STAGE_BYTES, ka = (STAGES - 1) * BK * 2, kb = (STAGES - 1) * kTileBytes;
+    int ra0 = rd + c_a0, ra1 = rd + c_a1, rb0 = rd + c_b0, rb1 = rd + c_b1;
+
+    auto dma_piece = [&](auto itag) {
+        constexpr int i = decltype(itag)::value;
+        if constexpr (i < 4)
+            dma16_imm<i * 1024>(x_rsrc, dma_voff[i], ka, smem + wr + dma_lds_a);
+        else
+            dma16_imm<(i - 4) * 1024>(w_rsrc, dma_voff[i], kb, smem + wr + dma_lds_b);
+    };
+
+    auto step = [&](const WFrag& wcur, const Frags& fcur, auto read_tag, Frags& fnext, WFrag& wnext, auto dma_tag) {
         constexpr bool READ = decltype(read_tag)::value;
         constexpr bool DMA  = decltype(dma_tag)::value;
-        const uint8_t* sa   = smem + nstage * STAGE_BYTES;
-        f16x2          wd[J][8];
+        u32            wd[J][8];
+        const f16x2    bias1152 = {(f16)1152.0f, (f16)1152.0f};
 #pragma unroll
         for (int i = 0; i < NMFMA; ++i) {
-            const int e = i / (4 * J), j = (i / 4) % J, mt = i & 3;
+            const int e = i >> 3, j = (i >> 2) & 1, mt = i & 3;
             if constexpr (!(ABLATE & 8))
                 acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur.f[j][e], fcur.xa[e][mt], acc[mt][j], 0, 0, 0);
-            else
-                asm volatile("" ::"v"(wcur.f[j][e]), "v"(fcur.xa[e][mt]));
+            __builtin_amdgcn_sched_barrier(0);  // the MFMA opens its gap: dependent VALU ops of adjacent gaps never abut
             if constexpr (READ && !(ABLATE & 4)) {
                 if (i == 0) {
-#pragma unroll
-                    for (int jj = 0; jj < J; ++jj) fnext.wq[jj] = *reinterpret_cast<const u32x4*>(sa + b_off[jj]);
+                    fnext.wq[0] = lds_read16(rb0);
+                    fnext.wq[1] = lds_read16(rb1);
                 }
-                if (i < 4) {
-                    const int ne = i >> 1;
+                // activation fragments q = 4e + mt: gap 1: q0; 2: q1,q2; 3: q3; 4: q4; 6: q5; 7: q6; 9: q7
+                auto xa_read = [&](int q) {
+                    fnext.xa[q >> 2][q & 3] =
+                        __builtin_bit_cast(f16x8, lds_read16(((q >> 2) ? ra1 : ra0) + (q & 3) * 32 * 128));
+                };
+                if (i == 1) xa_read(0);
+                if (i == 2) { xa_read(1); xa_read(2); }
+                if (i == 3) xa_read(3);
+                if (i == 4) xa_read(4);
+                if (i == 6) xa_read(5);
+                if (i == 7) xa_read(6);
+                if (i == 9) xa_read(7);
+            }
+            if constexpr (READ && !(ABLATE & 2)) {
+                if (i >= 4) {
+                    // dequant micro-ops: gap i works on column block jj = (i-4)/6, dword pair dp = ((i-4)/3)&1 and
+                    // applies ONE kind of op (perm / -1152 / *scale) to its four half-dwords: four independent VALU
+                    // ops per gap, dependent ops a gap apart (no hazard nops)
+                    const int jj = (i - 4) / 6, dp = ((i - 4) / 3) & 1, kind = (i - 4) % 3;
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
-                        const int nmt     = 2 * (i & 1) + t;
-                        fnext.xa[ne][nmt] = *reinterpret_cast<const f16x8*>(sa + nmt * 32 * 128 + a_row_off +
-                                                                            (ne ? a_slot1 : a_slot0));
+                    for (int u = 0; u < 4; ++u) {
+                        const int h = 4 * dp + u, d = h >> 1;
+                        if (kind == 0) {
+                            const u32 wdw = d == 0   ? fnext.wq[jj].x
+                                            : d == 1 ? fnext.wq[jj].y
+                                            : d == 2 ? fnext.wq[jj].z
+                                                     : fnext.wq[jj].w;
+                            wd[jj][h] = __builtin_amdgcn_perm(wdw, 0x64646464u, (h & 1) ? 0x00070005u : 0x00060004u);
+                        } else if (kind == 1) {
+                            wd[jj][h] = as_u32(as_f16x2(wd[jj][h]) - bias1152);
+                        } else {
+                            wd[jj][h] = as_u32(as_f16x2(wd[jj][h]) * scale2[jj]);
+                        }
                     }
-                } else if (i < 4 + 4 * J) {
-                    if constexpr (!(ABLATE & 2)) {
-                        const int jj = (i - 4) >> 2, d = (i - 4) & 3;
-                        const u32 wdw = d == 0   ? fnext.wq[jj].x
-                                        : d == 1 ? fnext.wq[jj].y
-                                        : d == 2 ? fnext.wq[jj].z
-                                                 : fnext.wq[jj].w;
-                        dequant_dword(wdw, scale2[jj], wd[jj][2 * d], wd[jj][2 * d + 1]);
-                        // pure VALU ops float freely through instruction selection; the empty asm pins them to this slot
-                        asm volatile("" : "+v"(wd[jj][2 * d]), "+v"(wd[jj][2 * d + 1]));
-                    }
+                    // pin the pure VALU ops to this gap (instruction selection would sink them to their uses); input-only
+                    // operands: an asm with VGPR outputs costs a hazard pad (s_nop) before the next instruction
+                    asm volatile("" ::"v"(wd[jj][4 * dp]), "v"(wd[jj][4 * dp + 1]), "v"(wd[jj][4 * dp + 2]),
+                                 "v"(wd[jj][4 * dp + 3]));
                 }
             }
             if constexpr (DMA && !(ABLATE & 1)) {
-                if (i < PIECES) dma_piece(i, dma_stage, dma_kt);
+                if (i == 0) dma_piece(std::integral_constant<int, 0>{});
+                if (i == 1) dma_piece(std::integral_constant<int, 1>{});
+                if (i == 3) dma_piece(std::integral_constant<int, 2>{});
+                if (i == 5) dma_piece(std::integral_constant<int, 3>{});
+                if (i == 8) dma_piece(std::integral_constant<int, 4>{});
+                if (i == 11) dma_piece(std::integral_constant<int, 5>{});
+            }
+            if constexpr (READ) {
+                // ring state and read addresses of the next step, in the gaps that carry little else
+                if (i == 12) {
+                    rd = rd + STAGE_BYTES == SMEM_BYTES ? 0 : rd + STAGE_BYTES;
+                    asm volatile("" : "+s"(rd));
+                }
+                if (i == 13) {
+                    wr = wr + STAGE_BYTES == SMEM_BYTES ? 0 : wr + STAGE_BYTES;
+                    ka += BK * 2;
+                    kb += kTileBytes;
+                    asm volatile("" : "+s"(wr), "+s"(ka), "+s"(kb));
+                }
+                if (i == 14) {
+                    ra0 = rd + c_a0;
+                    ra1 = rd + c_a1;
+                    asm volatile("" : "+v"(ra0), "+v"(ra1));
+                }
+                if (i == 15) {
+                    rb0 = rd + c_b0;
+                    rb1 = rd + c_b1;
+                    asm volatile("" : "+v"(rb0), "+v"(rb1));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        if constexpr (READ && !(ABLATE & 4)) {
+        if constexpr (READ && (ABLATE & 4)) fnext = fcur;
+        if constexpr (READ && (ABLATE & 2)) wnext = wcur;
+        if constexpr (READ && !(ABLATE & 2)) {
 #pragma unroll
             for (int jj = 0; jj < J; ++jj) {
-                if constexpr (!(ABLATE & 2)) {
-                    wnext.f[jj][0] = make_frag(wd[jj][0], wd[jj][1], wd[jj][2], wd[jj][3]);
-                    wnext.f[jj][1] = make_frag(wd[jj][4], wd[jj][5], wd[jj][6], wd[jj][7]);
-                } else {
-                    wnext.f[jj][0] = __builtin_bit_cast(f16x8, fnext.wq[jj]);
-                    wnext.f[jj][1] = __builtin_bit_cast(f16x8, fnext.wq[jj]);
-                }
+                wnext.f[jj][0] = make_frag(as_f16x2(wd[jj][0]), as_f16x2(wd[jj][1]), as_f16x2(wd[jj][2]), as_f16x2(wd[jj][3]));
+                wnext.f[jj][1] = make_frag(as_f16x2(wd[jj][4]), as_f16x2(wd[jj][5]), as_f16x2(wd[jj][6]), as_f16x2(wd[jj][7]));
             }
-            // the activation reads above are >= 4 MFMAs (128+ cycles) old: this wait is free, and it hands hipcc's
-            // wait-count pass an empty LDS queue at every step boundary (keeps its counted lgkmcnt waits exact)
-            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0), vmcnt/expcnt untouched
-        } else if constexpr (READ) {
-            wnext = wcur;
-            fnext = fcur;
+            __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): free here, keeps hipcc's counted LDS waits exact
         }
     };
 
     // ---- prologue: STAGES-1 stages in flight; stage 0 -> fragments ----
-    asm volatile("" ::"v"(scale2[0]));  // the (tiny) scale loads retire before LDS-DMA is queued behind them
+    asm volatile("" ::"v"(scale2[0]));
+    {
+        int pwr = 0, pka = 0, pkb = 0;
 #pragma unroll
-    for (int s = 0; s < STAGES - 1; ++s) {  // KT >= STAGES - 1 by launch contract
+        for (int s = 0; s < STAGES - 1; ++s) {  // KT >= STAGES - 1 by launch contract
 #pragma unroll
-        for (int i = 0; i < PIECES; ++i) dma_piece(i, s, s);
+            for (int i = 0; i < PIECES; ++i) {  // plain form: voff carries -IMM, so the LDS address gets it back here
+                if (i < 4)
+                    dma16(x_rsrc, dma_voff[i] + i * 1024, pka, smem + pwr + dma_lds_a + i * 1024);
+                else
+                    dma16(w_rsrc, dma_voff[i] + (i - 4) * 1024, pkb, smem + pwr + dma_lds_b + (i - 4) * 1024);
+            }
+            pwr += STAGE_BYTES;
+            pka += BK * 2;
+            pkb += kTileBytes;
+        }
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PIECES) : "memory");  // stage 0 landed
     __builtin_amdgcn_s_barrier();
     Frags f0, f1;
     WFrag w0, w1;
     {
+        f0.wq[0] = lds_read16(c_b0);
+        f0.wq[1] = lds_read16(c_b1);
 #pragma unroll
-        for (int j = 0; j < J; ++j) f0.wq[j] = *reinterpret_cast<const u32x4*>(smem + b_off[j]);
-#pragma unroll
-        for (int e = 0; e < 2; ++e)
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                f0.xa[e][mt] = *reinterpret_cast<const f16x8*>(smem + mt * 32 * 128 + a_row_off + (e ? a_slot1 : a_slot0));
+        for (int mt = 0; mt < 4; ++mt) {
+            f0.xa[0][mt] = __builtin_bit_cast(f16x8, lds_read16(c_a0 + mt * 32 * 128));
+            f0.xa[1][mt] = __builtin_bit_cast(f16x8, lds_read16(c_a1 + mt * 32 * 128));
+        }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
-            f16x2 wd[8];
-            dequant_16(f0.wq[j], scale2[j], wd);
-            w0.f[j][0] = make_frag(wd[0], wd[1], wd[2], wd[3]);
-            w0.f[j][1] = make_frag(wd[4], wd[5], wd[6], wd[7]);
+            f16x2 wdq[8];
+            dequant_16(f0.wq[j], scale2[j], wdq);
+            w0.f[j][0] = make_frag(wdq[0], wdq[1], wdq[2], wdq[3]);
+            w0.f[j][1] = make_frag(wdq[4], wdq[5], wdq[6], wdq[7]);
         }
         __builtin_amdgcn_s_waitcnt(0xC07F);
     }
 
     // REM = K steps after this one, clamped to STAGES-1.  REM >= STAGES-1: steady state (DMA for stage kt+STAGES-1).
-    int  stage = 0;
-    auto k_step = [&](int kt, auto rem_tag, const WFrag& wcur, const Frags& fcur, WFrag& wnext, Frags& fnext) {
-        constexpr int REM  = decltype(rem_tag)::value;
-        const int     next = stage + 1 == STAGES ? 0 : stage + 1;
+    auto k_step = [&](auto rem_tag, const WFrag& wcur, const Frags& fcur, WFrag& wnext, Frags& fnext) {
+        constexpr int REM = decltype(rem_tag)::value;
         if constexpr (REM >= 1) {
-            // stage kt+1 must have landed in LDS (all waves' pieces); younger stages stay in flight
             constexpr int younger = (REM - 1) < (STAGES - 3) ? (REM - 1) : (STAGES - 3);
             if constexpr (!(ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger * PIECES) : "memory");
             if constexpr (!(ABLATE & 16)) __builtin_amdgcn_s_barrier();
-            int dst = stage + STAGES - 1;
-            dst     = dst >= STAGES ? dst - STAGES : dst;
-            step(wcur, fcur, std::true_type{}, next, fnext, wnext, std::integral_constant<bool, (REM >= STAGES - 1)>{},
-                 dst, kt + STAGES - 1);
+            step(wcur, fcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= STAGES - 1)>{});
         } else {
-            step(wcur, fcur, std::false_type{}, 0, fnext, wnext, std::false_type{}, 0, 0);
+            step(wcur, fcur, std::false_type{}, fnext, wnext, std::false_type{});
         }
-        stage = next;
     };
     using Steady = std::integral_constant<int, STAGES - 1>;
-    // Main loop: two K steps per iteration so the two fragment sets alternate without register copies.  It stops
-    // 6 (KT even) or 5 (KT odd) steps before the end, so the drain below is fully static: no run-time choice of
-    // fragment set or of REM (both would push the fragment registers through scratch).  Needs KT >= 5.
     const int tail = (KT & 1) ? 5 : 6;
     int       kt   = 0;
     for (; kt < KT - tail; kt += 2) {
-        k_step(kt, Steady{}, w0, f0, w1, f1);
-        k_step(kt + 1, Steady{}, w1, f1, w0, f0);
+        k_step(Steady{}, w0, f0, w1, f1);
+        k_step(Steady{}, w1, f1, w0, f0);
     }
     if (tail == 6) {
-        k_step(kt, std::integral_constant<int, 5>{}, w0, f0, w1, f1);
-        k_step(kt + 1, std::integral_constant<int, 4>{}, w1, f1, w0, f0);
-        k_step(kt + 2, std::integral_constant<int, 3>{}, w0, f0, w1, f1);
-        k_step(kt + 3, std::integral_constant<int, 2>{}, w1, f1, w0, f0);
-        k_step(kt + 4, std::integral_constant<int, 1>{}, w0, f0, w1, f1);
-        k_step(kt + 5, std::integral_constant<int, 0>{}, w1, f1, w0, f0);
+        k_step(std::integral_constant<int, 5>{}, w0, f0, w1, f1);
+        k_step(std::integral_constant<int, 4>{}, w1, f1, w0, f0);
+        k_step(std::integral_constant<int, 3>{}, w0, f0, w1, f1);
+        k_step(std::integral_constant<int, 2>{}, w1, f1, w0, f0);
+        k_step(std::integral_constant<int, 1>{}, w0, f0, w1, f1);
+        k_step(std::integral_constant<int, 0>{}, w1, f1, w0, f0);
     } else {
-        k_step(kt, std::integral_constant<int, 4>{}, w0, f0, w1, f1);
-        k_step(kt + 1, std::integral_constant<int, 3>{}, w1, f1, w0, f0);
-        k_step(kt + 2, std::integral_constant<int, 2>{}, w0, f0, w1, f1);
-        k_step(kt + 3, std::integral_constant<int, 1>{}, w1, f1, w0, f0);
-        k_step(kt + 4, std::integral_constant<int, 0>{}, w0, f0, w1, f1);
+        k_step(std::integral_constant<int, 4>{}, w0, f0, w1, f1);
+        k_step(std::integral_constant<int, 3>{}, w1, f1, w0, f0);
+        k_step(std::integral_constant<int, 2>{}, w0, f0, w1, f1);
+        k_step(std::integral_constant<int, 1>{}, w1, f1, w0, f0);
+        k_step(std::integral_constant<int, 0>{}, w0, f0, w1, f1);
     }
 
     // ---- combine the two K halves: group 1 parks its accumulators in LDS, group 0 adds and stores ----
-    __builtin_amdgcn_s_barrier();  // every wave is done with the stage ring
+    __builtin_amdgcn_s_barrier();
     float* red = reinterpret_cast<float*>(smem) + (size_t)wn * (64 * J) * 64;  // [reg][lane]
     if (grp == 1) {
 #pragma unroll
@@ -295,16 +365,15 @@ __global__ __launch_bounds__(512 / J, J == 1 ? 2 : 1) void gemm_tile_kernel(
             for (int j = 0; j < J; ++j) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[mt][j][r] += red[((mt * J + j) * 16 + r) * 64 + lane];
-                // acc[mt][j][r] = y[m0 + 32*mt + fn][n0 + wn*WN_COLS + 32*j + 8*(r>>2) + 4*fh + (r&3)]
                 const int nbase = n0 + wn * WN_COLS + 32 * j + 4 * fh;
                 if (m < M) {
                     f16* yrow = y + (size_t)m * N + nbase;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        if (nbase + 8 * q < N) {  // N % 16 == 0: a group of 4 columns is all-in or all-out
+                        if (nbase + 8 * q < N) {
                             f16x2 lo = {(f16)acc[mt][j][4 * q + 0], (f16)acc[mt][j][4 * q + 1]};
                             f16x2 hi = {(f16)acc[mt][j][4 * q + 2], (f16)acc[mt][j][4 * q + 3]};
-                            if (bias) {  // fp16 add after the fp16 rounding: bit-identical to a separate `+ bias`
+                            if (bias) {
                                 const u32x2 b = *reinterpret_cast<const u32x2*>(bias + nbase + 8 * q);
                                 lo            = lo + as_f16x2(b.x);
                                 hi            = hi + as_f16x2(b.y);

@@ -163,30 +163,23 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
            name, N, K, M, st.mean, st.med, st.mn, st.p90, bytes / st.med / 1e3, g, bytes / g / 1e3);
 }
 
-template <int ABLATE, int J = 1>
-static void bench_gemm8(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
+template <int ABLATE>
+static void bench_gemm(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
                         const eetq::f16* scales, eetq::f16* y)
 {
     using namespace eetq::gemm;
-    auto kern = gemm_tile_kernel<ABLATE, J>;
-    constexpr int THREADS8 = 512 / J;
+    auto kern = gemm_tile_kernel<ABLATE>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     const int    tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const double flops = 2.0 * M * N * K;
     auto         st    = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
-            hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS8), SMEM_BYTES, 0, a, b, 0, x,
+            hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(256), SMEM_BYTES, 0, a, b, 0, x,
                                   (const uint8_t*)bufs[i % bufs.size()], scales, (const eetq::f16*)nullptr, y, M, N, K);
         },
         60, 10);
-    double g = time_graph(
-        [&](int i, hipStream_t s) {
-            hipLaunchKernelGGL(kern, dim3(tiles), dim3(THREADS8), SMEM_BYTES, s, x, (const uint8_t*)bufs[i % bufs.size()],
-                               scales, (const eetq::f16*)nullptr, y, M, N, K);
-        },
-        40);
-    printf("%-22s M=%5d N=%5d K=%5d | disp mean %7.2f med %7.2f min %7.2f us -> %7.1f TF(med) | graph %7.2f us/step -> %7.1f TF\n",
-           name, M, N, K, st.mean, st.med, st.mn, flops / st.med / 1e6, g, flops / g / 1e6);
+    printf("%-22s M=%5d N=%5d K=%5d | disp mean %7.2f med %7.2f min %7.2f us -> %7.1f TF(med)\n", name, M, N, K, st.mean,
+           st.med, st.mn, flops / st.med / 1e6);
 }
 
 template <int MT, int NT, int WAVES, int D, int OCC>
@@ -226,6 +219,67 @@ static void bench_mid(const char* name, int M, int N, int K, const std::vector<u
         200);
     printf("%-22s N=%5d K=%5d M=%3d | disp mean %6.2f med %6.2f min %6.2f us -> %6.0f GB/s(med) %7.1f TF\n", name, N, K, M,
            st.mean, st.med, st.mn, bytes / st.med / 1e3, 2.0 * M * N * K / st.med / 1e6);
+}
+
+
+// ---- data-path probe: how many bytes per second can one CU pull from L2 (a) into LDS by LDS-DMA, (b) into registers?
+// Every workgroup streams PER_WG bytes out of a `region`-byte window (window <= 4 MiB: L2-resident after the first pass;
+// 8 MiB: the M=1024 GEMM's activation matrix, served by L2 + Infinity Cache).  PATTERN 0: contiguous 1 KiB per wave
+// instruction (weight tiles);  PATTERN 1: 8 rows x 128 B at an 8 KiB row stride (activation tile of the tiled GEMM).
+template <int MODE, int PATTERN, int WAVES>
+__global__ __launch_bounds__(WAVES * 64) void datapath_kernel(const uint8_t* __restrict__ src, unsigned* __restrict__ out,
+                                                             int region, int per_wg)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(src), 0, region, 0x00020000);
+    const int pieces = per_wg / 1024 / WAVES;  // per wave
+    // workgroups of one XCD start at different offsets of the window, like tiles of different rows / columns
+    unsigned pos = (blockIdx.x * 37u + wave) * 1024u;
+    const int voff = PATTERN == 0 ? lane * 16 : (lane >> 3) * 8192 + (lane & 7) * 16;
+    u32x4 acc = {0, 0, 0, 0};
+    constexpr int RING = 8;
+    for (int i = 0; i < pieces; i += RING) {
+#pragma unroll
+        for (int r = 0; r < RING; ++r) {
+            unsigned base;
+            if (PATTERN == 0) {
+                base = pos % (unsigned)region;
+                pos += WAVES * 1024u;
+            } else {  // piece = 8 rows x 128 B: walk 128-B column blocks of an 8-row band, then the next band
+                const unsigned pc = pos >> 10, band = pc >> 6, col = pc & 63;
+                base = (band * 65536u + col * 128u) % (unsigned)(region - 65536);
+                pos += WAVES * 1024u;
+            }
+            if (MODE == 0) {
+                eetq::gemm::dma16(rsrc, voff, (int)base, smem + (wave * RING + r) * 1024);
+            } else {
+                const u32x4 v = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, (int)base, 0));
+                acc.x ^= v.x; acc.y ^= v.y; acc.z ^= v.z; acc.w ^= v.w;
+            }
+        }
+        if (MODE == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(RING) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (MODE == 0) acc.x = reinterpret_cast<unsigned*>(smem)[tid];
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678u) out[0] = 1;
+}
+
+template <int MODE, int PATTERN, int WAVES>
+static void bench_datapath(const char* name, const uint8_t* src, unsigned* out, int region, int per_wg, int grid = 256)
+{
+    auto kern = datapath_kernel<MODE, PATTERN, WAVES>;
+    const unsigned smem = MODE == 0 ? WAVES * 8 * 1024 : 1024 * 4;
+    if (smem > 64 * 1024) CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+    auto st = time_dispatch(
+        [&](int, hipEvent_t a, hipEvent_t b) {
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), smem, 0, a, b, 0, src, out, region, per_wg);
+        },
+        40, 10);
+    const double bytes = (double)per_wg * grid;
+    printf("%-34s grid %3d region %5d KiB %5d KiB/WG | med %7.2f us -> %6.1f GB/s per CU, %6.2f TB/s total\n", name, grid,
+           region >> 10, per_wg >> 10, st.med, per_wg / st.med / 1e3, bytes / st.med / 1e6);
 }
 
 int main(int argc, char** argv)
@@ -300,7 +354,7 @@ int main(int argc, char** argv)
         bench_gemv<4, 16, 4, false, false, 8, 4>("M4 loop lds 16x4 o4", 4096, 11008, bufs_big, x, scales, y);
     }
     if (!strcmp(what, "all") || !strcmp(what, "gemm")) {
-        printf("--- MFMA dequant-GEMM ---\n");
+        printf("--- MFMA dequant-GEMM (128 x 128 x 64 tile, 4 waves) ---\n");
         eetq::f16 *xg, *yg;
         CK(hipMalloc(&xg, 8192ull * 4096 * 2));
         CK(hipMalloc(&yg, 8192ull * 11008 * 2));
@@ -309,25 +363,22 @@ int main(int argc, char** argv)
             for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));  // +-[0.125, 0.5)
             CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         }
-        bench_gemm8<0>("gemm8 (8 waves)", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<0, 2>("gemm J=2 (4 wide waves)", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<0>("gemm8 (8 waves) again", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<0, 2>("gemm J=2 again", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<0, 2>("gemm J=2", 4096, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<0, 2>("gemm J=2", 1024, 11008, 4096, bufs_big, xg, scales, yg);
-        bench_gemm8<1>("gemm8 -dma", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<2>("gemm8 -dequant", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<4>("gemm8 -ldsread", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<8>("gemm8 -mfma", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<17>("gemm8 -dma -barrier", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<7>("gemm8 mfma only+bar", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<23>("gemm8 mfma only", 1024, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<23>("gemm8 mfma only M=64", 64, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<1>("gemm8 -dma M=64", 64, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<0>("gemm8 (8 waves)", 4096, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<0>("gemm8 (8 waves)", 8192, 4096, 4096, bufs, xg, scales, yg);
-        bench_gemm8<0>("gemm8 (8 waves)", 1024, 11008, 4096, bufs_big, xg, scales, yg);
-        bench_gemm8<0>("gemm8 (8 waves)", 64, 4096, 4096, bufs, xg, scales, yg);
+        for (int rep = 0; rep < 3; ++rep) bench_gemm<0>("gemm", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<0>("gemm", 4096, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<0>("gemm", 8192, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<0>("gemm", 1024, 11008, 4096, bufs_big, xg, scales, yg);
+        bench_gemm<0>("gemm", 256, 4096, 4096, bufs, xg, scales, yg);
+        printf("ablations (numerically wrong on purpose; they locate the time)\n");
+        bench_gemm<1>("gemm -dma", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<2>("gemm -dequant", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<4>("gemm -ldsread", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<8>("gemm -mfma", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<6>("gemm mfma+dma", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<7>("gemm mfma+barrier", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<23>("gemm mfma only", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<14>("gemm dma+barrier only", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<30>("gemm dma only", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<9>("gemm ldsread+dequant", 1024, 4096, 4096, bufs, xg, scales, yg);
     }
     if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
         eetq::f16 *xg, *yg;
@@ -337,8 +388,8 @@ int main(int argc, char** argv)
         for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
         CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         using namespace eetq::gemm;
-        auto kern = gemm_tile_kernel<0, 1>;
-        constexpr int THREADS8 = 512;
+        auto kern = gemm_tile_kernel<0>;
+        constexpr int THREADS8 = 256;
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         for (int i = 0; i < 20; ++i)
             hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
@@ -398,46 +449,6 @@ int main(int argc, char** argv)
             bench_streamk<1, 1, 16, 4, 8>("MT1 16x4 o8 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
             bench_streamk<1, 1, 8, 4, 8>("MT1 8x4 o8 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
         }
-    }
-    if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
-        eetq::f16 *xg, *yg;
-        CK(hipMalloc(&xg, 1024ull * 4096 * 2));
-        CK(hipMalloc(&yg, 1024ull * 4096 * 2));
-        std::vector<uint16_t> h(1024ull * 4096);
-        for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
-        CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-        using namespace eetq::gemm;
-        auto kern = gemm_tile_kernel<0, 1>;
-        constexpr int THREADS8 = 512;
-        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
-        for (int i = 0; i < 20; ++i)
-            hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
-                               (const eetq::f16*)nullptr, yg, 1024, 4096, 4096);
-        CK(hipDeviceSynchronize());
-        auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
-        for (int i = 0; i < 20; ++i)
-            hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, (const eetq::f16*)nullptr, y, 4096, 4096);
-        CK(hipDeviceSynchronize());
-    }
-    if (!strcmp(what, "all") || !strcmp(what, "mid")) {
-        printf("--- medium-batch tile kernel (32-column tiles, 256-deep K steps) ---\n");
-        eetq::f16 *xs, *ys;
-        CK(hipMalloc(&xs, 128ull * 13824 * 2));
-        CK(hipMalloc(&ys, 128ull * 13824 * 2));
-        {
-            std::vector<uint16_t> h(128ull * 13824);
-            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
-            CK(hipMemcpy(xs, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-        }
-        bench_mid<1, 3>("mid MT1 S3", 32, 4096, 4096, bufs, xs, scales, ys);
-        bench_mid<2, 3>("mid MT2 S3", 64, 4096, 4096, bufs, xs, scales, ys);
-        bench_mid<3, 2>("mid MT3 S2", 96, 4096, 4096, bufs, xs, scales, ys);
-        bench_mid<4, 2>("mid MT4 S2", 128, 4096, 4096, bufs, xs, scales, ys);
-        bench_mid<2, 2>("mid MT2 S2 N=11008", 64, 11008, 4096, bufs_big, xs, scales, ys);
-        bench_mid<2, 3>("mid MT2 S3 K=11008", 64, 4096, 11008, bufs_big, xs, scales, ys);
-        bench_mid<4, 2>("mid MT4 S2 N=11008", 128, 11008, 4096, bufs_big, xs, scales, ys);
-        bench_mid<1, 2>("mid MT1 S2 N=11008", 32, 11008, 4096, bufs_big, xs, scales, ys);
     }
     if (!strcmp(what, "all") || !strcmp(what, "streamk")) {
         printf("--- stream MFMA kernel with register-resident activations ---\n");
