@@ -7,17 +7,17 @@ namespace eetq {
 
 namespace {
 
-template <int MT, int WAVES, int D, int OCC>
+template <int MT, int NT, int WAVES, int D, int OCC>
 int launch_inst(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
                 hipStream_t stream)
 {
-    auto         kern = streamk::streamk_kernel<MT, 1, WAVES, D, OCC>;
-    const size_t smem = streamk::streamk_smem_bytes(MT, 1, WAVES);
+    auto         kern = streamk::streamk_kernel<MT, NT, WAVES, D, OCC>;
+    const size_t smem = streamk::streamk_smem_bytes(MT, NT, WAVES);
     if (smem > 64 * 1024) {
         EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
     }
-    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, bias, y, M, N, K);
+    launch_kernel(kern, dim3(N / (kTileN * NT)), dim3(WAVES * 64), smem, stream, x, w, scales, bias, y, M, N, K);
     return check_hip(hipGetLastError(), "streamk_kernel launch");
 }
 
@@ -26,10 +26,19 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, const f16* bias
                 hipStream_t stream)
 {
     const int KT = K / kTileK;  // every wave must own >= D k tiles
-    if (KT >= 32) return launch_inst<MT, 16, 2, 4>(x, w, scales, bias, y, M, N, K, stream);
-    if (KT >= 16) return launch_inst<MT, 8, 2, 2>(x, w, scales, bias, y, M, N, K, stream);
-    if (KT >= 4) return launch_inst<MT, 4, 1, 1>(x, w, scales, bias, y, M, N, K, stream);
-    return launch_inst<MT, 1, 1, 1>(x, w, scales, bias, y, M, N, K, stream);
+    if (KT >= 32) {
+        // every workgroup re-reads the activations (M x K fp16 from L2) for its columns: where two tile rows per
+        // workgroup still give every CU a workgroup, share each activation fragment between them
+        // (M = 8, N = 22016: 24.5 -> 17.0 us; N = 4096: 5.3 -> 5.8 us, so not there: profiles/r01_kbench_streamk_nt.txt)
+        if constexpr (MT == 1) {
+            if (N % (2 * kTileN) == 0 && N / (2 * kTileN) >= 256)
+                return launch_inst<MT, 2, 16, 2, 4>(x, w, scales, bias, y, M, N, K, stream);
+        }
+        return launch_inst<MT, 1, 16, 2, 4>(x, w, scales, bias, y, M, N, K, stream);
+    }
+    if (KT >= 16) return launch_inst<MT, 1, 8, 2, 2>(x, w, scales, bias, y, M, N, K, stream);
+    if (KT >= 4) return launch_inst<MT, 1, 4, 1, 1>(x, w, scales, bias, y, M, N, K, stream);
+    return launch_inst<MT, 1, 1, 1, 1>(x, w, scales, bias, y, M, N, K, stream);
 }
 
 }  // namespace

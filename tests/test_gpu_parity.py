@@ -136,6 +136,20 @@ def test_gemv_vs_oracle(ops, oracle, M, K, N):
                                           np.argwhere(~ok)[:4])
 
 
+@pytest.mark.parametrize("M", [2, 8, 13, 16])
+@pytest.mark.parametrize("K,N", [(2048, 8192), (2112, 8256), (2048, 8208)])
+def test_stream_wide_n_vs_oracle(ops, oracle, M, K, N):
+    """N / 32 >= 256 and N % 32 == 0: two 16-column tile rows per workgroup share the activation fragments (8208 is the
+    N % 32 != 0 fallback to one tile row)."""
+    w, x = _rand_case(K, N, M, seed=7 * K + N + M)
+    x[:, 1::2] *= -1
+    y, q, s = _run_gemm(ops, oracle, w, x, path="stream")
+    ref = oracle.w8a16_gemm(x, q, s)
+    ok = _tier_a(y, ref)
+    assert ok.all(), "max err %g at %s" % (np.abs(y.astype(np.float32) - ref.astype(np.float32)).max(),
+                                          np.argwhere(~ok)[:4])
+
+
 @pytest.mark.parametrize("M", [1, 2, 3, 4, 5, 8, 15, 16, 17, 31, 33, 48, 64])
 @pytest.mark.parametrize("K,N", [(64, 16), (128, 48), (1024, 256), (4096, 512), (11008, 64), (2048, 32), (2112, 16)])
 def test_stream_mfma_vs_oracle(ops, oracle, M, K, N):

@@ -436,6 +436,22 @@ int main(int argc, char** argv)
         std::vector<uint8_t*> bufs_huge;
         for (int i = 0; i < 12; ++i) bufs_huge.push_back(huge + (size_t)i * 4096 * 22016);
         CK(hipMemset(huge, 0x5a, 4096ull * 22016 * 12));
+        for (int M : {8, 16}) {
+            printf("NT sweep M=%d\n", M);
+            bench_streamk<1, 1, 16, 2, 4>("NT1 16x2 o4 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 2, 16, 2, 4>("NT2 16x2 o4 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 2, 16, 2, 2>("NT2 16x2 o2 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 2, 8, 4, 4>("NT2 8x4 o4 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 4, 16, 2, 2>("NT4 16x2 o2 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 4, 8, 4, 2>("NT4 8x4 o2 N=22016", M, 22016, 4096, bufs_huge, xs, scales, ys);
+            bench_streamk<1, 1, 16, 2, 4>("NT1 16x2 o4 N=11008", M, 11008, 4096, bufs_big, xs, scales, ys);
+            bench_streamk<1, 2, 16, 2, 4>("NT2 16x2 o4 N=11008", M, 11008, 4096, bufs_big, xs, scales, ys);
+            bench_streamk<1, 2, 8, 4, 4>("NT2 8x4 o4 N=11008", M, 11008, 4096, bufs_big, xs, scales, ys);
+            bench_streamk<1, 1, 16, 2, 4>("NT1 16x2 o4 K=11008", M, 4096, 11008, bufs_big, xs, scales, ys);
+            bench_streamk<1, 1, 16, 4, 4>("NT1 16x4 o4 K=11008", M, 4096, 11008, bufs_big, xs, scales, ys);
+            bench_streamk<1, 1, 16, 4, 2>("NT1 16x4 o2 K=11008", M, 4096, 11008, bufs_big, xs, scales, ys);
+        }
+        if (argc > 2)
         for (int M : {4, 8}) {
             printf("M=%d\n", M);
             bench_streamk<1, 1, 16, 2, 4>("MT1 16x2 o4 (shipping)", M, 4096, 4096, bufs, xs, scales, ys);
