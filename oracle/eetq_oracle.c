@@ -25,8 +25,11 @@
  *   - examples/layers/test_qlinear.py:20-36  (atol=1e-2 vs torch fp16 nn.Linear, seed 1, 128x1024x4096)
  *   - examples/layers/test_w8a16_gemm.py:33-41 (preprocess_weights(raw) == processed from quant_weights)
  * and against the CPU torch.nn.Linear fp16 forward that BASELINE.json names as config[0]; see
- * tests/test_oracle.py.  Bit-level behaviour of quantise/pack beyond that is restated from the source
- * lines cited above: for those bytes, parity is "restated, unpinned by a reference build".
+ * tests/test_oracle.py.  One known answer of the compiled reference survives in SURVEY.md (section 7,
+ * Appendix A): 208 of 32768 values differ from half-to-even rounding on a seed-1 fp16 Linear(256->128);
+ * the oracle reproduces it (test_round_half_even_would_differ).  Bit-level behaviour of quantise/pack
+ * beyond that is restated from the source lines cited above: for those bytes, parity is "restated,
+ * unpinned by a reference build".
  */
 #include <math.h>
 #include <stddef.h>

@@ -380,6 +380,35 @@ int main(int argc, char** argv)
         bench_gemm<30>("gemm dma only", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm<9>("gemm ldsread+dequant", 1024, 4096, 4096, bufs, xg, scales, yg);
     }
+    if (!strcmp(what, "gemv13b")) {  // Llama-13B shapes: workgroup-count quantisation and kernel variants
+        uint8_t* huge;
+        CK(hipMalloc(&huge, 13824ull * 5120 * 8));
+        CK(hipMemset(huge, 0x5a, 13824ull * 5120 * 8));
+        std::vector<uint8_t*> b70;
+        for (int i = 0; i < 8; ++i) b70.push_back(huge + (size_t)i * 13824 * 5120);
+        eetq::f16* xl;
+        CK(hipMalloc(&xl, 4 * 13824 * 2));
+        CK(hipMemset(xl, 0x30, 4 * 13824 * 2));
+        printf("--- K=5120, N sweep (generic loop kernel 16x2 o8) ---\n");
+        for (int N : {4096, 5120, 6144, 8192, 13824})
+            bench_gemv<1, 16, 2, false, false, 2, 8>("loop lds 16x2 o8", N, 5120, b70, xl, scales, y);
+        printf("--- N=5120 K=5120 variants ---\n");
+        bench_gemv<1, 16, 4, false, false, 2, 8>("loop lds 16x4 o8", 5120, 5120, b70, xl, scales, y);
+        bench_gemv<1, 16, 5, true, false, 2, 8>("exact lds 16x5 o8", 5120, 5120, b70, xl, scales, y);
+        bench_gemv<1, 16, 5, true, true, 1, 8>("exact xreg 16x5 o8", 5120, 5120, b70, xl, scales, y);
+        bench_gemv<1, 16, 5, true, true, 1, 4>("exact xreg 16x5 o4", 5120, 5120, b70, xl, scales, y);
+        bench_gemv<1, 8, 5, false, false, 2, 8>("loop lds 8x5 o8", 5120, 5120, b70, xl, scales, y);
+        bench_gemv<1, 8, 10, true, true, 1, 4>("exact xreg 8x10 o4", 5120, 5120, b70, xl, scales, y);
+        printf("--- N=5120 K=13824 variants ---\n");
+        bench_gemv<1, 16, 2, false, false, 4, 8>("loop lds 16x2 o8", 5120, 13824, b70, xl, scales, y);
+        bench_gemv<1, 16, 4, false, false, 4, 8>("loop lds 16x4 o8", 5120, 13824, b70, xl, scales, y);
+        bench_gemv<1, 16, 4, false, false, 4, 4>("loop lds 16x4 o4", 5120, 13824, b70, xl, scales, y);
+        bench_gemv<1, 8, 4, false, false, 4, 8>("loop lds 8x4 o8", 5120, 13824, b70, xl, scales, y);
+        bench_gemv<1, 8, 8, false, false, 4, 4>("loop lds 8x8 o4", 5120, 13824, b70, xl, scales, y);
+        printf("--- N=13824 K=5120 ---\n");
+        bench_gemv<1, 16, 2, false, false, 2, 8>("loop lds 16x2 o8", 13824, 5120, b70, xl, scales, y);
+        bench_gemv<1, 16, 5, true, true, 1, 8>("exact xreg 16x5 o8", 13824, 5120, b70, xl, scales, y);
+    }
     if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
         eetq::f16 *xg, *yg;
         CK(hipMalloc(&xg, 1024ull * 4096 * 2));
