@@ -218,16 +218,19 @@ int eetq_unpack_i8_host(const int8_t* q_packed, size_t K, size_t N, int8_t* q_ra
     return relayout_host(q_packed, K, N, q_raw, layout, false);
 }
 
-static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scales, const void* bias, void* y, int M,
-                         int N, int K, int path, void* stream)
+static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scales, const void* bias,
+                         const void* residual, void* y, int M, int N, int K, int path, void* stream)
 {
     int st = check_gemm_args(x, w_packed, scales, y, M, N, K);
     if (st != EETQ_OK) return st;
     EETQ_REQUIRE(!bias || (uintptr_t)bias % 8 == 0, "bias must be 8-byte aligned");
+    EETQ_REQUIRE(!residual || (uintptr_t)residual % 8 == 0, "residual must be 8-byte aligned");
     const f16*     xp = static_cast<const f16*>(x);
     const uint8_t* wp = reinterpret_cast<const uint8_t*>(w_packed);
     const f16*     sp = static_cast<const f16*>(scales);
-    const f16*     bp = static_cast<const f16*>(bias);
+    Epilogue       bp;
+    bp.bias     = static_cast<const f16*>(bias);
+    bp.residual = static_cast<const f16*>(residual);
     f16*           yp = static_cast<f16*>(y);
     hipStream_t    s  = static_cast<hipStream_t>(stream);
     switch (path) {
@@ -252,19 +255,25 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
 int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N, int K,
                        int path, void* stream)
 {
-    return gemm_dispatch(x, w_packed, scales, nullptr, y, M, N, K, path, stream);
+    return gemm_dispatch(x, w_packed, scales, nullptr, nullptr, y, M, N, K, path, stream);
 }
 
 int eetq_w8a16_gemm(const void* x, const int8_t* w_packed, const void* scales, void* y, int M, int N, int K,
                     void* stream)
 {
-    return gemm_dispatch(x, w_packed, scales, nullptr, y, M, N, K, EETQ_PATH_AUTO, stream);
+    return gemm_dispatch(x, w_packed, scales, nullptr, nullptr, y, M, N, K, EETQ_PATH_AUTO, stream);
 }
 
 int eetq_w8a16_gemm_bias(const void* x, const int8_t* w_packed, const void* scales, const void* bias, void* y, int M,
                          int N, int K, int path, void* stream)
 {
-    return gemm_dispatch(x, w_packed, scales, bias, y, M, N, K, path, stream);
+    return gemm_dispatch(x, w_packed, scales, bias, nullptr, y, M, N, K, path, stream);
+}
+
+int eetq_w8a16_gemm_fused(const void* x, const int8_t* w_packed, const void* scales, const void* bias,
+                          const void* residual, void* y, int M, int N, int K, int path, void* stream)
+{
+    return gemm_dispatch(x, w_packed, scales, bias, residual, y, M, N, K, path, stream);
 }
 
 int eetq_rmsnorm_f16(const void* x, const void* gamma, void* out, float eps, int rows, int cols, void* stream)
@@ -277,8 +286,17 @@ int eetq_rotary_neox_f16(const int64_t* positions, void* query, void* key, const
                          int heads, int head_size, int rot_dim, void* stream)
 {
     return launch_rotary(positions, static_cast<f16*>(query), static_cast<f16*>(key),
-                         static_cast<const f16*>(cos_sin_cache), tokens, heads, head_size, rot_dim,
-                         static_cast<hipStream_t>(stream));
+                         static_cast<const f16*>(cos_sin_cache), tokens, heads, heads, head_size, rot_dim,
+                         heads * head_size, heads * head_size, static_cast<hipStream_t>(stream));
+}
+
+int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
+                                 int tokens, int q_heads, int k_heads, int head_size, int rot_dim, int q_stride,
+                                 int k_stride, void* stream)
+{
+    return launch_rotary(positions, static_cast<f16*>(query), static_cast<f16*>(key),
+                         static_cast<const f16*>(cos_sin_cache), tokens, q_heads, k_heads, head_size, rot_dim, q_stride,
+                         k_stride, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

@@ -68,6 +68,14 @@ __device__ __forceinline__ void dequant_16(const u32x4& w, f16x2 scale2, f16x2 (
     dequant_dword(w.w, scale2, out[6], out[7]);
 }
 
+// ---- fused epilogue operands (either may be null).  y = fp16(acc) [+ bias[n]] [+ residual[m][n]], every step rounded to
+// fp16: bit-identical to the reference's separate `output + bias` (qlinear.py:61) and to a separate residual add
+// (FT's bias / residual epilogues, cutlass_kernels/fpA_intB_gemm.cu:35-97, are the reference's fused counterpart).
+struct Epilogue {
+    const f16* bias     = nullptr;  // [N]
+    const f16* residual = nullptr;  // [M][N], row stride N; must not alias y unless it is y itself element for element
+};
+
 // ---- launch helper: optionally attaches per-dispatch begin/end timestamps (eetq_prof_begin/_end) ---------
 struct ProfEvents {
     hipEvent_t start = nullptr, stop = nullptr;
@@ -89,23 +97,23 @@ int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_ra
                     int layout, void* scales, float* colmax, hipStream_t stream);
 int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
 int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
-int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream);
-int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                      hipStream_t stream);
 int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows, int cols, hipStream_t stream);
-int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int heads, int head_size,
-                  int rot_dim, hipStream_t stream);
+int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int q_heads, int k_heads,
+                  int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream);
 
 int  launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t stream);
 
-int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                     hipStream_t stream);
 
 constexpr int kGemvMaxM   = 4;
 constexpr int kStreamMaxM = 64;
 constexpr int kMidMaxM    = 128;
-int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                     hipStream_t stream);
 
 }  // namespace eetq

@@ -27,7 +27,7 @@ namespace eetq {
 
 using namespace gemm;
 
-int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                      hipStream_t stream)
 {
     if (K / BK < kMinKSteps) {
@@ -35,7 +35,9 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, const f1
         // second tiled kernel for it (the weights are re-read from L2, the activations are read once)
         for (int m = 0; m < M; m += kStreamMaxM) {
             const int rows = M - m < kStreamMaxM ? M - m : kStreamMaxM;
-            int       st   = launch_streamk(x + (size_t)m * K, w, scales, bias, y + (size_t)m * N, rows, N, K, stream);
+            Epilogue  e    = ep;
+            if (e.residual) e.residual += (size_t)m * N;
+            int       st   = launch_streamk(x + (size_t)m * K, w, scales, e, y + (size_t)m * N, rows, N, K, stream);
             if (st != EETQ_OK) return st;
         }
         return EETQ_OK;
@@ -58,7 +60,9 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, const f1
     for (int m = 0; m < M; m += max_rows) {
         const int rows  = M - m < max_rows ? M - m : max_rows;
         const int tiles = ((rows + BM - 1) / BM) * ((N + BN - 1) / BN);
-        launch_kernel(gemm_tile_kernel<0>, dim3(tiles), dim3(256), SMEM_BYTES, stream, x + (size_t)m * K, w, scales, bias,
+        Epilogue  e     = ep;
+        if (e.residual) e.residual += (size_t)m * N;
+        launch_kernel(gemm_tile_kernel<0>, dim3(tiles), dim3(256), SMEM_BYTES, stream, x + (size_t)m * K, w, scales, e,
                       y + (size_t)m * N, rows, N, K);
         EETQ_TRY_HIP(hipGetLastError());
     }

@@ -64,7 +64,7 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // ABLATE (kbench only): 1 = no DMA, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier
 template <int ABLATE>
 __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
-    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, const f16* __restrict__ bias,
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, Epilogue ep,
     f16* __restrict__ y, int M, int N, int K)
 {
     constexpr int J = 2, WN_COLS = 64, PIECES = 6, NMFMA = 16;
@@ -373,10 +373,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
                         if (nbase + 8 * q < N) {
                             f16x2 lo = {(f16)acc[mt][j][4 * q + 0], (f16)acc[mt][j][4 * q + 1]};
                             f16x2 hi = {(f16)acc[mt][j][4 * q + 2], (f16)acc[mt][j][4 * q + 3]};
-                            if (bias) {
-                                const u32x2 b = *reinterpret_cast<const u32x2*>(bias + nbase + 8 * q);
+                            if (ep.bias) {
+                                const u32x2 b = *reinterpret_cast<const u32x2*>(ep.bias + nbase + 8 * q);
                                 lo            = lo + as_f16x2(b.x);
                                 hi            = hi + as_f16x2(b.y);
+                            }
+                            if (ep.residual) {
+                                const u32x2 r =
+                                    *reinterpret_cast<const u32x2*>(ep.residual + (size_t)m * N + nbase + 8 * q);
+                                lo = lo + as_f16x2(r.x);
+                                hi = hi + as_f16x2(r.y);
                             }
                             *reinterpret_cast<u32x2*>(yrow + 8 * q) = u32x2{as_u32(lo), as_u32(hi)};
                         }

@@ -6,7 +6,7 @@ namespace eetq {
 namespace {
 
 template <int MT, int STAGES>
-int launch_inst(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream)
 {
     using C   = gemm_mid::Cfg<MT, STAGES>;
@@ -16,13 +16,13 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, const f16* bi
                                          C::kSmem));
     }
     const int tiles = ((N + gemm_mid::kBN - 1) / gemm_mid::kBN) * ((M + C::kRows - 1) / C::kRows);
-    launch_kernel(kern, dim3(tiles), dim3(gemm_mid::kThreads), C::kSmem, stream, x, w, scales, bias, y, M, N, K);
+    launch_kernel(kern, dim3(tiles), dim3(gemm_mid::kThreads), C::kSmem, stream, x, w, scales, ep, y, M, N, K);
     return check_hip(hipGetLastError(), "gemm_mid_kernel launch");
 }
 
 }  // namespace
 
-int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                     hipStream_t stream)
 {
     if (M < 1 || M > kMidMaxM) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] medium-batch tile path supports 1 <= M <= 128");
@@ -32,12 +32,12 @@ int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, const f16
     // 2-deep ring (<= 80 KiB) lets two workgroups share a CU instead (measured: profiles/r01_kbench_mid.txt)
     const bool deep = (N + gemm_mid::kBN - 1) / gemm_mid::kBN <= 256;
     switch ((M + 31) / 32) {
-        case 1: return deep ? launch_inst<1, 3>(x, w, scales, bias, y, M, N, K, stream)
-                            : launch_inst<1, 2>(x, w, scales, bias, y, M, N, K, stream);
-        case 2: return deep ? launch_inst<2, 3>(x, w, scales, bias, y, M, N, K, stream)
-                            : launch_inst<2, 2>(x, w, scales, bias, y, M, N, K, stream);
-        case 3: return launch_inst<3, 2>(x, w, scales, bias, y, M, N, K, stream);
-        default: return launch_inst<4, 2>(x, w, scales, bias, y, M, N, K, stream);
+        case 1: return deep ? launch_inst<1, 3>(x, w, scales, ep, y, M, N, K, stream)
+                            : launch_inst<1, 2>(x, w, scales, ep, y, M, N, K, stream);
+        case 2: return deep ? launch_inst<2, 3>(x, w, scales, ep, y, M, N, K, stream)
+                            : launch_inst<2, 2>(x, w, scales, ep, y, M, N, K, stream);
+        case 3: return launch_inst<3, 2>(x, w, scales, ep, y, M, N, K, stream);
+        default: return launch_inst<4, 2>(x, w, scales, ep, y, M, N, K, stream);
     }
 }
 

@@ -36,7 +36,7 @@ struct Cfg {
 // STAGES = 2: <= 80 KiB of LDS at MT <= 2, two workgroups per CU cover each other's barrier and DMA latency.
 template <int MT, int STAGES>
 __global__ __launch_bounds__(kThreads, (STAGES == 2 && MT <= 2) ? 2 : 1) void gemm_mid_kernel(
-    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, const f16* __restrict__ bias,
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, Epilogue ep,
     f16* __restrict__ y, int M, int N, int K)
 {
     using C = Cfg<MT, STAGES>;
@@ -186,10 +186,15 @@ __global__ __launch_bounds__(kThreads, (STAGES == 2 && MT <= 2) ? 2 : 1) void ge
         if (m < M && nb < N) {
             f16x2 lo = {(f16)s4[0], (f16)s4[1]};
             f16x2 hi = {(f16)s4[2], (f16)s4[3]};
-            if (bias) {
-                const u32x2 b = *reinterpret_cast<const u32x2*>(bias + nb);
+            if (ep.bias) {
+                const u32x2 b = *reinterpret_cast<const u32x2*>(ep.bias + nb);
                 lo            = lo + as_f16x2(b.x);
                 hi            = hi + as_f16x2(b.y);
+            }
+            if (ep.residual) {
+                const u32x2 r = *reinterpret_cast<const u32x2*>(ep.residual + (size_t)m * N + nb);
+                lo            = lo + as_f16x2(r.x);
+                hi            = hi + as_f16x2(r.y);
             }
             *reinterpret_cast<u32x2*>(y + (size_t)m * N + nb) = u32x2{as_u32(lo), as_u32(hi)};
         }

@@ -15,7 +15,7 @@ namespace {
 using gemv::gemv_kernel;
 
 template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int OCC>
-int launch_inst(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int N, int K,
+int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K,
                 hipStream_t stream)
 {
     auto         kern = gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC>;
@@ -24,54 +24,54 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, const f16* bi
         EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
     }
-    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, bias, y, N, K);
+    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, ep, y, N, K);
     return check_hip(hipGetLastError(), "gemv_kernel launch");
 }
 
 // LDS-staged activations: pick the number of 16-byte x loads per thread at compile time (no conditional loads)
 template <int M, int WAVES, int D, bool EXACT, int OCC>
-int launch_lds(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int N, int K,
+int launch_lds(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K,
                 hipStream_t stream)
 {
     const int xvecs = M * K / 8, threads = WAVES * 64;
     const int need  = (xvecs + threads - 1) / threads;
     if (gemv::gemv_smem_bytes(M, K, WAVES, false) > 160 * 1024 || need > 8)
         return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] GEMV: M*K too large for LDS staging");
-    if (need <= 1) return launch_inst<M, WAVES, D, EXACT, false, 1, OCC>(x, w, scales, bias, y, N, K, stream);
-    if (need <= 2) return launch_inst<M, WAVES, D, EXACT, false, 2, OCC>(x, w, scales, bias, y, N, K, stream);
-    if (need <= 4) return launch_inst<M, WAVES, D, EXACT, false, 4, OCC>(x, w, scales, bias, y, N, K, stream);
-    return launch_inst<M, WAVES, D, EXACT, false, 8, OCC>(x, w, scales, bias, y, N, K, stream);
+    if (need <= 1) return launch_inst<M, WAVES, D, EXACT, false, 1, OCC>(x, w, scales, ep, y, N, K, stream);
+    if (need <= 2) return launch_inst<M, WAVES, D, EXACT, false, 2, OCC>(x, w, scales, ep, y, N, K, stream);
+    if (need <= 4) return launch_inst<M, WAVES, D, EXACT, false, 4, OCC>(x, w, scales, ep, y, N, K, stream);
+    return launch_inst<M, WAVES, D, EXACT, false, 8, OCC>(x, w, scales, ep, y, N, K, stream);
 }
 
 template <int M>
-int launch_m(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int N, int K,
+int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K,
                 hipStream_t stream)
 {
     const int KT = K / kTileK;
     // Tuned on MI355X with tools/kbench (profiles/r01_kbench_gemv.txt):
     if (KT == 64) {  // K = 4096: 16 waves x 4 tiles, straight-line; <= 64 VGPRs so two workgroups fit a CU
         if constexpr (M <= 2)
-            return launch_inst<M, 16, 4, true, true, 1, 8>(x, w, scales, bias, y, N, K, stream);
+            return launch_inst<M, 16, 4, true, true, 1, 8>(x, w, scales, ep, y, N, K, stream);
         else
-            return launch_lds<M, 16, 4, true, 4>(x, w, scales, bias, y, N, K, stream);
+            return launch_lds<M, 16, 4, true, 4>(x, w, scales, ep, y, N, K, stream);
     }
     // generic K: every wave must own >= D tiles; D = 2 in flight per wave won at K = 11008
-    if (KT >= 32) return launch_lds<M, 16, 2, false, (M == 1 ? 8 : 4)>(x, w, scales, bias, y, N, K, stream);
-    if (KT >= 16) return launch_lds<M, 8, 2, false, 2>(x, w, scales, bias, y, N, K, stream);
-    if (KT >= 4) return launch_lds<M, 4, 1, false, 1>(x, w, scales, bias, y, N, K, stream);
-    return launch_lds<M, 1, 1, false, 1>(x, w, scales, bias, y, N, K, stream);
+    if (KT >= 32) return launch_lds<M, 16, 2, false, (M == 1 ? 8 : 4)>(x, w, scales, ep, y, N, K, stream);
+    if (KT >= 16) return launch_lds<M, 8, 2, false, 2>(x, w, scales, ep, y, N, K, stream);
+    if (KT >= 4) return launch_lds<M, 4, 1, false, 1>(x, w, scales, ep, y, N, K, stream);
+    return launch_lds<M, 1, 1, false, 1>(x, w, scales, ep, y, N, K, stream);
 }
 
 }  // namespace
 
-int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream)
 {
     switch (M) {
-        case 1: return launch_m<1>(x, w, scales, bias, y, N, K, stream);
-        case 2: return launch_m<2>(x, w, scales, bias, y, N, K, stream);
-        case 3: return launch_m<3>(x, w, scales, bias, y, N, K, stream);
-        case 4: return launch_m<4>(x, w, scales, bias, y, N, K, stream);
+        case 1: return launch_m<1>(x, w, scales, ep, y, N, K, stream);
+        case 2: return launch_m<2>(x, w, scales, ep, y, N, K, stream);
+        case 3: return launch_m<3>(x, w, scales, ep, y, N, K, stream);
+        case 4: return launch_m<4>(x, w, scales, ep, y, N, K, stream);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] GEMV path only supports M <= 4");
     }
 }

@@ -67,29 +67,31 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(const f16* __restrict_
     }
 }
 
+// q: [tokens][q_heads][head_size] with q_stride elements between tokens (the reference's layout is the contiguous case,
+// q_stride = heads * head_size, k_heads = q_heads); a fused QKV projection output is rotated in place with
+// q_stride = k_stride = its row length, and grouped-query models have k_heads < q_heads.
 __global__ void rotary_neox_kernel(const int64_t* __restrict__ positions, f16* __restrict__ query,
-                                   f16* __restrict__ key, const f16* __restrict__ cache, int rot_dim, int stride,
-                                   int heads, int head_size)
+                                   f16* __restrict__ key, const f16* __restrict__ cache, int rot_dim, int q_stride,
+                                   int k_stride, int q_heads, int k_heads, int head_size)
 {
 #pragma clang fp contract(off)
     const int     token = blockIdx.x;
     const int64_t pos   = positions[token];
     const f16*    cp    = cache + pos * rot_dim;
     const int     embed = rot_dim / 2;
-    const int     n     = heads * embed;
+    const int     nq = q_heads * embed, n = nq + k_heads * embed;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        const int    head = i / embed;
-        const int    off  = i - head * embed;
-        const size_t base = (size_t)token * stride + (size_t)head * head_size;
-        const f16    c = cp[off], s = cp[embed + off];
-        const f16    qx = query[base + off], qy = query[base + embed + off];
-        const f16    qxc = qx * c, qys = qy * s, qyc = qy * c, qxs = qx * s;
-        query[base + off]         = qxc - qys;
-        query[base + embed + off] = qyc + qxs;
-        const f16 kx = key[base + off], ky = key[base + embed + off];
-        const f16 kxc = kx * c, kys = ky * s, kyc = ky * c, kxs = kx * s;
-        key[base + off]         = kxc - kys;
-        key[base + embed + off] = kyc + kxs;
+        const bool   is_k = i >= nq;
+        const int    j    = is_k ? i - nq : i;
+        const int    head = j / embed;
+        const int    off  = j - head * embed;
+        f16*         p    = (is_k ? key + (size_t)token * k_stride : query + (size_t)token * q_stride) +
+                 (size_t)head * head_size;
+        const f16 c = cp[off], s = cp[embed + off];
+        const f16 vx = p[off], vy = p[embed + off];
+        const f16 xc = vx * c, ys = vy * s, yc = vy * c, xs = vx * s;
+        p[off]         = xc - ys;
+        p[embed + off] = yc + xs;
     }
 }
 
@@ -107,17 +109,20 @@ int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows
     return check_hip(hipGetLastError(), "rmsnorm_kernel launch");
 }
 
-int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int heads, int head_size,
-                  int rot_dim, hipStream_t stream)
+int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int q_heads, int k_heads,
+                  int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream)
 {
     EETQ_REQUIRE(pos && q && k && cache, "null pointer");
-    EETQ_REQUIRE(tokens >= 0 && heads > 0 && head_size > 0 && rot_dim > 0 && rot_dim % 2 == 0 && rot_dim <= head_size,
+    EETQ_REQUIRE(tokens >= 0 && q_heads > 0 && k_heads > 0 && head_size > 0 && rot_dim > 0 && rot_dim % 2 == 0 &&
+                     rot_dim <= head_size,
                  "invalid rotary shape");
+    EETQ_REQUIRE(q_stride >= q_heads * head_size && k_stride >= k_heads * head_size, "invalid rotary token stride");
     if (tokens == 0) return EETQ_OK;
-    int threads = heads * rot_dim / 2;
+    int threads = (q_heads + k_heads) * rot_dim / 2;
     threads     = threads < 512 ? threads : 512;
     threads     = (threads + 63) / 64 * 64;
-    rotary_neox_kernel<<<tokens, threads, 0, stream>>>(pos, q, k, cache, rot_dim, heads * head_size, heads, head_size);
+    rotary_neox_kernel<<<tokens, threads, 0, stream>>>(pos, q, k, cache, rot_dim, q_stride, k_stride, q_heads, k_heads,
+                                                       head_size);
     return check_hip(hipGetLastError(), "rotary_neox_kernel launch");
 }
 

@@ -8,7 +8,7 @@ namespace eetq {
 namespace {
 
 template <int MT, int NT, int WAVES, int D, int OCC>
-int launch_inst(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream)
 {
     auto         kern = streamk::streamk_kernel<MT, NT, WAVES, D, OCC>;
@@ -17,12 +17,12 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, const f16* bi
         EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
     }
-    launch_kernel(kern, dim3(N / (kTileN * NT)), dim3(WAVES * 64), smem, stream, x, w, scales, bias, y, M, N, K);
+    launch_kernel(kern, dim3(N / (kTileN * NT)), dim3(WAVES * 64), smem, stream, x, w, scales, ep, y, M, N, K);
     return check_hip(hipGetLastError(), "streamk_kernel launch");
 }
 
 template <int MT>
-int launch_mt(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream)
 {
     const int KT = K / kTileK;  // every wave must own >= D k tiles
@@ -32,27 +32,27 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, const f16* bias
         // (M = 8, N = 22016: 24.5 -> 17.0 us; N = 4096: 5.3 -> 5.8 us, so not there: profiles/r01_kbench_streamk_nt.txt)
         if constexpr (MT == 1) {
             if (N % (2 * kTileN) == 0 && N / (2 * kTileN) >= 256)
-                return launch_inst<MT, 2, 16, 2, 4>(x, w, scales, bias, y, M, N, K, stream);
+                return launch_inst<MT, 2, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
         }
-        return launch_inst<MT, 1, 16, 2, 4>(x, w, scales, bias, y, M, N, K, stream);
+        return launch_inst<MT, 1, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     }
-    if (KT >= 16) return launch_inst<MT, 1, 8, 2, 2>(x, w, scales, bias, y, M, N, K, stream);
-    if (KT >= 4) return launch_inst<MT, 1, 4, 1, 1>(x, w, scales, bias, y, M, N, K, stream);
-    return launch_inst<MT, 1, 1, 1, 1>(x, w, scales, bias, y, M, N, K, stream);
+    if (KT >= 16) return launch_inst<MT, 1, 8, 2, 2>(x, w, scales, ep, y, M, N, K, stream);
+    if (KT >= 4) return launch_inst<MT, 1, 4, 1, 1>(x, w, scales, ep, y, M, N, K, stream);
+    return launch_inst<MT, 1, 1, 1, 1>(x, w, scales, ep, y, M, N, K, stream);
 }
 
 }  // namespace
 
-int launch_streamk(const f16* x, const uint8_t* w, const f16* scales, const f16* bias, f16* y, int M, int N, int K,
+int launch_streamk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream)
 {
     if (M < 1 || M > kStreamMaxM)
         return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] stream-MFMA path supports 1 <= M <= 64");
     switch ((M + 15) / 16) {
-        case 1: return launch_mt<1>(x, w, scales, bias, y, M, N, K, stream);
-        case 2: return launch_mt<2>(x, w, scales, bias, y, M, N, K, stream);
-        case 3: return launch_mt<3>(x, w, scales, bias, y, M, N, K, stream);
-        default: return launch_mt<4>(x, w, scales, bias, y, M, N, K, stream);
+        case 1: return launch_mt<1>(x, w, scales, ep, y, M, N, K, stream);
+        case 2: return launch_mt<2>(x, w, scales, ep, y, M, N, K, stream);
+        case 3: return launch_mt<3>(x, w, scales, ep, y, M, N, K, stream);
+        default: return launch_mt<4>(x, w, scales, ep, y, M, N, K, stream);
     }
 }
 

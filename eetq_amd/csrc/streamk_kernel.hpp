@@ -18,7 +18,7 @@ namespace streamk {
 template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    const f16* __restrict__ bias, f16* __restrict__ y, int M, int N, int K)
+    Epilogue ep, f16* __restrict__ y, int M, int N, int K)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* red = reinterpret_cast<float*>(smem);
@@ -134,7 +134,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
 #pragma unroll
             for (int wv = 0; wv < WAVES; ++wv) s += red[wv * kPerWave + o];
             f16 v = (f16)s;
-            if (bias) v = v + bias[(ntile0 + tt) * 16 + cc];
+            if (ep.bias) v = v + ep.bias[(ntile0 + tt) * 16 + cc];
+            if (ep.residual) v = v + ep.residual[(size_t)m * N + (ntile0 + tt) * 16 + cc];
             y[(size_t)m * N + (ntile0 + tt) * 16 + cc] = v;
         }
     }

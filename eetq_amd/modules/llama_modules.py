@@ -1,0 +1,195 @@
+"""Llama attention / MLP blocks built on the library's ops.
+
+Host-side counterpart of /root/reference/python/eetq/modules/llama_modules.py: ``EETRotaryEmbedding`` (:19-65,
+cos|sin cache + the in-place ``rotary_embedding_neox`` op), ``EETLlamaAttention`` (:68-148, one fused QKV projection) and
+``EETQuantLlamaAttention`` (:151-240, W8A16 projections).  The reference targets the transformers 4.3x attention
+interface (``past_key_value`` tuples, flash-attn); these modules speak the interface of the installed transformers
+(``position_embeddings`` / ``past_key_values`` cache objects, the registered attention functions), support grouped-query
+models, rotate q and k *in place inside the fused QKV output* (``rotary_embedding_neox_strided``), and run the three W8A16
+projections as ONE launch over concatenated channels (bit-identical to three launches, eetq_amd/utils/fuse.py).
+``EETLlamaMLP`` (gate/up as one launch) has no counterpart in llama_modules.py; the reference fuses gate/up only in its
+offline export layer (python/eetq/models/llama.py:39-77).
+"""
+import torch
+import torch.nn as nn
+
+from .. import ops
+
+__all__ = ["EETRotaryEmbedding", "EETLlamaAttention", "EETQuantLlamaAttention", "EETLlamaMLP"]
+
+
+class EETRotaryEmbedding(nn.Module):
+    """cos|sin cache [max_position, dim] in fp16 and the in-place NeoX rotation (reference :19-65)."""
+
+    def __init__(self, dim, max_position_embeddings=2048, base=10000, device=None):
+        super().__init__()
+        self.dim = dim
+        self.max_position_embeddings = max_position_embeddings
+        self.base = base
+        inv_freq = 1.0 / (self.base ** (torch.arange(0, self.dim, 2, dtype=torch.float32, device=device) / self.dim))
+        self.register_buffer("inv_freq", inv_freq, persistent=False)
+        self._set_cos_sin_cache(max_position_embeddings, self.inv_freq.device)
+
+    def _set_cos_sin_cache(self, seq_len, device):
+        self.max_seq_len_cached = seq_len
+        t = torch.arange(seq_len, device=device, dtype=torch.float32)
+        freqs = torch.outer(t, self.inv_freq.to(device=device, dtype=torch.float32))
+        cache = torch.cat((freqs.cos(), freqs.sin()), dim=-1)
+        self.register_buffer("cos_sin_cache", cache.half().contiguous(), persistent=False)
+
+    def forward(self, query, key, positions):
+        """query [..., q_heads, dim], key [..., k_heads, dim] (dense last two dims, any token stride), positions int64
+        with one entry per token.  Rotates in place and returns (query, key)."""
+        ops.rotary_embedding_neox_strided(positions, query, key, self.dim, self.cos_sin_cache)
+        return query, key
+
+
+def _rope_base(config):
+    params = getattr(config, "rope_parameters", None) or {}
+    rope_type = params.get("rope_type", "default") if isinstance(params, dict) else "default"
+    if rope_type not in (None, "default"):
+        raise NotImplementedError("EETRotaryEmbedding implements the default RoPE only (got rope_type=%r)" % (rope_type,))
+    base = params.get("rope_theta") if isinstance(params, dict) else None
+    return float(base if base is not None else getattr(config, "rope_theta", 10000.0))
+
+
+class _EETAttentionBase(nn.Module):
+    def _setup(self, hidden_size, num_heads, dev, num_key_value_heads, layer_idx, config, max_position_embeddings,
+               rope_theta):
+        self.hidden_size = hidden_size
+        self.num_heads = num_heads
+        self.head_dim = getattr(config, "head_dim", None) or hidden_size // num_heads
+        self.num_key_value_heads = num_key_value_heads or num_heads
+        if config is None and self.head_dim * num_heads != hidden_size:
+            raise ValueError(f"hidden_size must be divisible by num_heads (got `hidden_size`: {hidden_size}"
+                             f" and `num_heads`: {num_heads}).")
+        if num_heads % self.num_key_value_heads:
+            raise ValueError("num_heads must be a multiple of num_key_value_heads")
+        self.layer_idx = layer_idx
+        self.config = config
+        # attributes the registered attention functions of transformers read from the module
+        self.num_key_value_groups = num_heads // self.num_key_value_heads
+        self.scaling = self.head_dim ** -0.5
+        self.attention_dropout = 0.0
+        self.is_causal = True
+        self.decode_math_attention = True
+        self.rotary_emb = EETRotaryEmbedding(self.head_dim, max_position_embeddings=max_position_embeddings,
+                                             base=rope_theta, device=dev)
+
+    def _positions(self, position_ids, past_key_values, batch, q_len, device):
+        if position_ids is None:
+            seen = past_key_values.get_seq_length(self.layer_idx) if past_key_values is not None else 0
+            position_ids = (torch.arange(q_len, device=device) + seen).unsqueeze(0)
+        if position_ids.shape[0] != batch:
+            position_ids = position_ids.expand(batch, q_len)
+        return position_ids.to(torch.int64).contiguous()
+
+    def _attend(self, q, k, v, attention_mask, past_key_values, input_shape, kwargs):
+        """q [B, T, H, D], k/v [B, T, Hkv, D] (views into the projection output) -> [B, T, H*D]"""
+        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
+        if past_key_values is not None:
+            k, v = past_key_values.update(k, v, self.layer_idx)
+        if q.shape[2] == 1 and self.decode_math_attention and not kwargs.get("output_attentions", False):
+            # one query token: the library attention kernels launch one workgroup per head (40 workgroups streaming
+            # the whole KV cache: 68 us per layer at Llama-13B shapes, S = 1.2 k); two batched matrix-vector products
+            # and a softmax spread the cache over the chip
+            if self.num_key_value_groups > 1:
+                k = k.repeat_interleave(self.num_key_value_groups, dim=1)
+                v = v.repeat_interleave(self.num_key_value_groups, dim=1)
+            scores = torch.matmul(q, k.transpose(2, 3)) * self.scaling          # [B, H, 1, S]
+            if attention_mask is not None:
+                mask = attention_mask[..., : k.shape[2]]
+                scores = scores.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else scores + mask
+            probs = torch.softmax(scores, dim=-1, dtype=torch.float32).to(q.dtype)
+            out = torch.matmul(probs, v).transpose(1, 2)
+            return out.reshape(*input_shape, -1).contiguous(), None
+        fn = None
+        impl = getattr(self.config, "_attn_implementation", None) if self.config is not None else None
+        if impl is not None:
+            from transformers.modeling_utils import ALL_ATTENTION_FUNCTIONS
+            from transformers.models.llama.modeling_llama import eager_attention_forward
+            fn = ALL_ATTENTION_FUNCTIONS.get_interface(impl, eager_attention_forward)
+        if fn is not None:
+            out, weights = fn(self, q, k, v, attention_mask, dropout=0.0, scaling=self.scaling, **kwargs)
+        else:  # stand-alone use without a transformers config: plain SDPA, causal when there is no cache
+            if self.num_key_value_groups > 1:
+                k = k.repeat_interleave(self.num_key_value_groups, dim=1)
+                v = v.repeat_interleave(self.num_key_value_groups, dim=1)
+            out = torch.nn.functional.scaled_dot_product_attention(
+                q, k, v, attn_mask=attention_mask, is_causal=attention_mask is None and q.shape[2] > 1,
+                scale=self.scaling).transpose(1, 2)
+            weights = None
+        return out.reshape(*input_shape, -1).contiguous(), weights
+
+
+class EETLlamaAttention(_EETAttentionBase):
+    """Multi-headed attention over ONE fused QKV projection (reference :68-148).
+
+    ``qkv_proj`` maps hidden -> (num_heads + 2 * num_key_value_heads) * head_dim (an ``nn.Linear`` or, after
+    ``eet_quantize``, a ``W8A16Linear``)."""
+
+    def __init__(self, hidden_size, num_heads, qkv_proj, o_proj, dev, num_key_value_heads=None, layer_idx=0, config=None,
+                 max_position_embeddings=2048, rope_theta=10000.0):
+        super().__init__()
+        self._setup(hidden_size, num_heads, dev, num_key_value_heads, layer_idx, config, max_position_embeddings,
+                    rope_theta)
+        self.qkv_proj = qkv_proj
+        self.o_proj = o_proj
+
+    def _qkv(self, hidden_states):
+        return self.qkv_proj(hidden_states)
+
+    def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None,
+                position_ids=None, residual=None, **kwargs):
+        """Input shape: Batch x Time x Channel.  ``position_embeddings`` (the model-level cos/sin) is accepted for
+        interface compatibility and unused: the rotation reads this module's fp16 cos|sin cache.  ``residual``
+        (extension): added to the output projection inside its epilogue when ``o_proj`` is a W8A16Linear."""
+        bsz, q_len, _ = hidden_states.shape
+        h, hkv, d = self.num_heads, self.num_key_value_heads, self.head_dim
+        qkv = self._qkv(hidden_states)                      # [B, T, (H + 2 Hkv) * D]
+        q = qkv[..., : h * d].unflatten(-1, (h, d))
+        k = qkv[..., h * d: (h + hkv) * d].unflatten(-1, (hkv, d))
+        v = qkv[..., (h + hkv) * d:].unflatten(-1, (hkv, d))
+        positions = self._positions(position_ids, past_key_values, bsz, q_len, hidden_states.device)
+        if positions.numel() and int(self.rotary_emb.max_seq_len_cached) <= 0:
+            raise RuntimeError("empty rotary cache")
+        self.rotary_emb(q, k, positions)
+        kwargs.pop("use_cache", None)
+        out, weights = self._attend(q, k, v, attention_mask, past_key_values, (bsz, q_len), kwargs)
+        if residual is None:
+            return self.o_proj(out), weights
+        if hasattr(self.o_proj, "qweight"):
+            return self.o_proj(out, residual=residual), weights
+        return residual + self.o_proj(out), weights
+
+
+class EETQuantLlamaAttention(EETLlamaAttention):
+    """W8A16 attention (reference :151-240).  The reference keeps q/k/v as three W8A16 linears; here they become one
+    launch over the concatenated output channels when all three are ``W8A16Linear`` (bit-identical results)."""
+
+    def __init__(self, hidden_size, num_heads, q_proj, k_proj, v_proj, o_proj, dev, num_key_value_heads=None,
+                 layer_idx=0, config=None, max_position_embeddings=2048, rope_theta=10000.0):
+        from ..utils.fuse import fuse_w8a16_linears
+        from .qlinear import W8A16Linear
+        if not all(isinstance(p, W8A16Linear) for p in (q_proj, k_proj, v_proj)):
+            raise TypeError("EETQuantLlamaAttention expects W8A16Linear q/k/v projections (run eet_quantize first)")
+        fused = fuse_w8a16_linears([q_proj, k_proj, v_proj]).fused
+        super().__init__(hidden_size, num_heads, fused, o_proj, dev, num_key_value_heads=num_key_value_heads,
+                         layer_idx=layer_idx, config=config, max_position_embeddings=max_position_embeddings,
+                         rope_theta=rope_theta)
+
+
+class EETLlamaMLP(nn.Module):
+    """down(silu(gate(x)) * up(x)) with gate and up as ONE W8A16 launch over concatenated channels."""
+
+    def __init__(self, gate_proj, up_proj, down_proj):
+        super().__init__()
+        from ..utils.fuse import fuse_w8a16_linears
+        self.gate_up_proj = fuse_w8a16_linears([gate_proj, up_proj]).fused
+        self.intermediate_size = gate_proj.out_features
+        self.down_proj = down_proj
+
+    def forward(self, x, residual=None):
+        gu = self.gate_up_proj(x)
+        gate, up = gu[..., : self.intermediate_size], gu[..., self.intermediate_size:]
+        return self.down_proj(torch.nn.functional.silu(gate) * up, residual=residual)

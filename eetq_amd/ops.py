@@ -21,7 +21,7 @@ from ._lib import (DTYPE_F16, DTYPE_F32, LAYOUT_GFX950, LAYOUT_ROW_MAJOR, LAYOUT
                    PATH_MFMA, check)
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_",
-           "layernorm_forward", "rotary_embedding_neox", "convert_layout"]
+           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "convert_layout"]
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
@@ -142,7 +142,7 @@ def convert_layout(weight, src_layout, dst_layout):
     return preprocess_weights(unprocess_weights(weight, src_layout), False, dst_layout)
 
 
-def _gemm_launch(input, weight, scale, output, m, n, k, path, bias=None):
+def _gemm_launch(input, weight, scale, output, m, n, k, path, bias=None, residual=None):
     if input.dtype != torch.float16:
         raise RuntimeError("w8_a16_gemm: input must be float16 (got %s)" % input.dtype)
     if not input.is_cuda:
@@ -157,8 +157,17 @@ def _gemm_launch(input, weight, scale, output, m, n, k, path, bias=None):
     if bias is not None:
         if bias.dtype != torch.float16 or bias.device != input.device or bias.numel() != n or not bias.is_contiguous():
             raise RuntimeError("w8_a16_gemm: bias must be a contiguous float16 [N] tensor on the input's device")
+    if residual is not None:
+        if (residual.dtype != torch.float16 or residual.device != input.device or residual.numel() != m * n
+                or not residual.is_contiguous() or residual.shape[-1] != n):
+            raise RuntimeError("w8_a16_gemm: residual must be a contiguous float16 [..., N] tensor with the output's "
+                               "element count, on the input's device")
     with torch.cuda.device(input.device):
-        if bias is None:
+        if residual is not None:
+            check(_lib.lib().eetq_w8a16_gemm_fused(_ptr(x), _ptr(weight), _ptr(scale),
+                                                   _ptr(bias) if bias is not None else None, _ptr(residual),
+                                                   _ptr(output), m, n, k, path, _stream_ptr()))
+        elif bias is None:
             check(_lib.lib().eetq_w8a16_gemm_ex(_ptr(x), _ptr(weight), _ptr(scale), _ptr(output), m, n, k, path,
                                                 _stream_ptr()))
         else:
@@ -167,12 +176,13 @@ def _gemm_launch(input, weight, scale, output, m, n, k, path, bias=None):
     return output
 
 
-def w8_a16_gemm(input, weight, scale, path="auto", bias=None):
+def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None):
     """``y = input @ dequant(weight, scale) (+ bias)``: fp16 [..., K] x int8 [K, N] (processed) -> fp16 [..., N].
 
     Reference: w8_a16_gemm_forward_cuda, fpA_intB_gemm_wrapper.cu:130-173 (fresh output tensor, current
     stream, asynchronous).  ``path`` ("auto" | "gemv" | "stream" | "mfma") is a testing hook.  ``bias`` (extension,
-    SURVEY 8f row 3) fuses the reference's separate ``output + bias`` into the kernel epilogue, bit-identically.
+    SURVEY 8f row 3) fuses the reference's separate ``output + bias`` into the kernel epilogue, bit-identically;
+    ``residual`` (same shape as the output) is added after it, again in fp16 -- the decoder block's ``residual + proj(x)``.
     """
     k = input.shape[-1]
     n = weight.shape[-1]
@@ -182,7 +192,7 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None):
     output = torch.empty(tuple(input.shape[:-1]) + (n,), dtype=input.dtype, device=input.device)
     if m == 0:
         return output
-    return _gemm_launch(input, weight, scale, output, m, n, k, _PATHS[path], bias)
+    return _gemm_launch(input, weight, scale, output, m, n, k, _PATHS[path], bias, residual)
 
 
 def w8_a16_gemm_(input, weight, scale, output, m, n, k):
@@ -222,4 +232,44 @@ def rotary_embedding_neox(positions, query, key, head_size, cos_sin_cache):
     with torch.cuda.device(query.device):
         check(_lib.lib().eetq_rotary_neox_f16(_ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), tokens,
                                               heads, int(head_size), rot_dim, _stream_ptr()))
+    return None
+
+
+def rotary_embedding_neox_strided(positions, query, key, head_size, cos_sin_cache):
+    """In-place NeoX rotary embedding of strided views: query [..., q_heads, head_size] and key [..., k_heads, head_size]
+    whose last two dimensions are dense and whose leading (token) dimensions share one stride -- e.g. the q and k
+    slices of a fused QKV projection output.  k_heads may differ from q_heads (grouped-query attention)."""
+    if query.dtype != torch.float16 or key.dtype != torch.float16 or cos_sin_cache.dtype != torch.float16:
+        raise RuntimeError("eetq_amd: rotary_embedding_neox is implemented for float16 only")
+    if positions.dtype != torch.int64 or not positions.is_contiguous() or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("rotary_embedding_neox_strided: positions must be contiguous int64, the cache contiguous")
+
+    def token_view(t):
+        heads, hs = t.shape[-2], t.shape[-1]
+        if hs != head_size or t.stride(-1) != 1 or t.stride(-2) != hs:
+            raise RuntimeError("rotary_embedding_neox_strided: the last two dimensions must be dense [heads, head_size]")
+        tokens = 1
+        for d in t.shape[:-2]:
+            tokens *= d
+        # the leading dimensions must collapse to one stride
+        stride, expect = None, None
+        for d, st in zip(reversed(t.shape[:-2]), reversed(t.stride()[:-2])):
+            if d == 1:
+                continue
+            if stride is None:
+                stride, expect = st, st * d
+            elif st != expect:
+                raise RuntimeError("rotary_embedding_neox_strided: leading dimensions do not collapse to one stride")
+            else:
+                expect = st * d
+        return tokens, heads, (stride if stride is not None else heads * hs)
+
+    tq, hq, sq = token_view(query)
+    tk, hk, sk = token_view(key)
+    if tq != tk or positions.numel() != tq:
+        raise RuntimeError("rotary_embedding_neox_strided: query, key and positions disagree on the token count")
+    with torch.cuda.device(query.device):
+        check(_lib.lib().eetq_rotary_neox_strided_f16(_ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), tq,
+                                                      hq, hk, int(head_size), cos_sin_cache.shape[1], sq, sk,
+                                                      _stream_ptr()))
     return None

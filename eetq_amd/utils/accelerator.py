@@ -1,0 +1,156 @@
+"""``eet_accelerator``: fused-attention rewrite of a transformers Llama model.
+
+Host-side mirror of /root/reference/python/eetq/utils/accelerator.py:15-78 (``eet_accelerator``,
+``replace_with_eet_fp16_fused_attn``, ``replace_with_eet_quant_fused_attn``) and of ``replace_with_eet_qlinear``
+(python/eetq/utils/quantizer.py:13-38) for the interface of the installed transformers (see
+eetq_amd/modules/llama_modules.py).  ``fused_mlp`` / ``fused_norm`` are extensions (default off): gate/up as one launch,
+and every ``LlamaRMSNorm`` through ``layernorm_forward``.
+"""
+import types
+
+import torch
+import torch.nn as nn
+
+from ..modules.llama_modules import EETLlamaAttention, EETLlamaMLP, EETQuantLlamaAttention, _rope_base
+from ..modules.qlinear import W8A16Linear
+from .quantizer import _progress, eet_quantize, find_layers, get_named_linears, set_op_by_name
+
+__all__ = ["eet_accelerator", "replace_with_eet_fp16_fused_attn", "replace_with_eet_quant_fused_attn",
+           "replace_with_eet_qlinear", "replace_with_eet_fused_mlp", "replace_with_eet_rmsnorm",
+           "replace_with_eet_fused_residual"]
+
+
+def _llama_attention_type():
+    from transformers.models.llama.modeling_llama import LlamaAttention
+    return LlamaAttention
+
+
+def _attn_geometry(m):
+    cfg = getattr(m, "config", None)
+    if cfg is not None:
+        heads, kv_heads, hidden = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.hidden_size
+        max_pos, theta = getattr(cfg, "max_position_embeddings", 2048), _rope_base(cfg)
+    else:  # transformers 4.3x attribute names, as the reference reads them (accelerator.py:39)
+        heads, hidden = m.num_heads, m.hidden_size
+        kv_heads, max_pos, theta = getattr(m, "num_key_value_heads", heads), 2048, 10000.0
+    return dict(hidden_size=hidden, num_heads=heads, num_key_value_heads=kv_heads, layer_idx=getattr(m, "layer_idx", 0),
+                config=cfg, max_position_embeddings=max_pos, rope_theta=theta)
+
+
+def replace_with_eet_fp16_fused_attn(model):
+    """Every LlamaAttention -> EETLlamaAttention over ONE fp16 nn.Linear holding [q; k; v] (reference :22-51)."""
+    named = find_layers(model, include=[_llama_attention_type()], exclude=[])
+    for name, m in _progress(list(named.items()), "[EET][INFO] attention fusion processiong..."):
+        q, k, v = m.q_proj, m.k_proj, m.v_proj
+        w = torch.cat([q.weight, k.weight, v.weight], dim=0)
+        bias = torch.cat([q.bias, k.bias, v.bias], dim=0) if q.bias is not None else None
+        qkv = nn.Linear(q.in_features, w.shape[0], bias is not None, dtype=w.dtype, device=w.device)
+        qkv.weight = nn.Parameter(w, requires_grad=False)
+        qkv.bias = nn.Parameter(bias, requires_grad=False) if bias is not None else None
+        attn = EETLlamaAttention(qkv_proj=qkv, o_proj=m.o_proj, dev=w.device, **_attn_geometry(m))
+        set_op_by_name(model, name, attn)
+    return model
+
+
+def replace_with_eet_quant_fused_attn(model, dev="cuda:0"):
+    """Every LlamaAttention whose projections are already W8A16Linear -> EETQuantLlamaAttention (reference :54-78)."""
+    for name, m in list(model.named_modules()):
+        if not isinstance(m, _llama_attention_type()):
+            continue
+        attn = EETQuantLlamaAttention(q_proj=m.q_proj, k_proj=m.k_proj, v_proj=m.v_proj, o_proj=m.o_proj,
+                                      dev=m.q_proj.qweight.device, **_attn_geometry(m))
+        set_op_by_name(model, name, attn)
+    return model
+
+
+def replace_with_eet_qlinear(model, init_only=False, target_model="llama", device="cuda:0"):
+    """W8A16 for every nn.Linear inside the decoder layers (lm_head untouched); reference quantizer.py:13-38, whose
+    ``structure_mapping`` table resolves to ``model.model.layers`` for llama."""
+    if target_model != "llama":
+        raise ValueError("replace_with_eet_qlinear: only target_model='llama' is mapped")
+    base = getattr(model, "model", model)
+    for layer in _progress(list(base.layers), "[EET][INFO] replace with eet weight quantize only linear..."
+                           + ("(init only)" if init_only else "")):
+        for name, linear in get_named_linears(layer).items():
+            if linear.weight.dtype == torch.float16:
+                q_linear = W8A16Linear.from_torch(linear, scales=None, init_only=init_only)
+            elif linear.weight.dtype == torch.int8:
+                q_linear = W8A16Linear.from_torch(linear, scales=torch.div(linear.state_dict()["SCB"], 127.0),
+                                                  init_only=init_only)
+            else:
+                raise ValueError("Unsupported data type: {}".format(linear.weight.dtype))
+            set_op_by_name(layer, name, q_linear)
+            if not init_only:
+                linear.cpu()
+            del linear
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+    return model
+
+
+def replace_with_eet_fused_mlp(model):
+    """Extension: every Llama MLP whose projections are W8A16Linear -> EETLlamaMLP (gate/up in one launch)."""
+    n = 0
+    for name, m in list(model.named_modules()):
+        if type(m).__name__ == "LlamaMLP" and all(isinstance(getattr(m, p, None), W8A16Linear)
+                                                   for p in ("gate_proj", "up_proj", "down_proj")):
+            set_op_by_name(model, name, EETLlamaMLP(m.gate_proj, m.up_proj, m.down_proj))
+            n += 1
+    return n
+
+
+def replace_with_eet_rmsnorm(model):
+    """Extension: route every LlamaRMSNorm through ``layernorm_forward`` (the reference binds that op but never calls
+    it from Python; csrc/layernorm_kernels/layernorm.cu:98-113)."""
+    from ..ops import layernorm_forward
+
+    def forward(self, hidden_states):
+        x = hidden_states if hidden_states.is_contiguous() else hidden_states.contiguous()
+        out = torch.empty_like(x)
+        layernorm_forward(x, self.weight, out, self.variance_epsilon)
+        return out
+
+    n = 0
+    for m in model.modules():
+        if type(m).__name__ == "LlamaRMSNorm" and m.weight.dtype == torch.float16:
+            m.forward = types.MethodType(forward, m)
+            n += 1
+    return n
+
+
+def replace_with_eet_fused_residual(model):
+    """Extension: decoder layers whose attention and MLP are the EET blocks add their residuals inside the o_proj /
+    down_proj epilogues (``eetq_w8a16_gemm_fused``) instead of two elementwise kernels per layer."""
+    from ..modules.llama_modules import EETLlamaAttention
+
+    def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
+                position_embeddings=None, **kwargs):
+        h, _ = self.self_attn(hidden_states=self.input_layernorm(hidden_states), attention_mask=attention_mask,
+                              position_ids=position_ids, past_key_values=past_key_values, use_cache=use_cache,
+                              position_embeddings=position_embeddings, residual=hidden_states, **kwargs)
+        return self.mlp(self.post_attention_layernorm(h), residual=h)
+
+    n = 0
+    for m in model.modules():
+        if (type(m).__name__ == "LlamaDecoderLayer" and isinstance(m.self_attn, EETLlamaAttention)
+                and isinstance(m.mlp, EETLlamaMLP) and isinstance(m.self_attn.o_proj, W8A16Linear)):
+            m.forward = types.MethodType(forward, m)
+            n += 1
+    return n
+
+
+def eet_accelerator(model, quantize=False, fused_attn=False, dev="cuda:0", fused_mlp=False, fused_norm=False,
+                    fused_residual=False):
+    """Reference semantics (accelerator.py:15-19): ``fused_attn`` first builds fp16 fused-QKV attention blocks, then
+    ``quantize`` turns every decoder nn.Linear -- the fused QKV included -- into W8A16."""
+    if fused_attn:
+        replace_with_eet_fp16_fused_attn(model)
+    if quantize:
+        replace_with_eet_qlinear(model, init_only=False, target_model="llama", device=dev)
+    if fused_mlp:
+        replace_with_eet_fused_mlp(model)
+    if fused_norm:
+        replace_with_eet_rmsnorm(model)
+    if fused_residual:
+        replace_with_eet_fused_residual(model)
+    return model

@@ -148,6 +148,9 @@ def main():
     ap.add_argument("--no-quant", action="store_true", help="fp16 nn.Linear baseline (rocBLAS) for comparison")
     ap.add_argument("--fuse-norm", action="store_true", help="LlamaRMSNorm -> eetq layernorm_forward kernel")
     ap.add_argument("--fuse-proj", action="store_true", help="one W8A16 launch for q/k/v and one for gate/up")
+    ap.add_argument("--accelerate", action="store_true",
+                    help="eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True): fused-QKV "
+                         "attention blocks with the in-place rotary kernel, gate/up in one launch, RMS-norm kernel")
     ap.add_argument("--graph", action="store_true",
                     help="greedy decode with a static KV cache and ONE captured HIP graph per token (launch-bound "
                          "inner loop -> hipGraph) instead of transformers' eager generate()")
@@ -159,7 +162,10 @@ def main():
     model = build_model(args, dev)
     t_build = time.perf_counter() - t0
     t0 = time.perf_counter()
-    if not args.no_quant:
+    if args.accelerate:
+        from eetq_amd.utils import eet_accelerator
+        eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True, fused_residual=True)
+    elif not args.no_quant:
         eet_quantize(model)
     if args.fuse_norm:
         fuse_rmsnorm(model)
@@ -203,7 +209,8 @@ def main():
         line = {"config": "Llama-2-13B shapes, random init fp16, %s, prompt=%d new=%d batch=%d, %s" %
                           ("fp16 nn.Linear" if args.no_quant else "eet_quantize (W8A16)", args.prompt, args.new, args.batch,
                            ("hipGraph decode" if args.graph else "transformers eager generate") +
-                           (", fused rmsnorm" if args.fuse_norm else "") + (", fused qkv + gate/up" if args.fuse_proj else "")),
+                           (", fused rmsnorm" if args.fuse_norm else "") + (", fused qkv + gate/up" if args.fuse_proj else "") +
+                           (", eet_accelerator(fused_attn, fused_mlp, fused_norm)" if args.accelerate else "")),
                 "n_gpus": grp.world_size, "end_to_end_s": round(secs, 4), "prefill_s": round(t_prefill, 4),
                 "tokens_per_s_per_replica": round(new_tokens / secs, 2),
                 "tokens_per_s_aggregate": round(grp.world_size * new_tokens / secs, 2),

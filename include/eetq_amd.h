@@ -97,6 +97,14 @@ int eetq_w8a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales
 int eetq_w8a16_gemm_bias(const void* x, const int8_t* w_packed, const void* scales, const void* bias, void* y, int M,
                          int N, int K, int path, void* stream);
 
+/* y = fp16(acc) [+ bias[n]] [+ residual[m][n]]: bias as above, then a residual tensor [M][N] (fp16, row stride N, 8-byte
+ * aligned) added in fp16 after it -- bit-identical to a separate elementwise add of the GEMM output.  The reference's
+ * counterpart is FT's bias / residual epilogue family (csrc/cutlass_kernels/fpA_intB_gemm.cu:35-97,
+ * fpA_intB_gemm_template.h:492-537), which its Python layer never reaches.  `residual` may be `y` itself (in-place
+ * accumulate into the residual stream); any other overlap is undefined.  Either pointer may be NULL. */
+int eetq_w8a16_gemm_fused(const void* x, const int8_t* w_packed, const void* scales, const void* bias,
+                          const void* residual, void* y, int M, int N, int K, int path, void* stream);
+
 /* ---- side ops --------------------------------------------------------------------------------------
  * Replaces EETQ.layernorm_forward -> layernorm_forward_cuda (csrc/layernorm_kernels/layernorm.cu:98-113):
  * T5/RMS norm, out = clamp_fp16( x * rsqrt(mean(x^2) + eps) * gamma ), fp32 math, fp16 I/O.
@@ -108,6 +116,14 @@ int eetq_rmsnorm_f16(const void* x, const void* gamma, void* out, float eps, int
  * ([max_pos][rot_dim], cos half then sin half), every product/sum rounded to fp16 like the reference. */
 int eetq_rotary_neox_f16(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
                          int tokens, int heads, int head_size, int rot_dim, void* stream);
+
+/* Same rotation on strided operands (no reference counterpart at the pybind boundary; it is what the reference's
+ * EETLlamaAttention, python/eetq/modules/llama_modules.py:94-106, needs to rotate the q and k slices of a fused QKV
+ * projection in place): q is [tokens][q_heads][head_size] with q_stride elements between tokens, k likewise with
+ * k_heads (< q_heads for grouped-query models) and k_stride. */
+int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
+                                 int tokens, int q_heads, int k_heads, int head_size, int rot_dim, int q_stride,
+                                 int k_stride, void* stream);
 
 /* ---- profiling hook (no reference counterpart; used by bench.py) -------------------------------------
  * Between eetq_prof_begin(n) and eetq_prof_end() every kernel this library launches from the calling thread

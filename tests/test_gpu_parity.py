@@ -338,6 +338,34 @@ def test_rotary_embedding_neox(ops, oracle, heads, hs, rot):
     assert np.array_equal(kd.cpu().numpy().reshape(b * t, heads, hs), ko)
 
 
+@pytest.mark.parametrize("hq,hk,hs", [(8, 8, 64), (8, 2, 128), (5, 1, 64)])
+def test_rotary_strided_in_fused_qkv(ops, oracle, hq, hk, hs):
+    """q and k slices of a fused QKV projection output are rotated in place (token stride = the fused row length,
+    k_heads <= q_heads); bit-exact against the oracle run on dense copies, v and nothing else touched."""
+    torch.manual_seed(hq * 10 + hk)
+    b, t = 2, 7
+    row = (hq + 2 * hk) * hs
+    qkv = torch.randn(b, t, row).half()
+    inv = 1.0 / (10000 ** (torch.arange(0, hs, 2).float() / hs))
+    fr = torch.einsum("i,j->ij", torch.arange(96).float(), inv)
+    cache = torch.cat([fr.cos(), fr.sin()], -1).half()
+    pos = torch.randint(0, 96, (b, t))
+    d = qkv.to(DEV)
+    q = d[..., : hq * hs].unflatten(-1, (hq, hs))
+    k = d[..., hq * hs: (hq + hk) * hs].unflatten(-1, (hk, hs))
+    assert ops.rotary_embedding_neox_strided(pos.to(DEV), q, k, hs, cache.to(DEV)) is None
+    q0 = qkv[..., : hq * hs].reshape(b * t, hq, hs).numpy()
+    k0 = qkv[..., hq * hs: (hq + hk) * hs].reshape(b * t, hk, hs).numpy()
+    qo, _ = oracle.rotary_neox_f16(pos.numpy(), q0, q0.copy(), cache.numpy(), hs)
+    ko, _ = oracle.rotary_neox_f16(pos.numpy(), k0, k0.copy(), cache.numpy(), hs)
+    got = d.cpu()
+    assert np.array_equal(got[..., : hq * hs].reshape(b * t, hq, hs).numpy(), qo)
+    assert np.array_equal(got[..., hq * hs: (hq + hk) * hs].reshape(b * t, hk, hs).numpy(), ko)
+    assert torch.equal(got[..., (hq + hk) * hs:], qkv[..., (hq + hk) * hs:])
+    with pytest.raises(RuntimeError):   # transposed views do not collapse to one token stride
+        ops.rotary_embedding_neox_strided(pos.to(DEV), q.transpose(1, 2), k.transpose(1, 2), hs, cache.to(DEV))
+
+
 # ---------------------------------------------------------------- modules / eet_quantize
 
 def test_eetq_linear_forward_backward(ops, oracle):
@@ -379,6 +407,38 @@ def test_fused_bias_is_bit_identical_to_separate_add(ops, oracle, M):
     assert torch.equal(fused, separate)
     ref = oracle.w8a16_gemm(x, q, s).astype(np.float32) + bias.float().cpu().numpy()
     assert np.allclose(fused.float().cpu().numpy(), ref, atol=3e-3, rtol=3e-3)
+
+
+@pytest.mark.parametrize("M,path", [(1, "auto"), (3, "gemv"), (8, "auto"), (8, "stream"), (48, "auto"), (64, "stream"),
+                                    (100, "mid"), (200, "auto"), (130, "mfma")])
+def test_fused_residual_is_bit_identical_to_separate_adds(ops, oracle, M, path):
+    """y = fp16(acc) + bias + residual inside the epilogue of every kernel == the three separate fp16 ops of a decoder
+    block (`residual + (proj(x) + bias)`), bit for bit; also with residual aliasing the output (in-place accumulate)."""
+    K, N = 512, 272
+    w, x = _rand_case(K, N, M, seed=900 + M)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    torch.manual_seed(M)
+    bias = torch.randn(N, dtype=torch.float16, device=DEV)
+    res = torch.randn(M, N, dtype=torch.float16, device=DEV)
+    plain = ops.w8_a16_gemm(xd, processed, scales, path=path)
+    for b in (None, bias):
+        fused = ops.w8_a16_gemm(xd, processed, scales, path=path, bias=b, residual=res)
+        separate = res + (plain + b if b is not None else plain)
+        assert torch.equal(fused, separate)
+    out = res.clone()
+    from eetq_amd import _lib
+    import ctypes
+    _lib.check(_lib.lib().eetq_w8a16_gemm_fused(ctypes.c_void_p(xd.data_ptr()), ctypes.c_void_p(processed.data_ptr()),
+                                                ctypes.c_void_p(scales.data_ptr()), None, ctypes.c_void_p(out.data_ptr()),
+                                                ctypes.c_void_p(out.data_ptr()), M, N, K, 0,
+                                                ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
+    torch.cuda.synchronize()
+    assert torch.equal(out, res + plain)
+    with pytest.raises(RuntimeError):
+        ops.w8_a16_gemm(xd, processed, scales, residual=res[:, :-16].contiguous())
 
 
 def test_fuse_w8a16_linears_qkv(ops):
@@ -445,3 +505,48 @@ def test_eet_quantize_tiny_model(ops):
     assert set(model.layers[0].state_dict().keys()) == {"qweight", "weight_scales", "bias"}
     out = model(x)
     assert torch.allclose(out, ref, atol=2e-2, rtol=2e-2)
+
+
+@pytest.mark.parametrize("kv_heads", [4, 2])
+def test_eet_accelerator_hf_llama_tiny(ops, kv_heads):
+    """eet_accelerator (reference python/eetq/utils/accelerator.py:15-19) on a toy transformers Llama: the fused-QKV /
+    in-place-rotary attention must reproduce the stock fp16 block, and the quantised + fused model must agree with
+    plain eet_quantize of the same weights (fusion of per-channel W8A16 projections is exact)."""
+    transformers = pytest.importorskip("transformers")
+    import copy
+    from eetq_amd.modules.llama_modules import EETLlamaAttention, EETLlamaMLP
+    from eetq_amd.modules.qlinear import W8A16Linear
+    from eetq_amd.utils import eet_accelerator, eet_quantize
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=kv_heads, vocab_size=512, max_position_embeddings=128)
+    torch.manual_seed(0)
+    stock = transformers.LlamaForCausalLM(cfg).half().to(DEV).eval()
+    prompt = torch.randint(0, 512, (2, 16), device=DEV)
+    with torch.no_grad():
+        ref = stock(prompt).logits.float()
+        ref_tokens = stock.generate(prompt, max_new_tokens=6, do_sample=False, pad_token_id=0)
+    spread = ref.abs().max().item()
+
+    fp16 = eet_accelerator(copy.deepcopy(stock), quantize=False, fused_attn=True)
+    assert sum(isinstance(m, EETLlamaAttention) for m in fp16.modules()) == 2
+    with torch.no_grad():
+        got = fp16(prompt).logits.float()
+        tokens = fp16.generate(prompt, max_new_tokens=6, do_sample=False, pad_token_id=0)
+    assert (got - ref).abs().max().item() < 4e-3 * spread + 4e-3   # same math, fp16 GEMM rounding differs with N
+    assert tokens.shape == ref_tokens.shape
+
+    plain = eet_quantize(copy.deepcopy(stock))
+    fused = eet_accelerator(copy.deepcopy(stock), quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True,
+                            fused_residual=True)
+    assert sum(isinstance(m, EETLlamaMLP) for m in fused.modules()) == 2
+    assert isinstance(fused.model.layers[0].self_attn.qkv_proj, W8A16Linear) and isinstance(fused.lm_head, torch.nn.Linear)
+    with torch.no_grad():
+        a = plain(prompt).logits.float()
+        b = fused(prompt).logits.float()
+        # decode through the KV cache, token by token, must follow the prefill path
+        out = fused.generate(prompt, max_new_tokens=6, do_sample=False, pad_token_id=0)
+    assert (a - b).abs().max().item() < 4e-3 * spread + 4e-3
+    assert out.shape == (2, 22)
+    with torch.no_grad():
+        full = fused(out[:, :-1]).logits[:, -1].float()
+        assert torch.equal(full.argmax(-1), out[:, -1]) or (full.topk(2).values[:, 0] - full.topk(2).values[:, 1]).min() < 1e-2
