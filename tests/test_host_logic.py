@@ -99,3 +99,44 @@ def test_ops_validate_before_touching_the_gpu():
     if not torch.cuda.is_available():
         with pytest.raises(RuntimeError, match="no HIP device"):  # no silent CPU fallback
             ops.quant_weights(w, torch.int8)
+
+
+def test_eet_accelerator_rewrites_llama_attention_on_cpu():
+    """Structure of eet_accelerator(fused_attn=True) (reference accelerator.py:22-51) without touching a GPU: every
+    LlamaAttention becomes an EETLlamaAttention over ONE nn.Linear holding [q; k; v] rows; grouped-query geometry and the
+    rotary cache follow the config; other rope types are refused rather than silently mis-rotated."""
+    transformers = pytest.importorskip("transformers")
+    from eetq.utils import eet_accelerator                      # README.md:80-81
+    from eetq_amd.modules.llama_modules import EETLlamaAttention, EETRotaryEmbedding, _rope_base
+    cfg = transformers.LlamaConfig(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=2, vocab_size=32, max_position_embeddings=48)
+    torch.manual_seed(0)
+    model = transformers.LlamaForCausalLM(cfg).half()
+    q0 = model.model.layers[0].self_attn.q_proj.weight.detach().clone()
+    v0 = model.model.layers[0].self_attn.v_proj.weight.detach().clone()
+    assert eet_accelerator(model, quantize=False, fused_attn=True) is model
+    attn = model.model.layers[0].self_attn
+    assert isinstance(attn, EETLlamaAttention) and isinstance(model.model.layers[1].self_attn, EETLlamaAttention)
+    assert attn.num_heads == 4 and attn.num_key_value_heads == 2 and attn.head_dim == 16 and attn.layer_idx == 0
+    assert model.model.layers[1].self_attn.layer_idx == 1
+    w = attn.qkv_proj.weight
+    assert w.shape == ((4 + 2 * 2) * 16, 64) and torch.equal(w[:64], q0) and torch.equal(w[96:], v0)
+    rope = attn.rotary_emb
+    assert isinstance(rope, EETRotaryEmbedding) and rope.cos_sin_cache.shape == (48, 16)
+    assert rope.cos_sin_cache.dtype == torch.float16 and rope.base == _rope_base(cfg)
+    # cache layout of the reference (llama_modules.py:33-46): cos half then sin half, position-major
+    t = torch.arange(48, dtype=torch.float32)
+    inv = 1.0 / (rope.base ** (torch.arange(0, 16, 2, dtype=torch.float32) / 16))
+    assert torch.equal(rope.cos_sin_cache[:, :8], torch.outer(t, inv).cos().half())
+    assert torch.equal(rope.cos_sin_cache[:, 8:], torch.outer(t, inv).sin().half())
+
+    class Scaled:
+        rope_parameters = {"rope_type": "llama3", "rope_theta": 1e4}
+    with pytest.raises(NotImplementedError):
+        _rope_base(Scaled())
+
+
+def test_replace_with_eet_qlinear_rejects_unmapped_models():
+    from eetq_amd.utils.accelerator import replace_with_eet_qlinear
+    with pytest.raises(ValueError):
+        replace_with_eet_qlinear(nn.Sequential(), target_model="opt")
