@@ -62,8 +62,8 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         const int tiles = ((rows + BM - 1) / BM) * ((N + BN - 1) / BN);
         Epilogue  e     = ep;
         if (e.residual) e.residual += (size_t)m * N;
-        launch_kernel(gemm_tile_kernel<0>, dim3(tiles), dim3(256), SMEM_BYTES, stream, x + (size_t)m * K, w, scales, e,
-                      y + (size_t)m * N, rows, N, K);
+        launch_kernel(gemm_tile_kernel<0>, dim3(tiles), dim3(256), SMEM_BYTES, stream, x + (size_t)m * K, w, scales,
+                      y + (size_t)m * N, rows, N, K, e);
         EETQ_TRY_HIP(hipGetLastError());
     }
     return EETQ_OK;

@@ -64,8 +64,8 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // ABLATE (kbench only): 1 = no DMA, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier
 template <int ABLATE>
 __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
-    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, Epilogue ep,
-    f16* __restrict__ y, int M, int N, int K)
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
+    f16* __restrict__ y, int M, int N, int K, Epilogue ep)
 {
     constexpr int J = 2, WN_COLS = 64, PIECES = 6, NMFMA = 16;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

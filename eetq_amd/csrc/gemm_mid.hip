@@ -16,7 +16,7 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
                                          C::kSmem));
     }
     const int tiles = ((N + gemm_mid::kBN - 1) / gemm_mid::kBN) * ((M + C::kRows - 1) / C::kRows);
-    launch_kernel(kern, dim3(tiles), dim3(gemm_mid::kThreads), C::kSmem, stream, x, w, scales, ep, y, M, N, K);
+    launch_kernel(kern, dim3(tiles), dim3(gemm_mid::kThreads), C::kSmem, stream, x, w, scales, y, M, N, K, ep);
     return check_hip(hipGetLastError(), "gemm_mid_kernel launch");
 }
 

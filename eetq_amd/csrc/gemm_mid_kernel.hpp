@@ -36,8 +36,8 @@ struct Cfg {
 // STAGES = 2: <= 80 KiB of LDS at MT <= 2, two workgroups per CU cover each other's barrier and DMA latency.
 template <int MT, int STAGES>
 __global__ __launch_bounds__(kThreads, (STAGES == 2 && MT <= 2) ? 2 : 1) void gemm_mid_kernel(
-    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, Epilogue ep,
-    f16* __restrict__ y, int M, int N, int K)
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
+    f16* __restrict__ y, int M, int N, int K, Epilogue ep)
 {
     using C = Cfg<MT, STAGES>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

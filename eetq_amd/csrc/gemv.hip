@@ -24,7 +24,7 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
     }
-    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, ep, y, N, K);
+    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep);
     return check_hip(hipGetLastError(), "gemv_kernel launch");
 }
 

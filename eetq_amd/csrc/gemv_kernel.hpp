@@ -63,7 +63,7 @@ __device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, cons
 template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    Epilogue ep, f16* __restrict__ y, int N, int K)
+    f16* __restrict__ y, int N, int K, Epilogue ep)
 {
     static_assert(!XREG || EXACT, "register-resident activations need the exact-fit shape");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

@@ -18,7 +18,7 @@ namespace streamk {
 template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    Epilogue ep, f16* __restrict__ y, int M, int N, int K)
+    f16* __restrict__ y, int M, int N, int K, Epilogue ep)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     float* red = reinterpret_cast<float*>(smem);

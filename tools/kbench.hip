@@ -1,7 +1,7 @@
 // Kernel micro-benchmark harness (no torch): times kernel variants on one MI355X with
 //   (a) per-dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events == what rocprof reports),
 //   (b) wall time per step of a HIP graph holding a chain of dependent launches.
-// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/kbench.hip -o tools/kbench
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16 tools/kbench.hip -o tools/kbench
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
@@ -150,13 +150,13 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
     auto st = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
             hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, eetq::Epilogue{}, y, N, K);
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, eetq::Epilogue{});
         },
         400);
     double g = time_graph(
         [&](int i, hipStream_t s) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, s, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, eetq::Epilogue{}, y, N, K);
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, eetq::Epilogue{});
         },
         400);
     printf("%-30s N=%5d K=%5d M=%d | disp mean %6.2f med %6.2f min %6.2f p90 %6.2f us -> %6.0f GB/s(med) | graph %6.2f us/step -> %6.0f GB/s\n",
@@ -175,7 +175,7 @@ static void bench_gemm(const char* name, int M, int N, int K, const std::vector<
     auto         st    = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
             hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(256), SMEM_BYTES, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, eetq::Epilogue{}, y, M, N, K);
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, eetq::Epilogue{});
         },
         60, 10);
     printf("%-22s M=%5d N=%5d K=%5d | disp mean %7.2f med %7.2f min %7.2f us -> %7.1f TF(med)\n", name, M, N, K, st.mean,
@@ -194,7 +194,7 @@ static void bench_streamk(const char* name, int M, int N, int K, const std::vect
     auto st = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
             hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, eetq::Epilogue{}, y, M, N, K);
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, eetq::Epilogue{});
         },
         200);
     printf("%-30s N=%5d K=%5d M=%3d | disp mean %6.2f med %6.2f min %6.2f us -> %6.0f GB/s(med) %7.1f TF\n", name, N, K, M,
@@ -214,7 +214,7 @@ static void bench_mid(const char* name, int M, int N, int K, const std::vector<u
     auto st = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
             hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(kThreads), C::kSmem, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, eetq::Epilogue{}, y, M, N, K);
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, eetq::Epilogue{});
         },
         200);
     printf("%-22s N=%5d K=%5d M=%3d | disp mean %6.2f med %6.2f min %6.2f us -> %6.0f GB/s(med) %7.1f TF\n", name, N, K, M,
@@ -422,12 +422,12 @@ int main(int argc, char** argv)
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         for (int i = 0; i < 20; ++i)
             hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
-                               eetq::Epilogue{}, yg, 1024, 4096, 4096);
+                               yg, 1024, 4096, 4096, eetq::Epilogue{});
         CK(hipDeviceSynchronize());
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
         for (int i = 0; i < 20; ++i)
             hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, eetq::Epilogue{}, y, 4096, 4096);
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{});
         CK(hipDeviceSynchronize());
     }
     if (!strcmp(what, "all") || !strcmp(what, "mid")) {
