@@ -5,12 +5,12 @@ namespace eetq {
 
 namespace {
 
-template <int MT, int STAGES>
-int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
+template <int MT, int STAGES, bool KFULL>
+int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream)
 {
     using C   = gemm_mid::Cfg<MT, STAGES>;
-    auto kern = gemm_mid::gemm_mid_kernel<MT, STAGES>;
+    auto kern = gemm_mid::gemm_mid_kernel<MT, STAGES, KFULL>;
     if (C::kSmem > 64 * 1024) {
         EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          C::kSmem));
@@ -18,6 +18,14 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     const int tiles = ((N + gemm_mid::kBN - 1) / gemm_mid::kBN) * ((M + C::kRows - 1) / C::kRows);
     launch_kernel(kern, dim3(tiles), dim3(gemm_mid::kThreads), C::kSmem, stream, x, w, scales, y, M, N, K, ep);
     return check_hip(hipGetLastError(), "gemm_mid_kernel launch");
+}
+
+template <int MT, int STAGES>
+int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
+                hipStream_t stream)
+{
+    return K % gemm_mid::kBK == 0 ? launch_full<MT, STAGES, true>(x, w, scales, ep, y, M, N, K, stream)
+                                  : launch_full<MT, STAGES, false>(x, w, scales, ep, y, M, N, K, stream);
 }
 
 }  // namespace

@@ -34,7 +34,10 @@ struct Cfg {
 
 // STAGES = 3: deeper prefetch, one workgroup per CU (when there are no more tiles than CUs anyway);
 // STAGES = 2: <= 80 KiB of LDS at MT <= 2, two workgroups per CU cover each other's barrier and DMA latency.
-template <int MT, int STAGES>
+// KFULL: K is a multiple of the 256-deep step (all Llama shapes): no wave ever skips a step, so the loop body has no
+// branch around the MFMAs -- with one, hipcc keeps the accumulators in VGPRs and copies all of them to AGPRs and back
+// around the MFMAs of every step (64 x MT extra VALU instructions per step).
+template <int MT, int STAGES, bool KFULL>
 __global__ __launch_bounds__(kThreads, (STAGES == 2 && MT <= 2) ? 2 : 1) void gemm_mid_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, Epilogue ep)
@@ -126,17 +129,15 @@ __global__ __launch_bounds__(kThreads, (STAGES == 2 && MT <= 2) ? 2 : 1) void ge
         else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // ... everyone's have; everyone is done with the buffer refilled below
-        if (step + C::kStages - 1 < steps) {
-            int nb = buf + C::kStages - 1;
-            nb     = nb >= C::kStages ? nb - C::kStages : nb;
-            issue_stage(nb, step + C::kStages - 1);
-        }
-        if (step * 4 + wave < KT) {  // wave-uniform: k tile beyond K on the last step
-            const uint8_t* sa = smem + buf * C::kStage;
-            // all fragment reads of the step are issued before the first MFMA (hipcc would otherwise serialise
-            // read -> wait -> MFMA to save registers); the second workgroup on the CU covers what is left
-            u32x4 wq[2];
-            f16x8 xa[2][2][MT];
+        const bool     active = KFULL || step * 4 + wave < KT;  // wave-uniform: k tile beyond K on the last step
+        const uint8_t* sa     = smem + buf * C::kStage;
+        // Order inside a step: (1) all fragment reads of the step are issued, (2) then this wave's DMA pieces of the
+        // stage two steps ahead -- an LDS-DMA instruction holds the wave's issue slot for 60+ cycles, ten of them right
+        // after the barrier used to delay the step's math by ~800 cycles; now they run under the LDS read latency --
+        // (3) then dequant + MFMA.
+        u32x4 wq[2];
+        f16x8 xa[2][2][MT];
+        if (active) {
 #pragma unroll
             for (int s = 0; s < 2; ++s) wq[s] = *reinterpret_cast<const u32x4*>(sa + b_off + s * 512);
 #pragma unroll
@@ -146,6 +147,15 @@ __global__ __launch_bounds__(kThreads, (STAGES == 2 && MT <= 2) ? 2 : 1) void ge
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         xa[s][e][mt] = *reinterpret_cast<const f16x8*>(sa + mt * 32 * 512 + a_row_off + a_slot[s][e]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (step + C::kStages - 1 < steps) {
+            int nb = buf + C::kStages - 1;
+            nb     = nb >= C::kStages ? nb - C::kStages : nb;
+            issue_stage(nb, step + C::kStages - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
             asm volatile("" : "+v"(wq[0]), "+v"(wq[1]));  // keep the reads above the dequant below in program order
 #pragma unroll
             for (int s = 0; s < 2; ++s) {

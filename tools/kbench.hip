@@ -207,7 +207,7 @@ static void bench_mid(const char* name, int M, int N, int K, const std::vector<u
 {
     using namespace eetq::gemm_mid;
     using C   = Cfg<MT, STAGES>;
-    auto kern = gemm_mid_kernel<MT, STAGES>;
+    auto kern = gemm_mid_kernel<MT, STAGES, true>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, C::kSmem));
     const int    tiles = ((N + kBN - 1) / kBN) * ((M + C::kRows - 1) / C::kRows);
     const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
