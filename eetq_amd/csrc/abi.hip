@@ -238,11 +238,17 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
             // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
             // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 16 -> MFMA stream kernel (same weight stream,
             // activations straight from L2 into MFMA operands); 17 <= M <= 128 -> medium-batch LDS tile (32 columns,
-            // 256-deep K steps); larger M -> 128 x 128 LDS-tiled MFMA GEMM.  Crossovers measured: profiles/r01_sweep.json.
+            // 256-deep K steps); larger M -> LDS-tiled MFMA GEMM (128 x 128 tiles, or 128 x 64 when those fill the chip better).
+            // Crossovers measured: profiles/r01_sweep.json.
             if (M == 1) return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
             if (M <= 16) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
-            if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31))
+            if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31)) {
+                // wide N: the 128 x 64 tiles of the tiled kernel already give most CUs a workgroup and read the
+                // activations once per 64 columns instead of once per 32 (N = 11008: M = 64 17.5 vs 20.2 us, M = 128
+                // 21.9 vs 40.4 us; N = 4096: 15.9 vs 11.1 us the other way; profiles/r01_kbench_tile_shapes.txt)
+                if (M >= 33 && (N + 63) / 64 >= 160 && K >= 320) return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
                 return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
+            }
             return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);

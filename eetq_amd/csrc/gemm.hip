@@ -47,8 +47,10 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
     int                       dev           = 0;
     EETQ_TRY_HIP(hipGetDevice(&dev));
     if (!(attr_set_mask >> (dev & 63) & 1ull)) {
-        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<0>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<0, 2>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<2>::SMEM_BYTES));
+        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<0, 1>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<1>::SMEM_BYTES));
         attr_set_mask |= 1ull << (dev & 63);
     }
     // the LDS-DMA path addresses its operands with 32-bit buffer offsets
@@ -57,13 +59,35 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
     const size_t row_bytes  = (size_t)K * 2;
     const int    max_rows   = (int)((((1ull << 31) - 1) / row_bytes) / BM * BM);
     EETQ_REQUIRE(max_rows >= BM, "K too large for the buffer-addressed DMA path");
+    int n_cu = 256;
+    {
+        static int cached_cus[64] = {0};
+        if (!cached_cus[dev & 63]) {
+            int v = 0;
+            EETQ_TRY_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+            cached_cus[dev & 63] = v > 0 ? v : 256;
+        }
+        n_cu = cached_cus[dev & 63];
+    }
     for (int m = 0; m < M; m += max_rows) {
-        const int rows  = M - m < max_rows ? M - m : max_rows;
-        const int tiles = ((rows + BM - 1) / BM) * ((N + BN - 1) / BN);
-        Epilogue  e     = ep;
+        const int rows    = M - m < max_rows ? M - m : max_rows;
+        const int tiles_m = (rows + BM - 1) / BM;
+        const int tiles2  = tiles_m * ((N + TileCfg<2>::BN - 1) / TileCfg<2>::BN);
+        const int tiles1  = tiles_m * ((N + TileCfg<1>::BN - 1) / TileCfg<1>::BN);
+        // 128 x 128 tiles are the efficient shape when they fill the chip; 128 x 64 tiles double the workgroup count:
+        // they win when the wide tiles leave CUs idle (tiles < CUs) or end in a mostly empty round.  Cost in units of one
+        // wide-tile pass; a narrow tile costs kNarrow of it (measured, profiles/r01_kbench_tile_shapes.txt).
+        constexpr double kNarrow = 0.70;
+        const double cost2 = (double)((tiles2 + n_cu - 1) / n_cu);
+        const double cost1 = kNarrow * (double)((tiles1 + n_cu - 1) / n_cu);
+        Epilogue     e     = ep;
         if (e.residual) e.residual += (size_t)m * N;
-        launch_kernel(gemm_tile_kernel<0>, dim3(tiles), dim3(256), SMEM_BYTES, stream, x + (size_t)m * K, w, scales,
-                      y + (size_t)m * N, rows, N, K, e);
+        if (cost1 < cost2)
+            launch_kernel(gemm_tile_kernel<0, 1>, dim3(tiles1), dim3(256), TileCfg<1>::SMEM_BYTES, stream, x + (size_t)m * K, w,
+                          scales, y + (size_t)m * N, rows, N, K, e);
+        else
+            launch_kernel(gemm_tile_kernel<0, 2>, dim3(tiles2), dim3(256), TileCfg<2>::SMEM_BYTES, stream, x + (size_t)m * K, w,
+                          scales, y + (size_t)m * N, rows, N, K, e);
         EETQ_TRY_HIP(hipGetLastError());
     }
     return EETQ_OK;

@@ -7,13 +7,19 @@
 namespace eetq {
 namespace gemm {
 
-constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int BM = 128, BK = 64;
 constexpr int A_STAGE_BYTES = BM * BK * 2;  // 16 KiB of fp16 activations per K step
-constexpr int B_STAGE_BYTES = BN * BK;      // 8 KiB of uint8 weights (8 native tiles) per K step
-constexpr int STAGE_BYTES   = A_STAGE_BYTES + B_STAGE_BYTES;
 constexpr int STAGES        = 6;
-constexpr int SMEM_BYTES    = STAGES * STAGE_BYTES;  // 144 KiB (also covers the 64 KiB end-of-kernel reduction)
-constexpr int kMinKSteps    = STAGES - 1;            // the statically unrolled drain needs K/64 >= 5
+constexpr int kMinKSteps    = STAGES - 1;   // the statically unrolled drain needs K/64 >= 5
+// J = 32-column blocks per wave: J = 2 -> 128 x 128 tile (the MFMA-bound shape), J = 1 -> 128 x 64 tile (twice the
+// workgroups: fills the chip at 129 <= M <= 512 and trims the last partial round of tiles on other shapes)
+template <int J>
+struct TileCfg {
+    static constexpr int BN            = 64 * J;
+    static constexpr int B_STAGE_BYTES = BN * BK;  // 4*J native 1 KiB tiles per K step
+    static constexpr int STAGE_BYTES   = A_STAGE_BYTES + B_STAGE_BYTES;
+    static constexpr int SMEM_BYTES    = STAGES * STAGE_BYTES;  // 144 / 120 KiB (also covers the end-of-kernel reduction)
+};
 
 typedef __attribute__((address_space(3))) void lds_void;
 
@@ -44,9 +50,9 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
     return f16x8{a.x, a.y, b.x, b.y, c.x, c.y, d.x, d.y};
 }
 
-// Workgroup tile 128 x 128 x 64, 4 waves = 2 K halves x 2 column halves: a wave owns 128 rows x 64 columns of one
-// 32-deep half of every K step (16 x v_mfma_f32_32x32x16_f16 per step, 128 fp32 accumulators per lane, one wave per
-// SIMD).  Every dequantised weight fragment feeds 4 MFMAs (row repeat), every activation fragment 2 (column repeat).
+// Workgroup tile 128 x (64*J) x 64, 4 waves = 2 K halves x 2 column halves: at J = 2 a wave owns 128 rows x 64 columns of
+// one 32-deep half of every K step (16 x v_mfma_f32_32x32x16_f16 per step, 128 fp32 accumulators per lane, one wave per
+// SIMD); at J = 1 it owns 32 columns (8 MFMAs per step; the slot tables below have a second, 8-gap form).  Every dequantised weight fragment feeds 4 MFMAs (row repeat), every activation fragment 2 (column repeat).
 // The two K halves' partial sums are added once at the end through LDS.  6-stage LDS-DMA ring, one barrier per K step.
 //
 // Where each instruction sits (one wave per SIMD hides roughly five single-issue instructions under one 32-cycle MFMA,
@@ -62,18 +68,21 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // An earlier schedule (all reads in gaps 0..3, DMA in gaps 0..5, dequant 6 ops per gap in gaps 4..11, bookkeeping after
 // the last MFMA) ran 3 % slower; see profiles/r01_kbench_ablation_gemm.txt.
 // ABLATE (kbench only): 1 = no DMA, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier
-template <int ABLATE>
+template <int ABLATE, int J>
 __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, Epilogue ep)
 {
-    constexpr int J = 2, WN_COLS = 64, PIECES = 6, NMFMA = 16;
+    using Cfg = TileCfg<J>;
+    constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES;
+    constexpr int WN_COLS = 32 * J, PIECES = 4 + J, NMFMA = 8 * J;
+    static_assert(J == 1 || J == 2, "slot tables exist for J = 1 and J = 2");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int grp  = wave >> 1;  // which 32-deep half of each K step
-    const int wn   = wave & 1;   // which 64-column half of the tile
+    const int wn   = wave & 1;   // which column half (32*J columns) of the tile
     const int KT   = K >> 6;
 
     const int tiles_m = (M + BM - 1) / BM;
@@ -103,7 +112,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(w) - kShift, 0, (int)((size_t)N * K) + kShift, 0x00020000);
     // DMA pieces of this wave: i < 4: activation piece 4*wave + i (rows 8p..8p+7, 128 B each); i >= 4: weight tile
-    // 2*wave + i - 4 of the stage's 8
+    // J*wave + i - 4 of the stage's 4*J
     int       dma_voff[PIECES];
     const int n_tiles_total = N >> 4;
 #pragma unroll
@@ -117,12 +126,12 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     }
 #pragma unroll
     for (int i = 4; i < PIECES; ++i) {
-        int nt      = (n0 >> 4) + wave * 2 + (i - 4);
+        int nt      = (n0 >> 4) + wave * J + (i - 4);
         nt          = nt < n_tiles_total ? nt : n_tiles_total - 1;
         dma_voff[i] = nt * KT * kTileBytes + lane * 16 + kShift - (i - 4) * 1024;
     }
     const int dma_lds_a = wave * 4 * 1024;                    // + i * 1024
-    const int dma_lds_b = A_STAGE_BYTES + wave * 2 * 1024;    // + (i - 4) * 1024
+    const int dma_lds_b = A_STAGE_BYTES + wave * J * 1024;    // + (i - 4) * 1024
 
     const int fn = lane & 31, fh = lane >> 5;
     const int a_key = (fn >> 1) & 7;
@@ -177,34 +186,40 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
         const f16x2    bias1152 = {(f16)1152.0f, (f16)1152.0f};
 #pragma unroll
         for (int i = 0; i < NMFMA; ++i) {
-            const int e = i >> 3, j = (i >> 2) & 1, mt = i & 3;
+            const int e = i / (4 * J), j = (i / 4) % J, mt = i & 3;
             if constexpr (!(ABLATE & 8))
                 acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur.f[j][e], fcur.xa[e][mt], acc[mt][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);  // the MFMA opens its gap: dependent VALU ops of adjacent gaps never abut
             if constexpr (READ && !(ABLATE & 4)) {
                 if (i == 0) {
                     fnext.wq[0] = lds_read16(rb0);
-                    fnext.wq[1] = lds_read16(rb1);
+                    if constexpr (J == 2) fnext.wq[1] = lds_read16(rb1);
                 }
-                // activation fragments q = 4e + mt: gap 1: q0; 2: q1,q2; 3: q3; 4: q4; 6: q5; 7: q6; 9: q7
+                // activation fragments q = 4e + mt.  J = 2: gap 1: q0; 2: q1,q2; 3: q3; 4: q4; 6: q5; 7: q6; 9: q7.
+                // J = 1: two per gap in gaps 1..4.
                 auto xa_read = [&](int q) {
                     fnext.xa[q >> 2][q & 3] =
                         __builtin_bit_cast(f16x8, lds_read16(((q >> 2) ? ra1 : ra0) + (q & 3) * 32 * 128));
                 };
-                if (i == 1) xa_read(0);
-                if (i == 2) { xa_read(1); xa_read(2); }
-                if (i == 3) xa_read(3);
-                if (i == 4) xa_read(4);
-                if (i == 6) xa_read(5);
-                if (i == 7) xa_read(6);
-                if (i == 9) xa_read(7);
+                if constexpr (J == 2) {
+                    if (i == 1) xa_read(0);
+                    if (i == 2) { xa_read(1); xa_read(2); }
+                    if (i == 3) xa_read(3);
+                    if (i == 4) xa_read(4);
+                    if (i == 6) xa_read(5);
+                    if (i == 7) xa_read(6);
+                    if (i == 9) xa_read(7);
+                } else {
+                    if (i >= 1 && i <= 4) { xa_read(2 * i - 2); xa_read(2 * i - 1); }
+                }
             }
             if constexpr (READ && !(ABLATE & 2)) {
-                if (i >= 4) {
-                    // dequant micro-ops: gap i works on column block jj = (i-4)/6, dword pair dp = ((i-4)/3)&1 and
+                constexpr int kDq0 = J == 2 ? 4 : 2;  // first gap that carries dequant ops (6*J gaps of them follow)
+                if (i >= kDq0) {
+                    // dequant micro-ops: gap i works on column block jj = (i-kDq0)/6, dword pair dp = ((i-kDq0)/3)&1 and
                     // applies ONE kind of op (perm / -1152 / *scale) to its four half-dwords: four independent VALU
                     // ops per gap, dependent ops a gap apart (no hazard nops)
-                    const int jj = (i - 4) / 6, dp = ((i - 4) / 3) & 1, kind = (i - 4) % 3;
+                    const int jj = (i - kDq0) / 6, dp = ((i - kDq0) / 3) & 1, kind = (i - kDq0) % 3;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int h = 4 * dp + u, d = h >> 1;
@@ -227,31 +242,40 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
                 }
             }
             if constexpr (DMA && !(ABLATE & 1)) {
-                if (i == 0) dma_piece(std::integral_constant<int, 0>{});
-                if (i == 1) dma_piece(std::integral_constant<int, 1>{});
-                if (i == 3) dma_piece(std::integral_constant<int, 2>{});
-                if (i == 5) dma_piece(std::integral_constant<int, 3>{});
-                if (i == 8) dma_piece(std::integral_constant<int, 4>{});
-                if (i == 11) dma_piece(std::integral_constant<int, 5>{});
+                if constexpr (J == 2) {
+                    if (i == 0) dma_piece(std::integral_constant<int, 0>{});
+                    if (i == 1) dma_piece(std::integral_constant<int, 1>{});
+                    if (i == 3) dma_piece(std::integral_constant<int, 2>{});
+                    if (i == 5) dma_piece(std::integral_constant<int, 3>{});
+                    if (i == 8) dma_piece(std::integral_constant<int, 4>{});
+                    if (i == 11) dma_piece(std::integral_constant<int, 5>{});
+                } else {
+                    if (i == 0) dma_piece(std::integral_constant<int, 0>{});
+                    if (i == 1) dma_piece(std::integral_constant<int, 1>{});
+                    if (i == 2) dma_piece(std::integral_constant<int, 2>{});
+                    if (i == 3) dma_piece(std::integral_constant<int, 3>{});
+                    if (i == 5) dma_piece(std::integral_constant<int, 4>{});
+                }
             }
             if constexpr (READ) {
                 // ring state and read addresses of the next step, in the gaps that carry little else
-                if (i == 12) {
+                // (after the step's last fragment read / last DMA piece: J = 2 gaps 12..15, J = 1 gaps 5..7)
+                if (i == (J == 2 ? 12 : 5)) {
                     rd = rd + STAGE_BYTES == SMEM_BYTES ? 0 : rd + STAGE_BYTES;
                     asm volatile("" : "+s"(rd));
                 }
-                if (i == 13) {
+                if (i == (J == 2 ? 13 : 6)) {
                     wr = wr + STAGE_BYTES == SMEM_BYTES ? 0 : wr + STAGE_BYTES;
                     ka += BK * 2;
                     kb += kTileBytes;
                     asm volatile("" : "+s"(wr), "+s"(ka), "+s"(kb));
                 }
-                if (i == 14) {
+                if (i == (J == 2 ? 14 : 6)) {
                     ra0 = rd + c_a0;
                     ra1 = rd + c_a1;
                     asm volatile("" : "+v"(ra0), "+v"(ra1));
                 }
-                if (i == 15) {
+                if (i == (J == 2 ? 15 : 7)) {
                     rb0 = rd + c_b0;
                     rb1 = rd + c_b1;
                     asm volatile("" : "+v"(rb0), "+v"(rb1));
@@ -295,7 +319,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     WFrag w0, w1;
     {
         f0.wq[0] = lds_read16(c_b0);
-        f0.wq[1] = lds_read16(c_b1);
+        if constexpr (J == 2) f0.wq[1] = lds_read16(c_b1);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             f0.xa[0][mt] = __builtin_bit_cast(f16x8, lds_read16(c_a0 + mt * 32 * 128));

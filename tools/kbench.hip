@@ -163,12 +163,13 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
            name, N, K, M, st.mean, st.med, st.mn, st.p90, bytes / st.med / 1e3, g, bytes / g / 1e3);
 }
 
-template <int ABLATE>
+template <int ABLATE, int J = 2>
 static void bench_gemm(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
                         const eetq::f16* scales, eetq::f16* y)
 {
     using namespace eetq::gemm;
-    auto kern = gemm_tile_kernel<ABLATE>;
+    auto kern = gemm_tile_kernel<ABLATE, J>;
+    constexpr int SMEM_BYTES = TileCfg<J>::SMEM_BYTES, BN = TileCfg<J>::BN;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     const int    tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const double flops = 2.0 * M * N * K;
@@ -409,6 +410,40 @@ int main(int argc, char** argv)
         bench_gemv<1, 16, 2, false, false, 2, 8>("loop lds 16x2 o8", 13824, 5120, b70, xl, scales, y);
         bench_gemv<1, 16, 5, true, true, 1, 8>("exact xreg 16x5 o8", 13824, 5120, b70, xl, scales, y);
     }
+    if (!strcmp(what, "tiles")) {  // 128 x 128 (J = 2) vs 128 x 64 (J = 1) tiles
+        eetq::f16 *xg, *yg;
+        CK(hipMalloc(&xg, 4096ull * 13824 * 2));
+        CK(hipMalloc(&yg, 4096ull * 13824 * 2));
+        {
+            std::vector<uint16_t> h(4096ull * 13824);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
+            CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        uint8_t* huge;
+        CK(hipMalloc(&huge, 13824ull * 5120 * 6));
+        CK(hipMemset(huge, 0x5a, 13824ull * 5120 * 6));
+        std::vector<uint8_t*> b70;
+        for (int i = 0; i < 6; ++i) b70.push_back(huge + (size_t)i * 13824 * 5120);
+        for (int M : {64, 96, 128}) {
+            bench_gemm<0, 1>("J=1 128x64", M, 4096, 4096, bufs, xg, scales, yg);
+            bench_gemm<0, 1>("J=1 128x64 N=11008", M, 11008, 4096, bufs_big, xg, scales, yg);
+            bench_gemm<0, 1>("J=1 128x64 K=11008", M, 4096, 11008, bufs_big, xg, scales, yg);
+        }
+        for (int M : {192, 256, 384, 512, 768, 1024}) {
+            bench_gemm<0, 2>("J=2 128x128", M, 4096, 4096, bufs, xg, scales, yg);
+            bench_gemm<0, 1>("J=1 128x64", M, 4096, 4096, bufs, xg, scales, yg);
+        }
+        bench_gemm<0, 2>("J=2 128x128", 1024, 5120, 5120, b70, xg, scales, yg);
+        bench_gemm<0, 1>("J=1 128x64", 1024, 5120, 5120, b70, xg, scales, yg);
+        bench_gemm<0, 2>("J=2 128x128", 1024, 5120, 13824, b70, xg, scales, yg);
+        bench_gemm<0, 1>("J=1 128x64", 1024, 5120, 13824, b70, xg, scales, yg);
+        bench_gemm<0, 2>("J=2 128x128", 1024, 13824, 5120, b70, xg, scales, yg);
+        bench_gemm<0, 1>("J=1 128x64", 1024, 13824, 5120, b70, xg, scales, yg);
+        bench_gemm<0, 2>("J=2 128x128", 1024, 11008, 4096, bufs_big, xg, scales, yg);
+        bench_gemm<0, 1>("J=1 128x64", 1024, 11008, 4096, bufs_big, xg, scales, yg);
+        bench_gemm<0, 2>("J=2 128x128", 2048, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<0, 1>("J=1 128x64", 2048, 4096, 4096, bufs, xg, scales, yg);
+    }
     if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
         eetq::f16 *xg, *yg;
         CK(hipMalloc(&xg, 1024ull * 4096 * 2));
@@ -417,8 +452,9 @@ int main(int argc, char** argv)
         for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
         CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
         using namespace eetq::gemm;
-        auto kern = gemm_tile_kernel<0>;
+        auto kern = gemm_tile_kernel<0, 2>;
         constexpr int THREADS8 = 256;
+        constexpr int SMEM_BYTES = TileCfg<2>::SMEM_BYTES;
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         for (int i = 0; i < 20; ++i)
             hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
