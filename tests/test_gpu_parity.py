@@ -176,7 +176,11 @@ def test_mid_tile_vs_oracle(ops, oracle, M, K, N):
 
 
 @pytest.mark.parametrize("M,K,N", [(5, 64, 16), (8, 256, 128), (17, 128, 144), (64, 1024, 256), (128, 512, 128),
-                                   (130, 192, 272), (300, 2048, 384), (8, 4096, 4096), (64, 4096, 1024)])
+                                   (130, 192, 272), (300, 2048, 384), (8, 4096, 4096), (64, 4096, 1024),
+                                   # narrow (128 x 64) and wide tiles with ragged edges: N below / not a multiple of the
+                                   # tile width, M one past a tile, odd and even K step counts
+                                   (200, 512, 16), (200, 576, 48), (129, 640, 80), (600, 704, 208), (257, 384, 8192),
+                                   (1100, 320, 4160)])
 def test_mfma_gemm_vs_oracle(ops, oracle, M, K, N):
     w, x = _rand_case(K, N, M, seed=K + N + M)
     x[:, ::7] *= -1  # signed activations
