@@ -554,3 +554,37 @@ def test_eet_accelerator_hf_llama_tiny(ops, kv_heads):
     with torch.no_grad():
         full = fused(out[:, :-1]).logits[:, -1].float()
         assert torch.equal(full.argmax(-1), out[:, -1]) or (full.topk(2).values[:, 0] - full.topk(2).values[:, 1]).min() < 1e-2
+
+
+def test_auto_dispatch_fuzz_vs_oracle(ops, oracle):
+    """Seeded random shapes through the AUTO dispatch (every kernel and every ragged edge the launchers can pick), with
+    bias and residual on a third of them; tier-A against the oracle."""
+    rng = np.random.default_rng(20260926)
+    cases = []
+    for _ in range(70):
+        M = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 31, 32, 33, 47, 64, 65, 96, 127, 128, 129, 160, 255, 256, 300]))
+        K = 64 * int(rng.integers(1, 18))
+        N = 16 * int(rng.integers(1, 40))
+        cases.append((M, K, N))
+    cases += [(40, 512, 10240), (100, 384, 10304), (129, 320, 8208), (8, 2048, 8192), (16, 2112, 8256)]  # wide-N rules
+    for idx, (M, K, N) in enumerate(cases):
+        w, x = _rand_case(K, N, M, seed=1000 + idx)
+        x[:, ::5] *= -1
+        q, s = oracle.quantize(w)
+        processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+        scales = torch.from_numpy(s).to(DEV)
+        xd = torch.from_numpy(x).to(DEV)
+        ref = oracle.w8a16_gemm(x, q, s).astype(np.float32)
+        if idx % 3 == 0:
+            torch.manual_seed(idx)
+            bias = torch.randn(N, dtype=torch.float16, device=DEV)
+            res = torch.randn(M, N, dtype=torch.float16, device=DEV)
+            y = ops.w8_a16_gemm(xd, processed, scales, bias=bias, residual=res)
+            plain = ops.w8_a16_gemm(xd, processed, scales)
+            assert torch.equal(y, res + (plain + bias)), (M, K, N)
+            y = plain
+        else:
+            y = ops.w8_a16_gemm(xd, processed, scales)
+        got = y.cpu().numpy().astype(np.float32)
+        ok = _tier_a(got, ref)
+        assert ok.all(), "M=%d K=%d N=%d: max err %g at %s" % (M, K, N, np.abs(got - ref).max(), np.argwhere(~ok)[:4])
