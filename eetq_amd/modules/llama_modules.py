@@ -89,18 +89,44 @@ class _EETAttentionBase(nn.Module):
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
         if past_key_values is not None:
             k, v = past_key_values.update(k, v, self.layer_idx)
-        if q.shape[2] == 1 and self.decode_math_attention and not kwargs.get("output_attentions", False):
+        use_math = self.decode_math_attention == "always" or (
+            self.decode_math_attention and q.is_cuda and torch.cuda.is_current_stream_capturing())
+        if q.shape[2] == 1 and use_math and not kwargs.get("output_attentions", False):
             # one query token: the library attention kernels launch one workgroup per head (40 workgroups streaming
             # the whole KV cache: 68 us per layer at Llama-13B shapes, S = 1.2 k); two batched matrix-vector products
-            # and a softmax spread the cache over the chip
+            # and a softmax spread the cache over the chip.  Used while the step is being captured into a HIP graph
+            # (GPU time is what counts there); in eager mode the single library call has fewer launches and wins.
             if self.num_key_value_groups > 1:
                 k = k.repeat_interleave(self.num_key_value_groups, dim=1)
                 v = v.repeat_interleave(self.num_key_value_groups, dim=1)
-            scores = torch.matmul(q, k.transpose(2, 3)) * self.scaling          # [B, H, 1, S]
+            bsz, heads, _, s_len = q.shape[0], q.shape[1], q.shape[2], k.shape[2]
+            add = None
             if attention_mask is not None:
-                mask = attention_mask[..., : k.shape[2]]
-                scores = scores.masked_fill(~mask, float("-inf")) if mask.dtype == torch.bool else scores + mask
-            probs = torch.softmax(scores, dim=-1, dtype=torch.float32).to(q.dtype)
+                # additive fp16 form of the mask, built once per forward and parked on the mask object (the model
+                # hands the same object to every layer)
+                add = getattr(attention_mask, "_eet_additive", None)
+                if add is None:
+                    add = attention_mask
+                    if add.dtype == torch.bool:
+                        add = torch.zeros(add.shape, dtype=q.dtype, device=q.device).masked_fill_(~attention_mask,
+                                                                                                 float("-inf"))
+                    elif add.dtype != q.dtype:
+                        add = add.to(q.dtype)
+                    try:
+                        attention_mask._eet_additive = add
+                    except Exception:
+                        pass
+                if add.shape[-1] != s_len:
+                    add = add[..., :s_len]
+            kt = k.transpose(2, 3)
+            if add is not None and bsz == 1:
+                # scaling * (q . k^T) + mask in one batched kernel
+                scores = torch.baddbmm(add.expand(1, heads, 1, s_len).reshape(heads, 1, s_len), q.reshape(heads, 1, -1),
+                                       kt.reshape(heads, -1, s_len), beta=1.0, alpha=self.scaling).unsqueeze(0)
+            else:
+                scores = torch.matmul(q, kt)                                           # [B, H, 1, S]
+                scores = torch.add(add, scores, alpha=self.scaling) if add is not None else scores * self.scaling
+            probs = torch.softmax(scores, dim=-1)      # fp16 in/out, fp32 accumulation inside
             out = torch.matmul(probs, v).transpose(1, 2)
             return out.reshape(*input_shape, -1).contiguous(), None
         fn = None
