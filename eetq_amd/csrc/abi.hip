@@ -305,4 +305,14 @@ int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* ke
                          k_stride, static_cast<hipStream_t>(stream));
 }
 
+int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* mask, void* out,
+                              float* workspace, int batch, int heads, int kv_heads, int positions, int head_dim,
+                              int splits, float scaling, const long* strides, void* stream)
+{
+    return launch_attn_decode(static_cast<const f16*>(q), static_cast<const f16*>(k_cache),
+                              static_cast<const f16*>(v_cache), static_cast<const f16*>(mask), static_cast<f16*>(out),
+                              workspace, batch, heads, kv_heads, positions, head_dim, splits, scaling, strides,
+                              static_cast<hipStream_t>(stream));
+}
+
 }  // extern "C"

@@ -105,6 +105,9 @@ int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows
 int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int q_heads, int k_heads,
                   int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream);
 
+int launch_attn_decode(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out, float* ws, int B, int H, int Hkv,
+                       int S, int D, int splits, float scaling, const long* strides, hipStream_t stream);
+
 int  launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t stream);
 
 int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,

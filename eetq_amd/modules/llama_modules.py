@@ -89,16 +89,14 @@ class _EETAttentionBase(nn.Module):
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
         if past_key_values is not None:
             k, v = past_key_values.update(k, v, self.layer_idx)
-        use_math = self.decode_math_attention == "always" or (
-            self.decode_math_attention and q.is_cuda and torch.cuda.is_current_stream_capturing())
+        # One query token.  The library attention kernels launch one workgroup per head (40 workgroups streaming the whole
+        # KV cache: 68 us per layer at Llama-13B shapes, S = 1.2 k).  decode_math_attention: True -> the library's own
+        # split-KV kernel (ops.decode_attention, ~10 us) whenever it applies, and a batched matrix-vector fallback while
+        # a HIP graph is being captured; "always" -> the fallback also in eager mode; False -> stock attention.
+        mode     = self.decode_math_attention
+        kernel_ok = self.head_dim in (64, 128) and q.is_cuda and (attention_mask is None or attention_mask.shape[1] == 1)
+        use_math = mode == "always" or (mode and q.is_cuda and (kernel_ok or torch.cuda.is_current_stream_capturing()))
         if q.shape[2] == 1 and use_math and not kwargs.get("output_attentions", False):
-            # one query token: the library attention kernels launch one workgroup per head (40 workgroups streaming
-            # the whole KV cache: 68 us per layer at Llama-13B shapes, S = 1.2 k); two batched matrix-vector products
-            # and a softmax spread the cache over the chip.  Used while the step is being captured into a HIP graph
-            # (GPU time is what counts there); in eager mode the single library call has fewer launches and wins.
-            if self.num_key_value_groups > 1:
-                k = k.repeat_interleave(self.num_key_value_groups, dim=1)
-                v = v.repeat_interleave(self.num_key_value_groups, dim=1)
             bsz, heads, _, s_len = q.shape[0], q.shape[1], q.shape[2], k.shape[2]
             add = None
             if attention_mask is not None:
@@ -118,6 +116,14 @@ class _EETAttentionBase(nn.Module):
                         pass
                 if add.shape[-1] != s_len:
                     add = add[..., :s_len]
+            if kernel_ok and mode != "always":
+                # split-KV decode kernel of the library: the whole chip streams the cache once
+                out = ops.decode_attention(q[:, :, 0], k, v, mask=None if add is None else add[:, 0, 0],
+                                           scaling=self.scaling).unsqueeze(1)            # [B, 1, H, D]
+                return out.reshape(*input_shape, -1), None
+            if self.num_key_value_groups > 1:
+                k = k.repeat_interleave(self.num_key_value_groups, dim=1)
+                v = v.repeat_interleave(self.num_key_value_groups, dim=1)
             kt = k.transpose(2, 3)
             if add is not None and bsz == 1:
                 # scaling * (q . k^T) + mask in one batched kernel

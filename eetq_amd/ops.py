@@ -21,7 +21,7 @@ from ._lib import (DTYPE_F16, DTYPE_F32, LAYOUT_GFX950, LAYOUT_ROW_MAJOR, LAYOUT
                    PATH_MFMA, check)
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_",
-           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "convert_layout"]
+           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "decode_attention", "convert_layout"]
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
@@ -273,3 +273,39 @@ def rotary_embedding_neox_strided(positions, query, key, head_size, cos_sin_cach
                                                       hq, hk, int(head_size), cos_sin_cache.shape[1], sq, sk,
                                                       _stream_ptr()))
     return None
+
+
+def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, splits=None):
+    """Single-query attention over a KV cache (extension; the decode step of the EET attention blocks).
+
+    query [B, H, D] (any batch/head strides, dense D), key_cache / value_cache [B, Hkv, S, D] (dense D), mask: additive
+    float16 [B, S] (or broadcastable [B, 1, 1, S]) with -inf at masked positions, or None.  Returns float16 [B, H, D].
+    fp32 softmax and accumulation; D must be 64 or 128."""
+    if query.dtype != torch.float16 or key_cache.dtype != torch.float16 or value_cache.dtype != torch.float16:
+        raise RuntimeError("decode_attention: query and caches must be float16")
+    if query.dim() != 3 or key_cache.dim() != 4 or value_cache.shape != key_cache.shape:
+        raise RuntimeError("decode_attention: expected query [B, H, D] and caches [B, Hkv, S, D]")
+    B, H, D = query.shape
+    Bk, Hkv, S, Dk = key_cache.shape
+    if Bk != B or Dk != D or H % Hkv or query.stride(-1) != 1 or key_cache.stride(-1) != 1 or value_cache.stride(-1) != 1:
+        raise RuntimeError("decode_attention: shape / stride mismatch")
+    mrow, m_sb = None, 0
+    if mask is not None:
+        mrow = mask.reshape(B, -1) if mask.dim() != 2 else mask
+        if mrow.dtype != torch.float16 or mrow.shape[-1] < S or mrow.stride(-1) != 1:
+            raise RuntimeError("decode_attention: mask must be additive float16 with a dense last dimension >= S")
+        m_sb = mrow.stride(0)
+    if scaling is None:
+        scaling = D ** -0.5
+    if splits is None:  # enough workgroups to cover the chip a few times over, at least 64 positions per chunk
+        splits = max(1, min((S + 63) // 64, max(1, 1024 // (B * H))))
+    out = torch.empty((B, H, D), dtype=torch.float16, device=query.device)
+    ws = torch.empty((B * H * splits * (D + 2),), dtype=torch.float32, device=query.device)
+    strides = (ctypes.c_long * 11)(query.stride(0), query.stride(1), key_cache.stride(0), key_cache.stride(1),
+                                   key_cache.stride(2), value_cache.stride(0), value_cache.stride(1), value_cache.stride(2),
+                                   m_sb, out.stride(0), out.stride(1))
+    with torch.cuda.device(query.device):
+        check(_lib.lib().eetq_decode_attention_f16(_ptr(query), _ptr(key_cache), _ptr(value_cache),
+                                                   _ptr(mrow) if mrow is not None else None, _ptr(out), _ptr(ws), B, H,
+                                                   Hkv, S, D, int(splits), float(scaling), strides, _stream_ptr()))
+    return out

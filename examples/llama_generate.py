@@ -151,6 +151,9 @@ def main():
     ap.add_argument("--accelerate", action="store_true",
                     help="eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True): fused-QKV "
                          "attention blocks with the in-place rotary kernel, gate/up in one launch, RMS-norm kernel")
+    ap.add_argument("--decode-attn", default="kernel", choices=["kernel", "math", "off"],
+                    help="single-token attention of the EET blocks: the library's split-KV kernel, batched matrix-vector "
+                         "products, or the stock attention call")
     ap.add_argument("--graph", action="store_true",
                     help="greedy decode with a static KV cache and ONE captured HIP graph per token (launch-bound "
                          "inner loop -> hipGraph) instead of transformers' eager generate()")
@@ -165,6 +168,8 @@ def main():
     if args.accelerate:
         from eetq_amd.utils import eet_accelerator
         eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True, fused_residual=True)
+        for layer in model.model.layers:
+            layer.self_attn.decode_math_attention = {"kernel": True, "math": "always", "off": False}[args.decode_attn]
     elif not args.no_quant:
         eet_quantize(model)
     if args.fuse_norm:

@@ -125,6 +125,16 @@ int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* ke
                                  int tokens, int q_heads, int k_heads, int head_size, int rot_dim, int q_stride,
                                  int k_stride, void* stream);
 
+/* Single-query (decode) attention over a KV cache; extension used by the EET attention blocks' decode step (the
+ * reference delegates the attention product to flash-attn, python/eetq/modules/llama_modules.py:131-143).
+ *   out[b][h][:] = softmax_j( scaling * q[b][h] . k[b][h / (heads/kv_heads)][j] + mask[b][j] ) @ v[...]   j < positions
+ * fp16 operands, fp32 softmax/accumulation.  strides (in elements): {q_b, q_h, k_b, k_h, k_pos, v_b, v_h, v_pos, mask_b,
+ * out_b, out_h}; head_dim (64 or 128) is the dense last dimension everywhere.  mask: additive fp16 [batch][positions]
+ * rows (-inf = masked) or NULL.  workspace: batch * heads * splits * (head_dim + 2) floats.  A fully masked row gives 0. */
+int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* mask, void* out,
+                              float* workspace, int batch, int heads, int kv_heads, int positions, int head_dim,
+                              int splits, float scaling, const long* strides, void* stream);
+
 /* ---- profiling hook (no reference counterpart; used by bench.py) -------------------------------------
  * Between eetq_prof_begin(n) and eetq_prof_end() every kernel this library launches from the calling thread
  * carries a start/stop event pair on its dispatch packet; eetq_prof_end synchronises the device and returns

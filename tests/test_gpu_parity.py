@@ -597,3 +597,36 @@ def test_auto_dispatch_fuzz_vs_oracle(ops, oracle):
         got = y.cpu().numpy().astype(np.float32)
         ok = _tier_a(got, ref)
         assert ok.all(), "M=%d K=%d N=%d: max err %g at %s" % (M, K, N, np.abs(got - ref).max(), np.argwhere(~ok)[:4])
+
+
+@pytest.mark.parametrize("B,H,Hkv,S,D", [(1, 40, 40, 1232, 128), (2, 8, 2, 77, 64), (3, 4, 4, 1, 128), (1, 5, 1, 300, 64)])
+def test_decode_attention_vs_torch(ops, B, H, Hkv, S, D):
+    """Split-KV single-query attention kernel against a plain PyTorch fp32 reference of the same op (softmax(scale q k^T
+    + mask) v), strided query (a slice of a fused QKV row), grouped-query heads, additive -inf mask incl. a fully masked
+    row; tolerance 2e-3 absolute on O(1) outputs (fp16 output rounding 5e-4, fp32 accumulation)."""
+    torch.manual_seed(B * 1000 + S)
+    row = (H + 2 * Hkv) * D
+    qkv = torch.randn(B, 1, row, dtype=torch.float16, device=DEV)
+    q = qkv[..., : H * D].unflatten(-1, (H, D))[:, 0]                     # [B, H, D], batch stride = fused row
+    k = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+    v = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+    mask = torch.zeros(B, 1, 1, S, dtype=torch.float16, device=DEV)
+    valid = torch.randint(1, S + 1, (B,))
+    for b in range(B):
+        mask[b, ..., int(valid[b]):] = float("-inf")
+    scale = D ** -0.5
+    for m in (None, mask):
+        for splits in (None, 1, min(S, 7)):
+            out = ops.decode_attention(q, k, v, mask=m, scaling=scale, splits=splits)
+            kk = k.float().repeat_interleave(H // Hkv, dim=1)
+            vv = v.float().repeat_interleave(H // Hkv, dim=1)
+            s = torch.einsum("bhd,bhsd->bhs", q.float(), kk) * scale
+            if m is not None:
+                s = s + m[:, 0].float()
+            ref = torch.einsum("bhs,bhsd->bhd", torch.softmax(s, dim=-1), vv)
+            assert out.shape == (B, H, D) and out.dtype == torch.float16
+            assert (out.float() - ref).abs().max().item() < 2e-3, (m is not None, splits)
+    dead = torch.full((B, 1, 1, S), float("-inf"), dtype=torch.float16, device=DEV)
+    assert torch.count_nonzero(ops.decode_attention(q, k, v, mask=dead, scaling=scale)) == 0
+    with pytest.raises(RuntimeError):
+        ops.decode_attention(q.float(), k, v)
