@@ -48,26 +48,38 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = 0.f;
 
-    for (int jb = j0 + wave * PPW; jb < j1; jb += (kAttnThreads / 64) * PPW) {
-        const int  j     = jb + grp;
-        const bool valid = j < j1;
-        const int  jj    = valid ? j : j1 - 1;  // clamped, predicated use: no load behind a branch
-        const f16x8 kv = *reinterpret_cast<const f16x8*>(kbase + (long)jj * k_ss);
-        const f16x8 vv = *reinterpret_cast<const f16x8*>(vbase + (long)jj * v_ss);
-        float s = 0.f;
+    // U position groups per trip: 2U independent 16-byte loads per lane in flight (the loop is latency-bound otherwise)
+    constexpr int U = 4, STEP = (kAttnThreads / 64) * PPW;
+    for (int jb = j0 + wave * PPW; jb < j1; jb += U * STEP) {
+        f16x8 kv[U], vv[U];
+        int   jj[U];
+        bool  valid[U];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) s += qf[i] * (float)kv[i];
+        for (int u = 0; u < U; ++u) {
+            const int j = jb + u * STEP + grp;
+            valid[u]    = j < j1;
+            jj[u]       = valid[u] ? j : j1 - 1;  // clamped, predicated use: no load behind a branch
+            kv[u]       = *reinterpret_cast<const f16x8*>(kbase + (long)jj[u] * k_ss);
+        }
 #pragma unroll
-        for (int off = 1; off < LPP; off <<= 1) s += __shfl_xor(s, off, 64);
-        if (mrow) s += (float)mrow[jj];
-        if (!valid) s = -INFINITY;
-        const float mn = fmaxf(m, s);
-        if (mn > -INFINITY) {  // group-uniform
-            const float sc = __expf(m - mn), p = __expf(s - mn);
-            l = l * sc + p;
+        for (int u = 0; u < U; ++u) vv[u] = *reinterpret_cast<const f16x8*>(vbase + (long)jj[u] * v_ss);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] = o[i] * sc + p * (float)vv[i];
-            m = mn;
+        for (int u = 0; u < U; ++u) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += qf[i] * (float)kv[u][i];
+#pragma unroll
+            for (int off = 1; off < LPP; off <<= 1) s += __shfl_xor(s, off, 64);
+            if (mrow) s += (float)mrow[jj[u]];
+            if (!valid[u]) s = -INFINITY;
+            const float mn = fmaxf(m, s);
+            if (mn > -INFINITY) {  // group-uniform
+                const float sc = __expf(m - mn), p = __expf(s - mn);
+                l = l * sc + p;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = o[i] * sc + p * (float)vv[u][i];
+                m = mn;
+            }
         }
     }
     const int set = wave * PPW + grp;
@@ -100,21 +112,35 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
     }
 }
 
+// one workgroup per (head, batch): thread t < splits fetches that chunk's (m, l) in parallel; D threads then sum the chunk
+// outputs with the loads of up to 8 chunks in flight
 template <int D>
 __global__ __launch_bounds__(D) void attn_decode_merge_kernel(const float* __restrict__ ws, f16* __restrict__ out,
                                                              int splits, long o_sb, long o_sh)
 {
+    extern __shared__ float sm_w[];  // [splits] weights exp(m_s - M), then sm_w[splits] = 1 / L
     const int    h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const float* p = ws + ((size_t)b * gridDim.x + h) * splits * (D + 2);
     float        M = -INFINITY;
-    for (int s = 0; s < splits; ++s) M = fmaxf(M, p[s * (D + 2)]);
+    for (int s = d; s < splits; s += D) M = fmaxf(M, p[s * (D + 2)]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
+    if (D > 64) {
+        __shared__ float sm_part[D / 64];
+        if ((d & 63) == 0) sm_part[d >> 6] = M;
+        __syncthreads();
+        M = sm_part[0];
+#pragma unroll
+        for (int i = 1; i < D / 64; ++i) M = fmaxf(M, sm_part[i]);
+    }
+    for (int s = d; s < splits; s += D) sm_w[s] = M > -INFINITY ? __expf(p[s * (D + 2)] - M) : 0.f;
+    __syncthreads();
     float L = 0.f, O = 0.f;
-    if (M > -INFINITY) {
-        for (int s = 0; s < splits; ++s) {
-            const float w = __expf(p[s * (D + 2)] - M);
-            L += p[s * (D + 2) + 1] * w;
-            O += p[s * (D + 2) + 2 + d] * w;
-        }
+#pragma unroll 8
+    for (int s = 0; s < splits; ++s) {
+        const float w = sm_w[s];
+        L += p[s * (D + 2) + 1] * w;
+        O += p[s * (D + 2) + 2 + d] * w;
     }
     out[b * o_sb + h * o_sh + d] = (f16)(L > 0.f ? O / L : 0.f);  // a fully masked row yields zeros, not NaN
 }
@@ -127,7 +153,7 @@ int launch_d(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out
     attn_decode_partial_kernel<D><<<dim3(splits, H, B), kAttnThreads, 0, stream>>>(
         q, k, v, mask, ws, scaling, S, chunk, H / Hkv, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8]);
     EETQ_TRY_HIP(hipGetLastError());
-    attn_decode_merge_kernel<D><<<dim3(H, B), D, 0, stream>>>(ws, out, splits, st[9], st[10]);
+    attn_decode_merge_kernel<D><<<dim3(H, B), D, splits * sizeof(float), stream>>>(ws, out, splits, st[9], st[10]);
     return check_hip(hipGetLastError(), "attn_decode kernels launch");
 }
 
