@@ -103,9 +103,19 @@ def lib():
     global _lib
     if _lib is None:
         _share_hip_runtime_with_torch()
-        if not os.path.exists(LIB_PATH) or (os.path.isdir(CSRC_DIR) and shutil.which("hipcc")
-                                            and _sources_newer_than_lib()):
-            build()
+        def _needs_build():
+            return not os.path.exists(LIB_PATH) or (os.path.isdir(CSRC_DIR) and shutil.which("hipcc")
+                                                    and _sources_newer_than_lib())
+        if _needs_build():
+            # several ranks of one node may get here together (torchrun): one builds, the others wait and re-check
+            import fcntl
+            with open(LIB_PATH + ".lock", "w") as lock:
+                fcntl.flock(lock, fcntl.LOCK_EX)
+                try:
+                    if _needs_build():
+                        build()
+                finally:
+                    fcntl.flock(lock, fcntl.LOCK_UN)
         try:
             _lib = _declare(ctypes.CDLL(LIB_PATH))
         except OSError as e:  # no fallback on purpose
