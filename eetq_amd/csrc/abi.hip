@@ -305,6 +305,25 @@ int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* ke
                          k_stride, static_cast<hipStream_t>(stream));
 }
 
+int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream)
+{
+    return launch_silu_mul(static_cast<const f16*>(gate_up), static_cast<f16*>(out), rows, intermediate,
+                           static_cast<hipStream_t>(stream));
+}
+
+int eetq_rotary_neox_kvcache_f16(const int64_t* positions, void* query, const void* key, const void* value,
+                                 const void* cos_sin_cache, void* k_cache, void* v_cache, int batch, int q_heads,
+                                 int k_heads, int head_size, int rot_dim, const long* strides, int max_positions,
+                                 void* stream)
+{
+    EETQ_REQUIRE(strides, "null pointer");
+    return launch_rotary_kvcache(positions, static_cast<f16*>(query), static_cast<const f16*>(key),
+                                 static_cast<const f16*>(value), static_cast<const f16*>(cos_sin_cache),
+                                 static_cast<f16*>(k_cache), static_cast<f16*>(v_cache), batch, q_heads, k_heads, head_size,
+                                 rot_dim, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5],
+                                 max_positions, static_cast<hipStream_t>(stream));
+}
+
 int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* mask, void* out,
                               float* workspace, int batch, int heads, int kv_heads, int positions, int head_dim,
                               int splits, float scaling, const long* strides, void* stream)

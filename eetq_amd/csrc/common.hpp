@@ -108,6 +108,12 @@ int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int toke
 int launch_attn_decode(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out, float* ws, int B, int H, int Hkv,
                        int S, int D, int splits, float scaling, const long* strides, hipStream_t stream);
 
+int launch_rotary_kvcache(const int64_t* pos, f16* q, const f16* k, const f16* v, const f16* cache, f16* kcache,
+                          f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,
+                          long k_stride, long v_stride, long c_sb, long c_sh, long c_ss, int max_pos, hipStream_t stream);
+
+int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t stream);
+
 int  launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t stream);
 
 int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,

@@ -95,7 +95,98 @@ __global__ void rotary_neox_kernel(const int64_t* __restrict__ positions, f16* _
     }
 }
 
+// out[r][i] = silu(gu[r][i]) * gu[r][I + i]: the gated-MLP activation on a fused gate|up projection output, one launch
+// (torch: silu, then mul).  silu in fp32, rounded to fp16, then an fp16 multiply -- the same roundings as the two torch ops.
+__global__ void silu_mul_kernel(const f16* __restrict__ gu, f16* __restrict__ out, int inter, long rows_x_inter)
+{
+    const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (idx >= rows_x_inter) return;
+    const long  r = idx / inter, i = idx - r * inter;
+    const f16x8 g = *reinterpret_cast<const f16x8*>(gu + r * 2 * inter + i);
+    const f16x8 u = *reinterpret_cast<const f16x8*>(gu + r * 2 * inter + inter + i);
+    f16x8       o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = (float)g[j];
+        o[j]          = (f16)(x / (1.0f + expf(-x))) * u[j];
+    }
+    *reinterpret_cast<f16x8*>(out + idx) = o;
+}
+
+// Decode-step form: one token per batch row.  blockIdx.y = 0 rotates q in place; 1 rotates k and writes it into the KV
+// cache at [b][head][pos]; 2 copies v there.  Replaces, for a static cache, the stock sequence arange + add + two index_copy
+// launches + the rotary launch by one.
+__global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions, f16* __restrict__ query,
+                                           const f16* __restrict__ key, const f16* __restrict__ value,
+                                           const f16* __restrict__ cache, f16* __restrict__ kcache,
+                                           f16* __restrict__ vcache, int rot_dim, long q_stride, long k_stride,
+                                           long v_stride, long c_sb, long c_sh, long c_ss, int q_heads, int k_heads,
+                                           int head_size, int max_pos)
+{
+#pragma clang fp contract(off)
+    const int     b   = blockIdx.x;
+    const int64_t pos = positions[b];
+    if (pos < 0 || pos >= max_pos) return;  // never write outside the cache
+    const f16* cp    = cache + pos * rot_dim;
+    const int  embed = rot_dim / 2;
+    if (blockIdx.y == 0) {
+        for (int i = threadIdx.x; i < q_heads * embed; i += blockDim.x) {
+            const int head = i / embed, off = i - head * embed;
+            f16*      p = query + b * q_stride + (long)head * head_size;
+            const f16 c = cp[off], s = cp[embed + off], vx = p[off], vy = p[embed + off];
+            const f16 xc = vx * c, ys = vy * s, yc = vy * c, xs = vx * s;
+            p[off]         = xc - ys;
+            p[embed + off] = yc + xs;
+        }
+    } else if (blockIdx.y == 1) {
+        for (int i = threadIdx.x; i < k_heads * embed; i += blockDim.x) {
+            const int  head = i / embed, off = i - head * embed;
+            const f16* p = key + b * k_stride + (long)head * head_size;
+            f16*       d = kcache + b * c_sb + head * c_sh + pos * c_ss;
+            const f16  c = cp[off], s = cp[embed + off], vx = p[off], vy = p[embed + off];
+            const f16  xc = vx * c, ys = vy * s, yc = vy * c, xs = vx * s;
+            d[off]         = xc - ys;
+            d[embed + off] = yc + xs;
+        }
+        const int tail = head_size - rot_dim;  // channels beyond the rotated ones are cached as they are
+        for (int i = threadIdx.x; i < k_heads * tail; i += blockDim.x) {
+            const int head = i / tail, off = rot_dim + (i - head * tail);
+            kcache[b * c_sb + head * c_sh + pos * c_ss + off] = key[b * k_stride + (long)head * head_size + off];
+        }
+    } else {
+        for (int i = threadIdx.x; i < k_heads * head_size; i += blockDim.x) {
+            const int head = i / head_size, off = i - head * head_size;
+            vcache[b * c_sb + head * c_sh + pos * c_ss + off] = value[b * v_stride + (long)head * head_size + off];
+        }
+    }
+}
+
 }  // namespace
+
+int launch_rotary_kvcache(const int64_t* pos, f16* q, const f16* k, const f16* v, const f16* cache, f16* kcache,
+                          f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,
+                          long k_stride, long v_stride, long c_sb, long c_sh, long c_ss, int max_pos, hipStream_t stream)
+{
+    EETQ_REQUIRE(pos && q && k && v && cache && kcache && vcache, "null pointer");
+    EETQ_REQUIRE(batch >= 0 && q_heads > 0 && k_heads > 0 && head_size > 0 && rot_dim > 0 && rot_dim % 2 == 0 &&
+                     rot_dim <= head_size && max_pos > 0,
+                 "invalid rotary shape");
+    if (batch == 0) return EETQ_OK;
+    rotary_neox_kvcache_kernel<<<dim3(batch, 3), 512, 0, stream>>>(pos, q, k, v, cache, kcache, vcache, rot_dim, q_stride,
+                                                                     k_stride, v_stride, c_sb, c_sh, c_ss, q_heads,
+                                                                     k_heads, head_size, max_pos);
+    return check_hip(hipGetLastError(), "rotary_neox_kvcache_kernel launch");
+}
+
+int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t stream)
+{
+    EETQ_REQUIRE(gu && out, "null pointer");
+    EETQ_REQUIRE(rows >= 0 && inter > 0 && inter % 8 == 0, "silu_mul: the intermediate size must be a multiple of 8");
+    if (rows == 0) return EETQ_OK;
+    const long n = (long)rows * inter;
+    silu_mul_kernel<<<(unsigned)((n / 8 + 255) / 256), 256, 0, stream>>>(gu, out, inter, n);
+    return check_hip(hipGetLastError(), "silu_mul_kernel launch");
+}
 
 int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows, int cols, hipStream_t stream)
 {

@@ -84,6 +84,37 @@ class _EETAttentionBase(nn.Module):
             position_ids = position_ids.expand(batch, q_len)
         return position_ids.to(torch.int64).contiguous()
 
+    def _static_cache_layer(self, past_key_values):
+        """The transformers StaticLayer of this block if the fused decode path applies, else None."""
+        layers = getattr(past_key_values, "layers", None)
+        if layers is None or self.layer_idx >= len(layers) or self.head_dim not in (64, 128):
+            return None
+        layer = layers[self.layer_idx]
+        if (type(layer).__name__ != "StaticLayer" or not getattr(layer, "is_initialized", False)
+                or not all(hasattr(layer, a) for a in ("keys", "values", "cumulative_length"))
+                or layer.keys.dtype != torch.float16 or layer.keys.dim() != 4):
+            return None
+        return layer
+
+    @staticmethod
+    def _additive_mask(attention_mask, dtype, device):
+        """additive fp16 form of the mask, built once per forward and parked on the mask object (the model hands the
+        same object to every layer)"""
+        if attention_mask is None:
+            return None
+        add = getattr(attention_mask, "_eet_additive", None)
+        if add is None:
+            add = attention_mask
+            if add.dtype == torch.bool:
+                add = torch.zeros(add.shape, dtype=dtype, device=device).masked_fill_(~attention_mask, float("-inf"))
+            elif add.dtype != dtype:
+                add = add.to(dtype)
+            try:
+                attention_mask._eet_additive = add
+            except Exception:
+                pass
+        return add
+
     def _attend(self, q, k, v, attention_mask, past_key_values, input_shape, kwargs):
         """q [B, T, H, D], k/v [B, T, Hkv, D] (views into the projection output) -> [B, T, H*D]"""
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
@@ -98,24 +129,9 @@ class _EETAttentionBase(nn.Module):
         use_math = mode == "always" or (mode and q.is_cuda and (kernel_ok or torch.cuda.is_current_stream_capturing()))
         if q.shape[2] == 1 and use_math and not kwargs.get("output_attentions", False):
             bsz, heads, _, s_len = q.shape[0], q.shape[1], q.shape[2], k.shape[2]
-            add = None
-            if attention_mask is not None:
-                # additive fp16 form of the mask, built once per forward and parked on the mask object (the model
-                # hands the same object to every layer)
-                add = getattr(attention_mask, "_eet_additive", None)
-                if add is None:
-                    add = attention_mask
-                    if add.dtype == torch.bool:
-                        add = torch.zeros(add.shape, dtype=q.dtype, device=q.device).masked_fill_(~attention_mask,
-                                                                                                 float("-inf"))
-                    elif add.dtype != q.dtype:
-                        add = add.to(q.dtype)
-                    try:
-                        attention_mask._eet_additive = add
-                    except Exception:
-                        pass
-                if add.shape[-1] != s_len:
-                    add = add[..., :s_len]
+            add = self._additive_mask(attention_mask, q.dtype, q.device)
+            if add is not None and add.shape[-1] != s_len:
+                add = add[..., :s_len]
             if kernel_ok and mode != "always":
                 # split-KV decode kernel of the library: the whole chip streams the cache once
                 out = ops.decode_attention(q[:, :, 0], k, v, mask=None if add is None else add[:, 0, 0],
@@ -183,11 +199,24 @@ class EETLlamaAttention(_EETAttentionBase):
         k = qkv[..., h * d: (h + hkv) * d].unflatten(-1, (hkv, d))
         v = qkv[..., (h + hkv) * d:].unflatten(-1, (hkv, d))
         positions = self._positions(position_ids, past_key_values, bsz, q_len, hidden_states.device)
-        if positions.numel() and int(self.rotary_emb.max_seq_len_cached) <= 0:
-            raise RuntimeError("empty rotary cache")
-        self.rotary_emb(q, k, positions)
         kwargs.pop("use_cache", None)
-        out, weights = self._attend(q, k, v, attention_mask, past_key_values, (bsz, q_len), kwargs)
+        layer = self._static_cache_layer(past_key_values) if q_len == 1 else None
+        if layer is not None and self.decode_math_attention is True and not kwargs.get("output_attentions", False):
+            # decode step on an initialised static cache: ONE launch rotates q in place and writes the rotated k and v
+            # straight into the cache rows (the stock cache update is arange + add + two index_copy launches, plus the
+            # rotary launch), then the split-KV attention kernel reads the cache
+            ops.rotary_embedding_neox_kvcache(positions[:, 0].contiguous(), q[:, 0], k[:, 0], v[:, 0], self.head_dim,
+                                              self.rotary_emb.cos_sin_cache, layer.keys, layer.values)
+            layer.cumulative_length.add_(1)  # the cache's own bookkeeping (next step's positions and mask come from it)
+            add = self._additive_mask(attention_mask, hidden_states.dtype, hidden_states.device)
+            if add is not None and add.shape[-1] != layer.keys.shape[2]:
+                add = add[..., : layer.keys.shape[2]]
+            out = ops.decode_attention(q[:, 0], layer.keys, layer.values, mask=None if add is None else add[:, 0, 0],
+                                       scaling=self.scaling).reshape(bsz, q_len, -1)
+            weights = None
+        else:
+            self.rotary_emb(q, k, positions)
+            out, weights = self._attend(q, k, v, attention_mask, past_key_values, (bsz, q_len), kwargs)
         if residual is None:
             return self.o_proj(out), weights
         if hasattr(self.o_proj, "qweight"):
@@ -223,5 +252,9 @@ class EETLlamaMLP(nn.Module):
 
     def forward(self, x, residual=None):
         gu = self.gate_up_proj(x)
-        gate, up = gu[..., : self.intermediate_size], gu[..., self.intermediate_size:]
-        return self.down_proj(torch.nn.functional.silu(gate) * up, residual=residual)
+        if self.intermediate_size % 8 == 0 and gu.is_cuda:
+            act = ops.silu_mul(gu)  # one launch instead of silu + mul
+        else:
+            gate, up = gu[..., : self.intermediate_size], gu[..., self.intermediate_size:]
+            act = torch.nn.functional.silu(gate) * up
+        return self.down_proj(act, residual=residual)

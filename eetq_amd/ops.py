@@ -21,7 +21,7 @@ from ._lib import (DTYPE_F16, DTYPE_F32, LAYOUT_GFX950, LAYOUT_ROW_MAJOR, LAYOUT
                    PATH_MFMA, check)
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_",
-           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "decode_attention", "convert_layout"]
+           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention", "silu_mul", "convert_layout"]
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
@@ -308,4 +308,48 @@ def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, spl
         check(_lib.lib().eetq_decode_attention_f16(_ptr(query), _ptr(key_cache), _ptr(value_cache),
                                                    _ptr(mrow) if mrow is not None else None, _ptr(out), _ptr(ws), B, H,
                                                    Hkv, S, D, int(splits), float(scaling), strides, _stream_ptr()))
+    return out
+
+
+def rotary_embedding_neox_kvcache(positions, query, key, value, head_size, cos_sin_cache, key_cache, value_cache):
+    """Decode step: rotate ``query`` [B, H, D] in place, write the rotated ``key`` [B, Hkv, D] and ``value`` [B, Hkv, D]
+    into the caches [B, Hkv, S, D] at ``positions`` [B] (int64).  One launch instead of rotary + two cache copies."""
+    for t in (query, key, value, cos_sin_cache, key_cache, value_cache):
+        if t.dtype != torch.float16:
+            raise RuntimeError("rotary_embedding_neox_kvcache: float16 tensors expected")
+    if positions.dtype != torch.int64 or not positions.is_contiguous():
+        raise RuntimeError("rotary_embedding_neox_kvcache: positions must be contiguous int64")
+    B, H, D = query.shape
+    Hkv = key.shape[1]
+    if (key.shape != (B, Hkv, D) or value.shape != (B, Hkv, D) or D != head_size or key_cache.dim() != 4
+            or key_cache.shape[0] != B or key_cache.shape[1] != Hkv or key_cache.shape[3] != D
+            or value_cache.shape != key_cache.shape or value_cache.stride() != key_cache.stride()
+            or positions.numel() != B):
+        raise RuntimeError("rotary_embedding_neox_kvcache: shape mismatch")
+    for t in (query, key, value):
+        if t.stride(-1) != 1 or t.stride(-2) != D:
+            raise RuntimeError("rotary_embedding_neox_kvcache: [heads, head_size] must be dense")
+    if key_cache.stride(-1) != 1 or not cos_sin_cache.is_contiguous():
+        raise RuntimeError("rotary_embedding_neox_kvcache: cache rows must be dense")
+    strides = (ctypes.c_long * 6)(query.stride(0), key.stride(0), value.stride(0), key_cache.stride(0),
+                                  key_cache.stride(1), key_cache.stride(2))
+    with torch.cuda.device(query.device):
+        check(_lib.lib().eetq_rotary_neox_kvcache_f16(_ptr(positions), _ptr(query), _ptr(key), _ptr(value),
+                                                      _ptr(cos_sin_cache), _ptr(key_cache), _ptr(value_cache), B, H, Hkv,
+                                                      int(head_size), cos_sin_cache.shape[1], strides,
+                                                      key_cache.shape[2], _stream_ptr()))
+    return None
+
+
+def silu_mul(gate_up):
+    """``silu(gate) * up`` on a fused gate|up projection output [..., 2*I] -> [..., I] in one launch (extension)."""
+    if gate_up.dtype != torch.float16 or not gate_up.is_cuda or not gate_up.is_contiguous():
+        raise RuntimeError("silu_mul: expected a contiguous float16 CUDA tensor")
+    inter = gate_up.shape[-1] // 2
+    if gate_up.shape[-1] != 2 * inter or inter % 8:
+        raise RuntimeError("silu_mul: last dimension must be 2*I with I a multiple of 8")
+    out = torch.empty(tuple(gate_up.shape[:-1]) + (inter,), dtype=torch.float16, device=gate_up.device)
+    rows = out.numel() // inter if inter else 0
+    with torch.cuda.device(gate_up.device):
+        check(_lib.lib().eetq_silu_mul_f16(_ptr(gate_up), _ptr(out), rows, inter, _stream_ptr()))
     return out

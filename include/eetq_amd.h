@@ -125,6 +125,21 @@ int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* ke
                                  int tokens, int q_heads, int k_heads, int head_size, int rot_dim, int q_stride,
                                  int k_stride, void* stream);
 
+/* Gated-MLP activation on a fused gate|up projection output (extension): out[r][i] = silu(gate_up[r][i]) *
+ * gate_up[r][intermediate + i], gate_up [rows][2 * intermediate] dense, intermediate % 8 == 0.  fp32 silu rounded to fp16,
+ * then an fp16 multiply. */
+int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream);
+
+/* Decode-step rotary + KV-cache write (extension for the EET attention blocks): one new token per batch row b at position
+ * positions[b]; q [batch][q_heads][head_size] is rotated in place, k is rotated and written to k_cache[b][head][pos][:],
+ * v is copied to v_cache[b][head][pos][:] (caches [batch][k_heads][max_positions][head_size]).  Same fp16 arithmetic as
+ * eetq_rotary_neox_f16.  strides (elements): {q_b, k_b, v_b, cache_b, cache_head, cache_pos}.  Rows whose position is
+ * outside [0, max_positions) are left untouched. */
+int eetq_rotary_neox_kvcache_f16(const int64_t* positions, void* query, const void* key, const void* value,
+                                 const void* cos_sin_cache, void* k_cache, void* v_cache, int batch, int q_heads,
+                                 int k_heads, int head_size, int rot_dim, const long* strides, int max_positions,
+                                 void* stream);
+
 /* Single-query (decode) attention over a KV cache; extension used by the EET attention blocks' decode step (the
  * reference delegates the attention product to flash-attn, python/eetq/modules/llama_modules.py:131-143).
  *   out[b][h][:] = softmax_j( scaling * q[b][h] . k[b][h / (heads/kv_heads)][j] + mask[b][j] ) @ v[...]   j < positions

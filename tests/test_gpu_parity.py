@@ -630,3 +630,87 @@ def test_decode_attention_vs_torch(ops, B, H, Hkv, S, D):
     assert torch.count_nonzero(ops.decode_attention(q, k, v, mask=dead, scaling=scale)) == 0
     with pytest.raises(RuntimeError):
         ops.decode_attention(q.float(), k, v)
+
+
+def test_rotary_kvcache_write(ops, oracle):
+    """Decode-step rotary + cache write: q rotated in place (bit-exact vs the oracle), rotated k and v land in the cache
+    rows at positions[b], every other cache element untouched, an out-of-range position writes nothing."""
+    torch.manual_seed(3)
+    B, H, Hkv, D, S = 3, 8, 2, 64, 40
+    row = (H + 2 * Hkv) * D
+    qkv = torch.randn(B, 1, row).half()
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.einsum("i,j->ij", torch.arange(64).float(), inv)
+    cache = torch.cat([fr.cos(), fr.sin()], -1).half()
+    pos = torch.tensor([5, 39, 17])
+    d = qkv.to(DEV)
+    q = d[..., : H * D].unflatten(-1, (H, D))[:, 0]
+    k = d[..., H * D: (H + Hkv) * D].unflatten(-1, (Hkv, D))[:, 0]
+    v = d[..., (H + Hkv) * D:].unflatten(-1, (Hkv, D))[:, 0]
+    kc = torch.full((B, Hkv, S, D), 7.0, dtype=torch.float16, device=DEV)
+    vc = torch.full((B, Hkv, S, D), -3.0, dtype=torch.float16, device=DEV)
+    ops.rotary_embedding_neox_kvcache(pos.to(DEV), q, k, v, D, cache.to(DEV), kc, vc)
+    q0 = qkv[:, 0, : H * D].reshape(B, H, D).numpy()
+    k0 = qkv[:, 0, H * D: (H + Hkv) * D].reshape(B, Hkv, D).numpy()
+    qo, _ = oracle.rotary_neox_f16(pos.numpy(), q0, q0.copy(), cache.numpy(), D)
+    ko, _ = oracle.rotary_neox_f16(pos.numpy(), k0, k0.copy(), cache.numpy(), D)
+    got = d.cpu()
+    assert np.array_equal(got[:, 0, : H * D].reshape(B, H, D).numpy(), qo)
+    assert torch.equal(got[:, 0, H * D:], qkv[:, 0, H * D:])                       # k and v rows of the projection: unchanged
+    kc, vc = kc.cpu(), vc.cpu()
+    for b in range(B):
+        assert np.array_equal(kc[b, :, int(pos[b])].numpy(), ko[b])
+        assert torch.equal(vc[b, :, int(pos[b])], qkv[b, 0, (H + Hkv) * D:].reshape(Hkv, D))
+        others = [j for j in range(S) if j != int(pos[b])]
+        assert (kc[b][:, others] == 7.0).all() and (vc[b][:, others] == -3.0).all()
+    kc2 = torch.zeros(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+    ops.rotary_embedding_neox_kvcache(torch.tensor([S, S + 3, -1]).to(DEV), q, k, v, D, cache.to(DEV), kc2, kc2.clone())
+    assert torch.count_nonzero(kc2) == 0
+
+
+def test_eet_attention_static_cache_decode_matches_stock_path(ops):
+    """Token-by-token decode on a transformers StaticCache: the fused path (rotary + cache write in one launch, split-KV
+    attention) must track the same model running its stock cache update and attention call."""
+    transformers = pytest.importorskip("transformers")
+    import copy
+    from eetq_amd.utils import eet_accelerator
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=2, vocab_size=512, max_position_embeddings=128)
+    torch.manual_seed(0)
+    stock = transformers.LlamaForCausalLM(cfg).half().to(DEV).eval()
+    model = eet_accelerator(copy.deepcopy(stock), quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True,
+                            fused_residual=True)
+    prompt = torch.randint(0, 512, (2, 9), device=DEV)
+
+    def run(mode):
+        for layer in model.model.layers:
+            layer.self_attn.decode_math_attention = mode
+        cache = transformers.StaticCache(config=cfg, max_cache_len=32)
+        logits = []
+        with torch.no_grad():
+            out = model(prompt, past_key_values=cache, use_cache=True)
+            tok = out.logits[:, -1].argmax(-1, keepdim=True)
+            for _ in range(6):
+                out = model(tok, past_key_values=cache, use_cache=True)
+                logits.append(out.logits[:, -1].float())
+                tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        return torch.stack(logits)
+
+    ref = run(False)      # stock cache update + stock attention call
+    got = run(True)       # fused decode path
+    spread = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 4e-3 * spread + 4e-3
+
+
+def test_silu_mul_matches_torch(ops):
+    torch.manual_seed(5)
+    gu = (torch.randn(3, 5, 2 * 704, device=DEV) * 3).half()
+    ref = torch.nn.functional.silu(gu[..., :704]) * gu[..., 704:]
+    out = ops.silu_mul(gu)
+    assert out.shape == ref.shape
+    # same roundings as the two torch ops (fp32 silu -> fp16, fp16 multiply); allow one fp16 ulp for expf differences
+    diff = (out.float() - ref.float()).abs()
+    assert (diff <= 1e-3 * ref.float().abs() + 1e-6).all()
+    assert (out == ref).float().mean().item() > 0.98
+    with pytest.raises(RuntimeError):
+        ops.silu_mul(gu[..., :-2].contiguous())
