@@ -28,6 +28,13 @@ _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM8
 _PATHS = {"auto": PATH_AUTO, "gemv": PATH_GEMV, "mfma": PATH_MFMA, "stream": _lib.PATH_STREAM, "mid": _lib.PATH_MID}
 
 
+def _eager_only(fn):
+    """The operators call the library through ctypes with raw pointers: keep torch.compile (which transformers turns on by
+    itself for `generate(cache_implementation="static")`) from tracing into them -- it breaks the graph around the call."""
+    disable = getattr(getattr(torch, "compiler", None), "disable", None)
+    return disable(fn) if disable is not None else fn
+
+
 def _layout_id(layout):
     try:
         return _LAYOUTS[layout]
@@ -55,6 +62,7 @@ def _work_device(t):
     return torch.device("cuda", torch.cuda.current_device())
 
 
+@_eager_only
 def quant_weights(origin_weight, quant_type, return_unprocessed_quantized_tensor=False, layout="gfx950"):
     """Per-column symmetric int8 quantisation of a [K, N] fp16/fp32 weight.
 
@@ -122,6 +130,7 @@ def _relayout(src, layout, pack):
         return out if src.is_cuda else out.cpu()
 
 
+@_eager_only
 def preprocess_weights(origin_weight, is_int4=False, layout="gfx950"):
     """Row-major int8 [K, N] -> processed layout (same shape, re-ordered bytes).
 
@@ -132,6 +141,7 @@ def preprocess_weights(origin_weight, is_int4=False, layout="gfx950"):
     return _relayout(origin_weight, layout, pack=True)
 
 
+@_eager_only
 def unprocess_weights(processed_weight, layout="gfx950"):
     """Inverse of :func:`preprocess_weights` (no reference counterpart; needed for checkpoint interop)."""
     return _relayout(processed_weight, layout, pack=False)
@@ -142,6 +152,7 @@ def convert_layout(weight, src_layout, dst_layout):
     return preprocess_weights(unprocess_weights(weight, src_layout), False, dst_layout)
 
 
+@_eager_only
 def _gemm_launch(input, weight, scale, output, m, n, k, path, bias=None, residual=None):
     if input.dtype != torch.float16:
         raise RuntimeError("w8_a16_gemm: input must be float16 (got %s)" % input.dtype)
@@ -200,6 +211,7 @@ def w8_a16_gemm_(input, weight, scale, output, m, n, k):
     return _gemm_launch(input, weight, scale, output, int(m), int(n), int(k), PATH_AUTO)
 
 
+@_eager_only
 def layernorm_forward(input, gamma, out, eps):
     """T5/RMS layernorm into ``out`` (reference: layernorm_forward_cuda, layernorm.cu:98-113). Returns None."""
     if input.dtype != torch.float16 or gamma.dtype != torch.float16 or out.dtype != torch.float16:
@@ -217,6 +229,7 @@ def layernorm_forward(input, gamma, out, eps):
     return None
 
 
+@_eager_only
 def rotary_embedding_neox(positions, query, key, head_size, cos_sin_cache):
     """In-place NeoX rotary embedding of query/key (reference: pos_encoding_kernels.cu:55-87). fp16 only."""
     if query.dtype != torch.float16 or key.dtype != torch.float16 or cos_sin_cache.dtype != torch.float16:
@@ -235,6 +248,7 @@ def rotary_embedding_neox(positions, query, key, head_size, cos_sin_cache):
     return None
 
 
+@_eager_only
 def rotary_embedding_neox_strided(positions, query, key, head_size, cos_sin_cache):
     """In-place NeoX rotary embedding of strided views: query [..., q_heads, head_size] and key [..., k_heads, head_size]
     whose last two dimensions are dense and whose leading (token) dimensions share one stride -- e.g. the q and k
@@ -275,6 +289,7 @@ def rotary_embedding_neox_strided(positions, query, key, head_size, cos_sin_cach
     return None
 
 
+@_eager_only
 def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, splits=None):
     """Single-query attention over a KV cache (extension; the decode step of the EET attention blocks).
 
@@ -311,6 +326,7 @@ def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, spl
     return out
 
 
+@_eager_only
 def rotary_embedding_neox_kvcache(positions, query, key, value, head_size, cos_sin_cache, key_cache, value_cache):
     """Decode step: rotate ``query`` [B, H, D] in place, write the rotated ``key`` [B, Hkv, D] and ``value`` [B, Hkv, D]
     into the caches [B, Hkv, S, D] at ``positions`` [B] (int64).  One launch instead of rotary + two cache copies."""
@@ -341,6 +357,7 @@ def rotary_embedding_neox_kvcache(positions, query, key, value, head_size, cos_s
     return None
 
 
+@_eager_only
 def silu_mul(gate_up):
     """``silu(gate) * up`` on a fused gate|up projection output [..., 2*I] -> [..., I] in one launch (extension)."""
     if gate_up.dtype != torch.float16 or not gate_up.is_cuda or not gate_up.is_contiguous():

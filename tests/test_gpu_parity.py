@@ -714,3 +714,26 @@ def test_silu_mul_matches_torch(ops):
     assert (out == ref).float().mean().item() > 0.98
     with pytest.raises(RuntimeError):
         ops.silu_mul(gu[..., :-2].contiguous())
+
+
+def test_generate_with_static_cache_under_torch_compile(ops):
+    """transformers compiles the decode forward on its own for generate(cache_implementation="static"); the ctypes-backed
+    operators must break the graph instead of being traced, and the tokens must equal the dynamic-cache run."""
+    transformers = pytest.importorskip("transformers")
+    import copy
+    from eetq_amd.utils import eet_accelerator
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=2, vocab_size=512, max_position_embeddings=128)
+    torch.manual_seed(0)
+    stock = transformers.LlamaForCausalLM(cfg).half().to(DEV).eval()
+    model = eet_accelerator(copy.deepcopy(stock), quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True,
+                            fused_residual=True)
+    prompt = torch.randint(0, 512, (2, 9), device=DEV)
+    a = model.generate(prompt, max_new_tokens=6, do_sample=False, pad_token_id=0)
+    try:
+        b = model.generate(prompt, max_new_tokens=6, do_sample=False, pad_token_id=0, cache_implementation="static")
+    except Exception as e:  # a missing compiler backend on the box is not this library's concern
+        if "ctypes" in str(e) or "cuda_stream" in str(e) or "data_ptr" in str(e):
+            raise
+        pytest.skip("torch.compile unavailable here: %s" % type(e).__name__)
+    assert (a == b).float().mean().item() > 0.9
