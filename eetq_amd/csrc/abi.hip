@@ -99,6 +99,19 @@ struct DevBuf {
 
 using namespace eetq;
 
+int eetq::device_cu_count()
+{
+    static int cached[64] = {0};
+    int        dev        = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    int& c = cached[dev & 63];
+    if (!c) {
+        int v = 0;
+        c     = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) ? v : 256;
+    }
+    return c;
+}
+
 extern "C" {
 
 const char* eetq_last_error(void) { return g_last_error.c_str(); }

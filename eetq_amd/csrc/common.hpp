@@ -114,6 +114,9 @@ int launch_rotary_kvcache(const int64_t* pos, f16* q, const f16* k, const f16* v
 
 int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t stream);
 
+// compute units of the current device (cached per device); 256 on MI355X
+int device_cu_count();
+
 int  launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t stream);
 
 int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,

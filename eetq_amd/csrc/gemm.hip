@@ -59,16 +59,7 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
     const size_t row_bytes  = (size_t)K * 2;
     const int    max_rows   = (int)((((1ull << 31) - 1) / row_bytes) / BM * BM);
     EETQ_REQUIRE(max_rows >= BM, "K too large for the buffer-addressed DMA path");
-    int n_cu = 256;
-    {
-        static int cached_cus[64] = {0};
-        if (!cached_cus[dev & 63]) {
-            int v = 0;
-            EETQ_TRY_HIP(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
-            cached_cus[dev & 63] = v > 0 ? v : 256;
-        }
-        n_cu = cached_cus[dev & 63];
-    }
+    const int n_cu = device_cu_count();
     for (int m = 0; m < M; m += max_rows) {
         const int rows    = M - m < max_rows ? M - m : max_rows;
         const int tiles_m = (rows + BM - 1) / BM;

@@ -27,12 +27,18 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
 {
     const int KT = K / kTileK;  // every wave must own >= D k tiles
     if (KT >= 32) {
-        // every workgroup re-reads the activations (M x K fp16 from L2) for its columns: where two tile rows per
-        // workgroup still give every CU a workgroup, share each activation fragment between them
-        // (M = 8, N = 22016: 24.5 -> 17.0 us; N = 4096: 5.3 -> 5.8 us, so not there: profiles/r01_kbench_streamk_nt.txt)
+        // every workgroup re-reads the activations (M x K fp16 from L2) for its columns; with two tile rows per
+        // workgroup each activation fragment feeds two weight tiles.  Cost per k tile in wave-load units: NT weight loads
+        // + 2 activation loads, times the workgroups the busiest CU gets.  N = 5120 (320 tile rows on 256 CUs): M = 8
+        // 10.0 -> 7.5 us, K = 13824 23.6 -> 17.2 us; N = 22016: 24.5 -> 17.0 us; N = 4096 stays at NT = 1 (5.0 vs 5.8 us)
+        // -- profiles/r01_kbench_streamk_nt.txt
         if constexpr (MT == 1) {
-            if (N % (2 * kTileN) == 0 && N / (2 * kTileN) >= 256)
-                return launch_inst<MT, 2, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+            if (N % (2 * kTileN) == 0) {
+                const int  ncu   = device_cu_count();
+                const long cost1 = (long)((N / kTileN + ncu - 1) / ncu) * 3;
+                const long cost2 = (long)((N / (2 * kTileN) + ncu - 1) / ncu) * 4;
+                if (cost2 < cost1) return launch_inst<MT, 2, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+            }
         }
         return launch_inst<MT, 1, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     }

@@ -137,10 +137,11 @@ def test_gemv_vs_oracle(ops, oracle, M, K, N):
 
 
 @pytest.mark.parametrize("M", [2, 8, 13, 16])
-@pytest.mark.parametrize("K,N", [(2048, 8192), (2112, 8256), (2048, 8208)])
+@pytest.mark.parametrize("K,N", [(2048, 8192), (2112, 8256), (2048, 8208), (2048, 5120), (2048, 6144)])
 def test_stream_wide_n_vs_oracle(ops, oracle, M, K, N):
-    """N / 32 >= 256 and N % 32 == 0: two 16-column tile rows per workgroup share the activation fragments (8208 is the
-    N % 32 != 0 fallback to one tile row)."""
+    """Shapes where the launcher's cost model puts two 16-column tile rows into one workgroup (they share the activation
+    fragments): N = 8192 / 8256, and N = 5120 / 6144 where one tile row per workgroup would leave a second, mostly empty
+    round of workgroups; 8208 is the N % 32 != 0 fallback to one tile row."""
     w, x = _rand_case(K, N, M, seed=7 * K + N + M)
     x[:, 1::2] *= -1
     y, q, s = _run_gemm(ops, oracle, w, x, path="stream")

@@ -381,6 +381,29 @@ int main(int argc, char** argv)
         bench_gemm<30>("gemm dma only", 1024, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm<9>("gemm ldsread+dequant", 1024, 4096, 4096, bufs, xg, scales, yg);
     }
+    if (!strcmp(what, "streamk13b")) {  // batched decode at Llama-13B shapes: tile rows per workgroup
+        uint8_t* huge;
+        CK(hipMalloc(&huge, 13824ull * 5120 * 8));
+        CK(hipMemset(huge, 0x5a, 13824ull * 5120 * 8));
+        std::vector<uint8_t*> b70;
+        for (int i = 0; i < 8; ++i) b70.push_back(huge + (size_t)i * 13824 * 5120);
+        eetq::f16 *xs, *ys;
+        CK(hipMalloc(&xs, 16ull * 13824 * 2));
+        CK(hipMalloc(&ys, 16ull * 27648 * 2));
+        CK(hipMemset(xs, 0x30, 16ull * 13824 * 2));
+        for (int M : {4, 8, 16}) {
+            printf("M=%d\n", M);
+            bench_streamk<1, 1, 16, 2, 4>("NT1 16x2 N=5120 K=5120", M, 5120, 5120, b70, xs, scales, ys);
+            bench_streamk<1, 2, 16, 2, 4>("NT2 16x2 N=5120 K=5120", M, 5120, 5120, b70, xs, scales, ys);
+            bench_streamk<1, 1, 16, 2, 4>("NT1 16x2 N=5120 K=13824", M, 5120, 13824, b70, xs, scales, ys);
+            bench_streamk<1, 2, 16, 2, 4>("NT2 16x2 N=5120 K=13824", M, 5120, 13824, b70, xs, scales, ys);
+            bench_streamk<1, 1, 16, 4, 4>("NT1 16x4 N=5120 K=13824", M, 5120, 13824, b70, xs, scales, ys);
+            bench_streamk<1, 2, 16, 2, 4>("NT2 16x2 N=13824 K=5120", M, 13824, 5120, b70, xs, scales, ys);
+            bench_streamk<1, 1, 16, 2, 4>("NT1 16x2 N=4096 K=4096", M, 4096, 4096, bufs, xs, scales, ys);
+            bench_streamk<1, 1, 16, 2, 4>("NT1 16x2 N=4096 K=11008", M, 4096, 11008, bufs_big, xs, scales, ys);
+            bench_streamk<1, 2, 16, 2, 4>("NT2 16x2 N=4096 K=11008", M, 4096, 11008, bufs_big, xs, scales, ys);
+        }
+    }
     if (!strcmp(what, "gemv13b")) {  // Llama-13B shapes: workgroup-count quantisation and kernel variants
         uint8_t* huge;
         CK(hipMalloc(&huge, 13824ull * 5120 * 8));
