@@ -60,11 +60,11 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
     const int    max_rows   = (int)((((1ull << 31) - 1) / row_bytes) / BM * BM);
     EETQ_REQUIRE(max_rows >= BM, "K too large for the buffer-addressed DMA path");
     const int n_cu = device_cu_count();
-    for (int m = 0; m < M; m += max_rows) {
-        const int rows    = M - m < max_rows ? M - m : max_rows;
+    // one launch over columns [c0, c0 + cols) of the problem with the cheaper of the two tile shapes
+    auto launch_cols = [&](int m, int rows, int c0, int cols, int force_j) -> int {
         const int tiles_m = (rows + BM - 1) / BM;
-        const int tiles2  = tiles_m * ((N + TileCfg<2>::BN - 1) / TileCfg<2>::BN);
-        const int tiles1  = tiles_m * ((N + TileCfg<1>::BN - 1) / TileCfg<1>::BN);
+        const int tiles2  = tiles_m * ((cols + TileCfg<2>::BN - 1) / TileCfg<2>::BN);
+        const int tiles1  = tiles_m * ((cols + TileCfg<1>::BN - 1) / TileCfg<1>::BN);
         // 128 x 128 tiles are the efficient shape when they fill the chip; 128 x 64 tiles double the workgroup count:
         // they win when the wide tiles leave CUs idle (tiles < CUs) or end in a mostly empty round.  Cost in units of one
         // wide-tile pass; a narrow tile costs kNarrow of it (measured, profiles/r01_kbench_tile_shapes.txt).
@@ -72,14 +72,39 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         const double cost2 = (double)((tiles2 + n_cu - 1) / n_cu);
         const double cost1 = kNarrow * (double)((tiles1 + n_cu - 1) / n_cu);
         Epilogue     e     = ep;
-        if (e.residual) e.residual += (size_t)m * N;
-        if (cost1 < cost2)
-            launch_kernel(gemm_tile_kernel<0, 1>, dim3(tiles1), dim3(256), TileCfg<1>::SMEM_BYTES, stream, x + (size_t)m * K, w,
-                          scales, y + (size_t)m * N, rows, N, K, e);
+        if (e.bias) e.bias += c0;
+        if (e.residual) e.residual += (size_t)m * N + c0;
+        const uint8_t* wc = w + (size_t)(c0 / kTileN) * (K / kTileK) * kTileBytes;
+        const bool     narrow = force_j == 1 || (force_j == 0 && cost1 < cost2);
+        if (narrow)
+            launch_kernel(gemm_tile_kernel<0, 1>, dim3(tiles1), dim3(256), TileCfg<1>::SMEM_BYTES, stream, x + (size_t)m * K, wc,
+                          scales + c0, y + (size_t)m * N + c0, rows, cols, K, N, e);
         else
-            launch_kernel(gemm_tile_kernel<0, 2>, dim3(tiles2), dim3(256), TileCfg<2>::SMEM_BYTES, stream, x + (size_t)m * K, w,
-                          scales, y + (size_t)m * N, rows, N, K, e);
-        EETQ_TRY_HIP(hipGetLastError());
+            launch_kernel(gemm_tile_kernel<0, 2>, dim3(tiles2), dim3(256), TileCfg<2>::SMEM_BYTES, stream, x + (size_t)m * K, wc,
+                          scales + c0, y + (size_t)m * N + c0, rows, cols, K, N, e);
+        return check_hip(hipGetLastError(), "gemm_tile_kernel launch");
+    };
+    for (int m = 0; m < M; m += max_rows) {
+        const int rows    = M - m < max_rows ? M - m : max_rows;
+        const int tiles_m = (rows + BM - 1) / BM;
+        const int tn2     = (N + TileCfg<2>::BN - 1) / TileCfg<2>::BN;
+        const int T2      = tiles_m * tn2;
+        // Whole rounds of wide tiles, then the ragged last round: when that round would be less than half full its
+        // columns go to narrow tiles in a second launch (M = 1024, N = 5120: 320 wide tiles = 256 + 64 -> 256 wide +
+        // 128 narrow: 73.8 -> ~59 us).  Tile rows of the weight layout are 16 columns, so any multiple of 128 splits.
+        const int rem = T2 % n_cu;
+        if (T2 > n_cu && rem != 0 && rem * 2 < n_cu && tiles_m <= n_cu) {
+            const int cols1 = ((T2 - rem) / tiles_m) * TileCfg<2>::BN;  // columns covered by complete rounds (rounded down)
+            if (cols1 > 0 && cols1 < N) {
+                int st = launch_cols(m, rows, 0, cols1, 2);
+                if (st != EETQ_OK) return st;
+                st = launch_cols(m, rows, cols1, N - cols1, 0);
+                if (st != EETQ_OK) return st;
+                continue;
+            }
+        }
+        int st = launch_cols(m, rows, 0, N, 0);
+        if (st != EETQ_OK) return st;
     }
     return EETQ_OK;
 }

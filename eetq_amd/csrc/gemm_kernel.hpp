@@ -71,8 +71,9 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 template <int ABLATE, int J>
 __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int M, int N, int K, Epilogue ep)
+    f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
 {
+    // N = columns of THIS launch (w, scales, y, ep.* already point at its first column); ldc = row stride of y / residual
     using Cfg = TileCfg<J>;
     constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES;
     constexpr int WN_COLS = 32 * J, PIECES = 4 + J, NMFMA = 8 * J;
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
                 for (int r = 0; r < 16; ++r) acc[mt][j][r] += red[((mt * J + j) * 16 + r) * 64 + lane];
                 const int nbase = n0 + wn * WN_COLS + 32 * j + 4 * fh;
                 if (m < M) {
-                    f16* yrow = y + (size_t)m * N + nbase;
+                    f16* yrow = y + (size_t)m * ldc + nbase;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (nbase + 8 * q < N) {
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
                             }
                             if (ep.residual) {
                                 const u32x2 r =
-                                    *reinterpret_cast<const u32x2*>(ep.residual + (size_t)m * N + nbase + 8 * q);
+                                    *reinterpret_cast<const u32x2*>(ep.residual + (size_t)m * ldc + nbase + 8 * q);
                                 lo = lo + as_f16x2(r.x);
                                 hi = hi + as_f16x2(r.y);
                             }

@@ -738,3 +738,25 @@ def test_generate_with_static_cache_under_torch_compile(ops):
             raise
         pytest.skip("torch.compile unavailable here: %s" % type(e).__name__)
     assert (a == b).float().mean().item() > 0.9
+
+
+@pytest.mark.parametrize("M,K,N", [(640, 320, 6784), (1024, 320, 5120), (300, 384, 11136)])
+def test_tiled_gemm_column_split_launches(ops, oracle, M, K, N):
+    """Shapes whose wide tiles end in a mostly empty last round: the launcher runs the complete rounds with 128 x 128 tiles
+    and the remaining columns with 128 x 64 tiles in a second launch (weights, scales, bias, residual and y offset by the
+    column split).  Parity against the oracle, and the fused epilogue against separate adds, across the split."""
+    w, x = _rand_case(K, N, M, seed=3 * M + N)
+    x[:, ::3] *= -1
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    y = ops.w8_a16_gemm(xd, processed, scales, path="mfma")
+    ref = oracle.w8a16_gemm(x, q, s)
+    ok = _tier_a(y.cpu().numpy(), ref)
+    assert ok.all(), "max err %g at %s" % (np.abs(y.cpu().numpy().astype(np.float32) - ref.astype(np.float32)).max(),
+                                          np.argwhere(~ok)[:4])
+    torch.manual_seed(M)
+    bias = torch.randn(N, dtype=torch.float16, device=DEV)
+    res = torch.randn(M, N, dtype=torch.float16, device=DEV)
+    assert torch.equal(ops.w8_a16_gemm(xd, processed, scales, path="mfma", bias=bias, residual=res), res + (y + bias))

@@ -176,7 +176,7 @@ static void bench_gemm(const char* name, int M, int N, int K, const std::vector<
     auto         st    = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
             hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(256), SMEM_BYTES, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, eetq::Epilogue{});
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, N, eetq::Epilogue{});
         },
         60, 10);
     printf("%-22s M=%5d N=%5d K=%5d | disp mean %7.2f med %7.2f min %7.2f us -> %7.1f TF(med)\n", name, M, N, K, st.mean,
@@ -481,7 +481,7 @@ int main(int argc, char** argv)
         CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
         for (int i = 0; i < 20; ++i)
             hipLaunchKernelGGL(kern, dim3(256), dim3(THREADS8), SMEM_BYTES, 0, xg, (const uint8_t*)bufs[i % bufs.size()], scales,
-                               yg, 1024, 4096, 4096, eetq::Epilogue{});
+                               yg, 1024, 4096, 4096, 4096, eetq::Epilogue{});
         CK(hipDeviceSynchronize());
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
         for (int i = 0; i < 20; ++i)

@@ -18,13 +18,18 @@ from eetq_amd import _lib, ops  # noqa: E402
 
 
 def kernel_us(run, n):
+    """Per-call kernel time: a call may be more than one launch (the tiled GEMM splits ragged shapes into two), so the
+    recorded per-launch durations are summed per call."""
     L = _lib.lib()
-    _lib.check(L.eetq_prof_begin(n))
+    cap = 4 * n
+    _lib.check(L.eetq_prof_begin(cap))
     run()
-    buf = (ctypes.c_float * n)()
+    buf = (ctypes.c_float * cap)()
     cnt = ctypes.c_int(0)
-    _lib.check(L.eetq_prof_end(buf, n, ctypes.byref(cnt)))
-    us = np.array(buf[:cnt.value])
+    _lib.check(L.eetq_prof_end(buf, cap, ctypes.byref(cnt)))
+    per_call = cnt.value // n
+    assert per_call >= 1 and per_call * n == cnt.value, (cnt.value, n)
+    us = np.array(buf[:cnt.value]).reshape(n, per_call).sum(axis=1)
     return float(np.median(us)), float(us.mean()), float(us.min())
 
 
