@@ -140,3 +140,69 @@ def test_replace_with_eet_qlinear_rejects_unmapped_models():
     from eetq_amd.utils.accelerator import replace_with_eet_qlinear
     with pytest.raises(ValueError):
         replace_with_eet_qlinear(nn.Sequential(), target_model="opt")
+
+
+def _ref_python_golden():
+    import json
+    import os
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return json.load(open(os.path.join(here, "ref_python_layer.json"))), here
+
+
+def test_python_layer_matches_the_reference_python_layer():
+    """tests/golden/ref_python_layer.json was produced by the REFERENCE's python/eetq package, imported unmodified in the
+    build container on top of this repo's `EETQ` module (tests/golden/make_reference_python_golden.py).  The mirrors here
+    must reproduce its buffer contracts, layer discovery and replacement results."""
+    from eetq_amd.modules.qlinear import EetqLinear, W8A16Linear
+    from eetq_amd.utils.quantizer import eet_quantize, find_layers, get_named_linears, set_op_by_name
+    g, _ = _ref_python_golden()
+
+    def sd_contract(m):
+        return {k: [list(v.shape), str(v.dtype)] for k, v in m.state_dict().items()}
+
+    def toy():
+        class Sub(nn.Linear):
+            pass
+        model = nn.Sequential()
+        model.add_module("blocks", nn.ModuleList([nn.Sequential(nn.Linear(8, 8), nn.ReLU()), nn.Sequential(Sub(8, 8))]))
+        model.add_module("head", nn.Sequential(nn.Linear(8, 16), nn.Linear(16, 4)))
+        model.add_module("lm_head", nn.Linear(8, 8))
+        return model
+
+    assert sd_contract(W8A16Linear(64, 32, bias=True, dev="cpu")) == g["w8a16linear_bias"]
+    assert sd_contract(W8A16Linear(64, 32, bias=False, dev="cpu")) == g["w8a16linear_nobias"]
+    init = W8A16Linear.from_torch(nn.Linear(64, 32, bias=True).half(), init_only=True)
+    assert {"in_features": init.in_features, "out_features": init.out_features, "state": sd_contract(init),
+            "qweight_all_zero": bool(init.qweight.abs().sum() == 0)} == g["from_torch_init_only"]
+    e = EetqLinear(64, 32, bias=False, device="cpu")
+    assert sd_contract(e) == g["eetqlinear_before_register_scale"]
+    e.register_scale("cpu")
+    assert sd_contract(e) == g["eetqlinear_after_register_scale"]
+    m = toy()
+    assert list(find_layers(m)) == g["find_layers_default"]
+    assert list(find_layers(m, exclude=[])) == g["find_layers_no_exclude"]
+    assert list(get_named_linears(m)) == g["get_named_linears"]
+    set_op_by_name(m, "head.0", nn.Identity())
+    ours = {n: type(s).__name__ for n, s in m.named_modules() if n.startswith("head.")}
+    assert ours == dict(g["after_set_op_by_name_head0"])
+    # deliberate difference: the reference's delattr + setattr moves the replaced child to the END of its container
+    # (its recorded order is head.1, head.0 -- it reorders an nn.Sequential); ours keeps the position
+    assert [n for n, _ in m.named_modules() if n.startswith("head.")] == ["head.0", "head.1"]
+    assert [p[0] for p in g["after_set_op_by_name_head0"]] == ["head.1", "head.0"]
+    m = toy().half()
+    eet_quantize(m, init_only=True)
+    assert [[n, type(s).__name__] for n, s in m.named_modules()
+            if isinstance(s, (nn.Linear, W8A16Linear))] == g["eet_quantize_init_only_types"]
+
+
+def test_rotary_cache_is_bit_identical_to_the_reference_module():
+    """cos|sin cache of the reference's EETRotaryEmbedding(64, 96, 10000), generated by running the reference module."""
+    import os
+    import numpy as np
+    from eetq_amd.modules.llama_modules import EETRotaryEmbedding
+    g, here = _ref_python_golden()
+    ref = np.load(os.path.join(here, "ref_rotary_cache_d64_p96.npy"))
+    rc = g["rotary_cache"]
+    ours = EETRotaryEmbedding(rc["dim"], max_position_embeddings=rc["max_position_embeddings"], base=rc["base"])
+    assert list(ours.cos_sin_cache.shape) == rc["shape"] and str(ours.cos_sin_cache.dtype) == rc["dtype"]
+    assert ours.cos_sin_cache.numpy().tobytes() == ref.tobytes()
