@@ -71,6 +71,23 @@ m = toy().half()
 eet_quantize(m, init_only=True)
 out["eet_quantize_init_only_types"] = [[n, type(s).__name__] for n, s in m.named_modules()
                                        if isinstance(s, (nn.Linear, W8A16Linear))]
+from eetq.modules.qlinear import quantize_and_preprocess_weights  # noqa: E402
+
+
+def raised(fn):
+    try:
+        fn()
+    except Exception as e:  # noqa: BLE001
+        return [type(e).__name__, str(e)[:80]]
+    return None
+
+
+out["errors"] = {
+    "quantize_and_preprocess_fp32": raised(lambda: quantize_and_preprocess_weights(torch.zeros(4, 4, dtype=torch.float32))),
+    "quantize_and_preprocess_int8_without_scales": raised(
+        lambda: quantize_and_preprocess_weights(torch.zeros(4, 4, dtype=torch.int8))),
+    "eet_quantize_fp32_model": raised(lambda: eet_quantize(nn.Sequential(nn.Linear(4, 4)), init_only=True)),
+}
 with open(os.path.join(HERE, "ref_python_layer.json"), "w") as f:
     json.dump(out, f, indent=1, sort_keys=True)
 print(json.dumps(out, indent=1, sort_keys=True)[:1500])

@@ -206,3 +206,28 @@ def test_rotary_cache_is_bit_identical_to_the_reference_module():
     ours = EETRotaryEmbedding(rc["dim"], max_position_embeddings=rc["max_position_embeddings"], base=rc["base"])
     assert list(ours.cos_sin_cache.shape) == rc["shape"] and str(ours.cos_sin_cache.dtype) == rc["dtype"]
     assert ours.cos_sin_cache.numpy().tobytes() == ref.tobytes()
+
+
+def test_error_behaviour_matches_the_reference_python_layer():
+    """Exception types and messages recorded from the reference's python layer (same fixture)."""
+    from eetq_amd.modules.qlinear import quantize_and_preprocess_weights
+    from eetq_amd.utils.quantizer import eet_quantize
+    g, _ = _ref_python_golden()
+
+    def raised(fn):
+        try:
+            fn()
+        except Exception as e:  # noqa: BLE001
+            return [type(e).__name__, str(e)[:80]]
+        return None
+
+    ours = {
+        "quantize_and_preprocess_fp32": raised(lambda: quantize_and_preprocess_weights(torch.zeros(4, 4, dtype=torch.float32))),
+        "quantize_and_preprocess_int8_without_scales": raised(
+            lambda: quantize_and_preprocess_weights(torch.zeros(4, 4, dtype=torch.int8))),
+        "eet_quantize_fp32_model": raised(lambda: eet_quantize(nn.Sequential(nn.Linear(4, 4)), init_only=True)),
+    }
+    for key, (etype, msg) in g["errors"].items():
+        assert ours[key] is not None and ours[key][0] == etype, (key, ours[key], etype)
+        if msg:
+            assert ours[key][1] == msg, (key, ours[key][1], msg)
