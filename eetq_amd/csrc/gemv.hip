@@ -43,11 +43,48 @@ int launch_lds(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f
     return launch_inst<M, WAVES, D, EXACT, false, 8, OCC>(x, w, scales, ep, y, N, K, stream);
 }
 
+// 8-column units (gemv_half_kernel), M = 1: when they put fewer bytes on the busiest CU than whole tile rows do
+template <int XV>
+int launch_half_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
+{
+    auto         kern = gemv::gemv_half_kernel<8, 2, XV, 8>;
+    const size_t smem = gemv::gemv_half_smem_bytes(K, 8);
+    if (smem > 64 * 1024) {
+        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)smem));
+    }
+    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep);
+    return check_hip(hipGetLastError(), "gemv_half_kernel launch");
+}
+
+bool half_units_pay(int N, int K)
+{
+    const int KT = K / kTileK;
+    if (KT % 2 || KT < 32 || K > 32768) return false;  // pairs of k tiles, >= 2 pairs per wave in flight, x fits in LDS
+    // Measured (profiles/r01_kbench_gemv.txt): worth it when whole tile rows leave CUs idle (rows <= CUs / 2) or put a
+    // second workgroup on only a few CUs (N = 5120: 320 rows on 256 CUs, K = 13824 14.5 -> 13.2 us, K = 5120 6.24 -> 6.04);
+    // a wash or a small loss elsewhere (N = 6144, 13824, 4096).
+    const int ncu = device_cu_count(), rows = N / kTileN;
+    return 2 * rows <= ncu || (rows > ncu && 10 * rows <= 13 * ncu);
+}
+
+int launch_half(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
+{
+    const int need = (K / 8 + 511) / 512;  // 16-byte activation loads per thread
+    if (need <= 2) return launch_half_xv<2>(x, w, scales, ep, y, N, K, stream);
+    if (need <= 4) return launch_half_xv<4>(x, w, scales, ep, y, N, K, stream);
+    return launch_half_xv<8>(x, w, scales, ep, y, N, K, stream);
+}
+
 template <int M>
 int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K,
                 hipStream_t stream)
 {
     const int KT = K / kTileK;
+    if constexpr (M == 1) {
+        // N = 5120: 320 tile rows on 256 CUs -> 640 half rows, 3 instead of 4 eight-column units on the busiest CU
+        if (half_units_pay(N, K)) return launch_half(x, w, scales, ep, y, N, K, stream);
+    }
     // Tuned on MI355X with tools/kbench (profiles/r01_kbench_gemv.txt):
     if (KT == 64) {  // K = 4096: 16 waves x 4 tiles, straight-line; <= 64 VGPRs so two workgroups fit a CU
         if constexpr (M <= 2)

@@ -197,6 +197,100 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Half-tile-row form, M = 1: one workgroup per 8 output columns (N/8 workgroups).  For N/16 a little above a multiple of
+// the CU count (N = 5120: 320 tile rows on 256 CUs) whole tile rows leave a quarter of the CUs with twice the bytes of the
+// others; in 8-column units the busiest CU gets 3 units of 8 instead of 2 units of 16.
+// A wave instruction covers the 8-column halves of TWO k tiles: lane = sub*32 + kg*8 + c reads the 16 bytes of column
+// half*8 + c, k-group kg of k tile 2p + sub -- eight full 128-byte lines.  Wave w owns pairs w, w+WAVES, ...; D pairs in
+// flight; K/64 must be even (launcher contract).  Activations are staged in LDS like the generic form.
+template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kernel(
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
+    f16* __restrict__ y, int N, int K, Epilogue ep)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    f16*   xs  = reinterpret_cast<f16*>(smem);
+    float* red = reinterpret_cast<float*>(smem + (size_t)K * 2);
+
+    const int tid  = threadIdx.x;
+    const int unit = blockIdx.x;  // 8-column unit: tile row unit >> 1, half unit & 1
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int sub = lane >> 5, kg = (lane >> 3) & 3, c = lane & 7;
+    const int KT = K >> 6, NP = KT >> 1;  // pairs of k tiles
+
+    u32 sraw = reinterpret_cast<const uint16_t*>(scales)[unit * 8 + c];
+
+    u32x4        xv[XV];
+    const int    xvecs = K >> 3;
+    const u32x4* xg    = reinterpret_cast<const u32x4*>(x);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int v = tid + i * WAVES * 64;
+        xv[i]       = xg[v < xvecs ? v : xvecs - 1];
+    }
+
+    // byte offset of this lane inside its k tile: lane index kg*16 + (half*8 + c) of the native tile
+    const uint8_t* wbase = w + (size_t)(unit >> 1) * KT * kTileBytes + (size_t)sub * kTileBytes +
+                           (kg * 16 + (unit & 1) * 8 + c) * 16;
+    auto wptr = [&](int pair) { return reinterpret_cast<const u32x4*>(wbase + (size_t)pair * 2 * kTileBytes); };
+    u32x4 buf[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) buf[d] = load_w<true>(wptr(wave + d * WAVES));
+
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const int v = tid + i * WAVES * 64;
+        if (v < xvecs) reinterpret_cast<u32x4*>(xs)[v] = xv[i];  // store (not load) behind the branch
+    }
+    asm volatile("" : "+v"(sraw));
+    const f16x2 scale2 = as_f16x2(sraw | (sraw << 16));
+    __syncthreads();
+
+    float      acc[1] = {0.f};
+    const f16* xl     = xs + sub * 64 + 16 * kg;  // + 128 halfs per pair
+    const int  n      = (NP - wave + WAVES - 1) / WAVES;  // pairs of this wave (>= D by launch contract)
+    int        i      = 0;
+    for (; i + 2 * D <= n; i += D) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            consume_tile<1>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * 128, K, acc);
+            buf[d] = load_w<true>(wptr(wave + (i + d + D) * WAVES));
+        }
+    }
+    const int r = n - (i + D);
+    u32x4     tail[D > 1 ? D - 1 : 1];
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d) {
+        const int t = i + D + d;
+        tail[d]     = load_w<true>(wptr(wave + (t < n ? t : n - 1) * WAVES));
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d) consume_tile<1>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * 128, K, acc);
+#pragma unroll
+    for (int d = 0; d < D - 1; ++d)
+        if (d < r) consume_tile<1>(tail[d], scale2, xl + (size_t)(wave + (i + D + d) * WAVES) * 128, K, acc);
+
+    // lanes with the same c: 4 k-groups (xor 8, 16) x 2 tiles of the pair (xor 32), then across waves via LDS
+    float a = acc[0];
+    a += __shfl_xor(a, 8, 64);
+    a = sum_xor32(sum_xor16(a));
+    if (lane < 8) red[wave * 8 + lane] = a;
+    __syncthreads();
+    if (tid < 8) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < WAVES; ++wv) s += red[wv * 8 + tid];
+        f16 v = (f16)s;
+        if (ep.bias) v = v + ep.bias[unit * 8 + tid];
+        if (ep.residual) v = v + ep.residual[unit * 8 + tid];
+        y[unit * 8 + tid] = v;
+    }
+}
+
+inline size_t gemv_half_smem_bytes(int K, int waves) { return (size_t)K * 2 + (size_t)waves * 8 * 4; }
+
 inline size_t gemv_smem_bytes(int M, int K, int waves, bool xreg)
 {
     return (xreg ? 0 : (size_t)M * K * 2) + (size_t)waves * M * 16 * 4;

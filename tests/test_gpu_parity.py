@@ -760,3 +760,32 @@ def test_tiled_gemm_column_split_launches(ops, oracle, M, K, N):
     bias = torch.randn(N, dtype=torch.float16, device=DEV)
     res = torch.randn(M, N, dtype=torch.float16, device=DEV)
     assert torch.equal(ops.w8_a16_gemm(xd, processed, scales, path="mfma", bias=bias, residual=res), res + (y + bias))
+
+
+@pytest.mark.parametrize("K,N", [(2048, 5120), (2176, 6144), (4096, 5120), (2048, 13824), (2048, 24), (4224, 40)])
+def test_gemv_half_tile_row_units_vs_oracle(ops, oracle, K, N):
+    """M = 1 shapes for which the launcher picks 8-column units (gemv_half_kernel): N/16 a little above a multiple of the
+    CU count, and small N; N = 24 / 40 end in half a tile row... which the native layout does not allow (N % 16), so those
+    must be rejected, not mis-computed."""
+    if N % 16:
+        w = np.zeros((K, 32), np.float16)
+        q, s = oracle.quantize(w)
+        with pytest.raises(RuntimeError):
+            ops.w8_a16_gemm(torch.zeros(1, K, dtype=torch.float16, device=DEV),
+                            torch.zeros(K, N, dtype=torch.int8, device=DEV), torch.zeros(N, dtype=torch.float16, device=DEV))
+        return
+    w, x = _rand_case(K, N, 1, seed=K + 3 * N)
+    x[:, ::2] *= -1
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    y = ops.w8_a16_gemm(xd, processed, scales)
+    ref = oracle.w8a16_gemm(x, q, s)
+    ok = _tier_a(y.cpu().numpy(), ref)
+    assert ok.all(), "max err %g at %s" % (np.abs(y.cpu().numpy().astype(np.float32) - ref.astype(np.float32)).max(),
+                                          np.argwhere(~ok)[:4])
+    torch.manual_seed(N)
+    bias = torch.randn(N, dtype=torch.float16, device=DEV)
+    res = torch.randn(1, N, dtype=torch.float16, device=DEV)
+    assert torch.equal(ops.w8_a16_gemm(xd, processed, scales, bias=bias, residual=res), res + (y + bias))

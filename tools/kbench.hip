@@ -429,6 +429,29 @@ int main(int argc, char** argv)
         bench_gemv<1, 16, 4, false, false, 4, 4>("loop lds 16x4 o4", 5120, 13824, b70, xl, scales, y);
         bench_gemv<1, 8, 4, false, false, 4, 8>("loop lds 8x4 o8", 5120, 13824, b70, xl, scales, y);
         bench_gemv<1, 8, 8, false, false, 4, 4>("loop lds 8x8 o4", 5120, 13824, b70, xl, scales, y);
+        printf("--- 8-column units (gemv_half_kernel) ---\n");
+        {
+            auto bench_half = [&](const char* name, auto kern, int N, int K) {
+                const size_t smem = eetq::gemv::gemv_half_smem_bytes(K, 8);
+                const double bytes = (double)K * N + 2.0 * K + 2.0 * N + 2.0 * N;
+                auto st = time_dispatch(
+                    [&](int i, hipEvent_t a, hipEvent_t b) {
+                        hipExtLaunchKernelGGL(kern, dim3(N / 8), dim3(512), (unsigned)smem, 0, a, b, 0, xl,
+                                              (const uint8_t*)b70[i % b70.size()], scales, y, N, K, eetq::Epilogue{});
+                    },
+                    400);
+                printf("%-30s N=%5d K=%5d M=1 | disp mean %6.2f med %6.2f min %6.2f us -> %6.0f GB/s(med)\n", name, N, K,
+                       st.mean, st.med, st.mn, bytes / st.med / 1e3);
+            };
+            bench_half("half 8x2 o8 xv2", eetq::gemv::gemv_half_kernel<8, 2, 2, 8>, 5120, 5120);
+            bench_half("half 8x4 o8 xv2", eetq::gemv::gemv_half_kernel<8, 4, 2, 8>, 5120, 5120);
+            bench_half("half 8x2 o4 xv2", eetq::gemv::gemv_half_kernel<8, 2, 2, 4>, 5120, 5120);
+            bench_half("half 8x2 o8 xv4", eetq::gemv::gemv_half_kernel<8, 2, 4, 8>, 5120, 13824);
+            bench_half("half 8x4 o8 xv4", eetq::gemv::gemv_half_kernel<8, 4, 4, 8>, 5120, 13824);
+            bench_half("half 8x2 o8 xv2", eetq::gemv::gemv_half_kernel<8, 2, 2, 8>, 6144, 5120);
+            bench_half("half 8x2 o8 xv2", eetq::gemv::gemv_half_kernel<8, 2, 2, 8>, 13824, 5120);
+            bench_half("half 8x2 o8 xv2", eetq::gemv::gemv_half_kernel<8, 2, 2, 8>, 4096, 5120);
+        }
         printf("--- N=13824 K=5120 ---\n");
         bench_gemv<1, 16, 2, false, false, 2, 8>("loop lds 16x2 o8", 13824, 5120, b70, xl, scales, y);
         bench_gemv<1, 16, 5, true, true, 1, 8>("exact xreg 16x5 o8", 13824, 5120, b70, xl, scales, y);
