@@ -201,6 +201,18 @@ class EETLlamaAttention(_EETAttentionBase):
         positions = self._positions(position_ids, past_key_values, bsz, q_len, hidden_states.device)
         kwargs.pop("use_cache", None)
         layer = self._static_cache_layer(past_key_values) if q_len == 1 else None
+        # the rotation indexes the cos|sin cache by position: grow it (host-side, never during graph capture -- the first
+        # eager pass already sees the same lengths) when the cache or the sequence is longer than the table
+        need = q_len
+        if layer is not None:
+            need = layer.keys.shape[2]
+        elif past_key_values is not None:
+            seen = past_key_values.get_seq_length(self.layer_idx)
+            if isinstance(seen, int):
+                need = seen + q_len
+        if need > self.rotary_emb.max_seq_len_cached:
+            self.rotary_emb._set_cos_sin_cache(max(need, 2 * self.rotary_emb.max_seq_len_cached),
+                                               self.rotary_emb.cos_sin_cache.device)
         if layer is not None and self.decode_math_attention is True and not kwargs.get("output_attentions", False):
             # decode step on an initialised static cache: ONE launch rotates q in place and writes the rotated k and v
             # straight into the cache rows (the stock cache update is arange + add + two index_copy launches, plus the

@@ -789,3 +789,18 @@ def test_gemv_half_tile_row_units_vs_oracle(ops, oracle, K, N):
     bias = torch.randn(N, dtype=torch.float16, device=DEV)
     res = torch.randn(1, N, dtype=torch.float16, device=DEV)
     assert torch.equal(ops.w8_a16_gemm(xd, processed, scales, bias=bias, residual=res), res + (y + bias))
+
+
+def test_eet_attention_grows_its_rotary_table(ops):
+    """A sequence longer than config.max_position_embeddings must not index past the cos|sin table."""
+    transformers = pytest.importorskip("transformers")
+    from eetq_amd.utils import eet_accelerator
+    cfg = transformers.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                                   num_key_value_heads=2, vocab_size=64, max_position_embeddings=16)
+    torch.manual_seed(0)
+    model = eet_accelerator(transformers.LlamaForCausalLM(cfg).half().to(DEV).eval(), quantize=True, fused_attn=True)
+    attn = model.model.layers[0].self_attn
+    assert attn.rotary_emb.max_seq_len_cached == 16
+    with torch.no_grad():
+        out = model(torch.randint(0, 64, (1, 40), device=DEV)).logits
+    assert attn.rotary_emb.max_seq_len_cached >= 40 and torch.isfinite(out).all()
