@@ -118,6 +118,42 @@ __global__ void stream_read_kernel(const u32x4* __restrict__ p, unsigned* __rest
     if (acc == 0x9e3779b9u) out[0] = acc;  // practically never: keeps the loads alive
 }
 
+// dispatch-overhead probes: what a kernel costs that touches no memory / one cache line per wave
+__global__ void empty_kernel(unsigned* out, int never)
+{
+    if (never == 12345) out[0] = threadIdx.x;
+}
+__global__ void touch_kernel(const unsigned* __restrict__ src, unsigned* out)
+{
+    const unsigned v = src[(size_t)blockIdx.x * 16384 + (threadIdx.x >> 6) * 32];  // one 128-byte line per wave
+    if (v == 0x12345678u) out[0] = v;
+}
+
+static void bench_overhead(const std::vector<uint8_t*>& bufs, unsigned* out)
+{
+    for (int threads : {64, 1024}) {
+        for (int grid : {1, 256, 1024}) {
+            auto st = time_dispatch(
+                [&](int, hipEvent_t a, hipEvent_t b) {
+                    hipExtLaunchKernelGGL(empty_kernel, dim3(grid), dim3(threads), 0, 0, a, b, 0, out, 0);
+                },
+                400);
+            printf("empty kernel      grid=%5d thr=%4d | disp mean %6.2f med %6.2f min %6.2f us\n", grid, threads, st.mean,
+                   st.med, st.mn);
+        }
+    }
+    for (int grid : {256}) {
+        auto st = time_dispatch(
+            [&](int i, hipEvent_t a, hipEvent_t b) {
+                hipExtLaunchKernelGGL(touch_kernel, dim3(grid), dim3(1024), 0, 0, a, b, 0,
+                                      (const unsigned*)bufs[i % bufs.size()], out);
+            },
+            400);
+        printf("one HBM line/wave grid=%5d thr=1024 | disp mean %6.2f med %6.2f min %6.2f us\n", grid, st.mean, st.med,
+               st.mn);
+    }
+}
+
 template <int LOADS, bool NT>
 static void bench_stream(const char* name, int threads, const std::vector<uint8_t*>& bufs, size_t bytes, unsigned* out)
 {
@@ -317,6 +353,8 @@ int main(int argc, char** argv)
     CK(hipMalloc(&out, 64));
 
     if (!strcmp(what, "all") || !strcmp(what, "stream")) {
+        printf("--- dispatch overhead ---\n");
+        bench_overhead(bufs, out);
         printf("--- streaming read floor, 16 MiB per launch, %d rotating buffers ---\n", NBUF);
         bench_stream<4, true>("read nt 1024thr x4", 1024, bufs, W4K, out);
         bench_stream<4, false>("read    1024thr x4", 1024, bufs, W4K, out);
@@ -489,6 +527,20 @@ int main(int argc, char** argv)
         bench_gemm<0, 1>("J=1 128x64", 1024, 11008, 4096, bufs_big, xg, scales, yg);
         bench_gemm<0, 2>("J=2 128x128", 2048, 4096, 4096, bufs, xg, scales, yg);
         bench_gemm<0, 1>("J=1 128x64", 2048, 4096, 4096, bufs, xg, scales, yg);
+    }
+    if (!strcmp(what, "overhead1")) {  // plain launches for rocprofv3 --kernel-trace: empty / read-only / GEMV
+        for (int i = 0; i < 300; ++i) hipLaunchKernelGGL(empty_kernel, dim3(1), dim3(64), 0, 0, out, 0);
+        CK(hipDeviceSynchronize());
+        for (int i = 0; i < 300; ++i) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(1024), 0, 0, out, 0);
+        CK(hipDeviceSynchronize());
+        for (int i = 0; i < 300; ++i)
+            hipLaunchKernelGGL((stream_read_kernel<4, true>), dim3(256), dim3(1024), 0, 0, (const u32x4*)bufs[i % bufs.size()], out);
+        CK(hipDeviceSynchronize());
+        auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
+        for (int i = 0; i < 300; ++i)
+            hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{});
+        CK(hipDeviceSynchronize());
     }
     if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
         eetq::f16 *xg, *yg;
