@@ -318,6 +318,24 @@ int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* ke
                          k_stride, static_cast<hipStream_t>(stream));
 }
 
+int eetq_w8a16_gemv_rmsnorm(const void* x, const void* gamma, float eps, const int8_t* w_packed, const void* scales,
+                            const void* bias, const void* residual, void* y, int N, int K, void* stream)
+{
+    int st = check_gemm_args(x, w_packed, scales, y, 1, N, K);
+    if (st != EETQ_OK) return st;
+    EETQ_REQUIRE(gamma, "null pointer");
+    EETQ_REQUIRE((uintptr_t)gamma % 16 == 0, "gamma must be 16-byte aligned");
+    Epilogue ep;
+    ep.bias     = static_cast<const f16*>(bias);
+    ep.residual = static_cast<const f16*>(residual);
+    Prologue pro;
+    pro.gamma = static_cast<const f16*>(gamma);
+    pro.eps   = eps;
+    return launch_gemv(static_cast<const f16*>(x), reinterpret_cast<const uint8_t*>(w_packed),
+                       static_cast<const f16*>(scales), ep, static_cast<f16*>(y), 1, N, K, static_cast<hipStream_t>(stream),
+                       pro);
+}
+
 int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream)
 {
     return launch_silu_mul(static_cast<const f16*>(gate_up), static_cast<f16*>(out), rows, intermediate,

@@ -76,6 +76,14 @@ struct Epilogue {
     const f16* residual = nullptr;  // [M][N], row stride N; must not alias y unless it is y itself element for element
 };
 
+// ---- fused activation prologue of the M = 1 GEMV (gamma may be null = none): the activation vector is RMS-normalised while
+// it is staged in LDS, x_eff[k] = fp16(clamp((x[k] * rsqrt(mean(x^2) + eps)) * gamma[k])) -- the arithmetic of
+// eetq_rmsnorm_f16 (layernorm.cu:35-50), so a decoder block's norm -> projection pair is one launch.
+struct Prologue {
+    const f16* gamma = nullptr;  // [K]
+    float      eps   = 0.f;
+};
+
 // ---- launch helper: optionally attaches per-dispatch begin/end timestamps (eetq_prof_begin/_end) ---------
 struct ProfEvents {
     hipEvent_t start = nullptr, stop = nullptr;
@@ -98,7 +106,7 @@ int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_ra
 int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
 int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
 int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
-                hipStream_t stream);
+                hipStream_t stream, Prologue pro = Prologue{});
 int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                      hipStream_t stream);
 int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows, int cols, hipStream_t stream);

@@ -14,46 +14,53 @@ namespace {
 
 using gemv::gemv_kernel;
 
-template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int OCC>
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int OCC, bool NORM = false>
 int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K,
-                hipStream_t stream)
+                hipStream_t stream, Prologue pro = Prologue{})
 {
-    auto         kern = gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC>;
+    if constexpr (!NORM && !XREG && M == 1) {
+        if (pro.gamma) return launch_inst<M, WAVES, D, EXACT, XREG, XV, OCC, true>(x, w, scales, ep, y, N, K, stream, pro);
+    }
+    auto         kern = gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC, NORM>;
     const size_t smem = gemv::gemv_smem_bytes(M, K, WAVES, XREG);
     if (smem > 64 * 1024) {  // opt in to > 64 KiB dynamic LDS (host-side attribute, cheap)
         EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
     }
-    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep);
+    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep, pro);
     return check_hip(hipGetLastError(), "gemv_kernel launch");
 }
 
 // LDS-staged activations: pick the number of 16-byte x loads per thread at compile time (no conditional loads)
 template <int M, int WAVES, int D, bool EXACT, int OCC>
 int launch_lds(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K,
-                hipStream_t stream)
+                hipStream_t stream, Prologue pro = Prologue{})
 {
     const int xvecs = M * K / 8, threads = WAVES * 64;
     const int need  = (xvecs + threads - 1) / threads;
     if (gemv::gemv_smem_bytes(M, K, WAVES, false) > 160 * 1024 || need > 8)
         return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] GEMV: M*K too large for LDS staging");
-    if (need <= 1) return launch_inst<M, WAVES, D, EXACT, false, 1, OCC>(x, w, scales, ep, y, N, K, stream);
-    if (need <= 2) return launch_inst<M, WAVES, D, EXACT, false, 2, OCC>(x, w, scales, ep, y, N, K, stream);
-    if (need <= 4) return launch_inst<M, WAVES, D, EXACT, false, 4, OCC>(x, w, scales, ep, y, N, K, stream);
-    return launch_inst<M, WAVES, D, EXACT, false, 8, OCC>(x, w, scales, ep, y, N, K, stream);
+    if (need <= 1) return launch_inst<M, WAVES, D, EXACT, false, 1, OCC>(x, w, scales, ep, y, N, K, stream, pro);
+    if (need <= 2) return launch_inst<M, WAVES, D, EXACT, false, 2, OCC>(x, w, scales, ep, y, N, K, stream, pro);
+    if (need <= 4) return launch_inst<M, WAVES, D, EXACT, false, 4, OCC>(x, w, scales, ep, y, N, K, stream, pro);
+    return launch_inst<M, WAVES, D, EXACT, false, 8, OCC>(x, w, scales, ep, y, N, K, stream, pro);
 }
 
 // 8-column units (gemv_half_kernel), M = 1: when they put fewer bytes on the busiest CU than whole tile rows do
-template <int XV>
-int launch_half_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
+template <int XV, bool NORM = false>
+int launch_half_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream,
+                   Prologue pro)
 {
-    auto         kern = gemv::gemv_half_kernel<8, 2, XV, 8>;
+    if constexpr (!NORM) {
+        if (pro.gamma) return launch_half_xv<XV, true>(x, w, scales, ep, y, N, K, stream, pro);
+    }
+    auto         kern = gemv::gemv_half_kernel<8, 2, XV, 8, NORM>;
     const size_t smem = gemv::gemv_half_smem_bytes(K, 8);
     if (smem > 64 * 1024) {
         EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
                                          (int)smem));
     }
-    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep);
+    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep, pro);
     return check_hip(hipGetLastError(), "gemv_half_kernel launch");
 }
 
@@ -68,47 +75,53 @@ bool half_units_pay(int N, int K)
     return 2 * rows <= ncu || (rows > ncu && 10 * rows <= 13 * ncu);
 }
 
-int launch_half(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
+int launch_half(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream,
+                Prologue pro)
 {
     const int need = (K / 8 + 511) / 512;  // 16-byte activation loads per thread
-    if (need <= 2) return launch_half_xv<2>(x, w, scales, ep, y, N, K, stream);
-    if (need <= 4) return launch_half_xv<4>(x, w, scales, ep, y, N, K, stream);
-    return launch_half_xv<8>(x, w, scales, ep, y, N, K, stream);
+    if (need <= 2) return launch_half_xv<2>(x, w, scales, ep, y, N, K, stream, pro);
+    if (need <= 4) return launch_half_xv<4>(x, w, scales, ep, y, N, K, stream, pro);
+    return launch_half_xv<8>(x, w, scales, ep, y, N, K, stream, pro);
 }
 
 template <int M>
 int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K,
-                hipStream_t stream)
+                hipStream_t stream, Prologue pro)
 {
+    if constexpr (M != 1) {
+        if (pro.gamma) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] the RMS-norm prologue is implemented for M = 1");
+    }
     const int KT = K / kTileK;
     if constexpr (M == 1) {
         // N = 5120: 320 tile rows on 256 CUs -> 640 half rows, 3 instead of 4 eight-column units on the busiest CU
-        if (half_units_pay(N, K)) return launch_half(x, w, scales, ep, y, N, K, stream);
+        if (half_units_pay(N, K)) return launch_half(x, w, scales, ep, y, N, K, stream, pro);
     }
     // Tuned on MI355X with tools/kbench (profiles/r01_kbench_gemv.txt):
     if (KT == 64) {  // K = 4096: 16 waves x 4 tiles, straight-line; <= 64 VGPRs so two workgroups fit a CU
-        if constexpr (M <= 2)
-            return launch_inst<M, 16, 4, true, true, 1, 8>(x, w, scales, ep, y, N, K, stream);
-        else
+        if constexpr (M <= 2) {
+            if (!pro.gamma) return launch_inst<M, 16, 4, true, true, 1, 8>(x, w, scales, ep, y, N, K, stream);
+            return launch_lds<M, 16, 4, true, 4>(x, w, scales, ep, y, N, K, stream, pro);  // the prologue needs x in LDS
+        } else {
             return launch_lds<M, 16, 4, true, 4>(x, w, scales, ep, y, N, K, stream);
+        }
     }
     // generic K: every wave must own >= D tiles; D = 2 in flight per wave won at K = 11008
-    if (KT >= 32) return launch_lds<M, 16, 2, false, (M == 1 ? 8 : 4)>(x, w, scales, ep, y, N, K, stream);
-    if (KT >= 16) return launch_lds<M, 8, 2, false, 2>(x, w, scales, ep, y, N, K, stream);
-    if (KT >= 4) return launch_lds<M, 4, 1, false, 1>(x, w, scales, ep, y, N, K, stream);
-    return launch_lds<M, 1, 1, false, 1>(x, w, scales, ep, y, N, K, stream);
+    if (KT >= 32) return launch_lds<M, 16, 2, false, (M == 1 ? 8 : 4)>(x, w, scales, ep, y, N, K, stream, pro);
+    if (KT >= 16) return launch_lds<M, 8, 2, false, 2>(x, w, scales, ep, y, N, K, stream, pro);
+    if (KT >= 4) return launch_lds<M, 4, 1, false, 1>(x, w, scales, ep, y, N, K, stream, pro);
+    return launch_lds<M, 1, 1, false, 1>(x, w, scales, ep, y, N, K, stream, pro);
 }
 
 }  // namespace
 
 int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
-                hipStream_t stream)
+                hipStream_t stream, Prologue pro)
 {
     switch (M) {
-        case 1: return launch_m<1>(x, w, scales, ep, y, N, K, stream);
-        case 2: return launch_m<2>(x, w, scales, ep, y, N, K, stream);
-        case 3: return launch_m<3>(x, w, scales, ep, y, N, K, stream);
-        case 4: return launch_m<4>(x, w, scales, ep, y, N, K, stream);
+        case 1: return launch_m<1>(x, w, scales, ep, y, N, K, stream, pro);
+        case 2: return launch_m<2>(x, w, scales, ep, y, N, K, stream, pro);
+        case 3: return launch_m<3>(x, w, scales, ep, y, N, K, stream, pro);
+        case 4: return launch_m<4>(x, w, scales, ep, y, N, K, stream, pro);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] GEMV path only supports M <= 4");
     }
 }

@@ -31,6 +31,47 @@ __device__ __forceinline__ float sum_xor32(float v)
     return __builtin_bit_cast(float, (u32)r[0]) + __builtin_bit_cast(float, (u32)r[1]);
 }
 
+// RMS-norm of the activation vector while it sits in the staging registers (M = 1): every thread holds XV 16-byte
+// vectors xv[i] of x (vector index tid + i*THREADS, valid below xvecs) and the matching gamma vectors.  Same arithmetic as
+// rmsnorm_kernel (norm_rope.hip): fp32 sum of squares, rsqrtf(mean + eps), ((x * s) * gamma) clamped to the fp16 range.
+// `red` is the (not yet used) cross-wave reduction area; one extra barrier.
+template <int XV, int WAVES>
+__device__ __forceinline__ void rmsnorm_staged(u32x4 (&xv)[XV], const u32x4 (&gv)[XV], int tid, int xvecs, int K, float eps,
+                                               float* red)
+{
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const bool  valid = tid + i * WAVES * 64 < xvecs;
+        const f16x8 v     = __builtin_bit_cast(f16x8, xv[i]);
+        float       p     = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) p += (float)v[j] * (float)v[j];
+        ss += valid ? p : 0.f;
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ss += __shfl_xor(ss, m, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = ss;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int wv = 0; wv < WAVES; ++wv) tot += red[wv];
+    const float s = rsqrtf(tot / (float)K + eps);
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const f16x8 v = __builtin_bit_cast(f16x8, xv[i]);
+        const f16x8 g = __builtin_bit_cast(f16x8, gv[i]);
+        f16x8       o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float f = ((float)v[j] * s) * (float)g[j];
+            f       = f > 0.f ? fminf(f, 65504.f - 1000.f) : fmaxf(f, -(65504.f - 1000.f));
+            o[j]    = (f16)f;
+        }
+        xv[i] = __builtin_bit_cast(u32x4, o);
+    }
+}
+
 // One 1 KiB tile: this lane's 16 k of column c against the matching 16 activations of every batch row.
 // xs = this lane's window of the LDS copy of x (row m at xs + m*K halfs).
 template <int M>
@@ -60,12 +101,13 @@ __device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, cons
 //           retire at L2 latency; no LDS, no barrier before the math.
 //   else  : activations are staged once per workgroup in LDS (XV 16-byte loads per thread, clamped).
 // Dynamic LDS: [M*K fp16 activations unless XREG] + WAVES*M*16 floats (cross-wave reduction).
-template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD>
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, bool NORM = false>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, Epilogue ep)
+    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
 {
     static_assert(!XREG || EXACT, "register-resident activations need the exact-fit shape");
+    static_assert(!NORM || (!XREG && M == 1), "the RMS-norm prologue lives in the LDS-staged M = 1 form");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     f16*   xs  = reinterpret_cast<f16*>(smem);
     float* red = reinterpret_cast<float*>(smem + (XREG ? 0 : (size_t)M * K * 2));
@@ -101,6 +143,16 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
             xv[i]       = xg[v < xvecs ? v : xvecs - 1];
         }
     }
+    u32x4 gv[NORM ? XV : 1];
+    if constexpr (NORM) {
+        const int    xvecs = K >> 3;
+        const u32x4* gg    = reinterpret_cast<const u32x4*>(pro.gamma);
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * WAVES * 64;
+            gv[i]       = gg[v < xvecs ? v : xvecs - 1];
+        }
+    }
 
     const u32x4* wp     = reinterpret_cast<const u32x4*>(w + (size_t)ntile * KT * kTileBytes) + wave * 64 + lane;
     const size_t stride = (size_t)WAVES * 64;  // u32x4 elements between consecutive tiles of this wave
@@ -110,6 +162,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
 
     if constexpr (!XREG) {
         const int xvecs = (M * K) >> 3;
+        if constexpr (NORM) rmsnorm_staged<XV, WAVES>(xv, gv, tid, xvecs, K, pro.eps, red);
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int v = tid + i * WAVES * 64;
@@ -204,10 +257,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
 // A wave instruction covers the 8-column halves of TWO k tiles: lane = sub*32 + kg*8 + c reads the 16 bytes of column
 // half*8 + c, k-group kg of k tile 2p + sub -- eight full 128-byte lines.  Wave w owns pairs w, w+WAVES, ...; D pairs in
 // flight; K/64 must be even (launcher contract).  Activations are staged in LDS like the generic form.
-template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD>
+template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, bool NORM = false>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, Epilogue ep)
+    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     f16*   xs  = reinterpret_cast<f16*>(smem);
@@ -230,6 +283,15 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
         const int v = tid + i * WAVES * 64;
         xv[i]       = xg[v < xvecs ? v : xvecs - 1];
     }
+    u32x4 gv[NORM ? XV : 1];
+    if constexpr (NORM) {
+        const u32x4* gg = reinterpret_cast<const u32x4*>(pro.gamma);
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int v = tid + i * WAVES * 64;
+            gv[i]       = gg[v < xvecs ? v : xvecs - 1];
+        }
+    }
 
     // byte offset of this lane inside its k tile: lane index kg*16 + (half*8 + c) of the native tile
     const uint8_t* wbase = w + (size_t)(unit >> 1) * KT * kTileBytes + (size_t)sub * kTileBytes +
@@ -239,6 +301,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[d] = load_w<true>(wptr(wave + d * WAVES));
 
+    if constexpr (NORM) rmsnorm_staged<XV, WAVES>(xv, gv, tid, xvecs, K, pro.eps, red);
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
         const int v = tid + i * WAVES * 64;

@@ -184,17 +184,26 @@ class EETLlamaAttention(_EETAttentionBase):
         self.qkv_proj = qkv_proj
         self.o_proj = o_proj
 
-    def _qkv(self, hidden_states):
-        return self.qkv_proj(hidden_states)
+    def _qkv(self, hidden_states, input_norm=None):
+        if input_norm is None:
+            return self.qkv_proj(hidden_states)
+        if hasattr(self.qkv_proj, "qweight"):  # W8A16Linear: RMS-norm inside the launch for single-token steps
+            return self.qkv_proj(hidden_states, norm=input_norm)
+        x = hidden_states.contiguous()
+        normed = torch.empty_like(x)
+        ops.layernorm_forward(x, input_norm[0], normed, input_norm[1])
+        return self.qkv_proj(normed)
 
     def forward(self, hidden_states, position_embeddings=None, attention_mask=None, past_key_values=None,
-                position_ids=None, residual=None, **kwargs):
+                position_ids=None, residual=None, input_norm=None, **kwargs):
         """Input shape: Batch x Time x Channel.  ``position_embeddings`` (the model-level cos/sin) is accepted for
         interface compatibility and unused: the rotation reads this module's fp16 cos|sin cache.  ``residual``
-        (extension): added to the output projection inside its epilogue when ``o_proj`` is a W8A16Linear."""
+        (extension): added to the output projection inside its epilogue when ``o_proj`` is a W8A16Linear.
+        ``input_norm=(gamma, eps)`` (extension): ``hidden_states`` is the un-normalised residual stream and the block's
+        input RMS-norm is applied here (fused into the QKV launch for single-token steps)."""
         bsz, q_len, _ = hidden_states.shape
         h, hkv, d = self.num_heads, self.num_key_value_heads, self.head_dim
-        qkv = self._qkv(hidden_states)                      # [B, T, (H + 2 Hkv) * D]
+        qkv = self._qkv(hidden_states, input_norm)          # [B, T, (H + 2 Hkv) * D]
         q = qkv[..., : h * d].unflatten(-1, (h, d))
         k = qkv[..., h * d: (h + hkv) * d].unflatten(-1, (hkv, d))
         v = qkv[..., (h + hkv) * d:].unflatten(-1, (hkv, d))
@@ -262,8 +271,8 @@ class EETLlamaMLP(nn.Module):
         self.intermediate_size = gate_proj.out_features
         self.down_proj = down_proj
 
-    def forward(self, x, residual=None):
-        gu = self.gate_up_proj(x)
+    def forward(self, x, residual=None, norm=None):
+        gu = self.gate_up_proj(x, norm=norm)
         if self.intermediate_size % 8 == 0 and gu.is_cuda:
             act = ops.silu_mul(gu)  # one launch instead of silu + mul
         else:

@@ -61,10 +61,11 @@ class W8A16Linear(nn.Module):
         return mod
 
     @torch.no_grad()
-    def forward(self, input, residual=None):
+    def forward(self, input, residual=None, norm=None):
         # bias is fused into the kernel epilogue: same bits as the reference's `output + self.bias` (qlinear.py:61);
         # `residual` (extension) is added after it in the same epilogue: the decoder block's `residual + proj(x)`
-        return w8_a16_gemm(input, self.qweight, self.weight_scales, bias=self.bias, residual=residual)
+        # `norm=(gamma, eps)` (extension): RMS-norm of the input, fused into the launch for single-row inputs
+        return w8_a16_gemm(input, self.qweight, self.weight_scales, bias=self.bias, residual=residual, norm=norm)
 
     def extra_repr(self):
         return "in_features={}, out_features={}, bias={}".format(self.in_features, self.out_features,

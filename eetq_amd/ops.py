@@ -187,13 +187,15 @@ def _gemm_launch(input, weight, scale, output, m, n, k, path, bias=None, residua
     return output
 
 
-def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None):
+def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, norm=None):
     """``y = input @ dequant(weight, scale) (+ bias)``: fp16 [..., K] x int8 [K, N] (processed) -> fp16 [..., N].
 
     Reference: w8_a16_gemm_forward_cuda, fpA_intB_gemm_wrapper.cu:130-173 (fresh output tensor, current
     stream, asynchronous).  ``path`` ("auto" | "gemv" | "stream" | "mfma") is a testing hook.  ``bias`` (extension,
     SURVEY 8f row 3) fuses the reference's separate ``output + bias`` into the kernel epilogue, bit-identically;
     ``residual`` (same shape as the output) is added after it, again in fp16 -- the decoder block's ``residual + proj(x)``.
+    ``norm=(gamma, eps)`` (extension) RMS-normalises the input first: inside the GEMV launch for a single row, as a
+    separate ``layernorm_forward`` otherwise.
     """
     k = input.shape[-1]
     n = weight.shape[-1]
@@ -203,7 +205,36 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None):
     output = torch.empty(tuple(input.shape[:-1]) + (n,), dtype=input.dtype, device=input.device)
     if m == 0:
         return output
+    if norm is not None:
+        gamma, eps = norm
+        if m == 1 and path == "auto" and gamma.dtype == torch.float16 and gamma.is_contiguous() and gamma.numel() == k:
+            return _gemv_rmsnorm_launch(input, gamma, eps, weight, scale, output, n, k, bias, residual)
+        normed = torch.empty_like(input if input.is_contiguous() else input.contiguous())
+        layernorm_forward(input if input.is_contiguous() else input.contiguous(), gamma, normed, eps)
+        input = normed
     return _gemm_launch(input, weight, scale, output, m, n, k, _PATHS[path], bias, residual)
+
+
+@_eager_only
+def _gemv_rmsnorm_launch(input, gamma, eps, weight, scale, output, n, k, bias, residual):
+    if input.dtype != torch.float16 or not input.is_cuda:
+        raise RuntimeError("w8_a16_gemm: input must be a float16 CUDA tensor")
+    if weight.dtype != torch.int8 or scale.dtype != torch.float16 or not weight.is_contiguous():
+        raise RuntimeError("w8_a16_gemm: weight must be contiguous int8 and scale float16")
+    for t in (weight, scale, gamma, output) + ((bias,) if bias is not None else ()) + ((residual,) if residual is not None else ()):
+        if t.device != input.device:
+            raise RuntimeError("w8_a16_gemm: all tensors must be on the input's device")
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != n or not bias.is_contiguous()):
+        raise RuntimeError("w8_a16_gemm: bias must be a contiguous float16 [N] tensor")
+    if residual is not None and (residual.dtype != torch.float16 or residual.numel() != n or not residual.is_contiguous()):
+        raise RuntimeError("w8_a16_gemm: residual must be a contiguous float16 tensor with the output's element count")
+    x = input if input.is_contiguous() else input.contiguous()
+    with torch.cuda.device(input.device):
+        check(_lib.lib().eetq_w8a16_gemv_rmsnorm(_ptr(x), _ptr(gamma), float(eps), _ptr(weight), _ptr(scale),
+                                                 _ptr(bias) if bias is not None else None,
+                                                 _ptr(residual) if residual is not None else None, _ptr(output), n, k,
+                                                 _stream_ptr()))
+    return output
 
 
 def w8_a16_gemm_(input, weight, scale, output, m, n, k):

@@ -118,20 +118,23 @@ def replace_with_eet_rmsnorm(model):
 
 def replace_with_eet_fused_residual(model):
     """Extension: decoder layers whose attention and MLP are the EET blocks add their residuals inside the o_proj /
-    down_proj epilogues (``eetq_w8a16_gemm_fused``) instead of two elementwise kernels per layer."""
+    down_proj epilogues (``eetq_w8a16_gemm_fused``) instead of two elementwise kernels per layer, and hand their two RMS-norms
+    to the QKV and gate/up projections (inside the GEMV launch for single-token steps, ``eetq_w8a16_gemv_rmsnorm``)."""
     from ..modules.llama_modules import EETLlamaAttention
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
                 position_embeddings=None, **kwargs):
-        h, _ = self.self_attn(hidden_states=self.input_layernorm(hidden_states), attention_mask=attention_mask,
-                              position_ids=position_ids, past_key_values=past_key_values, use_cache=use_cache,
-                              position_embeddings=position_embeddings, residual=hidden_states, **kwargs)
-        return self.mlp(self.post_attention_layernorm(h), residual=h)
+        n1, n2 = self.input_layernorm, self.post_attention_layernorm
+        h, _ = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                              past_key_values=past_key_values, use_cache=use_cache, position_embeddings=position_embeddings,
+                              residual=hidden_states, input_norm=(n1.weight, n1.variance_epsilon), **kwargs)
+        return self.mlp(h, residual=h, norm=(n2.weight, n2.variance_epsilon))
 
     n = 0
     for m in model.modules():
         if (type(m).__name__ == "LlamaDecoderLayer" and isinstance(m.self_attn, EETLlamaAttention)
-                and isinstance(m.mlp, EETLlamaMLP) and isinstance(m.self_attn.o_proj, W8A16Linear)):
+                and isinstance(m.mlp, EETLlamaMLP) and isinstance(m.self_attn.o_proj, W8A16Linear)
+                and m.input_layernorm.weight.dtype == torch.float16 and hasattr(m.input_layernorm, "variance_epsilon")):
             m.forward = types.MethodType(forward, m)
             n += 1
     return n

@@ -125,6 +125,12 @@ int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* ke
                                  int tokens, int q_heads, int k_heads, int head_size, int rot_dim, int q_stride,
                                  int k_stride, void* stream);
 
+/* RMS-norm -> W8A16 GEMV as one launch, M = 1 (extension): y = fp16(sum_k fp32(xn[k]) * fp32(fp16(q*s))) [+ bias] [+ residual]
+ * with xn = eetq_rmsnorm_f16(x, gamma, eps) computed while the activation vector is staged in LDS (same arithmetic; the
+ * sum of squares is added in a different order, so xn may differ from the separate op by one fp16 ulp in rare elements). */
+int eetq_w8a16_gemv_rmsnorm(const void* x, const void* gamma, float eps, const int8_t* w_packed, const void* scales,
+                            const void* bias, const void* residual, void* y, int N, int K, void* stream);
+
 /* Gated-MLP activation on a fused gate|up projection output (extension): out[r][i] = silu(gate_up[r][i]) *
  * gate_up[r][intermediate + i], gate_up [rows][2 * intermediate] dense, intermediate % 8 == 0.  fp32 silu rounded to fp16,
  * then an fp16 multiply. */

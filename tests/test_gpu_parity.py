@@ -804,3 +804,37 @@ def test_eet_attention_grows_its_rotary_table(ops):
     with torch.no_grad():
         out = model(torch.randint(0, 64, (1, 40), device=DEV)).logits
     assert attn.rotary_emb.max_seq_len_cached >= 40 and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("K,N", [(4096, 512), (5120, 5120), (2048, 8192), (13824, 64), (1024, 48)])
+def test_gemv_rmsnorm_prologue(ops, oracle, K, N):
+    """norm -> projection as one launch (M = 1) against the two separate operators: the normalised vector may differ by an
+    fp16 ulp in rare elements (the sum of squares is added in another order), so outputs are compared within
+    2e-3 * max|y|; with residual and bias the fused epilogue must still match separate adds of the fused result's base."""
+    w, x = _rand_case(K, N, 1, seed=K + N)
+    x *= 3.0
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    torch.manual_seed(K)
+    gamma = (torch.rand(K, device=DEV) + 0.5).half()
+    eps = 1e-5
+    normed = torch.empty_like(xd)
+    ops.layernorm_forward(xd, gamma, normed, eps)
+    sep = ops.w8_a16_gemm(normed, processed, scales)
+    fused = ops.w8_a16_gemm(xd, processed, scales, norm=(gamma, eps))
+    assert (fused.float() - sep.float()).abs().max().item() <= 2e-3 * sep.float().abs().max().item() + 1e-4
+    # the oracle's RMS-norm + GEMM as the independent reference
+    xn = oracle.rmsnorm_f16(x, gamma.cpu().numpy(), eps)
+    ref = oracle.w8a16_gemm(xn, q, s).astype(np.float32)
+    assert np.all(np.abs(fused.cpu().numpy().astype(np.float32) - ref) <= 2e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref))
+    bias = torch.randn(N, dtype=torch.float16, device=DEV)
+    res = torch.randn(1, N, dtype=torch.float16, device=DEV)
+    assert torch.equal(ops.w8_a16_gemm(xd, processed, scales, norm=(gamma, eps), bias=bias, residual=res),
+                       res + (fused + bias))
+    # more than one row: the operator falls back to a separate norm launch, same results as the separate ops
+    x2 = torch.cat([xd, xd * 0.5])
+    n2 = torch.empty_like(x2)
+    ops.layernorm_forward(x2, gamma, n2, eps)
+    assert torch.equal(ops.w8_a16_gemm(x2, processed, scales, norm=(gamma, eps)), ops.w8_a16_gemm(n2, processed, scales))

@@ -186,13 +186,13 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
     auto st = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
             hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, eetq::Epilogue{});
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, eetq::Epilogue{}, eetq::Prologue{});
         },
         400);
     double g = time_graph(
         [&](int i, hipStream_t s) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, s, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, eetq::Epilogue{});
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, eetq::Epilogue{}, eetq::Prologue{});
         },
         400);
     printf("%-30s N=%5d K=%5d M=%d | disp mean %6.2f med %6.2f min %6.2f p90 %6.2f us -> %6.0f GB/s(med) | graph %6.2f us/step -> %6.0f GB/s\n",
@@ -475,7 +475,7 @@ int main(int argc, char** argv)
                 auto st = time_dispatch(
                     [&](int i, hipEvent_t a, hipEvent_t b) {
                         hipExtLaunchKernelGGL(kern, dim3(N / 8), dim3(512), (unsigned)smem, 0, a, b, 0, xl,
-                                              (const uint8_t*)b70[i % b70.size()], scales, y, N, K, eetq::Epilogue{});
+                                              (const uint8_t*)b70[i % b70.size()], scales, y, N, K, eetq::Epilogue{}, eetq::Prologue{});
                     },
                     400);
                 printf("%-30s N=%5d K=%5d M=1 | disp mean %6.2f med %6.2f min %6.2f us -> %6.0f GB/s(med)\n", name, N, K,
@@ -539,7 +539,7 @@ int main(int argc, char** argv)
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
         for (int i = 0; i < 300; ++i)
             hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{});
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{}, eetq::Prologue{});
         CK(hipDeviceSynchronize());
     }
     if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
@@ -561,7 +561,7 @@ int main(int argc, char** argv)
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
         for (int i = 0; i < 20; ++i)
             hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{});
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{}, eetq::Prologue{});
         CK(hipDeviceSynchronize());
     }
     if (!strcmp(what, "all") || !strcmp(what, "mid")) {
