@@ -73,6 +73,7 @@ class _EETAttentionBase(nn.Module):
         self.attention_dropout = 0.0
         self.is_causal = True
         self.decode_math_attention = True
+        self.bulk_cache_counter = False  # set by eet_accelerator when every attention block of the model is an EET block
         self.rotary_emb = EETRotaryEmbedding(self.head_dim, max_position_embeddings=max_position_embeddings,
                                              base=rope_theta, device=dev)
 
@@ -228,7 +229,14 @@ class EETLlamaAttention(_EETAttentionBase):
             # rotary launch), then the split-KV attention kernel reads the cache
             ops.rotary_embedding_neox_kvcache(positions[:, 0].contiguous(), q[:, 0], k[:, 0], v[:, 0], self.head_dim,
                                               self.rotary_emb.cos_sin_cache, layer.keys, layer.values)
-            layer.cumulative_length.add_(1)  # the cache's own bookkeeping (next step's positions and mask come from it)
+            # the cache's own bookkeeping (next step's positions and mask come from it): one multi-tensor launch from layer 0
+            # for every layer's counter when all attention blocks of the model are EET blocks, else this layer's own
+            if self.bulk_cache_counter and all(getattr(l, "is_initialized", False) and hasattr(l, "cumulative_length")
+                                               for l in past_key_values.layers):
+                if self.layer_idx == 0:
+                    torch._foreach_add_([l.cumulative_length for l in past_key_values.layers], 1)
+            else:
+                layer.cumulative_length.add_(1)
             add = self._additive_mask(attention_mask, hidden_states.dtype, hidden_states.device)
             if add is not None and add.shape[-1] != layer.keys.shape[2]:
                 add = add[..., : layer.keys.shape[2]]
