@@ -336,6 +336,21 @@ int eetq_w8a16_gemv_rmsnorm(const void* x, const void* gamma, float eps, const i
                        pro);
 }
 
+int eetq_w8a16_gemv_silu_gated(const void* gate_up, const int8_t* w_packed, const void* scales, const void* bias,
+                               const void* residual, void* y, int N, int K, void* stream)
+{
+    int st = check_gemm_args(gate_up, w_packed, scales, y, 1, N, K);
+    if (st != EETQ_OK) return st;
+    Epilogue ep;
+    ep.bias     = static_cast<const f16*>(bias);
+    ep.residual = static_cast<const f16*>(residual);
+    Prologue pro;
+    pro.up = static_cast<const f16*>(gate_up) + K;
+    return launch_gemv(static_cast<const f16*>(gate_up), reinterpret_cast<const uint8_t*>(w_packed),
+                       static_cast<const f16*>(scales), ep, static_cast<f16*>(y), 1, N, K, static_cast<hipStream_t>(stream),
+                       pro);
+}
+
 int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream)
 {
     return launch_silu_mul(static_cast<const f16*>(gate_up), static_cast<f16*>(out), rows, intermediate,

@@ -82,6 +82,9 @@ struct Epilogue {
 struct Prologue {
     const f16* gamma = nullptr;  // [K]
     float      eps   = 0.f;
+    // gated-MLP activation instead of a norm: x points at the `gate` half of a fused gate|up row, `up` at the other half;
+    // x_eff[k] = fp16(silu(gate[k])) * up[k] (fp32 silu rounded to fp16, fp16 multiply: the roundings of eetq_silu_mul_f16)
+    const f16* up = nullptr;     // [K]
 };
 
 // ---- launch helper: optionally attaches per-dispatch begin/end timestamps (eetq_prof_begin/_end) ---------

@@ -14,12 +14,13 @@ namespace {
 
 using gemv::gemv_kernel;
 
-template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int OCC, bool NORM = false>
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int OCC, int NORM = 0>
 int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K,
                 hipStream_t stream, Prologue pro = Prologue{})
 {
     if constexpr (!NORM && !XREG && M == 1) {
-        if (pro.gamma) return launch_inst<M, WAVES, D, EXACT, XREG, XV, OCC, true>(x, w, scales, ep, y, N, K, stream, pro);
+        if (pro.gamma) return launch_inst<M, WAVES, D, EXACT, XREG, XV, OCC, 1>(x, w, scales, ep, y, N, K, stream, pro);
+        if (pro.up) return launch_inst<M, WAVES, D, EXACT, XREG, XV, OCC, 2>(x, w, scales, ep, y, N, K, stream, pro);
     }
     auto         kern = gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC, NORM>;
     const size_t smem = gemv::gemv_smem_bytes(M, K, WAVES, XREG);
@@ -47,12 +48,13 @@ int launch_lds(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f
 }
 
 // 8-column units (gemv_half_kernel), M = 1: when they put fewer bytes on the busiest CU than whole tile rows do
-template <int XV, bool NORM = false>
+template <int XV, int NORM = 0>
 int launch_half_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream,
                    Prologue pro)
 {
     if constexpr (!NORM) {
-        if (pro.gamma) return launch_half_xv<XV, true>(x, w, scales, ep, y, N, K, stream, pro);
+        if (pro.gamma) return launch_half_xv<XV, 1>(x, w, scales, ep, y, N, K, stream, pro);
+        if (pro.up) return launch_half_xv<XV, 2>(x, w, scales, ep, y, N, K, stream, pro);
     }
     auto         kern = gemv::gemv_half_kernel<8, 2, XV, 8, NORM>;
     const size_t smem = gemv::gemv_half_smem_bytes(K, 8);
@@ -89,7 +91,8 @@ int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16
                 hipStream_t stream, Prologue pro)
 {
     if constexpr (M != 1) {
-        if (pro.gamma) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] the RMS-norm prologue is implemented for M = 1");
+        if (pro.gamma || pro.up)
+            return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] the activation prologues are implemented for M = 1");
     }
     const int KT = K / kTileK;
     if constexpr (M == 1) {
@@ -99,7 +102,7 @@ int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16
     // Tuned on MI355X with tools/kbench (profiles/r01_kbench_gemv.txt):
     if (KT == 64) {  // K = 4096: 16 waves x 4 tiles, straight-line; <= 64 VGPRs so two workgroups fit a CU
         if constexpr (M <= 2) {
-            if (!pro.gamma) return launch_inst<M, 16, 4, true, true, 1, 8>(x, w, scales, ep, y, N, K, stream);
+            if (!pro.gamma && !pro.up) return launch_inst<M, 16, 4, true, true, 1, 8>(x, w, scales, ep, y, N, K, stream);
             return launch_lds<M, 16, 4, true, 4>(x, w, scales, ep, y, N, K, stream, pro);  // the prologue needs x in LDS
         } else {
             return launch_lds<M, 16, 4, true, 4>(x, w, scales, ep, y, N, K, stream);

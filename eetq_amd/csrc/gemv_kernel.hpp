@@ -72,6 +72,24 @@ __device__ __forceinline__ void rmsnorm_staged(u32x4 (&xv)[XV], const u32x4 (&gv
     }
 }
 
+// Gated-MLP activation on the staged vectors: xv = gate, uv = up -> xv = fp16(silu(gate)) * up (no reduction, no barrier).
+template <int XV>
+__device__ __forceinline__ void silu_mul_staged(u32x4 (&xv)[XV], const u32x4 (&uv)[XV])
+{
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+        const f16x8 g = __builtin_bit_cast(f16x8, xv[i]);
+        const f16x8 u = __builtin_bit_cast(f16x8, uv[i]);
+        f16x8       o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = (float)g[j];
+            o[j]          = (f16)(x / (1.0f + expf(-x))) * u[j];
+        }
+        xv[i] = __builtin_bit_cast(u32x4, o);
+    }
+}
+
 // One 1 KiB tile: this lane's 16 k of column c against the matching 16 activations of every batch row.
 // xs = this lane's window of the LDS copy of x (row m at xs + m*K halfs).
 template <int M>
@@ -101,13 +119,14 @@ __device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, cons
 //           retire at L2 latency; no LDS, no barrier before the math.
 //   else  : activations are staged once per workgroup in LDS (XV 16-byte loads per thread, clamped).
 // Dynamic LDS: [M*K fp16 activations unless XREG] + WAVES*M*16 floats (cross-wave reduction).
-template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, bool NORM = false>
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
 {
     static_assert(!XREG || EXACT, "register-resident activations need the exact-fit shape");
-    static_assert(!NORM || (!XREG && M == 1), "the RMS-norm prologue lives in the LDS-staged M = 1 form");
+    // NORM: 0 = none, 1 = RMS-norm prologue, 2 = gated-MLP activation prologue
+    static_assert(!NORM || (!XREG && M == 1), "the activation prologues live in the LDS-staged M = 1 form");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     f16*   xs  = reinterpret_cast<f16*>(smem);
     float* red = reinterpret_cast<float*>(smem + (XREG ? 0 : (size_t)M * K * 2));
@@ -146,7 +165,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     u32x4 gv[NORM ? XV : 1];
     if constexpr (NORM) {
         const int    xvecs = K >> 3;
-        const u32x4* gg    = reinterpret_cast<const u32x4*>(pro.gamma);
+        const u32x4* gg    = reinterpret_cast<const u32x4*>(NORM == 1 ? pro.gamma : pro.up);
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int v = tid + i * WAVES * 64;
@@ -162,7 +181,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
 
     if constexpr (!XREG) {
         const int xvecs = (M * K) >> 3;
-        if constexpr (NORM) rmsnorm_staged<XV, WAVES>(xv, gv, tid, xvecs, K, pro.eps, red);
+        if constexpr (NORM == 1) rmsnorm_staged<XV, WAVES>(xv, gv, tid, xvecs, K, pro.eps, red);
+        if constexpr (NORM == 2) silu_mul_staged<XV>(xv, gv);
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int v = tid + i * WAVES * 64;
@@ -257,7 +277,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
 // A wave instruction covers the 8-column halves of TWO k tiles: lane = sub*32 + kg*8 + c reads the 16 bytes of column
 // half*8 + c, k-group kg of k tile 2p + sub -- eight full 128-byte lines.  Wave w owns pairs w, w+WAVES, ...; D pairs in
 // flight; K/64 must be even (launcher contract).  Activations are staged in LDS like the generic form.
-template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, bool NORM = false>
+template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
@@ -285,7 +305,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
     }
     u32x4 gv[NORM ? XV : 1];
     if constexpr (NORM) {
-        const u32x4* gg = reinterpret_cast<const u32x4*>(pro.gamma);
+        const u32x4* gg = reinterpret_cast<const u32x4*>(NORM == 1 ? pro.gamma : pro.up);
 #pragma unroll
         for (int i = 0; i < XV; ++i) {
             const int v = tid + i * WAVES * 64;
@@ -301,7 +321,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[d] = load_w<true>(wptr(wave + d * WAVES));
 
-    if constexpr (NORM) rmsnorm_staged<XV, WAVES>(xv, gv, tid, xvecs, K, pro.eps, red);
+    if constexpr (NORM == 1) rmsnorm_staged<XV, WAVES>(xv, gv, tid, xvecs, K, pro.eps, red);
+    if constexpr (NORM == 2) silu_mul_staged<XV>(xv, gv);
 #pragma unroll
     for (int i = 0; i < XV; ++i) {
         const int v = tid + i * WAVES * 64;

@@ -278,12 +278,17 @@ class EETLlamaMLP(nn.Module):
         self.gate_up_proj = fuse_w8a16_linears([gate_proj, up_proj]).fused
         self.intermediate_size = gate_proj.out_features
         self.down_proj = down_proj
+        # silu(gate) * up inside the down projection's GEMV launch (eetq_w8a16_gemv_silu_gated) is available but off: every
+        # workgroup recomputes the activation of the whole vector, which costs more than the one launch it saves
+        # (Llama-13B decode on one box: 241 vs 247 tokens/s)
+        self.fuse_activation = False
 
     def forward(self, x, residual=None, norm=None):
         gu = self.gate_up_proj(x, norm=norm)
         if self.intermediate_size % 8 == 0 and gu.is_cuda:
-            act = ops.silu_mul(gu)  # one launch instead of silu + mul
-        else:
-            gate, up = gu[..., : self.intermediate_size], gu[..., self.intermediate_size:]
-            act = torch.nn.functional.silu(gate) * up
-        return self.down_proj(act, residual=residual)
+            if self.fuse_activation:
+                # silu(gate) * up inside the down projection's launch for a single token, one silu_mul launch otherwise
+                return self.down_proj(gu, residual=residual, gated=True)
+            return self.down_proj(ops.silu_mul(gu), residual=residual)
+        gate, up = gu[..., : self.intermediate_size], gu[..., self.intermediate_size:]
+        return self.down_proj(torch.nn.functional.silu(gate) * up, residual=residual)

@@ -61,11 +61,13 @@ class W8A16Linear(nn.Module):
         return mod
 
     @torch.no_grad()
-    def forward(self, input, residual=None, norm=None):
+    def forward(self, input, residual=None, norm=None, gated=False):
         # bias is fused into the kernel epilogue: same bits as the reference's `output + self.bias` (qlinear.py:61);
         # `residual` (extension) is added after it in the same epilogue: the decoder block's `residual + proj(x)`
         # `norm=(gamma, eps)` (extension): RMS-norm of the input, fused into the launch for single-row inputs
-        return w8_a16_gemm(input, self.qweight, self.weight_scales, bias=self.bias, residual=residual, norm=norm)
+        # `gated=True` (extension): input is a fused gate|up block and the projection runs on silu(gate) * up
+        return w8_a16_gemm(input, self.qweight, self.weight_scales, bias=self.bias, residual=residual, norm=norm,
+                           gated=gated)
 
     def extra_repr(self):
         return "in_features={}, out_features={}, bias={}".format(self.in_features, self.out_features,

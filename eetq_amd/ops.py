@@ -187,7 +187,7 @@ def _gemm_launch(input, weight, scale, output, m, n, k, path, bias=None, residua
     return output
 
 
-def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, norm=None):
+def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, norm=None, gated=False):
     """``y = input @ dequant(weight, scale) (+ bias)``: fp16 [..., K] x int8 [K, N] (processed) -> fp16 [..., N].
 
     Reference: w8_a16_gemm_forward_cuda, fpA_intB_gemm_wrapper.cu:130-173 (fresh output tensor, current
@@ -195,8 +195,21 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, nor
     SURVEY 8f row 3) fuses the reference's separate ``output + bias`` into the kernel epilogue, bit-identically;
     ``residual`` (same shape as the output) is added after it, again in fp16 -- the decoder block's ``residual + proj(x)``.
     ``norm=(gamma, eps)`` (extension) RMS-normalises the input first: inside the GEMV launch for a single row, as a
-    separate ``layernorm_forward`` otherwise.
+    separate ``layernorm_forward`` otherwise.  ``gated=True`` (extension): ``input`` is a fused gate|up row block [..., 2K]
+    and the GEMM runs on ``silu(gate) * up`` -- inside the GEMV launch for a single row, through ``silu_mul`` otherwise.
     """
+    if gated:
+        k2 = input.shape[-1]
+        k = weight.shape[-2]
+        if k2 != 2 * k:
+            raise RuntimeError("w8_a16_gemm: gated input must be [..., 2K] for a [K, N] weight")
+        rows = input.numel() // k2 if k2 else 0
+        if (rows == 1 and path == "auto" and norm is None and input.is_cuda and input.dtype == torch.float16
+                and input.is_contiguous() and k % 8 == 0):
+            n = weight.shape[-1]
+            output = torch.empty(tuple(input.shape[:-1]) + (n,), dtype=input.dtype, device=input.device)
+            return _gemv_gated_launch(input, weight, scale, output, n, k, bias, residual)
+        input = silu_mul(input if input.is_contiguous() else input.contiguous())
     k = input.shape[-1]
     n = weight.shape[-1]
     if weight.shape[-2] != k:
@@ -213,6 +226,25 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, nor
         layernorm_forward(input if input.is_contiguous() else input.contiguous(), gamma, normed, eps)
         input = normed
     return _gemm_launch(input, weight, scale, output, m, n, k, _PATHS[path], bias, residual)
+
+
+@_eager_only
+def _gemv_gated_launch(gate_up, weight, scale, output, n, k, bias, residual):
+    if weight.dtype != torch.int8 or scale.dtype != torch.float16 or not weight.is_contiguous():
+        raise RuntimeError("w8_a16_gemm: weight must be contiguous int8 and scale float16")
+    for t in (weight, scale, output) + ((bias,) if bias is not None else ()) + ((residual,) if residual is not None else ()):
+        if t.device != gate_up.device:
+            raise RuntimeError("w8_a16_gemm: all tensors must be on the input's device")
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != n or not bias.is_contiguous()):
+        raise RuntimeError("w8_a16_gemm: bias must be a contiguous float16 [N] tensor")
+    if residual is not None and (residual.dtype != torch.float16 or residual.numel() != n or not residual.is_contiguous()):
+        raise RuntimeError("w8_a16_gemm: residual must be a contiguous float16 tensor with the output's element count")
+    with torch.cuda.device(gate_up.device):
+        check(_lib.lib().eetq_w8a16_gemv_silu_gated(_ptr(gate_up), _ptr(weight), _ptr(scale),
+                                                    _ptr(bias) if bias is not None else None,
+                                                    _ptr(residual) if residual is not None else None, _ptr(output), n, k,
+                                                    _stream_ptr()))
+    return output
 
 
 @_eager_only

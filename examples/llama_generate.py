@@ -154,6 +154,7 @@ def main():
     ap.add_argument("--decode-attn", default="kernel", choices=["kernel", "math", "off"],
                     help="single-token attention of the EET blocks: the library's split-KV kernel, batched matrix-vector "
                          "products, or the stock attention call")
+    ap.add_argument("--gated-fusion", action="store_true", help="silu*mul inside the down GEMV launch instead of its own launch")
     ap.add_argument("--graph", action="store_true",
                     help="greedy decode with a static KV cache and ONE captured HIP graph per token (launch-bound "
                          "inner loop -> hipGraph) instead of transformers' eager generate()")
@@ -170,6 +171,7 @@ def main():
         eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True, fused_residual=True)
         for layer in model.model.layers:
             layer.self_attn.decode_math_attention = {"kernel": True, "math": "always", "off": False}[args.decode_attn]
+            layer.mlp.fuse_activation = args.gated_fusion
     elif not args.no_quant:
         eet_quantize(model)
     if args.fuse_norm:

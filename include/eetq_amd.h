@@ -131,6 +131,12 @@ int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* ke
 int eetq_w8a16_gemv_rmsnorm(const void* x, const void* gamma, float eps, const int8_t* w_packed, const void* scales,
                             const void* bias, const void* residual, void* y, int N, int K, void* stream);
 
+/* Gated-MLP activation -> W8A16 GEMV as one launch, M = 1 (extension): gate_up is one row [gate(K) | up(K)] (16-byte
+ * aligned, K % 8 == 0); y = W^T . (silu(gate) * up) [+ bias] [+ residual] with the activation computed while the vector is
+ * staged in LDS, in the roundings of eetq_silu_mul_f16. */
+int eetq_w8a16_gemv_silu_gated(const void* gate_up, const int8_t* w_packed, const void* scales, const void* bias,
+                               const void* residual, void* y, int N, int K, void* stream);
+
 /* Gated-MLP activation on a fused gate|up projection output (extension): out[r][i] = silu(gate_up[r][i]) *
  * gate_up[r][intermediate + i], gate_up [rows][2 * intermediate] dense, intermediate % 8 == 0.  fp32 silu rounded to fp16,
  * then an fp16 multiply. */

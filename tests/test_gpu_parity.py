@@ -838,3 +838,28 @@ def test_gemv_rmsnorm_prologue(ops, oracle, K, N):
     n2 = torch.empty_like(x2)
     ops.layernorm_forward(x2, gamma, n2, eps)
     assert torch.equal(ops.w8_a16_gemm(x2, processed, scales, norm=(gamma, eps)), ops.w8_a16_gemm(n2, processed, scales))
+
+
+@pytest.mark.parametrize("K,N", [(4096, 512), (13824, 5120), (2048, 8192), (1024, 48)])
+def test_gemv_gated_activation_prologue(ops, oracle, K, N):
+    """silu(gate) * up -> projection as one launch (M = 1) against silu_mul + GEMV: the same roundings, so bit-identical;
+    with residual/bias; multi-row inputs take the two-launch route."""
+    w, _ = _rand_case(K, N, 1, seed=K + N)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    torch.manual_seed(K)
+    gu = (torch.randn(1, 2 * K, device=DEV) * 2).half()
+    sep = ops.w8_a16_gemm(ops.silu_mul(gu), processed, scales)
+    fused = ops.w8_a16_gemm(gu, processed, scales, gated=True)
+    assert torch.equal(fused, sep)
+    ref = oracle.w8a16_gemm(ops.silu_mul(gu).cpu().numpy(), q, s).astype(np.float32)
+    assert np.all(np.abs(fused.cpu().numpy().astype(np.float32) - ref) <= 1e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref))
+    bias = torch.randn(N, dtype=torch.float16, device=DEV)
+    res = torch.randn(1, N, dtype=torch.float16, device=DEV)
+    assert torch.equal(ops.w8_a16_gemm(gu, processed, scales, gated=True, bias=bias, residual=res), res + (sep + bias))
+    gu3 = (torch.randn(3, 2 * K, device=DEV)).half()
+    assert torch.equal(ops.w8_a16_gemm(gu3, processed, scales, gated=True),
+                       ops.w8_a16_gemm(ops.silu_mul(gu3), processed, scales))
+    with pytest.raises(RuntimeError):
+        ops.w8_a16_gemm(gu[:, : K], processed, scales, gated=True)
