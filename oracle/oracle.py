@@ -10,7 +10,7 @@ _LIB_PATH = os.path.join(_HERE, "libeetq_oracle.so")
 
 __all__ = [
     "build", "lib", "quantize", "sm80_pack", "sm80_pack_closed_form", "sm80_unpack", "gfx950_pack",
-    "gfx950_unpack", "w8a16_gemm", "w8a16_gemm_f32acc", "dequant", "rmsnorm_f16", "rotary_neox_f16",
+    "gfx950_unpack", "sm80_reader_unpack", "ref_gemv_sm80", "w8a16_gemm", "w8a16_gemm_f32acc", "dequant", "rmsnorm_f16", "rotary_neox_f16",
     "f32_to_f16_bits", "f16_bits_to_f32",
 ]
 
@@ -34,10 +34,12 @@ def lib():
         L.oracle_quantize_f16.argtypes = [vp, sz, sz, vp, vp]
         L.oracle_quantize_f32.argtypes = [vp, sz, sz, vp, vp]
         for name in ("oracle_sm80_pack", "oracle_sm80_pack_closed_form", "oracle_sm80_unpack",
-                     "oracle_gfx950_pack", "oracle_gfx950_unpack"):
+                     "oracle_gfx950_pack", "oracle_gfx950_unpack", "oracle_sm80_reader_unpack"):
             getattr(L, name).argtypes = [vp, sz, sz, vp]
             getattr(L, name).restype = i32
         L.oracle_w8a16_gemm.argtypes = [vp, vp, vp, vp, sz, sz, sz]
+        L.oracle_ref_gemv_sm80.argtypes = [vp, vp, vp, vp, sz, sz, sz]
+        L.oracle_ref_gemv_sm80.restype = i32
         L.oracle_w8a16_gemm_f32acc.argtypes = [vp, vp, vp, vp, sz, sz, sz]
         L.oracle_dequant.argtypes = [vp, vp, vp, sz, sz]
         L.oracle_rmsnorm_f16.argtypes = [vp, vp, vp, ctypes.c_float, sz, sz]
@@ -106,6 +108,27 @@ def sm80_pack_closed_form(q_raw):
 
 def sm80_unpack(packed):
     return _layout_call(lib().oracle_sm80_unpack, packed)
+
+
+def sm80_reader_unpack(packed):
+    """Raw int8 recovered from sm80 bytes by the reference GEMV's reader (kernel.h:294-376 + the int8->fp16 converter):
+    the second, independent reference source for the processed layout."""
+    return _layout_call(lib().oracle_sm80_reader_unpack, packed)
+
+
+def ref_gemv_sm80(x, packed_sm80, scales):
+    """The reference batched GEMV's own arithmetic (fp16 per-thread accumulation) on sm80 bytes, M <= 4."""
+    x = _c(x, np.float16)
+    packed_sm80 = _c(packed_sm80, np.int8)
+    scales = _c(scales, np.float16)
+    M, K = x.shape
+    K2, N = packed_sm80.shape
+    assert K == K2 and scales.shape == (N,)
+    y = np.empty((M, N), np.float16)
+    rc = lib().oracle_ref_gemv_sm80(_p(x), _p(packed_sm80), _p(scales), _p(y), M, N, K)
+    if rc != 0:
+        raise ValueError("oracle_ref_gemv_sm80 failed: %d" % rc)
+    return y
 
 
 def gfx950_pack(q_raw):

@@ -102,6 +102,52 @@ def test_sm80_four_step_equals_closed_form(oracle):
         assert np.array_equal(oracle.sm80_unpack(a), q)
 
 
+def test_sm80_reader_recovers_writer_input(oracle):
+    """Second-source pin of the processed layout.  The writer (cutlass_preprocessors.cc:137-195, 201-335, 337-358,
+    432-495, restated as oracle.sm80_pack) and the reader (the reference GEMV's addressing, converter and un-shuffle:
+    weightOnlyBatchedGemv/kernel.h:118-214, 233-292, 294-376; interleaved_numeric_conversion.h:53-85, restated as
+    oracle.sm80_reader_unpack) are separate reference files written by different authors: the reader recovering the
+    writer's input for every byte value and position is what the reference itself relies on."""
+    rng = np.random.default_rng(17)
+    for K, N in [(64, 64), (128, 64), (192, 256), (4096, 64), (2048 + 64, 128)]:
+        q = rng.integers(-128, 128, (K, N), dtype=np.int8)
+        q[:256 if K >= 256 else K, 0] = np.arange(-128, 128, dtype=np.int16)[:min(K, 256)].astype(np.int8)  # every byte value
+        packed = oracle.sm80_pack(q)
+        assert np.array_equal(oracle.sm80_reader_unpack(packed), q), (K, N)
+        assert np.array_equal(oracle.sm80_reader_unpack(packed), oracle.sm80_unpack(packed))
+    # one-hot probes: every (k mod 128, n mod 4) position of a 128 x 64 weight lands where the reader looks for it
+    K, N = 128, 64
+    for k in range(0, K, 7):
+        for n in range(0, N, 5):
+            q = np.zeros((K, N), np.int8)
+            q[k, n] = -77
+            assert np.array_equal(oracle.sm80_reader_unpack(oracle.sm80_pack(q)), q)
+
+
+def test_reference_gemv_numerics_vs_contract(oracle):
+    """The reference GEMV's own arithmetic (fp16 hfma2 accumulation per thread, fp32 across threads, kernel.h:325-329,
+    411-467) restated on sm80 bytes: it must agree with the contract oracle (fp32 accumulate of the same fp16(q*s)
+    weights) to fp16-accumulation accuracy, which also proves the reader consumes scales / activations at the right
+    indices.  The contract is the tighter of the two: the HIP kernels are held to it, not to the fp16 chain."""
+    torch.manual_seed(1)
+    K, N = 4096, 64
+    w = torch.nn.Linear(K, N, bias=False, dtype=torch.float16).weight.detach().t().contiguous().numpy()
+    q, s = oracle.quantize(w)
+    sm80 = oracle.sm80_pack(q)
+    for M in (1, 3):
+        x = torch.rand(M, K, dtype=torch.float16).numpy()
+        y_ref = oracle.ref_gemv_sm80(x, sm80, s).astype(np.float64)
+        y = oracle.w8a16_gemm(x, q, s).astype(np.float64)
+        # each thread adds 32 products (|p| <= ~0.016) in fp16: error per thread ~ 32 * 2^-11 * 0.25, 256 threads in fp32
+        assert np.abs(y_ref - y).max() <= 2e-2 * np.abs(y).max()
+        assert np.corrcoef(y_ref.ravel(), y.ravel())[0, 1] > 0.9999
+    # permuting the activations must change the reader-based result: it really indexes k
+    x = torch.rand(1, K, dtype=torch.float16).numpy()
+    y1 = oracle.ref_gemv_sm80(x, sm80, s)
+    y2 = oracle.ref_gemv_sm80(np.ascontiguousarray(x[:, ::-1]), sm80, s)
+    assert not np.array_equal(y1, y2)
+
+
 def test_sm80_layout_spot_values(oracle):
     """Hand-derived positions: out[swz((n>>1)*2K + (k>>6)*128 + (n&1)*64 + (k&63))] = q[perm16 row][n] + 128."""
     K, N = 64, 64
