@@ -65,8 +65,9 @@ def _declare(L):
         "eetq_w8a16_gemv_rmsnorm": [vp, vp, f32, vp, vp, vp, vp, vp, i32, i32, vp],
         "eetq_w8a16_gemv_silu_gated": [vp, vp, vp, vp, vp, vp, i32, i32, vp],
         "eetq_silu_mul_f16": [vp, vp, i32, i32, vp],
-        "eetq_rotary_neox_kvcache_f16": [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp],
-        "eetq_decode_attention_f16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_float, vp, vp],
+        "eetq_rotary_neox_kvcache_f16": [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i32, vp],
+        "eetq_decode_attention_f16": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, ctypes.c_float, vp, vp, i32, vp,
+                                      vp],
         "eetq_prof_begin": [i32],
         "eetq_prof_end": [vp, i32, vp],
         "eetq_diag_stream_read": [vp, sz, vp, vp],

@@ -357,13 +357,14 @@ int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate
                            static_cast<hipStream_t>(stream));
 }
 
-int eetq_rotary_neox_kvcache_f16(const int64_t* positions, void* query, const void* key, const void* value,
-                                 const void* cos_sin_cache, void* k_cache, void* v_cache, int batch, int q_heads,
-                                 int k_heads, int head_size, int rot_dim, const long* strides, int max_positions,
-                                 void* stream)
+int eetq_rotary_neox_kvcache_f16(const int64_t* positions, const int64_t* slots, int slot_stride, void* query,
+                                 const void* key, const void* value, const void* cos_sin_cache, void* k_cache,
+                                 void* v_cache, int batch, int q_heads, int k_heads, int head_size, int rot_dim,
+                                 const long* strides, int max_positions, void* stream)
 {
     EETQ_REQUIRE(strides, "null pointer");
-    return launch_rotary_kvcache(positions, static_cast<f16*>(query), static_cast<const f16*>(key),
+    EETQ_REQUIRE(slot_stride == 0 || slot_stride == 1, "slot_stride must be 0 (one slot for the batch) or 1");
+    return launch_rotary_kvcache(positions, slots, slot_stride, static_cast<f16*>(query), static_cast<const f16*>(key),
                                  static_cast<const f16*>(value), static_cast<const f16*>(cos_sin_cache),
                                  static_cast<f16*>(k_cache), static_cast<f16*>(v_cache), batch, q_heads, k_heads, head_size,
                                  rot_dim, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5],
@@ -372,12 +373,13 @@ int eetq_rotary_neox_kvcache_f16(const int64_t* positions, void* query, const vo
 
 int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* mask, void* out,
                               float* workspace, int batch, int heads, int kv_heads, int positions, int head_dim,
-                              int splits, float scaling, const long* strides, void* stream)
+                              int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
+                              int64_t* advance, void* stream)
 {
     return launch_attn_decode(static_cast<const f16*>(q), static_cast<const f16*>(k_cache),
                               static_cast<const f16*>(v_cache), static_cast<const f16*>(mask), static_cast<f16*>(out),
-                              workspace, batch, heads, kv_heads, positions, head_dim, splits, scaling, strides,
-                              static_cast<hipStream_t>(stream));
+                              workspace, batch, heads, kv_heads, positions, head_dim, splits, scaling, strides, kv_len,
+                              kv_len_bias, advance, static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C"

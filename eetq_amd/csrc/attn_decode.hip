@@ -21,7 +21,7 @@ template <int D>
 __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
     const f16* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc, const f16* __restrict__ mask,
     float* __restrict__ ws, float scaling, int S, int chunk, int groups, long q_sb, long q_sh, long k_sb, long k_sh,
-    long k_ss, long v_sb, long v_sh, long v_ss, long m_sb)
+    long k_ss, long v_sb, long v_sh, long v_ss, long m_sb, const int64_t* __restrict__ kv_len, int kv_len_bias)
 {
     constexpr int LPP  = D / 8;               // lanes per position
     constexpr int PPW  = 64 / LPP;            // positions per wave instruction
@@ -32,7 +32,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z, hk = h / groups;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int grp = lane / LPP, li = lane % LPP, d0 = li * 8;
-    const int j0 = split * chunk, j1 = min(S, j0 + chunk);
+    // rows at and beyond the valid length of a pre-allocated (static) cache hold zeros or stale tokens: never attended
+    const int Sv = kv_len ? max(0, min(S, (int)min((int64_t)S, *kv_len + kv_len_bias))) : S;
+    const int j0 = split * chunk, j1 = min(Sv, j0 + chunk);
 
     float qf[8];
     {
@@ -116,7 +118,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
 // outputs with the loads of up to 8 chunks in flight
 template <int D>
 __global__ __launch_bounds__(D) void attn_decode_merge_kernel(const float* __restrict__ ws, f16* __restrict__ out,
-                                                             int splits, long o_sb, long o_sh)
+                                                             int splits, long o_sb, long o_sh, int64_t* advance)
 {
     extern __shared__ float sm_w[];  // [splits] weights exp(m_s - M), then sm_w[splits] = 1 / L
     const int    h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
@@ -143,32 +145,40 @@ __global__ __launch_bounds__(D) void attn_decode_merge_kernel(const float* __res
         O += p[s * (D + 2) + 2 + d] * w;
     }
     out[b * o_sb + h * o_sh + d] = (f16)(L > 0.f ? O / L : 0.f);  // a fully masked row yields zeros, not NaN
+    // the cache's token counter (every reader of it in this step -- the cache-write launch and the partial kernel -- has
+    // completed: they are earlier launches on the stream)
+    if (advance && h == 0 && b == 0 && d == 0) *advance += 1;
 }
 
 template <int D>
 int launch_d(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out, float* ws, int B, int H, int Hkv, int S,
-             int splits, float scaling, const long* st, hipStream_t stream)
+             int splits, float scaling, const long* st, const int64_t* kv_len, int kv_len_bias, int64_t* advance,
+             hipStream_t stream)
 {
     const int chunk = (S + splits - 1) / splits;
     attn_decode_partial_kernel<D><<<dim3(splits, H, B), kAttnThreads, 0, stream>>>(
-        q, k, v, mask, ws, scaling, S, chunk, H / Hkv, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8]);
+        q, k, v, mask, ws, scaling, S, chunk, H / Hkv, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8],
+        kv_len, kv_len_bias);
     EETQ_TRY_HIP(hipGetLastError());
-    attn_decode_merge_kernel<D><<<dim3(H, B), D, splits * sizeof(float), stream>>>(ws, out, splits, st[9], st[10]);
+    attn_decode_merge_kernel<D><<<dim3(H, B), D, splits * sizeof(float), stream>>>(ws, out, splits, st[9], st[10], advance);
     return check_hip(hipGetLastError(), "attn_decode kernels launch");
 }
 
 }  // namespace
 
 int launch_attn_decode(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out, float* ws, int B, int H, int Hkv,
-                       int S, int D, int splits, float scaling, const long* strides, hipStream_t stream)
+                       int S, int D, int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
+                       int64_t* advance, hipStream_t stream)
 {
     EETQ_REQUIRE(q && k && v && out && ws && strides, "null pointer");
     EETQ_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && S > 0 && splits > 0 && splits <= S, "invalid attention shape");
     for (int i = 0; i < 9; ++i)
         if (i != 8) EETQ_REQUIRE(strides[i] % 8 == 0, "q / k / v strides must be multiples of 8 elements (16-byte loads)");
     EETQ_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0, "q, k, v must be 16-byte aligned");
-    if (D == 128) return launch_d<128>(q, k, v, mask, out, ws, B, H, Hkv, S, splits, scaling, strides, stream);
-    if (D == 64) return launch_d<64>(q, k, v, mask, out, ws, B, H, Hkv, S, splits, scaling, strides, stream);
+    if (D == 128)
+        return launch_d<128>(q, k, v, mask, out, ws, B, H, Hkv, S, splits, scaling, strides, kv_len, kv_len_bias, advance, stream);
+    if (D == 64)
+        return launch_d<64>(q, k, v, mask, out, ws, B, H, Hkv, S, splits, scaling, strides, kv_len, kv_len_bias, advance, stream);
     return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] decode attention supports head_dim 64 and 128");
 }
 

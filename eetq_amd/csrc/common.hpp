@@ -117,10 +117,11 @@ int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int toke
                   int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream);
 
 int launch_attn_decode(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out, float* ws, int B, int H, int Hkv,
-                       int S, int D, int splits, float scaling, const long* strides, hipStream_t stream);
+                       int S, int D, int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
+                       int64_t* advance, hipStream_t stream);
 
-int launch_rotary_kvcache(const int64_t* pos, f16* q, const f16* k, const f16* v, const f16* cache, f16* kcache,
-                          f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,
+int launch_rotary_kvcache(const int64_t* pos, const int64_t* slots, int slot_stride, f16* q, const f16* k, const f16* v,
+                          const f16* cache, f16* kcache, f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,
                           long k_stride, long v_stride, long c_sb, long c_sh, long c_ss, int max_pos, hipStream_t stream);
 
 int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t stream);

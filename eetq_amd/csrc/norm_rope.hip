@@ -116,7 +116,8 @@ __global__ void silu_mul_kernel(const f16* __restrict__ gu, f16* __restrict__ ou
 // Decode-step form: one token per batch row.  blockIdx.y = 0 rotates q in place; 1 rotates k and writes it into the KV
 // cache at [b][head][pos]; 2 copies v there.  Replaces, for a static cache, the stock sequence arange + add + two index_copy
 // launches + the rotary launch by one.
-__global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions, f16* __restrict__ query,
+__global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions, const int64_t* __restrict__ slots,
+                                           int slot_stride, f16* __restrict__ query,
                                            const f16* __restrict__ key, const f16* __restrict__ value,
                                            const f16* __restrict__ cache, f16* __restrict__ kcache,
                                            f16* __restrict__ vcache, int rot_dim, long q_stride, long k_stride,
@@ -124,10 +125,11 @@ __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions
                                            int head_size, int max_pos)
 {
 #pragma clang fp contract(off)
-    const int     b   = blockIdx.x;
-    const int64_t pos = positions[b];
-    if (pos < 0 || pos >= max_pos) return;  // never write outside the cache
-    const f16* cp    = cache + pos * rot_dim;
+    const int     b    = blockIdx.x;
+    const int64_t rpos = positions[b];                               // index into the cos|sin table
+    const int64_t pos  = slots ? slots[(long)b * slot_stride] : rpos;  // cache row the new token is written to
+    if (pos < 0 || pos >= max_pos || rpos < 0) return;  // never write outside the cache
+    const f16* cp    = cache + rpos * rot_dim;
     const int  embed = rot_dim / 2;
     if (blockIdx.y == 0) {
         for (int i = threadIdx.x; i < q_heads * embed; i += blockDim.x) {
@@ -163,8 +165,8 @@ __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions
 
 }  // namespace
 
-int launch_rotary_kvcache(const int64_t* pos, f16* q, const f16* k, const f16* v, const f16* cache, f16* kcache,
-                          f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,
+int launch_rotary_kvcache(const int64_t* pos, const int64_t* slots, int slot_stride, f16* q, const f16* k, const f16* v,
+                          const f16* cache, f16* kcache, f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,
                           long k_stride, long v_stride, long c_sb, long c_sh, long c_ss, int max_pos, hipStream_t stream)
 {
     EETQ_REQUIRE(pos && q && k && v && cache && kcache && vcache, "null pointer");
@@ -172,7 +174,7 @@ int launch_rotary_kvcache(const int64_t* pos, f16* q, const f16* k, const f16* v
                      rot_dim <= head_size && max_pos > 0,
                  "invalid rotary shape");
     if (batch == 0) return EETQ_OK;
-    rotary_neox_kvcache_kernel<<<dim3(batch, 3), 512, 0, stream>>>(pos, q, k, v, cache, kcache, vcache, rot_dim, q_stride,
+    rotary_neox_kvcache_kernel<<<dim3(batch, 3), 512, 0, stream>>>(pos, slots, slot_stride, q, k, v, cache, kcache, vcache, rot_dim, q_stride,
                                                                      k_stride, v_stride, c_sb, c_sh, c_ss, q_heads,
                                                                      k_heads, head_size, max_pos);
     return check_hip(hipGetLastError(), "rotary_neox_kvcache_kernel launch");

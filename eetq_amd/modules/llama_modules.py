@@ -73,7 +73,6 @@ class _EETAttentionBase(nn.Module):
         self.attention_dropout = 0.0
         self.is_causal = True
         self.decode_math_attention = True
-        self.bulk_cache_counter = False  # set by eet_accelerator when every attention block of the model is an EET block
         self.rotary_emb = EETRotaryEmbedding(self.head_dim, max_position_embeddings=max_position_embeddings,
                                              base=rope_theta, device=dev)
 
@@ -97,24 +96,40 @@ class _EETAttentionBase(nn.Module):
             return None
         return layer
 
-    @staticmethod
-    def _additive_mask(attention_mask, dtype, device):
-        """additive fp16 form of the mask, built once per forward and parked on the mask object (the model hands the
-        same object to every layer)"""
+    _mask_memo = [None, None]  # (key, additive rows) of the most recent conversion: the model hands every layer the same mask
+
+    @classmethod
+    def _decode_mask_rows(cls, attention_mask, batch, s_len, dtype, device):
+        """Additive fp16 mask rows [B or 1, S] for a single-token step, ``None`` for "no mask", or ``False`` when the mask
+        has a form this path does not understand (the caller then takes the stock attention path).  Accepts the 4-D
+        [B, 1, 1, S'] masks transformers builds (bool or additive) and 2-D [B, S'] padding masks (bool / integer keep
+        flags or additive floats).  The conversion is done once per forward: the result is remembered against the mask's
+        identity AND version counter, so a caller that updates one mask buffer in place never gets a stale copy."""
         if attention_mask is None:
             return None
-        add = getattr(attention_mask, "_eet_additive", None)
-        if add is None:
-            add = attention_mask
-            if add.dtype == torch.bool:
-                add = torch.zeros(add.shape, dtype=dtype, device=device).masked_fill_(~attention_mask, float("-inf"))
-            elif add.dtype != dtype:
-                add = add.to(dtype)
-            try:
-                attention_mask._eet_additive = add
-            except Exception:
-                pass
-        return add
+        if attention_mask.dim() == 4:
+            if attention_mask.shape[1] != 1 or attention_mask.shape[2] != 1:
+                return False
+            rows = attention_mask[:, 0, 0]
+        elif attention_mask.dim() == 2:
+            rows = attention_mask
+        else:
+            return False
+        if rows.shape[0] not in (1, batch) or rows.shape[-1] < s_len or rows.device != device:
+            return False
+        if rows.dtype == dtype and rows.is_floating_point():
+            return rows[..., :s_len] if rows.shape[-1] != s_len else rows
+        key = (id(attention_mask), attention_mask._version, attention_mask.data_ptr(), tuple(attention_mask.shape),
+               attention_mask.dtype, dtype)
+        memo = cls._mask_memo
+        if memo[0] != key:
+            if rows.is_floating_point():
+                add = rows.to(dtype)
+            else:  # bool / integer: non-zero = attend
+                add = torch.zeros(rows.shape, dtype=dtype, device=device).masked_fill_(rows == 0, float("-inf"))
+            memo[0], memo[1] = key, add
+        add = memo[1]
+        return add[..., :s_len] if add.shape[-1] != s_len else add
 
     def _attend(self, q, k, v, attention_mask, past_key_values, input_shape, kwargs):
         """q [B, T, H, D], k/v [B, T, Hkv, D] (views into the projection output) -> [B, T, H*D]"""
@@ -126,32 +141,34 @@ class _EETAttentionBase(nn.Module):
         # split-KV kernel (ops.decode_attention, ~10 us) whenever it applies, and a batched matrix-vector fallback while
         # a HIP graph is being captured; "always" -> the fallback also in eager mode; False -> stock attention.
         mode     = self.decode_math_attention
-        kernel_ok = self.head_dim in (64, 128) and q.is_cuda and (attention_mask is None or attention_mask.shape[1] == 1)
+        kernel_ok = self.head_dim in (64, 128) and q.is_cuda
         use_math = mode == "always" or (mode and q.is_cuda and (kernel_ok or torch.cuda.is_current_stream_capturing()))
         if q.shape[2] == 1 and use_math and not kwargs.get("output_attentions", False):
             bsz, heads, _, s_len = q.shape[0], q.shape[1], q.shape[2], k.shape[2]
-            add = self._additive_mask(attention_mask, q.dtype, q.device)
-            if add is not None and add.shape[-1] != s_len:
-                add = add[..., :s_len]
-            if kernel_ok and mode != "always":
-                # split-KV decode kernel of the library: the whole chip streams the cache once
-                out = ops.decode_attention(q[:, :, 0], k, v, mask=None if add is None else add[:, 0, 0],
-                                           scaling=self.scaling).unsqueeze(1)            # [B, 1, H, D]
-                return out.reshape(*input_shape, -1), None
-            if self.num_key_value_groups > 1:
-                k = k.repeat_interleave(self.num_key_value_groups, dim=1)
-                v = v.repeat_interleave(self.num_key_value_groups, dim=1)
-            kt = k.transpose(2, 3)
-            if add is not None and bsz == 1:
-                # scaling * (q . k^T) + mask in one batched kernel
-                scores = torch.baddbmm(add.expand(1, heads, 1, s_len).reshape(heads, 1, s_len), q.reshape(heads, 1, -1),
-                                       kt.reshape(heads, -1, s_len), beta=1.0, alpha=self.scaling).unsqueeze(0)
-            else:
-                scores = torch.matmul(q, kt)                                           # [B, H, 1, S]
-                scores = torch.add(add, scores, alpha=self.scaling) if add is not None else scores * self.scaling
-            probs = torch.softmax(scores, dim=-1)      # fp16 in/out, fp32 accumulation inside
-            out = torch.matmul(probs, v).transpose(1, 2)
-            return out.reshape(*input_shape, -1).contiguous(), None
+            add = self._decode_mask_rows(attention_mask, bsz, s_len, q.dtype, q.device)
+            if add is not False:
+                static = self._static_cache_layer(past_key_values)
+                if kernel_ok and mode != "always":
+                    # split-KV decode kernel of the library: the whole chip streams the cache once (a static cache is
+                    # returned whole by update(): only its filled rows are attended, whatever the mask says)
+                    out = ops.decode_attention(q[:, :, 0], k, v, mask=add, scaling=self.scaling,
+                                               kv_len=static.cumulative_length if static is not None else None
+                                               ).unsqueeze(1)  # [B, 1, H, D]
+                    return out.reshape(*input_shape, -1), None
+                if static is not None and add is None:
+                    add = torch.zeros(1, s_len, dtype=q.dtype, device=q.device).masked_fill_(
+                        torch.arange(s_len, device=q.device)[None, :] >= static.cumulative_length, float("-inf"))
+                if self.num_key_value_groups > 1:
+                    k = k.repeat_interleave(self.num_key_value_groups, dim=1)
+                    v = v.repeat_interleave(self.num_key_value_groups, dim=1)
+                scores = torch.matmul(q, k.transpose(2, 3))                                # [B, H, 1, S]
+                if add is not None:
+                    scores = torch.add(add[:, None, None, :], scores, alpha=self.scaling)
+                else:
+                    scores = scores * self.scaling
+                probs = torch.softmax(scores, dim=-1)      # fp16 in/out, fp32 accumulation inside
+                out = torch.matmul(probs, v).transpose(1, 2)
+                return out.reshape(*input_shape, -1).contiguous(), None
         fn = None
         impl = getattr(self.config, "_attn_implementation", None) if self.config is not None else None
         if impl is not None:
@@ -223,25 +240,21 @@ class EETLlamaAttention(_EETAttentionBase):
         if need > self.rotary_emb.max_seq_len_cached:
             self.rotary_emb._set_cos_sin_cache(max(need, 2 * self.rotary_emb.max_seq_len_cached),
                                                self.rotary_emb.cos_sin_cache.device)
+        add = False
         if layer is not None and self.decode_math_attention is True and not kwargs.get("output_attentions", False):
-            # decode step on an initialised static cache: ONE launch rotates q in place and writes the rotated k and v
-            # straight into the cache rows (the stock cache update is arange + add + two index_copy launches, plus the
-            # rotary launch), then the split-KV attention kernel reads the cache
+            add = self._decode_mask_rows(attention_mask, bsz, layer.keys.shape[2], hidden_states.dtype, hidden_states.device)
+        if add is not False:
+            # decode step on an initialised static cache: ONE launch rotates q in place (by its position) and writes the
+            # rotated k and v straight into the cache row the cache's own token counter names -- for a left-padded batch
+            # the position (real tokens so far) is smaller than that row -- instead of the stock arange + add + two
+            # index_copy launches plus the rotary launch.  Then the split-KV attention kernel reads the cache: rows beyond
+            # counter + 1 are never attended, mask or no mask, and the kernel's last launch advances the counter (the
+            # cache's bookkeeping: the next step's positions and mask come from it).
+            counter = layer.cumulative_length
             ops.rotary_embedding_neox_kvcache(positions[:, 0].contiguous(), q[:, 0], k[:, 0], v[:, 0], self.head_dim,
-                                              self.rotary_emb.cos_sin_cache, layer.keys, layer.values)
-            # the cache's own bookkeeping (next step's positions and mask come from it): one multi-tensor launch from layer 0
-            # for every layer's counter when all attention blocks of the model are EET blocks, else this layer's own
-            if self.bulk_cache_counter and all(getattr(l, "is_initialized", False) and hasattr(l, "cumulative_length")
-                                               for l in past_key_values.layers):
-                if self.layer_idx == 0:
-                    torch._foreach_add_([l.cumulative_length for l in past_key_values.layers], 1)
-            else:
-                layer.cumulative_length.add_(1)
-            add = self._additive_mask(attention_mask, hidden_states.dtype, hidden_states.device)
-            if add is not None and add.shape[-1] != layer.keys.shape[2]:
-                add = add[..., : layer.keys.shape[2]]
-            out = ops.decode_attention(q[:, 0], layer.keys, layer.values, mask=None if add is None else add[:, 0, 0],
-                                       scaling=self.scaling).reshape(bsz, q_len, -1)
+                                              self.rotary_emb.cos_sin_cache, layer.keys, layer.values, slots=counter)
+            out = ops.decode_attention(q[:, 0], layer.keys, layer.values, mask=add, scaling=self.scaling, kv_len=counter,
+                                       kv_len_bias=1, advance=counter).reshape(bsz, q_len, -1)
             weights = None
         else:
             self.rotary_emb(q, k, positions)

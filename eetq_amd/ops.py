@@ -353,12 +353,15 @@ def rotary_embedding_neox_strided(positions, query, key, head_size, cos_sin_cach
 
 
 @_eager_only
-def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, splits=None):
+def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, splits=None, kv_len=None, kv_len_bias=0,
+                     advance=None):
     """Single-query attention over a KV cache (extension; the decode step of the EET attention blocks).
 
     query [B, H, D] (any batch/head strides, dense D), key_cache / value_cache [B, Hkv, S, D] (dense D), mask: additive
-    float16 [B, S] (or broadcastable [B, 1, 1, S]) with -inf at masked positions, or None.  Returns float16 [B, H, D].
-    fp32 softmax and accumulation; D must be 64 or 128."""
+    float16 [B, S] or [1, S] (or broadcastable [B, 1, 1, S]) with -inf at masked positions, or None.  ``kv_len`` (int64
+    device scalar): only rows below ``kv_len + kv_len_bias`` are attended (the filled part of a static cache); ``advance``
+    (int64 device scalar, may be the same tensor): incremented by one when the attention has been computed.  Returns
+    float16 [B, H, D].  fp32 softmax and accumulation; D must be 64 or 128."""
     if query.dtype != torch.float16 or key_cache.dtype != torch.float16 or value_cache.dtype != torch.float16:
         raise RuntimeError("decode_attention: query and caches must be float16")
     if query.dim() != 3 or key_cache.dim() != 4 or value_cache.shape != key_cache.shape:
@@ -369,10 +372,15 @@ def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, spl
         raise RuntimeError("decode_attention: shape / stride mismatch")
     mrow, m_sb = None, 0
     if mask is not None:
-        mrow = mask.reshape(B, -1) if mask.dim() != 2 else mask
-        if mrow.dtype != torch.float16 or mrow.shape[-1] < S or mrow.stride(-1) != 1:
+        mrow = mask.reshape(mask.shape[0], -1) if mask.dim() != 2 else mask
+        if mrow.dtype != torch.float16 or mrow.shape[-1] < S or mrow.stride(-1) != 1 or mrow.device != query.device:
             raise RuntimeError("decode_attention: mask must be additive float16 with a dense last dimension >= S")
-        m_sb = mrow.stride(0)
+        if mrow.shape[0] not in (1, B):
+            raise RuntimeError("decode_attention: the mask needs one row per batch entry (or a single shared row)")
+        m_sb = mrow.stride(0) if mrow.shape[0] == B and B > 1 else 0
+    for name, t in (("kv_len", kv_len), ("advance", advance)):
+        if t is not None and (t.dtype != torch.int64 or t.numel() != 1 or t.device != query.device):
+            raise RuntimeError("decode_attention: %s must be a one-element int64 tensor on the query's device" % name)
     if scaling is None:
         scaling = D ** -0.5
     if splits is None:  # enough workgroups to cover the chip a few times over, at least 64 positions per chunk
@@ -385,14 +393,19 @@ def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, spl
     with torch.cuda.device(query.device):
         check(_lib.lib().eetq_decode_attention_f16(_ptr(query), _ptr(key_cache), _ptr(value_cache),
                                                    _ptr(mrow) if mrow is not None else None, _ptr(out), _ptr(ws), B, H,
-                                                   Hkv, S, D, int(splits), float(scaling), strides, _stream_ptr()))
+                                                   Hkv, S, D, int(splits), float(scaling), strides,
+                                                   _ptr(kv_len) if kv_len is not None else None, int(kv_len_bias),
+                                                   _ptr(advance) if advance is not None else None, _stream_ptr()))
     return out
 
 
 @_eager_only
-def rotary_embedding_neox_kvcache(positions, query, key, value, head_size, cos_sin_cache, key_cache, value_cache):
-    """Decode step: rotate ``query`` [B, H, D] in place, write the rotated ``key`` [B, Hkv, D] and ``value`` [B, Hkv, D]
-    into the caches [B, Hkv, S, D] at ``positions`` [B] (int64).  One launch instead of rotary + two cache copies."""
+def rotary_embedding_neox_kvcache(positions, query, key, value, head_size, cos_sin_cache, key_cache, value_cache,
+                                  slots=None):
+    """Decode step: rotate ``query`` [B, H, D] in place by ``positions`` [B] (int64), write the rotated ``key`` [B, Hkv, D]
+    and ``value`` [B, Hkv, D] into the caches [B, Hkv, S, D] at row ``slots`` (int64 on the device: one element = the same
+    row for the whole batch, e.g. a static cache's token counter, or [B]); ``slots=None`` writes at ``positions`` (they
+    differ for left-padded batches).  One launch instead of rotary + two cache copies."""
     for t in (query, key, value, cos_sin_cache, key_cache, value_cache):
         if t.dtype != torch.float16:
             raise RuntimeError("rotary_embedding_neox_kvcache: float16 tensors expected")
@@ -410,10 +423,17 @@ def rotary_embedding_neox_kvcache(positions, query, key, value, head_size, cos_s
             raise RuntimeError("rotary_embedding_neox_kvcache: [heads, head_size] must be dense")
     if key_cache.stride(-1) != 1 or not cos_sin_cache.is_contiguous():
         raise RuntimeError("rotary_embedding_neox_kvcache: cache rows must be dense")
+    slot_stride = 0
+    if slots is not None:
+        if (slots.dtype != torch.int64 or slots.device != query.device or slots.numel() not in (1, B)
+                or not slots.is_contiguous()):
+            raise RuntimeError("rotary_embedding_neox_kvcache: slots must be contiguous int64 on the device, 1 or B elements")
+        slot_stride = 1 if (slots.numel() == B and B > 1) else 0
     strides = (ctypes.c_long * 6)(query.stride(0), key.stride(0), value.stride(0), key_cache.stride(0),
                                   key_cache.stride(1), key_cache.stride(2))
     with torch.cuda.device(query.device):
-        check(_lib.lib().eetq_rotary_neox_kvcache_f16(_ptr(positions), _ptr(query), _ptr(key), _ptr(value),
+        check(_lib.lib().eetq_rotary_neox_kvcache_f16(_ptr(positions), _ptr(slots) if slots is not None else None,
+                                                      slot_stride, _ptr(query), _ptr(key), _ptr(value),
                                                       _ptr(cos_sin_cache), _ptr(key_cache), _ptr(value_cache), B, H, Hkv,
                                                       int(head_size), cos_sin_cache.shape[1], strides,
                                                       key_cache.shape[2], _stream_ptr()))

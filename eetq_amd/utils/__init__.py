@@ -4,3 +4,4 @@ from .fuse import FusedW8A16Linear, fuse_w8a16_linears  # noqa: F401,E402
 from .accelerator import (eet_accelerator, replace_with_eet_fp16_fused_attn, replace_with_eet_fused_mlp,  # noqa: F401,E402
                           replace_with_eet_fused_residual, replace_with_eet_qlinear, replace_with_eet_quant_fused_attn,
                           replace_with_eet_rmsnorm)
+from .graph_decoder import GraphDecoder  # noqa: F401,E402

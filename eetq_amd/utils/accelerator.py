@@ -140,16 +140,6 @@ def replace_with_eet_fused_residual(model):
     return n
 
 
-def _mark_bulk_cache_counter(model):
-    """When every attention block of the model is an EET block, layer 0 advances all static-cache counters at once."""
-    from ..modules.llama_modules import EETLlamaAttention
-    attn = [m for m in model.modules() if isinstance(m, EETLlamaAttention)]
-    stock = [m for m in model.modules() if isinstance(m, _llama_attention_type())]
-    ok = bool(attn) and not stock and sorted(a.layer_idx for a in attn) == list(range(len(attn)))
-    for a in attn:
-        a.bulk_cache_counter = ok
-
-
 def eet_accelerator(model, quantize=False, fused_attn=False, dev="cuda:0", fused_mlp=False, fused_norm=False,
                     fused_residual=False):
     """Reference semantics (accelerator.py:15-19): ``fused_attn`` first builds fp16 fused-QKV attention blocks, then
@@ -164,6 +154,4 @@ def eet_accelerator(model, quantize=False, fused_attn=False, dev="cuda:0", fused
         replace_with_eet_rmsnorm(model)
     if fused_residual:
         replace_with_eet_fused_residual(model)
-    if fused_attn:
-        _mark_bulk_cache_counter(model)
     return model

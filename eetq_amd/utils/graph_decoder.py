@@ -1,0 +1,76 @@
+"""Greedy decode with a static KV cache and ONE captured HIP graph per generated token.
+
+The reference's end-to-end recipe (examples/models/llama_transformers_example.py:68-79) calls transformers'
+``generate``; with ~360 short kernels per token at Llama-13B shapes that loop is bound by host launch time, not by the
+GPU.  The decode step is launch-bound inner-loop work, so it is captured once (token id and position live in static device
+tensors; the static cache's own token counter is advanced on the device by the attention kernel) and replayed per token.
+Prefill stays eager.  Works with any transformers causal LM whose forward accepts ``past_key_values`` / ``cache_position``
+(stock Llama, ``eet_quantize``-d or ``eet_accelerator``-ed).
+"""
+import torch
+
+__all__ = ["GraphDecoder"]
+
+
+class GraphDecoder:
+    def __init__(self, model, batch, max_len, capture=True):
+        """``max_len``: cache rows (prompt + new tokens).  ``capture=False`` keeps the same static-cache stepping but runs
+        every step eagerly (used to check the graph against the launches it was captured from)."""
+        from transformers import StaticCache
+        self.model = model
+        self.batch = int(batch)
+        self.max_len = int(max_len)
+        dev = next(model.parameters()).device
+        self.device = dev
+        try:
+            self.cache = StaticCache(config=model.config, max_cache_len=self.max_len)
+        except TypeError:  # older constructor
+            self.cache = StaticCache(config=model.config, max_batch_size=self.batch, max_cache_len=self.max_len, device=dev,
+                                     dtype=torch.float16)
+        self.s_tok = torch.zeros(self.batch, 1, dtype=torch.long, device=dev)
+        self.s_pos = torch.zeros(1, dtype=torch.long, device=dev)
+        self.graph = None
+        self.s_out = None
+        with torch.no_grad():
+            # the cache tensors are allocated lazily by the first forward: run one tiny prefill before capturing
+            model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True)
+            if capture:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self._step()
+                torch.cuda.current_stream().wait_stream(side)
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph):
+                    self.s_out = self._step()
+        self.cache.reset()
+
+    def _step(self):
+        lg = self.model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True).logits
+        return lg[:, -1].argmax(-1, keepdim=True)
+
+    @torch.no_grad()
+    def generate(self, prompt, new_tokens, return_prefill_logits=False):
+        """prompt [batch, P] int64 on the model's device -> [batch, P + new_tokens]."""
+        B, P = prompt.shape
+        if B != self.batch or P + new_tokens > self.max_len:
+            raise ValueError("GraphDecoder: built for batch %d and %d cache rows" % (self.batch, self.max_len))
+        self.cache.reset()
+        out = self.model(prompt, past_key_values=self.cache, cache_position=torch.arange(P, device=prompt.device),
+                         use_cache=True)
+        tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        generated = [tok]
+        self.s_tok.copy_(tok)
+        self.s_pos.fill_(P)
+        for _ in range(new_tokens - 1):
+            if self.graph is not None:
+                self.graph.replay()
+                nxt = self.s_out
+            else:
+                nxt = self._step()
+            self.s_tok.copy_(nxt)
+            self.s_pos += 1
+            generated.append(nxt.clone())
+        tokens = torch.cat([prompt] + generated, dim=1)
+        return (tokens, out.logits[:, -1]) if return_prefill_logits else tokens

@@ -19,6 +19,7 @@ import torch  # noqa: E402
 
 from eetq_amd.utils.quantizer import eet_quantize  # noqa: E402
 from eetq_amd.utils.replicas import ReplicaGroup  # noqa: E402
+from eetq_amd.utils.graph_decoder import GraphDecoder  # noqa: E402
 
 
 def build_model(args, dev):
@@ -35,54 +36,6 @@ def build_model(args, dev):
     finally:
         torch.set_default_dtype(old)
     return model.eval()
-
-
-class GraphDecoder:
-    """Greedy decode with a static KV cache: the single-token forward is captured ONCE as a HIP graph (token id and
-    position live in static device tensors) and replayed per generated token; prefill stays eager."""
-
-    def __init__(self, model, batch, max_len):
-        from transformers import StaticCache
-        self.model = model
-        dev = next(model.parameters()).device
-        try:
-            self.cache = StaticCache(config=model.config, max_cache_len=max_len)
-        except TypeError:
-            self.cache = StaticCache(config=model.config, max_batch_size=batch, max_cache_len=max_len, device=dev,
-                                     dtype=torch.float16)
-        self.s_tok = torch.zeros(batch, 1, dtype=torch.long, device=dev)
-        self.s_pos = torch.zeros(1, dtype=torch.long, device=dev)
-        # the cache tensors are allocated lazily by the first forward: run one tiny prefill before capturing
-        model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True)
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self._step()
-        torch.cuda.current_stream().wait_stream(side)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.s_out = self._step()
-
-    def _step(self):
-        lg = self.model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True).logits
-        return lg[:, -1].argmax(-1, keepdim=True)
-
-    def generate(self, prompt, new_tokens):
-        B, P = prompt.shape
-        self.cache.reset()
-        out = self.model(prompt, past_key_values=self.cache, cache_position=torch.arange(P, device=prompt.device),
-                         use_cache=True)
-        tok = out.logits[:, -1].argmax(-1, keepdim=True)
-        generated = [tok]
-        self.s_tok.copy_(tok)
-        self.s_pos.fill_(P)
-        for _ in range(new_tokens - 1):
-            self.graph.replay()
-            self.s_tok.copy_(self.s_out)
-            self.s_pos += 1
-            generated.append(self.s_out.clone())
-        return torch.cat([prompt] + generated, dim=1)
 
 
 def fuse_rmsnorm(model):

@@ -142,25 +142,33 @@ int eetq_w8a16_gemv_silu_gated(const void* gate_up, const int8_t* w_packed, cons
  * then an fp16 multiply. */
 int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream);
 
-/* Decode-step rotary + KV-cache write (extension for the EET attention blocks): one new token per batch row b at position
- * positions[b]; q [batch][q_heads][head_size] is rotated in place, k is rotated and written to k_cache[b][head][pos][:],
- * v is copied to v_cache[b][head][pos][:] (caches [batch][k_heads][max_positions][head_size]).  Same fp16 arithmetic as
- * eetq_rotary_neox_f16.  strides (elements): {q_b, k_b, v_b, cache_b, cache_head, cache_pos}.  Rows whose position is
- * outside [0, max_positions) are left untouched. */
-int eetq_rotary_neox_kvcache_f16(const int64_t* positions, void* query, const void* key, const void* value,
-                                 const void* cos_sin_cache, void* k_cache, void* v_cache, int batch, int q_heads,
-                                 int k_heads, int head_size, int rot_dim, const long* strides, int max_positions,
-                                 void* stream);
+/* Decode-step rotary + KV-cache write (extension for the EET attention blocks): one new token per batch row b, rotated
+ * by cos_sin_cache[positions[b]]; q [batch][q_heads][head_size] is rotated in place, k is rotated and written to
+ * k_cache[b][head][slot][:], v is copied to v_cache[b][head][slot][:] (caches [batch][k_heads][max_positions][head_size]).
+ * The cache row is slots[b * slot_stride] (DEVICE int64; slot_stride 0 = one slot for the whole batch, e.g. a static
+ * cache's token counter; 1 = per row) or, with slots == NULL, positions[b].  The two differ for left-padded batches:
+ * the rotary position counts real tokens, the slot counts cache rows.  Same fp16 arithmetic as eetq_rotary_neox_f16.
+ * strides (elements): {q_b, k_b, v_b, cache_b, cache_head, cache_pos}.  Rows whose slot is outside [0, max_positions)
+ * are left untouched. */
+int eetq_rotary_neox_kvcache_f16(const int64_t* positions, const int64_t* slots, int slot_stride, void* query,
+                                 const void* key, const void* value, const void* cos_sin_cache, void* k_cache,
+                                 void* v_cache, int batch, int q_heads, int k_heads, int head_size, int rot_dim,
+                                 const long* strides, int max_positions, void* stream);
 
 /* Single-query (decode) attention over a KV cache; extension used by the EET attention blocks' decode step (the
  * reference delegates the attention product to flash-attn, python/eetq/modules/llama_modules.py:131-143).
  *   out[b][h][:] = softmax_j( scaling * q[b][h] . k[b][h / (heads/kv_heads)][j] + mask[b][j] ) @ v[...]   j < positions
  * fp16 operands, fp32 softmax/accumulation.  strides (in elements): {q_b, q_h, k_b, k_h, k_pos, v_b, v_h, v_pos, mask_b,
  * out_b, out_h}; head_dim (64 or 128) is the dense last dimension everywhere.  mask: additive fp16 [batch][positions]
- * rows (-inf = masked) or NULL.  workspace: batch * heads * splits * (head_dim + 2) floats.  A fully masked row gives 0. */
+ * rows (-inf = masked; mask_b may be 0 to share one row) or NULL.  workspace: batch * heads * splits * (head_dim + 2)
+ * floats.  A fully masked row gives 0.
+ * kv_len (DEVICE int64 scalar or NULL): only cache rows j < min(positions, *kv_len + kv_len_bias) are attended -- the
+ * valid length of a pre-allocated cache whose tail holds zeros or stale tokens.  advance (DEVICE int64 scalar or NULL): incremented by one
+ * when the call's last kernel finishes (the cache's token counter; may alias kv_len). */
 int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* mask, void* out,
                               float* workspace, int batch, int heads, int kv_heads, int positions, int head_dim,
-                              int splits, float scaling, const long* strides, void* stream);
+                              int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
+                              int64_t* advance, void* stream);
 
 /* ---- profiling hook (no reference counterpart; used by bench.py) -------------------------------------
  * Between eetq_prof_begin(n) and eetq_prof_end() every kernel this library launches from the calling thread

@@ -703,6 +703,142 @@ def test_eet_attention_static_cache_decode_matches_stock_path(ops):
     assert (got - ref).abs().max().item() < 4e-3 * spread + 4e-3
 
 
+def test_rotary_kvcache_slot_differs_from_position(ops, oracle):
+    """Left-padded batches: the rotary index (real tokens so far) and the cache row (the cache's token counter) differ.
+    The rotation must use positions[b], the write must go to the slot -- one shared device scalar or one per row."""
+    torch.manual_seed(4)
+    B, H, Hkv, D, S = 3, 4, 2, 64, 24
+    row = (H + 2 * Hkv) * D
+    qkv = torch.randn(B, 1, row).half()
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.einsum("i,j->ij", torch.arange(64).float(), inv)
+    cache = torch.cat([fr.cos(), fr.sin()], -1).half()
+    pos = torch.tensor([3, 9, 6])                      # rotary positions (padding not counted)
+    k0 = qkv[:, 0, H * D: (H + Hkv) * D].reshape(B, Hkv, D).numpy()
+    ko, _ = oracle.rotary_neox_f16(pos.numpy(), k0, k0.copy(), cache.numpy(), D)
+    for slots in (torch.tensor(9), torch.tensor([9]), torch.tensor([11, 2, 20])):
+        d = qkv.to(DEV)
+        q = d[..., : H * D].unflatten(-1, (H, D))[:, 0]
+        k = d[..., H * D: (H + Hkv) * D].unflatten(-1, (Hkv, D))[:, 0]
+        v = d[..., (H + Hkv) * D:].unflatten(-1, (Hkv, D))[:, 0]
+        kc = torch.zeros(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+        vc = torch.zeros(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+        ops.rotary_embedding_neox_kvcache(pos.to(DEV), q, k, v, D, cache.to(DEV), kc, vc, slots=slots.to(DEV))
+        kc, vc = kc.cpu(), vc.cpu()
+        for b in range(B):
+            slot = int(slots.reshape(-1)[b if slots.numel() == B else 0])
+            assert np.array_equal(kc[b, :, slot].numpy(), ko[b])
+            assert torch.equal(vc[b, :, slot], qkv[b, 0, (H + Hkv) * D:].reshape(Hkv, D))
+            others = [j for j in range(S) if j != slot]
+            assert torch.count_nonzero(kc[b][:, others]) == 0 and torch.count_nonzero(vc[b][:, others]) == 0
+    with pytest.raises(RuntimeError):
+        ops.rotary_embedding_neox_kvcache(pos.to(DEV), q, k, v, D, cache.to(DEV), kc.to(DEV), vc.to(DEV),
+                                          slots=torch.tensor([1, 2]).to(DEV))
+
+
+def test_decode_attention_valid_length_and_counter(ops):
+    """kv_len bounds the attended rows of a pre-allocated cache without any mask (rows beyond it hold garbage here), a
+    shared [1, S] mask row serves the whole batch, a mask with the wrong batch is refused, `advance` bumps the counter once."""
+    torch.manual_seed(11)
+    B, H, Hkv, S, D = 2, 8, 4, 96, 64
+    q = torch.randn(B, H, D, dtype=torch.float16, device=DEV)
+    k = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+    v = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+    k[:, :, 41:] = 300.0      # "stale" rows: attending any of them would dominate the softmax
+    v[:, :, 41:] = -500.0
+    counter = torch.tensor(40, dtype=torch.int64, device=DEV)
+
+    def ref(n, mask=None):
+        kk = k[:, :, :n].float().repeat_interleave(H // Hkv, dim=1)
+        vv = v[:, :, :n].float().repeat_interleave(H // Hkv, dim=1)
+        s = torch.einsum("bhd,bhsd->bhs", q.float(), kk) * D ** -0.5
+        if mask is not None:
+            s = s + mask[..., :n].float()[:, None, :]
+        return torch.einsum("bhs,bhsd->bhd", torch.softmax(s, -1), vv)
+
+    out = ops.decode_attention(q, k, v, kv_len=counter, kv_len_bias=1, advance=counter)
+    assert (out.float() - ref(41)).abs().max().item() < 2e-3
+    assert int(counter.item()) == 41
+    out = ops.decode_attention(q, k, v, kv_len=counter, splits=5)          # bias 0: rows < 41
+    assert (out.float() - ref(41)).abs().max().item() < 2e-3 and int(counter.item()) == 41
+    shared = torch.zeros(1, S, dtype=torch.float16, device=DEV)
+    shared[0, 7:19] = float("-inf")
+    out = ops.decode_attention(q, k, v, mask=shared, kv_len=counter)
+    assert (out.float() - ref(41, shared.expand(B, S))).abs().max().item() < 2e-3
+    with pytest.raises(RuntimeError):
+        ops.decode_attention(q, k, v, mask=torch.zeros(3, S, dtype=torch.float16, device=DEV))
+    with pytest.raises(RuntimeError):
+        ops.decode_attention(q, k, v, kv_len=torch.tensor([1, 2], device=DEV))
+    zero = torch.tensor(0, dtype=torch.int64, device=DEV)
+    assert torch.count_nonzero(ops.decode_attention(q, k, v, kv_len=zero)) == 0   # nothing valid -> zeros, not NaN
+
+
+@pytest.mark.parametrize("with_mask", [True, False])
+def test_eet_attention_static_cache_left_padded_batch(ops, with_mask):
+    """A left-padded batch on a transformers StaticCache: position_ids (= cumsum(mask) - 1) are smaller than the cache's
+    token counter for the padded row.  The fused decode path must write the new token at the counter's row (not at the
+    position) and give the same logits as the stock cache update + stock attention.  Without a mask on the decode steps
+    (stand-alone use) rows beyond the counter must still not be attended."""
+    transformers = pytest.importorskip("transformers")
+    import copy
+    from eetq_amd.utils import eet_accelerator
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=2, vocab_size=512, max_position_embeddings=128)
+    torch.manual_seed(0)
+    stock = transformers.LlamaForCausalLM(cfg).half().to(DEV).eval()
+    model = eet_accelerator(copy.deepcopy(stock), quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True,
+                            fused_residual=True)
+    T, NEW, L = 9, 5, 32
+    prompt = torch.randint(1, 512, (2, T), device=DEV)
+    keep = torch.ones(2, T, dtype=torch.int64, device=DEV)
+    if with_mask:
+        keep[1, :4] = 0                                  # row 1 is left-padded by 4 tokens
+        prompt[1, :4] = 0
+
+    def run(mode):
+        for layer in model.model.layers:
+            layer.self_attn.decode_math_attention = mode
+        cache = transformers.StaticCache(config=cfg, max_cache_len=L)
+        mask = keep.clone()
+        pos = (mask.cumsum(-1) - 1).clamp(min=0)
+        logits = []
+        with torch.no_grad():
+            out = model(prompt, attention_mask=mask, position_ids=pos, past_key_values=cache, use_cache=True)
+            tok = out.logits[:, -1].argmax(-1, keepdim=True)
+            for _ in range(NEW):
+                mask = torch.cat([mask, torch.ones(2, 1, dtype=mask.dtype, device=DEV)], -1)
+                pos = pos[:, -1:] + 1
+                out = model(tok, attention_mask=mask if with_mask else None, position_ids=pos, past_key_values=cache,
+                            use_cache=True)
+                logits.append(out.logits[:, -1].float())
+                tok = out.logits[:, -1].argmax(-1, keepdim=True)
+        counters = [int(l.cumulative_length.item()) for l in cache.layers]
+        return torch.stack(logits), counters
+
+    ref, c_ref = run(False)     # stock cache update + stock attention
+    got, c_got = run(True)      # fused decode path
+    assert c_ref == c_got == [T + NEW] * cfg.num_hidden_layers
+    spread = ref.abs().max().item()
+    assert (got - ref).abs().max().item() < 4e-3 * spread + 4e-3
+
+
+def test_eet_attention_mask_updated_in_place_is_not_stale(ops):
+    """One boolean mask buffer updated in place between steps (custom static decode loops do this): the additive form must
+    be rebuilt, not served from the previous step."""
+    from eetq_amd.modules.llama_modules import _EETAttentionBase
+    m = torch.ones(1, 1, 1, 16, dtype=torch.bool, device=DEV)
+    a = _EETAttentionBase._decode_mask_rows(m, 1, 16, torch.float16, torch.device(DEV))
+    assert torch.count_nonzero(a) == 0
+    m[..., 5] = False
+    b = _EETAttentionBase._decode_mask_rows(m, 1, 16, torch.float16, torch.device(DEV))
+    assert b[0, 5].item() == float("-inf") and torch.count_nonzero(b) == 1
+    f = torch.zeros(1, 1, 1, 16, dtype=torch.float16, device=DEV)
+    assert _EETAttentionBase._decode_mask_rows(f, 1, 16, torch.float16, torch.device(DEV)).data_ptr() == f.data_ptr()
+    assert not hasattr(f, "_eet_additive")
+    assert _EETAttentionBase._decode_mask_rows(torch.zeros(1, 2, 3, 16, device=DEV), 1, 16, torch.float16,
+                                               torch.device(DEV)) is False
+
+
 def test_silu_mul_matches_torch(ops):
     torch.manual_seed(5)
     gu = (torch.randn(3, 5, 2 * 704, device=DEV) * 3).half()
