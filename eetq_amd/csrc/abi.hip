@@ -151,6 +151,11 @@ int eetq_diag_stream_read(const void* p, size_t bytes, void* sink, void* stream)
     return launch_stream_read(p, bytes, static_cast<unsigned*>(sink), static_cast<hipStream_t>(stream));
 }
 
+int eetq_diag_empty(void* sink, int grid, int block, void* stream)
+{
+    return launch_empty(static_cast<unsigned*>(sink), grid, block, static_cast<hipStream_t>(stream));
+}
+
 int eetq_device_supported(void)
 {
     int dev = 0;

@@ -3,6 +3,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 
 #include "../../include/eetq_amd.h"
@@ -103,6 +104,24 @@ inline void launch_kernel(Kern kern, dim3 grid, dim3 block, size_t smem, hipStre
         hipLaunchKernelGGL(kern, grid, block, (unsigned)smem, stream, args...);
 }
 
+// > 64 KiB of dynamic LDS needs a per-kernel opt-in (hipFuncSetAttribute, a host-side call of a few microseconds).  It is
+// made ONCE per kernel and device -- `done` is the call site's bit mask of devices already opted in (one static atomic per
+// kernel instantiation; lock-free, safe from several host threads) -- and asks for the CU's whole 160 KiB, so the launch
+// path of every later call is a relaxed load.
+constexpr int kMaxDynamicLds = 160 * 1024;
+template <typename Kern>
+inline int opt_in_large_lds(Kern kern, std::atomic<unsigned long long>& done)
+{
+    int dev = 0;
+    EETQ_TRY_HIP(hipGetDevice(&dev));
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_relaxed) & bit) return EETQ_OK;
+    EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     kMaxDynamicLds));
+    done.fetch_or(bit, std::memory_order_relaxed);
+    return EETQ_OK;
+}
+
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------
 int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
                     int layout, void* scales, float* colmax, hipStream_t stream);
@@ -130,6 +149,7 @@ int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t st
 int device_cu_count();
 
 int  launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t stream);
+int  launch_empty(unsigned* sink, int grid, int block, hipStream_t stream);
 
 int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                     hipStream_t stream);

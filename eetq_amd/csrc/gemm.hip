@@ -42,16 +42,11 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         }
         return EETQ_OK;
     }
-    // > 64 KiB of dynamic LDS needs an explicit opt-in, once per device
-    static unsigned long long attr_set_mask = 0;
-    int                       dev           = 0;
-    EETQ_TRY_HIP(hipGetDevice(&dev));
-    if (!(attr_set_mask >> (dev & 63) & 1ull)) {
-        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<0, 2>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<2>::SMEM_BYTES));
-        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tile_kernel<0, 1>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<1>::SMEM_BYTES));
-        attr_set_mask |= 1ull << (dev & 63);
+    {   // > 64 KiB of dynamic LDS: one opt-in per kernel and device (common.hpp)
+        static std::atomic<unsigned long long> opted2{0}, opted1{0};
+        int st = opt_in_large_lds(gemm_tile_kernel<0, 2>, opted2);
+        if (st == EETQ_OK) st = opt_in_large_lds(gemm_tile_kernel<0, 1>, opted1);
+        if (st != EETQ_OK) return st;
     }
     // the LDS-DMA path addresses its operands with 32-bit buffer offsets
     EETQ_REQUIRE((size_t)N * K < (1ull << 31), "weight larger than 2 GiB is not supported by the buffer-addressed DMA path");

@@ -12,8 +12,9 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     using C   = gemm_mid::Cfg<MT, STAGES>;
     auto kern = gemm_mid::gemm_mid_kernel<MT, STAGES, KFULL>;
     if (C::kSmem > 64 * 1024) {
-        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         C::kSmem));
+        static std::atomic<unsigned long long> opted{0};
+        int st = opt_in_large_lds(kern, opted);
+        if (st != EETQ_OK) return st;
     }
     const int tiles = ((N + gemm_mid::kBN - 1) / gemm_mid::kBN) * ((M + C::kRows - 1) / C::kRows);
     launch_kernel(kern, dim3(tiles), dim3(gemm_mid::kThreads), C::kSmem, stream, x, w, scales, y, M, N, K, ep);

@@ -24,9 +24,10 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     }
     auto         kern = gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC, NORM>;
     const size_t smem = gemv::gemv_smem_bytes(M, K, WAVES, XREG);
-    if (smem > 64 * 1024) {  // opt in to > 64 KiB dynamic LDS (host-side attribute, cheap)
-        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)smem));
+    if (smem > 64 * 1024) {
+        static std::atomic<unsigned long long> opted{0};
+        int st = opt_in_large_lds(kern, opted);
+        if (st != EETQ_OK) return st;
     }
     launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep, pro);
     return check_hip(hipGetLastError(), "gemv_kernel launch");
@@ -59,8 +60,9 @@ int launch_half_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue e
     auto         kern = gemv::gemv_half_kernel<8, 2, XV, 8, NORM>;
     const size_t smem = gemv::gemv_half_smem_bytes(K, 8);
     if (smem > 64 * 1024) {
-        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)smem));
+        static std::atomic<unsigned long long> opted{0};
+        int st = opt_in_large_lds(kern, opted);
+        if (st != EETQ_OK) return st;
     }
     launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep, pro);
     return check_hip(hipGetLastError(), "gemv_half_kernel launch");

@@ -5,6 +5,29 @@
 namespace eetq {
 namespace gemv {
 
+// tools/kbench_stamps only (never defined in the library build): wave 0 and the last wave of every workgroup record the
+// 100 MHz device clock at kernel entry (0), after their last dot product (1) and after the final store (2), for the
+// launch-ramp / stream / tail decomposition under profiles/.
+#ifdef EETQ_KBENCH_STAMPS
+__device__ unsigned long long* g_gemv_stamps = nullptr;
+#define EETQ_STAMP(i)                                                                                          \
+    do {                                                                                                       \
+        if (g_gemv_stamps && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == (blockDim.x >> 6) - 1)) \
+            g_gemv_stamps[((size_t)blockIdx.x * 2 + ((threadIdx.x >> 6) != 0)) * 4 + (i)] = __builtin_amdgcn_s_memrealtime(); \
+    } while (0)
+// same, issued only once `val` (a VGPR) has been produced: orders the stamp behind the math that waited for the loads
+#define EETQ_STAMP_AFTER(i, val)                                                                               \
+    do {                                                                                                       \
+        unsigned long long t_;                                                                                 \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(val) : "memory");              \
+        if (g_gemv_stamps && (threadIdx.x & 63) == 0 && ((threadIdx.x >> 6) == 0 || (threadIdx.x >> 6) == (blockDim.x >> 6) - 1)) \
+            g_gemv_stamps[((size_t)blockIdx.x * 2 + ((threadIdx.x >> 6) != 0)) * 4 + (i)] = t_;                \
+    } while (0)
+#else
+#define EETQ_STAMP(i) do { } while (0)
+#define EETQ_STAMP_AFTER(i, val) do { } while (0)
+#endif
+
 template <bool NT>
 __device__ __forceinline__ u32x4 load_w(const u32x4* p)
 {
@@ -127,6 +150,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     static_assert(!XREG || EXACT, "register-resident activations need the exact-fit shape");
     // NORM: 0 = none, 1 = RMS-norm prologue, 2 = gated-MLP activation prologue
     static_assert(!NORM || (!XREG && M == 1), "the activation prologues live in the LDS-staged M = 1 form");
+    EETQ_STAMP(0);
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     f16*   xs  = reinterpret_cast<f16*>(smem);
     float* red = reinterpret_cast<float*>(smem + (XREG ? 0 : (size_t)M * K * 2));
@@ -244,6 +268,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     // ---- reduction: 4 k-groups of the wave (lanes c, c+16, c+32, c+48), then across waves via LDS ----
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[m] = sum_xor32(sum_xor16(acc[m]));
+    EETQ_STAMP_AFTER(1, acc[0]);
     if (lane < 16) {
 #pragma unroll
         for (int m = 0; m < M; ++m) red[(wave * M + m) * 16 + lane] = acc[m];
@@ -268,6 +293,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
             }
         }
     }
+    EETQ_STAMP(2);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

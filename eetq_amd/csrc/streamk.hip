@@ -14,8 +14,9 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     auto         kern = streamk::streamk_kernel<MT, NT, WAVES, D, OCC>;
     const size_t smem = streamk::streamk_smem_bytes(MT, NT, WAVES);
     if (smem > 64 * 1024) {
-        EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)smem));
+        static std::atomic<unsigned long long> opted{0};
+        int st = opt_in_large_lds(kern, opted);
+        if (st != EETQ_OK) return st;
     }
     launch_kernel(kern, dim3(N / (kTileN * NT)), dim3(WAVES * 64), smem, stream, x, w, scales, y, M, N, K, ep);
     return check_hip(hipGetLastError(), "streamk_kernel launch");

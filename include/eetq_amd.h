@@ -180,6 +180,9 @@ int eetq_prof_end(float* durations_us, int capacity, int* count);
 /* Diagnostic: a kernel that only reads `bytes` (multiple of 64 KiB) from p with the GEMV's load pattern; its
  * duration is the read floor for that many bytes on this chip.  `sink` = 4 writable device bytes. */
 int eetq_diag_stream_read(const void* p, size_t bytes, void* sink, void* stream);
+/* Diagnostic: a kernel of `grid` x `block` threads that touches no memory (the fixed cost of a dispatch, and the resolution
+ * floor of the timing method it is measured with). */
+int eetq_diag_empty(void* sink, int grid, int block, void* stream);
 
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* eetq_last_error(void);   /* thread-local, never NULL */

@@ -542,6 +542,90 @@ int main(int argc, char** argv)
                                (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{}, eetq::Prologue{});
         CK(hipDeviceSynchronize());
     }
+#ifdef EETQ_KBENCH_STAMPS
+    if (!strcmp(what, "decompose")) {
+        // Where do the GEMV's microseconds go?  Same process, same buffers, interleaved rounds of
+        //   E  empty kernel, GEMV launch geometry (256 x 1024)      -> what a dispatch costs with no work
+        //   R  load-only kernel, 16 MiB (the read floor)
+        //   G  the shipping GEMV (M = 1, N = K = 4096) with device-clock stamps from every workgroup
+        // each with begin/end dispatch timestamps (the quantity rocprofv3 --kernel-trace reports; run this mode under
+        // rocprofv3 --kernel-trace to get the tool's own numbers for the same dispatches).  Device clock: 100 MHz
+        // s_memrealtime, one tick = 10 ns.
+        const int NWG = 256, ROUNDS = 400;
+        unsigned long long* stamps;
+        CK(hipMalloc(&stamps, (size_t)NWG * 2 * 4 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(eetq::gemv::g_gemv_stamps), &stamps, sizeof(stamps)));
+        auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
+        const unsigned gsm = (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true);
+        std::vector<float> dE, dR, dG, span, ramp, wgdur, tail, first_done, last_start;
+        std::vector<unsigned long long> h((size_t)NWG * 8);
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a));
+        CK(hipEventCreate(&b));
+        auto timed = [&](auto&& launch) {
+            launch(a, b);
+            CK(hipDeviceSynchronize());
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            return ms * 1e3f;
+        };
+        for (int r = -20; r < ROUNDS; ++r) {
+            const uint8_t* wbuf = bufs[(r + 20) % bufs.size()];
+            float e = timed([&](hipEvent_t s0, hipEvent_t s1) {
+                hipExtLaunchKernelGGL(empty_kernel, dim3(256), dim3(1024), 0, 0, s0, s1, 0, out, 0);
+            });
+            float rd = timed([&](hipEvent_t s0, hipEvent_t s1) {
+                hipExtLaunchKernelGGL((stream_read_kernel<4, true>), dim3(256), dim3(1024), 0, 0, s0, s1, 0, (const u32x4*)wbuf, out);
+            });
+            const uint8_t* wbuf2 = bufs[(r + 33) % bufs.size()];
+            float g = timed([&](hipEvent_t s0, hipEvent_t s1) {
+                hipExtLaunchKernelGGL(gk, dim3(256), dim3(1024), gsm, 0, s0, s1, 0, x, wbuf2, scales, y, 4096, 4096, eetq::Epilogue{},
+                                      eetq::Prologue{});
+            });
+            if (r < 0) continue;
+            CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, t0max = 0, t1min = ~0ull, t2 = 0;
+            double             wsum = 0;
+            for (int w = 0; w < NWG; ++w) {
+                const unsigned long long s0 = std::min(h[(w * 2) * 4], h[(w * 2 + 1) * 4]);
+                const unsigned long long e2 = h[(w * 2) * 4 + 2];  // wave 0 writes y last
+                const unsigned long long e1 = std::max(h[(w * 2) * 4 + 1], h[(w * 2 + 1) * 4 + 1]);
+                t0    = std::min(t0, s0);
+                t0max = std::max(t0max, s0);
+                t1min = std::min(t1min, e1);
+                t2    = std::max(t2, e2);
+                wsum += (double)(e2 - s0);
+            }
+            dE.push_back(e);
+            dR.push_back(rd);
+            dG.push_back(g);
+            span.push_back((t2 - t0) * 0.01f);
+            ramp.push_back((t0max - t0) * 0.01f);
+            wgdur.push_back((float)(wsum / NWG) * 0.01f);
+            first_done.push_back((t1min - t0) * 0.01f);
+        }
+        auto pr = [&](const char* name, std::vector<float>& v) {
+            Stats st = stats_of(v);
+            printf("%-58s mean %6.2f  med %6.2f  min %6.2f  p10 %6.2f  p90 %6.2f us\n", name, st.mean, st.med, st.mn, st.p10, st.p90);
+        };
+        printf("--- GEMV M=1 N=K=4096 decomposition, %d interleaved rounds, un-profiled dispatch timestamps ---\n", ROUNDS);
+        pr("E  empty kernel 256x1024: dispatch begin->end", dE);
+        pr("R  load-only 16 MiB: dispatch begin->end", dR);
+        pr("G  GEMV: dispatch begin->end", dG);
+        pr("G  device span: first wave in -> last store out", span);
+        pr("G  launch ramp: first workgroup in -> last workgroup in", ramp);
+        pr("G  first workgroup's data complete (since first wave in)", first_done);
+        pr("G  mean workgroup residency (entry -> final store)", wgdur);
+        std::vector<float> cp(dG.size());
+        for (size_t i = 0; i < dG.size(); ++i) cp[i] = dG[i] - span[i];
+        pr("G  dispatch begin->end MINUS device span (CP / fences)", cp);
+        Stats sg = stats_of(dG), ss = stats_of(span), sr = stats_of(dR);
+        printf("bytes/launch 16801792: begin->end %.0f GB/s (%.3f of 8 TB/s), device span %.0f GB/s (%.3f), load-only floor %.0f GB/s;"
+               " GEMV / floor = %.3f\n",
+               16801792.0 / sg.mean / 1e3, 16801792.0 / sg.mean / 1e3 / 8000, 16801792.0 / ss.mean / 1e3,
+               16801792.0 / ss.mean / 1e3 / 8000, 16777216.0 / sr.mean / 1e3, sg.mean / sr.mean);
+    }
+#endif
     if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
         eetq::f16 *xg, *yg;
         CK(hipMalloc(&xg, 1024ull * 4096 * 2));

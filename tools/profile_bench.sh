@@ -1,0 +1,84 @@
+#!/bin/bash
+# One command (run on the GPU box from the repo root) that regenerates the profiler evidence bench.py cites:
+#   gpurun_out/<tag>_bench.json               the un-profiled JSON line of bench.py
+#   gpurun_out/<tag>_bench_kernel_stats.csv   rocprofv3 --kernel-trace --stats of the same bench.py command (our kernels only)
+#   gpurun_out/<tag>_bench_trace_gemv.txt     percentiles of the GEMV / GEMM / floor / empty dispatches of that trace
+#   gpurun_out/pmc_traffic.json               HBM/fabric bytes per launch from separate --pmc passes (kernel-trace only)
+#   gpurun_out/<tag>_gemv_decomposition.txt   tools/kbench_stamps decompose (un-profiled) + the same under rocprofv3
+# Copy the files you want judged into profiles/ (pmc_traffic.json keeps its name; bench.py reads it from there).
+# usage: tools/profile_bench.sh [tag] [bench args...]      e.g.  tools/profile_bench.sh r02 --steps 2000 --warmup 200
+set -u
+TAG=${1:-rXX}
+shift || true
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+cd "$ROOT"
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+PY=${PYTHON:-python}
+
+echo "== 1. un-profiled bench line" >&2
+$PY bench.py "$@" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || echo "bench.py failed" >&2
+
+echo "== 2. rocprofv3 --kernel-trace --stats of the same command" >&2
+rm -rf /tmp/prof_bench
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- $PY "$ROOT/bench.py" "$@" --no-cpu-baseline \
+    > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_rocprof.err" ) || echo "rocprofv3 stats run failed" >&2
+STATS=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1)
+if [ -n "$STATS" ]; then
+    # our kernels only, name column cut to 120 characters (torch's template names run to kilobytes)
+    $PY - "$STATS" > "$OUT/${TAG}_bench_kernel_stats.csv" <<'PYEOF'
+import csv, sys
+rows = list(csv.reader(open(sys.argv[1])))
+w = csv.writer(sys.stdout)
+w.writerow(rows[0])
+for r in rows[1:]:
+    if "eetq" in r[0]:
+        w.writerow([r[0][:120]] + r[1:])
+PYEOF
+fi
+TRACE=$(find /tmp/prof_bench -name '*kernel_trace.csv' | head -1)
+[ -n "$TRACE" ] && $PY tools/trace_durations.py /tmp/prof_bench | grep -i "eetq\|gemv\|gemm\|stream_read\|empty" > "$OUT/${TAG}_bench_trace_gemv.txt"
+
+echo "== 3. PMC passes (separate runs, --kernel-trace only) on tools/kbench gemm1" >&2
+if [ -x tools/kbench ]; then
+    for pass in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE" "TCC_EA0_WRREQ_sum"; do
+        d=/tmp/prof_pmc_$(echo $pass | tr ' ' '_')
+        rm -rf $d
+        ( cd /tmp && rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $d -- "$ROOT/tools/kbench" gemm1 > /dev/null 2>> "$OUT/${TAG}_rocprof.err" ) \
+            || echo "pmc pass '$pass' failed" >&2
+    done
+    $PY - > "$OUT/pmc_traffic.json" <<'PYEOF'
+import csv, glob, json, time
+def mean_counter(counter, kern):
+    v = []
+    for f in glob.glob("/tmp/prof_pmc_*/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] == counter and kern in r["Kernel_Name"]:
+                v.append(float(r["Counter_Value"]))
+    return sum(v) / len(v) if v else None
+doc = {"source": "rocprofv3 --pmc on tools/kbench gemm1 via tools/profile_bench.sh (%s, MI355X): separate --pmc passes with "
+                 "--kernel-trace only; 20 dispatches per kernel, mean per dispatch" % time.strftime("%Y-%m-%d")}
+for key, kern in (("gemv", "gemv_kernel"), ("gemm_m1024", "gemm_tile_kernel")):
+    rd, fs = mean_counter("TCC_EA0_RDREQ_sum", kern), mean_counter("FETCH_SIZE", kern)
+    wr, ws = mean_counter("TCC_EA0_WRREQ_sum", kern), mean_counter("WRITE_SIZE", kern)
+    hit, miss = mean_counter("TCC_HIT_sum", kern), mean_counter("TCC_MISS_sum", kern)
+    # gfx950: a 16 B/lane stream's requests are 128 B each; FETCH_SIZE (KiB) reports half the bytes of such a stream
+    # (MI355X_MICROARCH.md, HBM section) -> doubled.  The two must agree; the request count is the one reported.
+    doc[key + "_hbm_bytes_per_launch"] = int(rd * 128) if rd else (int(fs * 1024 * 2) if fs else None)
+    doc[key + "_raw"] = {"TCC_EA0_RDREQ_sum": rd, "FETCH_SIZE_KiB": fs, "FETCH_SIZE_x2_bytes": fs * 2048 if fs else None,
+                         "TCC_EA0_WRREQ_sum": wr, "WRITE_SIZE_KiB": ws, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss}
+print(json.dumps(doc, indent=1))
+PYEOF
+fi
+
+echo "== 4. GEMV decomposition (device-clock stamps), un-profiled and under the kernel trace" >&2
+if [ -x tools/kbench_stamps ]; then
+    ./tools/kbench_stamps decompose > "$OUT/${TAG}_gemv_decomposition.txt" 2>&1
+    rm -rf /tmp/prof_dec
+    ( cd /tmp && rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_dec -- "$ROOT/tools/kbench_stamps" decompose > /tmp/dec_under.txt 2>&1 )
+    { echo; echo "# the same run under rocprofv3 --kernel-trace: the tool's own begin->end per dispatch"; \
+      $PY tools/trace_durations.py /tmp/prof_dec; echo "# (kbench's own lines while the tool was attached)"; grep -v "^device" /tmp/dec_under.txt; } \
+        >> "$OUT/${TAG}_gemv_decomposition.txt" 2>&1
+fi
+echo "done: $(ls $OUT | tr '\n' ' ')" >&2
