@@ -319,6 +319,70 @@ static void bench_datapath(const char* name, const uint8_t* src, unsigned* out, 
            region >> 10, per_wg >> 10, st.med, per_wg / st.med / 1e3, bytes / st.med / 1e6);
 }
 
+
+#ifdef EETQ_KBENCH_STAMPS
+// load-only kernel with device-clock stamps: geometry study for the 16 MiB stream (which launch shape gets the bytes on
+// chip soonest after the first wave starts?)
+template <int LOADS, bool NT>
+__global__ void stream_read_stamped(const u32x4* __restrict__ p, unsigned* __restrict__ out, unsigned long long* __restrict__ st)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const u32x4* q = p + (size_t)blockIdx.x * blockDim.x * LOADS + threadIdx.x;
+    u32x4        v[LOADS];
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) v[i] = eetq::gemv::load_w<NT>(q + (size_t)i * blockDim.x);
+    unsigned acc = 0;
+#pragma unroll
+    for (int i = 0; i < LOADS; ++i) acc ^= v[i].x ^ v[i].y ^ v[i].z ^ v[i].w;
+    unsigned long long t1;
+    asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1) : "v"(acc) : "memory");
+    if (acc == 0x9e3779b9u) out[0] = acc;
+    if ((threadIdx.x & 63) == 0) {
+        const size_t w = (size_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        st[w * 2]     = t0;
+        st[w * 2 + 1] = t1;
+    }
+}
+
+template <int LOADS, bool NT>
+static void bench_geometry(const char* name, int threads, const std::vector<uint8_t*>& bufs, size_t bytes, unsigned* out,
+                           unsigned long long* st)
+{
+    const int grid  = (int)(bytes / ((size_t)threads * LOADS * 16));
+    const int waves = grid * threads / 64;
+    std::vector<unsigned long long> h((size_t)waves * 2);
+    std::vector<float> span, ramp, ev;
+    hipEvent_t a, b;
+    CK(hipEventCreate(&a));
+    CK(hipEventCreate(&b));
+    for (int r = -10; r < 200; ++r) {
+        // a short burst of plain launches keeps the clocks up; the last one of the burst is the measured one
+        for (int k = 0; k < 4; ++k)
+            hipLaunchKernelGGL((stream_read_stamped<LOADS, NT>), dim3(grid), dim3(threads), 0, 0,
+                               (const u32x4*)bufs[(r + 10 + k) % bufs.size()], out, st);
+        hipExtLaunchKernelGGL((stream_read_stamped<LOADS, NT>), dim3(grid), dim3(threads), 0, 0, a, b, 0,
+                              (const u32x4*)bufs[(r + 17) % bufs.size()], out, st);
+        CK(hipDeviceSynchronize());
+        if (r < 0) continue;
+        float ms;
+        CK(hipEventElapsedTime(&ms, a, b));
+        CK(hipMemcpy(h.data(), st, h.size() * 8, hipMemcpyDeviceToHost));
+        unsigned long long t0 = ~0ull, t0max = 0, t1 = 0;
+        for (int w = 0; w < waves; ++w) {
+            t0    = std::min(t0, h[w * 2]);
+            t0max = std::max(t0max, h[w * 2]);
+            t1    = std::max(t1, h[w * 2 + 1]);
+        }
+        span.push_back((t1 - t0) * 0.01f);
+        ramp.push_back((t0max - t0) * 0.01f);
+        ev.push_back(ms * 1e3f);
+    }
+    Stats ss = stats_of(span), sr = stats_of(ramp), se = stats_of(ev);
+    printf("%-34s grid %5d x %4d thr x %2d loads: device span med %5.2f min %5.2f p90 %5.2f | ramp med %4.2f | events med %5.2f us | %5.0f GB/s over the span\n",
+           name, grid, threads, LOADS, ss.med, ss.mn, ss.p90, sr.med, se.med, bytes / ss.med / 1e3);
+}
+#endif
+
 int main(int argc, char** argv)
 {
     const char* what = argc > 1 ? argv[1] : "all";
@@ -542,6 +606,26 @@ int main(int argc, char** argv)
                                (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{}, eetq::Prologue{});
         CK(hipDeviceSynchronize());
     }
+#ifdef EETQ_KBENCH_STAMPS
+    if (!strcmp(what, "geometry")) {
+        unsigned long long* st;
+        CK(hipMalloc(&st, (size_t)65536 * 2 * 8));
+        printf("--- 16 MiB load-only stream, launch geometry vs device span (100 MHz device clock) ---\n");
+        bench_geometry<4, true>("256 WG x 16 waves x 4", 1024, bufs, W4K, out, st);
+        bench_geometry<8, true>("256 WG x 8 waves x 8", 512, bufs, W4K, out, st);
+        bench_geometry<16, true>("256 WG x 4 waves x 16", 256, bufs, W4K, out, st);
+        bench_geometry<8, true>("512 WG x 4 waves x 8", 256, bufs, W4K, out, st);
+        bench_geometry<4, true>("1024 WG x 4 waves x 4", 256, bufs, W4K, out, st);
+        bench_geometry<4, true>("512 WG x 8 waves x 4", 512, bufs, W4K, out, st);
+        bench_geometry<2, true>("512 WG x 16 waves x 2", 1024, bufs, W4K, out, st);
+        bench_geometry<16, true>("1024 WG x 1 wave x 16", 64, bufs, W4K, out, st);
+        bench_geometry<4, false>("256 WG x 16 waves x 4 (no nt)", 1024, bufs, W4K, out, st);
+        bench_geometry<16, false>("256 WG x 4 waves x 16 (no nt)", 256, bufs, W4K, out, st);
+        printf("--- 43 MiB ---\n");
+        bench_geometry<4, true>("688 WG x 16 waves x 4", 1024, bufs_big, WBIG, out, st);
+        bench_geometry<16, true>("688 WG x 4 waves x 16", 256, bufs_big, WBIG, out, st);
+    }
+#endif
 #ifdef EETQ_KBENCH_STAMPS
     if (!strcmp(what, "decompose")) {
         // Where do the GEMV's microseconds go?  Same process, same buffers, interleaved rounds of
