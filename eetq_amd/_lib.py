@@ -15,7 +15,8 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 EETQ_OK = 0
 DTYPE_F16, DTYPE_F32 = 0, 1
 LAYOUT_ROW_MAJOR, LAYOUT_GFX950, LAYOUT_SM80 = 0, 1, 2
-PATH_AUTO, PATH_GEMV, PATH_MFMA, PATH_STREAM, PATH_MID = 0, 1, 2, 3, 4
+PATH_AUTO, PATH_GEMV, PATH_MFMA, PATH_STREAM, PATH_MID, PATH_SPLITK = 0, 1, 2, 3, 4, 5
+ACT_IDENTITY, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
 
 _lib = None
 
@@ -59,6 +60,11 @@ def _declare(L):
         "eetq_w8a16_gemm_ex": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "eetq_w8a16_gemm_bias": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "eetq_w8a16_gemm_fused": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
+        "eetq_w8a16_gemm_act": [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp],
+        "eetq_quantize_i4": [vp, i32, sz, sz, vp, vp, i32, vp, vp, vp],
+        "eetq_pack_i4": [vp, sz, sz, vp, i32, vp],
+        "eetq_unpack_i4": [vp, sz, sz, vp, i32, vp],
+        "eetq_w4a16_gemm": [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp],
         "eetq_rmsnorm_f16": [vp, vp, vp, f32, i32, i32, vp],
         "eetq_rotary_neox_f16": [vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "eetq_rotary_neox_strided_f16": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp],
@@ -88,7 +94,7 @@ def _declare(L):
 
 EXPORTED_SYMBOLS = (
     "eetq_quantize_i8", "eetq_quantize_i8_host", "eetq_pack_i8", "eetq_unpack_i8", "eetq_pack_i8_host",
-    "eetq_unpack_i8_host", "eetq_w8a16_gemm", "eetq_w8a16_gemm_ex", "eetq_w8a16_gemm_bias", "eetq_w8a16_gemm_fused", "eetq_rmsnorm_f16",
+    "eetq_unpack_i8_host", "eetq_w8a16_gemm", "eetq_w8a16_gemm_ex", "eetq_w8a16_gemm_bias", "eetq_w8a16_gemm_fused", "eetq_w8a16_gemm_act", "eetq_quantize_i4", "eetq_pack_i4", "eetq_unpack_i4", "eetq_w4a16_gemm", "eetq_rmsnorm_f16",
     "eetq_rotary_neox_f16", "eetq_rotary_neox_strided_f16", "eetq_w8a16_gemv_rmsnorm", "eetq_w8a16_gemv_silu_gated", "eetq_silu_mul_f16", "eetq_rotary_neox_kvcache_f16", "eetq_decode_attention_f16", "eetq_prof_begin", "eetq_prof_end", "eetq_diag_stream_read", "eetq_diag_empty", "eetq_last_error", "eetq_version", "eetq_device_supported",
 )
 

@@ -237,7 +237,7 @@ int eetq_unpack_i8_host(const int8_t* q_packed, size_t K, size_t N, int8_t* q_ra
 }
 
 static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scales, const void* bias,
-                         const void* residual, void* y, int M, int N, int K, int path, void* stream)
+                         const void* residual, void* y, int M, int N, int K, int path, void* stream, int act = EETQ_ACT_IDENTITY)
 {
     int st = check_gemm_args(x, w_packed, scales, y, M, N, K);
     if (st != EETQ_OK) return st;
@@ -249,6 +249,8 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
     Epilogue       bp;
     bp.bias     = static_cast<const f16*>(bias);
     bp.residual = static_cast<const f16*>(residual);
+    EETQ_REQUIRE(act >= EETQ_ACT_IDENTITY && act <= EETQ_ACT_SILU, "Invalid activation type.");
+    bp.act         = act;
     f16*           yp = static_cast<f16*>(y);
     hipStream_t    s  = static_cast<hipStream_t>(stream);
     switch (path) {
@@ -298,6 +300,47 @@ int eetq_w8a16_gemm_fused(const void* x, const int8_t* w_packed, const void* sca
                           const void* residual, void* y, int M, int N, int K, int path, void* stream)
 {
     return gemm_dispatch(x, w_packed, scales, bias, residual, y, M, N, K, path, stream);
+}
+
+int eetq_w8a16_gemm_act(const void* x, const int8_t* w_packed, const void* scales, const void* bias, const void* residual,
+                        void* y, int M, int N, int K, int path, int act, void* stream)
+{
+    return gemm_dispatch(x, w_packed, scales, bias, residual, y, M, N, K, path, stream, act);
+}
+
+int eetq_quantize_i4(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
+                     void* scales, float* workspace, void* stream)
+{
+    if (!workspace) {
+        int st = colmax_scratch(N, &workspace);
+        if (st != EETQ_OK) return st;
+    }
+    return launch_quantize_i4(w, w_dtype, K, N, q_raw, q_packed, layout, scales, workspace, static_cast<hipStream_t>(stream));
+}
+
+int eetq_pack_i4(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, void* stream)
+{
+    return launch_pack_i4(q_raw, K, N, q_packed, layout, static_cast<hipStream_t>(stream));
+}
+
+int eetq_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, void* stream)
+{
+    return launch_unpack_i4(q_packed, K, N, q_raw, layout, static_cast<hipStream_t>(stream));
+}
+
+int eetq_w4a16_gemm(const void* x, const int8_t* w_packed, const void* scales, const void* bias, const void* residual,
+                    void* y, int M, int N, int K, void* stream)
+{
+    EETQ_REQUIRE(x && w_packed && scales && y, "null pointer");
+    EETQ_REQUIRE(M >= 1 && N >= 1 && K >= 1, "invalid GEMM shape");
+    EETQ_REQUIRE(K % 128 == 0, "int4: k must be a multiple of 128");
+    EETQ_REQUIRE(N % 16 == 0, "n must be a multiple of 16");
+    EETQ_REQUIRE(((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)y) % 16 == 0, "x, weight and y must be 16-byte aligned");
+    Epilogue ep;
+    ep.bias     = static_cast<const f16*>(bias);
+    ep.residual = static_cast<const f16*>(residual);
+    return launch_w4a16(static_cast<const f16*>(x), reinterpret_cast<const uint8_t*>(w_packed),
+                        static_cast<const f16*>(scales), ep, static_cast<f16*>(y), M, N, K, static_cast<hipStream_t>(stream));
 }
 
 int eetq_rmsnorm_f16(const void* x, const void* gamma, void* out, float eps, int rows, int cols, void* stream)

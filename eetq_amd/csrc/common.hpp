@@ -75,7 +75,58 @@ __device__ __forceinline__ void dequant_16(const u32x4& w, f16x2 scale2, f16x2 (
 struct Epilogue {
     const f16* bias     = nullptr;  // [N]
     const f16* residual = nullptr;  // [M][N], row stride N; must not alias y unless it is y itself element for element
+    int        act      = 0;        // EETQ_ACT_*: 0 = identity (the Python-level `output + bias` above)
 };
+
+// Activation epilogues (EETQ_ACT_RELU / GELU / SILU): FT's bias + activation family, which the reference compiles but never
+// reaches from Python (cutlass_kernels/fpA_intB_gemm.cu:35-97 -> fpA_intB_gemm_template.h:492-537 -> epilogue_helpers.h:20-71:
+// LinearCombinationRelu / LinearCombinationSilu / LinearCombinationGeneric<GELU_taylor>, ScaleType::NoBetaScaling, compute
+// type float): D = fp16( act( acc + float(bias) ) ) -- sum and activation in fp32, ONE rounding to fp16.  GELU is the tanh
+// form 0.5 z (1 + tanh(0.7978845608 z (1 + 0.044715 z^2))) (cutlass_extensions/epilogue/thread/ft_fused_activations.h:73-84).
+__device__ __forceinline__ float apply_act(float z, int act)
+{
+    if (act == EETQ_ACT_RELU) return z > 0.f ? z : 0.f;
+    if (act == EETQ_ACT_SILU) return z / (1.0f + expf(-z));
+    // EETQ_ACT_GELU
+    return 0.5f * z * (1.0f + tanhf(0.7978845608028654f * z * (1.0f + 0.044715f * z * z)));
+}
+
+// one output element: identity keeps the reference's Python-level order (round to fp16, then an fp16 bias add)
+__device__ __forceinline__ f16 finish_element(float acc, const Epilogue& ep, int n)
+{
+    if (ep.act == 0) {
+        f16 v = (f16)acc;
+        if (ep.bias) v = v + ep.bias[n];
+        return v;
+    }
+    return (f16)apply_act(ep.bias ? acc + (float)ep.bias[n] : acc, ep.act);
+}
+
+// four consecutive columns n..n+3 (n % 4 == 0; bias 8-byte aligned) -> two packed pairs
+__device__ __forceinline__ void finish_quad(const float (&a)[4], const Epilogue& ep, int n, f16x2& lo, f16x2& hi)
+{
+    if (ep.act == 0) {
+        lo = f16x2{(f16)a[0], (f16)a[1]};
+        hi = f16x2{(f16)a[2], (f16)a[3]};
+        if (ep.bias) {
+            const u32x2 b = *reinterpret_cast<const u32x2*>(ep.bias + n);
+            lo            = lo + as_f16x2(b.x);
+            hi            = hi + as_f16x2(b.y);
+        }
+        return;
+    }
+    float z[4] = {a[0], a[1], a[2], a[3]};
+    if (ep.bias) {
+        const u32x2 b  = *reinterpret_cast<const u32x2*>(ep.bias + n);
+        const f16x2 b0 = as_f16x2(b.x), b1 = as_f16x2(b.y);
+        z[0] += (float)b0[0];
+        z[1] += (float)b0[1];
+        z[2] += (float)b1[0];
+        z[3] += (float)b1[1];
+    }
+    lo = f16x2{(f16)apply_act(z[0], ep.act), (f16)apply_act(z[1], ep.act)};
+    hi = f16x2{(f16)apply_act(z[2], ep.act), (f16)apply_act(z[3], ep.act)};
+}
 
 // ---- fused activation prologue of the M = 1 GEMV (gamma may be null = none): the activation vector is RMS-normalised while
 // it is staged in LDS, x_eff[k] = fp16(clamp((x[k] * rsqrt(mean(x^2) + eps)) * gamma[k])) -- the arithmetic of
@@ -127,6 +178,13 @@ int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_ra
                     int layout, void* scales, float* colmax, hipStream_t stream);
 int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
 int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
+// int4 (W4A16): int4.hip
+int launch_quantize_i4(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
+                       void* scales, float* colmax, hipStream_t stream);
+int launch_pack_i4(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
+int launch_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
+int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
+                 hipStream_t stream);
 int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream, Prologue pro = Prologue{});
 int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,

@@ -396,13 +396,10 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (nbase + 8 * q < N) {
-                            f16x2 lo = {(f16)acc[mt][j][4 * q + 0], (f16)acc[mt][j][4 * q + 1]};
-                            f16x2 hi = {(f16)acc[mt][j][4 * q + 2], (f16)acc[mt][j][4 * q + 3]};
-                            if (ep.bias) {
-                                const u32x2 b = *reinterpret_cast<const u32x2*>(ep.bias + nbase + 8 * q);
-                                lo            = lo + as_f16x2(b.x);
-                                hi            = hi + as_f16x2(b.y);
-                            }
+                            f16x2       lo, hi;
+                            const float a4[4] = {acc[mt][j][4 * q + 0], acc[mt][j][4 * q + 1], acc[mt][j][4 * q + 2],
+                                                 acc[mt][j][4 * q + 3]};
+                            finish_quad(a4, ep, nbase + 8 * q, lo, hi);
                             if (ep.residual) {
                                 const u32x2 r =
                                     *reinterpret_cast<const u32x2*>(ep.residual + (size_t)m * ldc + nbase + 8 * q);

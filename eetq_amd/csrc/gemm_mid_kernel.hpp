@@ -194,13 +194,8 @@ __global__ __launch_bounds__(kThreads, (STAGES == 2 && MT <= 2) ? 2 : 1) void ge
         }
         const int m = m0 + 32 * mt + fn;
         if (m < M && nb < N) {
-            f16x2 lo = {(f16)s4[0], (f16)s4[1]};
-            f16x2 hi = {(f16)s4[2], (f16)s4[3]};
-            if (ep.bias) {
-                const u32x2 b = *reinterpret_cast<const u32x2*>(ep.bias + nb);
-                lo            = lo + as_f16x2(b.x);
-                hi            = hi + as_f16x2(b.y);
-            }
+            f16x2 lo, hi;
+            finish_quad(s4, ep, nb, lo, hi);
             if (ep.residual) {
                 const u32x2 r = *reinterpret_cast<const u32x2*>(ep.residual + (size_t)m * N + nb);
                 lo            = lo + as_f16x2(r.x);

@@ -286,8 +286,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
             }
             s = sum_xor32(sum_xor16(s));
             if (lane < 16) {
-                f16 v = (f16)s;
-                if (ep.bias) v = v + ep.bias[ntile * 16 + c];  // fp16 add after the fp16 rounding == the reference's separate `+ bias`
+                f16 v = finish_element(s, ep, ntile * 16 + c);  // identity: fp16 add after the fp16 rounding == the reference's separate `+ bias`
                 if (ep.residual) v = v + ep.residual[(size_t)m * N + ntile * 16 + c];
                 y[(size_t)m * N + ntile * 16 + c] = v;
             }
@@ -392,8 +391,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
         float s = 0.f;
 #pragma unroll
         for (int wv = 0; wv < WAVES; ++wv) s += red[wv * 8 + tid];
-        f16 v = (f16)s;
-        if (ep.bias) v = v + ep.bias[unit * 8 + tid];
+        f16 v = finish_element(s, ep, unit * 8 + tid);
         if (ep.residual) v = v + ep.residual[unit * 8 + tid];
         y[unit * 8 + tid] = v;
     }

@@ -133,8 +133,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
             float s = 0.f;
 #pragma unroll
             for (int wv = 0; wv < WAVES; ++wv) s += red[wv * kPerWave + o];
-            f16 v = (f16)s;
-            if (ep.bias) v = v + ep.bias[(ntile0 + tt) * 16 + cc];
+            f16 v = finish_element(s, ep, (ntile0 + tt) * 16 + cc);
             if (ep.residual) v = v + ep.residual[(size_t)m * N + (ntile0 + tt) * 16 + cc];
             y[(size_t)m * N + (ntile0 + tt) * 16 + cc] = v;
         }

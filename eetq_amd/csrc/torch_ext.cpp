@@ -1,0 +1,468 @@
+// The compiled operator module `EETQ`: torch::Tensor in / torch::Tensor out over the C ABI of libeetq_amd.so.
+//
+// Drop-in for the reference's pybind module (csrc/eetpy.cpp:7-19): the six functions it binds keep their names, argument
+// order, py::arg names and defaults, current-stream / device-guard behaviour and error type (C++ exception ->
+// RuntimeError).  Host code only (g++): every kernel lives behind include/eetq_amd.h.  Optional trailing keyword arguments
+// (layout=, path=, bias=, residual=, norm=, gated=) and five further functions are extensions of this library
+// (include/eetq_amd.h says which reference interface, if any, each one stands in for).
+#include <torch/extension.h>
+
+#include <c10/core/DeviceGuard.h>
+#include <c10/hip/HIPStream.h>
+
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/eetq_amd.h"
+
+namespace {
+
+using torch::Tensor;
+using OptTensor = std::optional<Tensor>;
+
+void check(int status)
+{
+    if (status != EETQ_OK) {
+        const char* msg = eetq_last_error();
+        throw std::runtime_error(msg && *msg ? msg : "eetq_amd: error " + std::to_string(status));
+    }
+}
+
+void* stream_of(const Tensor& t) { return c10::hip::getCurrentHIPStream(t.device().index()).stream(); }
+
+int layout_id(const std::string& name)
+{
+    if (name == "gfx950" || name == "native") return EETQ_LAYOUT_GFX950;
+    if (name == "sm80") return EETQ_LAYOUT_SM80;
+    if (name == "row_major") return EETQ_LAYOUT_ROW_MAJOR;
+    throw std::runtime_error("unknown weight layout '" + name + "' (expected 'gfx950', 'sm80' or 'row_major')");
+}
+
+int path_id(const std::string& name)
+{
+    if (name == "auto") return EETQ_PATH_AUTO;
+    if (name == "gemv") return EETQ_PATH_GEMV;
+    if (name == "mfma") return EETQ_PATH_MFMA;
+    if (name == "stream") return EETQ_PATH_STREAM;
+    if (name == "mid") return EETQ_PATH_MID;
+    if (name == "splitk") return EETQ_PATH_SPLITK;
+    throw std::runtime_error("unknown GEMM path '" + name + "'");
+}
+
+c10::Device work_device(const Tensor& t)
+{
+    if (t.is_cuda()) return t.device();
+    TORCH_CHECK(torch::cuda::is_available(), "eetq_amd: no HIP device available; the W8A16 path has no CPU implementation");
+    return c10::Device(c10::kCUDA, c10::hip::current_device());
+}
+
+// ---- quantise (reference: symmetric_quantize_last_axis_of_tensor, fpA_intB_gemm_wrapper.cu:28-107) ----------------
+std::vector<Tensor> quant_weights(const Tensor& weight, py::object quant_type, bool return_unprocessed_quantized_tensor,
+                                  const std::string& layout)
+{
+    const at::ScalarType qt = torch::python::detail::py_object_to_dtype(quant_type);
+    TORCH_CHECK(weight.is_contiguous(), "weight must be contiguous");
+    TORCH_CHECK(weight.numel() != 0, "weight should not be empty tensor");
+    TORCH_CHECK(weight.dim() == 2 || weight.dim() == 3, "Invalid dim. The dim of weight should be 2 or 3");
+    const auto st = weight.scalar_type();
+    TORCH_CHECK(st == at::kHalf || st == at::kFloat, "Invalid datatype. Weight must be FP16 or FP32");
+    TORCH_CHECK(qt == at::kChar || qt == at::kQUInt4x2, "Must be int4 or int8 quantization");
+    // the reference quantises a 3-D stack and then fails in preprocess_weights_for_mixed_gemm
+    // (cutlass_preprocessors.cc:504): same observable behaviour
+    if (weight.dim() == 3) throw std::runtime_error("[FT][ERROR] Shape must be 2-D");
+    const bool   int4 = qt == at::kQUInt4x2;
+    const int    lay  = layout_id(layout);
+    const size_t K = weight.size(0), N = weight.size(1);
+    const auto   dev = work_device(weight);
+    c10::DeviceGuard guard(dev);
+    Tensor       w_dev = weight.is_cuda() ? weight : weight.to(dev);
+    const auto   i8    = torch::TensorOptions().dtype(at::kChar).device(dev);
+    Tensor       raw, processed, scales = torch::empty({(int64_t)N}, weight.options().device(dev));
+    Tensor       colmax = torch::empty({(int64_t)N}, torch::TensorOptions().dtype(at::kFloat).device(dev));
+    if (!int4) {
+        if (return_unprocessed_quantized_tensor) raw = torch::empty({(int64_t)K, (int64_t)N}, i8);
+        processed = torch::empty({(int64_t)K, (int64_t)N}, i8);
+        check(eetq_quantize_i8(w_dev.data_ptr(), st == at::kHalf ? EETQ_DTYPE_F16 : EETQ_DTYPE_F32, K, N,
+                               raw.defined() ? raw.data_ptr<int8_t>() : nullptr, processed.data_ptr<int8_t>(), lay,
+                               scales.data_ptr(), colmax.data_ptr<float>(), stream_of(w_dev)));
+    } else {
+        // packed int4: two values per byte along N (reference output shape [K, N/2], fpA_intB_gemm_wrapper.cu:60-66)
+        TORCH_CHECK(N % 2 == 0, "int4 quantization needs an even number of columns");
+        if (return_unprocessed_quantized_tensor) raw = torch::empty({(int64_t)K, (int64_t)N / 2}, i8);
+        processed = torch::empty({(int64_t)K, (int64_t)N / 2}, i8);
+        check(eetq_quantize_i4(w_dev.data_ptr(), st == at::kHalf ? EETQ_DTYPE_F16 : EETQ_DTYPE_F32, K, N,
+                               raw.defined() ? raw.data_ptr<int8_t>() : nullptr, processed.data_ptr<int8_t>(), lay,
+                               scales.data_ptr(), colmax.data_ptr<float>(), stream_of(w_dev)));
+    }
+    if (!weight.is_cuda()) {  // CPU tensors in -> CPU tensors out, like the reference (:33)
+        processed = processed.cpu();
+        scales    = scales.cpu();
+        if (raw.defined()) raw = raw.cpu();
+    }
+    if (return_unprocessed_quantized_tensor) return {raw, processed, scales};
+    return {processed, scales};
+}
+
+Tensor relayout(const Tensor& src_in, const std::string& layout, bool pack, bool is_int4)
+{
+    TORCH_CHECK(src_in.scalar_type() == at::kChar, "expected an int8 tensor");
+    if (src_in.dim() != 2) throw std::runtime_error("[FT][ERROR] Shape must be 2-D");
+    Tensor       src = src_in.contiguous();
+    const int    lay = layout_id(layout);
+    const size_t K = src.size(0), Nb = src.size(1);
+    const auto   dev = work_device(src);
+    c10::DeviceGuard guard(dev);
+    Tensor       s_dev = src.is_cuda() ? src : src.to(dev);
+    Tensor       out   = torch::empty_like(s_dev);
+    if (is_int4)
+        check((pack ? eetq_pack_i4 : eetq_unpack_i4)(s_dev.data_ptr<int8_t>(), K, Nb * 2, out.data_ptr<int8_t>(), lay,
+                                                     stream_of(s_dev)));
+    else
+        check((pack ? eetq_pack_i8 : eetq_unpack_i8)(s_dev.data_ptr<int8_t>(), K, Nb, out.data_ptr<int8_t>(), lay,
+                                                     stream_of(s_dev)));
+    return src.is_cuda() ? out : out.cpu();
+}
+
+// reference: preprocess_weights_cuda, fpA_intB_gemm_wrapper.cu:109-128
+Tensor preprocess_weights(const Tensor& origin_weight, bool is_int4, const std::string& layout)
+{
+    return relayout(origin_weight, layout, true, is_int4);
+}
+
+Tensor unprocess_weights(const Tensor& processed_weight, const std::string& layout, bool is_int4)
+{
+    return relayout(processed_weight, layout, false, is_int4);
+}
+
+// ---- fused dequant + GEMM ---------------------------------------------------------------------------------------------
+void layernorm_forward(const Tensor& input, const Tensor& gamma, Tensor& out, double eps);
+Tensor silu_mul(const Tensor& gate_up);
+
+void check_epilogue(const Tensor& input, const OptTensor& bias, const OptTensor& residual, int64_t m, int64_t n)
+{
+    if (bias) {
+        const Tensor& b = *bias;
+        TORCH_CHECK(b.scalar_type() == at::kHalf && b.device() == input.device() && b.numel() == n && b.is_contiguous(),
+                    "w8_a16_gemm: bias must be a contiguous float16 [N] tensor on the input's device");
+    }
+    if (residual) {
+        const Tensor& r = *residual;
+        TORCH_CHECK(r.scalar_type() == at::kHalf && r.device() == input.device() && r.numel() == m * n &&
+                        r.is_contiguous() && r.size(-1) == n,
+                    "w8_a16_gemm: residual must be a contiguous float16 [..., N] tensor with the output's element count, "
+                    "on the input's device");
+    }
+}
+
+Tensor& gemm_launch(const Tensor& input, const Tensor& weight, const Tensor& scale, Tensor& output, int64_t m, int64_t n,
+                    int64_t k, int path, const OptTensor& bias, const OptTensor& residual, int act)
+{
+    TORCH_CHECK(input.scalar_type() == at::kHalf, "w8_a16_gemm: input must be float16 (got ", input.scalar_type(), ")");
+    TORCH_CHECK(input.is_cuda(), "input must be a CUDA tensor");
+    TORCH_CHECK(weight.scalar_type() == at::kChar && scale.scalar_type() == at::kHalf,
+                "w8_a16_gemm: weight must be int8 and scale float16");
+    TORCH_CHECK(weight.device() == input.device() && scale.device() == input.device() && output.device() == input.device(),
+                "w8_a16_gemm: input, weight, scale and output must be on the same device");
+    TORCH_CHECK(weight.is_contiguous() && scale.is_contiguous() && output.is_contiguous(),
+                "w8_a16_gemm: weight, scale and output must be contiguous");
+    check_epilogue(input, bias, residual, m, n);
+    Tensor           x = input.contiguous();
+    c10::DeviceGuard guard(input.device());
+    const bool       int4 = weight.size(-1) * 2 == n && weight.size(-1) != n;  // packed int4: [K, N/2] bytes
+    if (int4)
+        check(eetq_w4a16_gemm(x.data_ptr(), weight.data_ptr<int8_t>(), scale.data_ptr(), bias ? bias->data_ptr() : nullptr,
+                              residual ? residual->data_ptr() : nullptr, output.data_ptr(), (int)m, (int)n, (int)k,
+                              stream_of(input)));
+    else
+        check(eetq_w8a16_gemm_act(x.data_ptr(), weight.data_ptr<int8_t>(), scale.data_ptr(),
+                                  bias ? bias->data_ptr() : nullptr, residual ? residual->data_ptr() : nullptr,
+                                  output.data_ptr(), (int)m, (int)n, (int)k, path, act, stream_of(input)));
+    return output;
+}
+
+int act_id(const std::string& name)
+{
+    if (name.empty() || name == "identity" || name == "none") return EETQ_ACT_IDENTITY;
+    if (name == "relu") return EETQ_ACT_RELU;
+    if (name == "gelu") return EETQ_ACT_GELU;
+    if (name == "silu") return EETQ_ACT_SILU;
+    throw std::runtime_error("unknown activation '" + name + "' (identity, relu, gelu, silu)");
+}
+
+std::vector<int64_t> out_shape(const Tensor& input, int64_t n)
+{
+    std::vector<int64_t> s(input.sizes().begin(), input.sizes().end());
+    s.back() = n;
+    return s;
+}
+
+// reference: w8_a16_gemm_forward_cuda, fpA_intB_gemm_wrapper.cu:130-173 (fresh output, current stream, asynchronous)
+Tensor w8_a16_gemm(const Tensor& input_in, const Tensor& weight, const Tensor& scale, const std::string& path,
+                   const OptTensor& bias, const OptTensor& residual, const std::optional<std::tuple<Tensor, double>>& norm,
+                   bool gated, const std::string& activation)
+{
+    Tensor  input = input_in;
+    int64_t n     = scale.numel();  // [N]; for packed int4 weights the byte tensor is [K, N/2]
+    TORCH_CHECK(input.dim() >= 1 && weight.dim() == 2, "w8_a16_gemm: expected input [..., K] and weight [K, N]");
+    const int64_t kw = weight.size(0);
+    if (gated) {
+        TORCH_CHECK(input.size(-1) == 2 * kw, "w8_a16_gemm: gated input must be [..., 2K] for a [K, N] weight");
+        const int64_t rows = input.numel() / input.size(-1);
+        if (rows == 1 && path == "auto" && !norm && input.is_cuda() && input.scalar_type() == at::kHalf &&
+            input.is_contiguous() && kw % 8 == 0 && weight.size(1) == n && activation.empty()) {
+            TORCH_CHECK(weight.scalar_type() == at::kChar && scale.scalar_type() == at::kHalf && weight.is_contiguous(),
+                        "w8_a16_gemm: weight must be contiguous int8 and scale float16");
+            Tensor output = torch::empty(out_shape(input, n), input.options());
+            check_epilogue(input, bias, residual, 1, n);
+            c10::DeviceGuard guard(input.device());
+            check(eetq_w8a16_gemv_silu_gated(input.data_ptr(), weight.data_ptr<int8_t>(), scale.data_ptr(),
+                                             bias ? bias->data_ptr() : nullptr, residual ? residual->data_ptr() : nullptr,
+                                             output.data_ptr(), (int)n, (int)kw, stream_of(input)));
+            return output;
+        }
+        input = silu_mul(input.contiguous());
+    }
+    const int64_t k = input.size(-1);
+    TORCH_CHECK(kw == k, "w8_a16_gemm: weight is [", kw, ", ", n, "] but input has K=", k);
+    const int64_t m      = k ? input.numel() / k : 0;
+    Tensor        output = torch::empty(out_shape(input, n), input.options());
+    if (m == 0) return output;
+    if (norm) {
+        const Tensor& gamma = std::get<0>(*norm);
+        const double  eps   = std::get<1>(*norm);
+        if (m == 1 && path == "auto" && gamma.scalar_type() == at::kHalf && gamma.is_contiguous() && gamma.numel() == k &&
+            weight.size(1) == n && activation.empty()) {
+            TORCH_CHECK(input.scalar_type() == at::kHalf && input.is_cuda(), "w8_a16_gemm: input must be a float16 CUDA tensor");
+            TORCH_CHECK(weight.scalar_type() == at::kChar && scale.scalar_type() == at::kHalf && weight.is_contiguous(),
+                        "w8_a16_gemm: weight must be contiguous int8 and scale float16");
+            TORCH_CHECK(gamma.device() == input.device() && weight.device() == input.device() &&
+                            scale.device() == input.device(),
+                        "w8_a16_gemm: all tensors must be on the input's device");
+            check_epilogue(input, bias, residual, 1, n);
+            Tensor           x = input.contiguous();
+            c10::DeviceGuard guard(input.device());
+            check(eetq_w8a16_gemv_rmsnorm(x.data_ptr(), gamma.data_ptr(), (float)eps, weight.data_ptr<int8_t>(),
+                                          scale.data_ptr(), bias ? bias->data_ptr() : nullptr,
+                                          residual ? residual->data_ptr() : nullptr, output.data_ptr(), (int)n, (int)k,
+                                          stream_of(input)));
+            return output;
+        }
+        Tensor xin    = input.contiguous();
+        Tensor normed = torch::empty_like(xin);
+        layernorm_forward(xin, gamma, normed, eps);
+        input = normed;
+    }
+    return gemm_launch(input, weight, scale, output, m, n, k, path_id(path), bias, residual, act_id(activation));
+}
+
+// reference: w8_a16_gemm_forward_cuda_, fpA_intB_gemm_wrapper.cu:176-202 (writes into `output`, returns it)
+Tensor w8_a16_gemm_(const Tensor& input, const Tensor& weight, const Tensor& scale, Tensor& output, int64_t m, int64_t n,
+                    int64_t k)
+{
+    return gemm_launch(input, weight, scale, output, m, n, k, EETQ_PATH_AUTO, std::nullopt, std::nullopt, EETQ_ACT_IDENTITY);
+}
+
+// ---- side ops ---------------------------------------------------------------------------------------------------------
+// reference: layernorm_forward_cuda, layernorm.cu:98-113 (returns void; current stream here, default stream there)
+void layernorm_forward(const Tensor& input, const Tensor& gamma, Tensor& out, double eps)
+{
+    TORCH_CHECK(input.scalar_type() == at::kHalf && gamma.scalar_type() == at::kHalf && out.scalar_type() == at::kHalf,
+                "layernorm_forward: expected scalar type Half");
+    TORCH_CHECK(input.is_cuda() && gamma.is_cuda() && out.is_cuda(), "layernorm_forward: tensors must be CUDA tensors");
+    TORCH_CHECK(input.is_contiguous() && gamma.is_contiguous() && out.is_contiguous(),
+                "layernorm_forward: tensors must be contiguous");
+    const int64_t cols = input.size(-1);
+    const int64_t rows = cols ? input.numel() / cols : 0;
+    TORCH_CHECK(gamma.numel() == cols && out.numel() == input.numel(), "layernorm_forward: shape mismatch");
+    c10::DeviceGuard guard(input.device());
+    check(eetq_rmsnorm_f16(input.data_ptr(), gamma.data_ptr(), out.data_ptr(), (float)eps, (int)rows, (int)cols,
+                           stream_of(input)));
+}
+
+// reference: rotary_embedding_neox, pos_encoding_kernels.cu:55-87 (fp16 only here)
+void rotary_embedding_neox(const Tensor& positions, Tensor& query, Tensor& key, int64_t head_size, const Tensor& cos_sin_cache)
+{
+    TORCH_CHECK(query.scalar_type() == at::kHalf && key.scalar_type() == at::kHalf && cos_sin_cache.scalar_type() == at::kHalf,
+                "eetq_amd: rotary_embedding_neox is implemented for float16 only");
+    TORCH_CHECK(positions.scalar_type() == at::kLong, "rotary_embedding_neox: positions must be int64");
+    TORCH_CHECK(query.is_contiguous() && key.is_contiguous() && cos_sin_cache.is_contiguous() && positions.is_contiguous(),
+                "rotary_embedding_neox: tensors must be contiguous");
+    TORCH_CHECK(query.dim() >= 3, "rotary_embedding_neox: query must be [batch, seq, heads, head_size] or [tokens, heads, head_size]");
+    const int64_t tokens = positions.numel();
+    const int64_t heads  = query.size(-2);
+    c10::DeviceGuard guard(query.device());
+    check(eetq_rotary_neox_f16(positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(), cos_sin_cache.data_ptr(),
+                               (int)tokens, (int)heads, (int)head_size, (int)cos_sin_cache.size(1), stream_of(query)));
+}
+
+// tokens / heads / token stride of a [..., heads, head_size] view whose leading dimensions collapse to one stride
+std::tuple<int64_t, int64_t, int64_t> token_view(const Tensor& t, int64_t head_size)
+{
+    TORCH_CHECK(t.dim() >= 2, "rotary_embedding_neox_strided: expected [..., heads, head_size]");
+    const int64_t heads = t.size(-2), hs = t.size(-1);
+    TORCH_CHECK(hs == head_size && t.stride(-1) == 1 && t.stride(-2) == hs,
+                "rotary_embedding_neox_strided: the last two dimensions must be dense [heads, head_size]");
+    int64_t tokens = 1, stride = -1, expect = -1;
+    for (int64_t d = t.dim() - 3; d >= 0; --d) {
+        tokens *= t.size(d);
+        if (t.size(d) == 1) continue;
+        if (stride < 0) {
+            stride = t.stride(d);
+            expect = stride * t.size(d);
+        } else {
+            TORCH_CHECK(t.stride(d) == expect, "rotary_embedding_neox_strided: leading dimensions do not collapse to one stride");
+            expect = t.stride(d) * t.size(d);
+        }
+    }
+    return {tokens, heads, stride >= 0 ? stride : heads * hs};
+}
+
+void rotary_embedding_neox_strided(const Tensor& positions, Tensor& query, Tensor& key, int64_t head_size,
+                                   const Tensor& cos_sin_cache)
+{
+    TORCH_CHECK(query.scalar_type() == at::kHalf && key.scalar_type() == at::kHalf && cos_sin_cache.scalar_type() == at::kHalf,
+                "eetq_amd: rotary_embedding_neox is implemented for float16 only");
+    TORCH_CHECK(positions.scalar_type() == at::kLong && positions.is_contiguous() && cos_sin_cache.is_contiguous(),
+                "rotary_embedding_neox_strided: positions must be contiguous int64, the cache contiguous");
+    auto [tq, hq, sq] = token_view(query, head_size);
+    auto [tk, hk, sk] = token_view(key, head_size);
+    TORCH_CHECK(tq == tk && positions.numel() == tq,
+                "rotary_embedding_neox_strided: query, key and positions disagree on the token count");
+    c10::DeviceGuard guard(query.device());
+    check(eetq_rotary_neox_strided_f16(positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(),
+                                       cos_sin_cache.data_ptr(), (int)tq, (int)hq, (int)hk, (int)head_size,
+                                       (int)cos_sin_cache.size(1), (int)sq, (int)sk, stream_of(query)));
+}
+
+void rotary_embedding_neox_kvcache(const Tensor& positions, Tensor& query, const Tensor& key, const Tensor& value,
+                                   int64_t head_size, const Tensor& cos_sin_cache, Tensor& key_cache, Tensor& value_cache,
+                                   const OptTensor& slots)
+{
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&query, &key, &value, &cos_sin_cache, &key_cache, &value_cache})
+        TORCH_CHECK(t->scalar_type() == at::kHalf, "rotary_embedding_neox_kvcache: float16 tensors expected");
+    TORCH_CHECK(positions.scalar_type() == at::kLong && positions.is_contiguous(),
+                "rotary_embedding_neox_kvcache: positions must be contiguous int64");
+    TORCH_CHECK(query.dim() == 3 && key.dim() == 3 && value.dim() == 3 && key_cache.dim() == 4,
+                "rotary_embedding_neox_kvcache: shape mismatch");
+    const int64_t B = query.size(0), H = query.size(1), D = query.size(2), Hkv = key.size(1);
+    TORCH_CHECK(key.size(0) == B && key.size(2) == D && value.sizes() == key.sizes() && D == head_size &&
+                    key_cache.size(0) == B && key_cache.size(1) == Hkv && key_cache.size(3) == D &&
+                    value_cache.sizes() == key_cache.sizes() && value_cache.strides() == key_cache.strides() &&
+                    positions.numel() == B,
+                "rotary_embedding_neox_kvcache: shape mismatch");
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&query, &key, &value})
+        TORCH_CHECK(t->stride(-1) == 1 && t->stride(-2) == D, "rotary_embedding_neox_kvcache: [heads, head_size] must be dense");
+    TORCH_CHECK(key_cache.stride(-1) == 1 && cos_sin_cache.is_contiguous(), "rotary_embedding_neox_kvcache: cache rows must be dense");
+    int slot_stride = 0;
+    if (slots) {
+        const Tensor& s = *slots;
+        TORCH_CHECK(s.scalar_type() == at::kLong && s.device() == query.device() && (s.numel() == 1 || s.numel() == B) &&
+                        s.is_contiguous(),
+                    "rotary_embedding_neox_kvcache: slots must be contiguous int64 on the device, 1 or B elements");
+        slot_stride = (s.numel() == B && B > 1) ? 1 : 0;
+    }
+    const long strides[6] = {(long)query.stride(0), (long)key.stride(0), (long)value.stride(0), (long)key_cache.stride(0),
+                             (long)key_cache.stride(1), (long)key_cache.stride(2)};
+    c10::DeviceGuard guard(query.device());
+    check(eetq_rotary_neox_kvcache_f16(positions.data_ptr<int64_t>(), slots ? slots->data_ptr<int64_t>() : nullptr,
+                                       slot_stride, query.data_ptr(), key.data_ptr(), value.data_ptr(),
+                                       cos_sin_cache.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)B, (int)H,
+                                       (int)Hkv, (int)head_size, (int)cos_sin_cache.size(1), strides, (int)key_cache.size(2),
+                                       stream_of(query)));
+}
+
+Tensor decode_attention(const Tensor& query, const Tensor& key_cache, const Tensor& value_cache, const OptTensor& mask,
+                        std::optional<double> scaling, std::optional<int64_t> splits_in, const OptTensor& kv_len,
+                        int64_t kv_len_bias, const OptTensor& advance)
+{
+    TORCH_CHECK(query.scalar_type() == at::kHalf && key_cache.scalar_type() == at::kHalf && value_cache.scalar_type() == at::kHalf,
+                "decode_attention: query and caches must be float16");
+    TORCH_CHECK(query.dim() == 3 && key_cache.dim() == 4 && value_cache.sizes() == key_cache.sizes(),
+                "decode_attention: expected query [B, H, D] and caches [B, Hkv, S, D]");
+    const int64_t B = query.size(0), H = query.size(1), D = query.size(2);
+    const int64_t Hkv = key_cache.size(1), S = key_cache.size(2);
+    TORCH_CHECK(key_cache.size(0) == B && key_cache.size(3) == D && H % Hkv == 0 && query.stride(-1) == 1 &&
+                    key_cache.stride(-1) == 1 && value_cache.stride(-1) == 1,
+                "decode_attention: shape / stride mismatch");
+    Tensor  mrow;
+    int64_t m_sb = 0;
+    if (mask) {
+        mrow = mask->dim() != 2 ? mask->reshape({mask->size(0), -1}) : *mask;
+        TORCH_CHECK(mrow.scalar_type() == at::kHalf && mrow.size(-1) >= S && mrow.stride(-1) == 1 && mrow.device() == query.device(),
+                    "decode_attention: mask must be additive float16 with a dense last dimension >= S");
+        TORCH_CHECK(mrow.size(0) == 1 || mrow.size(0) == B,
+                    "decode_attention: the mask needs one row per batch entry (or a single shared row)");
+        m_sb = (mrow.size(0) == B && B > 1) ? mrow.stride(0) : 0;
+    }
+    for (const OptTensor* t : std::initializer_list<const OptTensor*>{&kv_len, &advance})
+        if (*t)
+            TORCH_CHECK((*t)->scalar_type() == at::kLong && (*t)->numel() == 1 && (*t)->device() == query.device(),
+                        "decode_attention: kv_len / advance must be a one-element int64 tensor on the query's device");
+    const double  sc = scaling ? *scaling : 1.0 / std::sqrt((double)D);
+    int64_t       splits = splits_in ? *splits_in
+                                     : std::max<int64_t>(1, std::min<int64_t>((S + 63) / 64, std::max<int64_t>(1, 1024 / (B * H))));
+    Tensor        out = torch::empty({B, H, D}, query.options());
+    Tensor        ws  = torch::empty({B * H * splits * (D + 2)}, query.options().dtype(at::kFloat));
+    const long    strides[11] = {(long)query.stride(0),       (long)query.stride(1),       (long)key_cache.stride(0),
+                                 (long)key_cache.stride(1),   (long)key_cache.stride(2),   (long)value_cache.stride(0),
+                                 (long)value_cache.stride(1), (long)value_cache.stride(2), (long)m_sb,
+                                 (long)out.stride(0),         (long)out.stride(1)};
+    c10::DeviceGuard guard(query.device());
+    check(eetq_decode_attention_f16(query.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+                                    mrow.defined() ? mrow.data_ptr() : nullptr, out.data_ptr(), ws.data_ptr<float>(), (int)B,
+                                    (int)H, (int)Hkv, (int)S, (int)D, (int)splits, (float)sc, strides,
+                                    kv_len ? kv_len->data_ptr<int64_t>() : nullptr, (int)kv_len_bias,
+                                    advance ? advance->data_ptr<int64_t>() : nullptr, stream_of(query)));
+    return out;
+}
+
+Tensor silu_mul(const Tensor& gate_up)
+{
+    TORCH_CHECK(gate_up.scalar_type() == at::kHalf && gate_up.is_cuda() && gate_up.is_contiguous(),
+                "silu_mul: expected a contiguous float16 CUDA tensor");
+    const int64_t inter = gate_up.size(-1) / 2;
+    TORCH_CHECK(gate_up.size(-1) == 2 * inter && inter % 8 == 0, "silu_mul: last dimension must be 2*I with I a multiple of 8");
+    Tensor        out  = torch::empty(out_shape(gate_up, inter), gate_up.options());
+    const int64_t rows = inter ? out.numel() / inter : 0;
+    c10::DeviceGuard guard(gate_up.device());
+    check(eetq_silu_mul_f16(gate_up.data_ptr(), out.data_ptr(), (int)rows, (int)inter, stream_of(gate_up)));
+    return out;
+}
+
+}  // namespace
+
+PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
+{
+    m.doc() = "EETQ operator module on libeetq_amd.so (MI355X / gfx950)";
+    // ---- the reference's six functions (csrc/eetpy.cpp:9-19): names, order, py::arg names and defaults kept ----------
+    m.def("w8_a16_gemm", &w8_a16_gemm, "Weight only gemm", py::arg("input"), py::arg("weight"), py::arg("scale"),
+          py::arg("path") = "auto", py::arg("bias") = py::none(), py::arg("residual") = py::none(),
+          py::arg("norm") = py::none(), py::arg("gated") = false, py::arg("activation") = "");
+    m.def("w8_a16_gemm_", &w8_a16_gemm_, "Weight only gemm inplace", py::arg("input"), py::arg("weight"), py::arg("scale"),
+          py::arg("output"), py::arg("m"), py::arg("n"), py::arg("k"));
+    m.def("preprocess_weights", &preprocess_weights, "transform_int8_weights_for_cutlass", py::arg("origin_weight"),
+          py::arg("is_int4") = false, py::arg("layout") = "gfx950");
+    m.def("quant_weights", &quant_weights, "quantize weight", py::arg("origin_weight"), py::arg("quant_type"),
+          py::arg("return_unprocessed_quantized_tensor") = false, py::arg("layout") = "gfx950");
+    m.def("rotary_embedding_neox", &rotary_embedding_neox, "Apply GPT-NeoX style rotary embedding to query and key",
+          py::arg("positions"), py::arg("query"), py::arg("key"), py::arg("head_size"), py::arg("cos_sin_cache"));
+    m.def("layernorm_forward", &layernorm_forward, "LayerNorm kernel", py::arg("input"), py::arg("gamma"), py::arg("out"),
+          py::arg("eps"));
+    // ---- extensions of this library ----------------------------------------------------------------------------------
+    m.def("unprocess_weights", &unprocess_weights, "inverse of preprocess_weights", py::arg("processed_weight"),
+          py::arg("layout") = "gfx950", py::arg("is_int4") = false);
+    m.def("rotary_embedding_neox_strided", &rotary_embedding_neox_strided, "rotary embedding on strided q/k views",
+          py::arg("positions"), py::arg("query"), py::arg("key"), py::arg("head_size"), py::arg("cos_sin_cache"));
+    m.def("rotary_embedding_neox_kvcache", &rotary_embedding_neox_kvcache, "decode-step rotary + KV-cache write",
+          py::arg("positions"), py::arg("query"), py::arg("key"), py::arg("value"), py::arg("head_size"),
+          py::arg("cos_sin_cache"), py::arg("key_cache"), py::arg("value_cache"), py::arg("slots") = py::none());
+    m.def("decode_attention", &decode_attention, "single-query attention over a KV cache", py::arg("query"),
+          py::arg("key_cache"), py::arg("value_cache"), py::arg("mask") = py::none(), py::arg("scaling") = py::none(),
+          py::arg("splits") = py::none(), py::arg("kv_len") = py::none(), py::arg("kv_len_bias") = 0,
+          py::arg("advance") = py::none());
+    m.def("silu_mul", &silu_mul, "silu(gate) * up on a fused gate|up block", py::arg("gate_up"));
+    m.attr("__eetq_amd_version__") = eetq_version();
+}

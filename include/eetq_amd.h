@@ -45,7 +45,13 @@ enum { EETQ_LAYOUT_ROW_MAJOR = 0, EETQ_LAYOUT_GFX950 = 1, EETQ_LAYOUT_SM80 = 2 }
 
 /* Kernel selection for eetq_w8a16_gemm_ex (tests and tuning).  AUTO is what eetq_w8a16_gemm uses. */
 enum { EETQ_PATH_AUTO = 0, EETQ_PATH_GEMV = 1 /* M <= 4 */, EETQ_PATH_MFMA = 2 /* LDS-tiled */, EETQ_PATH_STREAM = 3 /* M <= 64; AUTO uses it for 2..16 */,
-       EETQ_PATH_MID = 4 /* M <= 128: 32-column tiles, 256-deep K steps */ };
+       EETQ_PATH_MID = 4 /* M <= 128: 32-column tiles, 256-deep K steps */,
+       EETQ_PATH_SPLITK = 5 /* M <= 128: split-K tiles with an in-launch deterministic reduction */ };
+
+/* Activation of the fused bias + activation epilogue (eetq_w8a16_gemm_act).  Reference: ActivationType
+ * (csrc/utils/activation_types.h:23-38) as dispatched by CutlassFpAIntBGemmRunner::gemm_bias_act
+ * (fpA_intB_gemm/fpA_intB_gemm_template.h:492-537): Relu, Gelu (tanh form), Silu, Identity. */
+enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SILU = 3 };
 
 /* ---- quantise --------------------------------------------------------------------------------------
  * Replaces EETQ.quant_weights -> symmetric_quantize_last_axis_of_tensor
@@ -104,6 +110,31 @@ int eetq_w8a16_gemm_bias(const void* x, const int8_t* w_packed, const void* scal
  * accumulate into the residual stream); any other overlap is undefined.  Either pointer may be NULL. */
 int eetq_w8a16_gemm_fused(const void* x, const int8_t* w_packed, const void* scales, const void* bias,
                           const void* residual, void* y, int M, int N, int K, int path, void* stream);
+
+/* Bias + activation epilogue: replaces ft::gemm_fp16_int_bias_act (csrc/cutlass_kernels/fpA_intB_gemm.cu:35-62;
+ * epilogues cutlass_extensions/.../epilogue_helpers.h:20-71), which the reference compiles but does not bind.
+ *   act == EETQ_ACT_IDENTITY: exactly eetq_w8a16_gemm_fused (fp16 bias add after the fp16 rounding);
+ *   otherwise               : y = fp16( act( acc + fp32(bias[n]) ) ) -- sum and activation in fp32, one rounding, as the
+ *                             CUTLASS LinearCombinationRelu / Silu / Generic<GELU_taylor> epilogues compute it -- and the
+ *                             optional residual is then added in fp16.  bias may be NULL. */
+int eetq_w8a16_gemm_act(const void* x, const int8_t* w_packed, const void* scales, const void* bias, const void* residual,
+                        void* y, int M, int N, int K, int path, int act, void* stream);
+
+/* ---- int4 (W4A16) -----------------------------------------------------------------------------------
+ * Replaces the quint4x2 branches of EETQ.quant_weights / preprocess_weights (fpA_intB_gemm_wrapper.cu:41-66,
+ * cutlass_preprocessors.cc:360-418, 581-678 with PACKED_INT4_WEIGHT_ONLY) and the Int4b instantiations of the GEMV /
+ * GEMM (weightOnlyBatchedGemv/kernel.h:68-116; fpA_intB_gemm.cu with uint4b_t).
+ * Per column: s32 = max|w| * 2^-3; q = clamp(round_half_away(w / s32), -8, 7); ROW_MAJOR packing = two values per byte
+ * along N (element 2j in the low nibble, 2j+1 in the high nibble), tensor [K][N/2] bytes.  N is the LOGICAL column count.
+ * GFX950 layout: 1 KiB tiles of 16 columns x 128 k, unsigned nibbles q + 8.  Requires K % 128 == 0,
+ * N % 16 == 0 (GFX950) / K % 64 == 0, N % 64 == 0 (SM80). */
+int eetq_quantize_i4(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
+                     void* scales, float* workspace, void* stream);
+int eetq_pack_i4(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, void* stream);
+int eetq_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, void* stream);
+/* y = fp16( sum_k fp32(x) * fp32( fp16( q4[k][n] * scales[n] ) ) ) [+ bias] [+ residual]; w_packed in the GFX950 int4 layout. */
+int eetq_w4a16_gemm(const void* x, const int8_t* w_packed, const void* scales, const void* bias, const void* residual,
+                    void* y, int M, int N, int K, void* stream);
 
 /* ---- side ops --------------------------------------------------------------------------------------
  * Replaces EETQ.layernorm_forward -> layernorm_forward_cuda (csrc/layernorm_kernels/layernorm.cu:98-113):

@@ -15,6 +15,8 @@
  *                            int8->fp16), gemm/warp/mma_tensorop_dequantizer.h:259-274 (fp16
  *                            multiply by the per-column scale), default_fpA_intB_traits.h:110 (fp32
  *                            accumulate), epilogue_helpers.h:73-80 (fp16 store, alpha=1 beta=0)
+ *   oracle_w8a16_gemm_bias_act  cutlass_kernels/fpA_intB_gemm.cu:35-62, cutlass_extensions/.../epilogue_helpers.h:20-71,
+ *                            epilogue/thread/ft_fused_activations.h:73-84 (bias + ReLU / GELU / SiLU epilogues)
  *   oracle_rmsnorm_f16       csrc/layernorm_kernels/layernorm.cu:25-51, reduction.cuh:78-82
  *   oracle_rotary_neox_f16   csrc/embedding_kernels/pos_encoding_kernels.cu:12-53
  *
@@ -501,6 +503,39 @@ void oracle_w8a16_gemm(const uint16_t* x, const int8_t* q_raw, const uint16_t* s
     }
     free(wdq);
     free(acc);
+}
+
+/* Bias + activation epilogue of the FT family the reference compiles but does not bind (ft::gemm_fp16_int_bias_act,
+ * csrc/cutlass_kernels/fpA_intB_gemm.cu:35-62 -> fpA_intB_gemm_template.h:492-537 -> epilogue_helpers.h:20-71):
+ * CUTLASS LinearCombinationRelu / LinearCombinationSilu / LinearCombinationGeneric<GELU_taylor>, ScaleType::NoBetaScaling,
+ * compute type float: D = fp16( act( fp32(acc) + fp32(bias[n]) ) ).  act: 1 = ReLU, 2 = GELU in the tanh form
+ * 0.5 z (1 + tanh(0.7978845608028654 z (1 + 0.044715 z^2))) (ft_fused_activations.h:73-84), 3 = SiLU z * sigmoid(z).
+ * bias may be NULL.  The activation is evaluated in double and rounded to fp32 (the device's expf / tanhf differ from any
+ * particular libm by ulps: tests compare with the tier-A tolerance). */
+void oracle_w8a16_gemm_bias_act(const uint16_t* x, const int8_t* q_raw, const uint16_t* scales, const uint16_t* bias,
+                                int act, uint16_t* y, size_t M, size_t N, size_t K)
+{
+    float* wdq = (float*)malloc(K * sizeof(float));
+    for (size_t n = 0; n < N; ++n) {
+        const float s = h2f(scales[n]);
+        for (size_t k = 0; k < K; ++k) wdq[k] = h2f(f2h((float)q_raw[k * N + n] * s));
+        for (size_t m = 0; m < M; ++m) {
+            const uint16_t* xr = x + m * K;
+            double          a  = 0.0;
+            for (size_t k = 0; k < K; ++k) a += (double)h2f(xr[k]) * (double)wdq[k];
+            float z = (float)a;
+            if (bias) z = z + h2f(bias[n]);
+            double r;
+            switch (act) {
+                case 1: r = z > 0.f ? (double)z : 0.0; break;
+                case 2: r = 0.5 * z * (1.0 + tanh(0.7978845608028654 * z * (1.0 + 0.044715 * (double)z * z))); break;
+                case 3: r = (double)z / (1.0 + exp(-(double)z)); break;
+                default: r = z; break;
+            }
+            y[m * N + n] = f2h((float)r);
+        }
+    }
+    free(wdq);
 }
 
 /* Same contract with strict left-to-right fp32 accumulation (one legal order): used to size the

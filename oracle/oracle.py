@@ -10,7 +10,7 @@ _LIB_PATH = os.path.join(_HERE, "libeetq_oracle.so")
 
 __all__ = [
     "build", "lib", "quantize", "sm80_pack", "sm80_pack_closed_form", "sm80_unpack", "gfx950_pack",
-    "gfx950_unpack", "sm80_reader_unpack", "ref_gemv_sm80", "w8a16_gemm", "w8a16_gemm_f32acc", "dequant", "rmsnorm_f16", "rotary_neox_f16",
+    "gfx950_unpack", "sm80_reader_unpack", "ref_gemv_sm80", "w8a16_gemm", "w8a16_gemm_bias_act", "w8a16_gemm_f32acc", "dequant", "rmsnorm_f16", "rotary_neox_f16",
     "f32_to_f16_bits", "f16_bits_to_f32",
 ]
 
@@ -38,6 +38,7 @@ def lib():
             getattr(L, name).argtypes = [vp, sz, sz, vp]
             getattr(L, name).restype = i32
         L.oracle_w8a16_gemm.argtypes = [vp, vp, vp, vp, sz, sz, sz]
+        L.oracle_w8a16_gemm_bias_act.argtypes = [vp, vp, vp, vp, i32, vp, sz, sz, sz]
         L.oracle_ref_gemv_sm80.argtypes = [vp, vp, vp, vp, sz, sz, sz]
         L.oracle_ref_gemv_sm80.restype = i32
         L.oracle_w8a16_gemm_f32acc.argtypes = [vp, vp, vp, vp, sz, sz, sz]
@@ -154,6 +155,21 @@ def _gemm(fn, x, q_raw, scales):
 def w8a16_gemm(x, q_raw, scales):
     """Contract y = fp16(sum_k fp32(x) * fp32(fp16(q*s))) with exact (double) accumulation."""
     return _gemm(lib().oracle_w8a16_gemm, x, q_raw, scales)
+
+
+def w8a16_gemm_bias_act(x, q_raw, scales, bias, act):
+    """FT bias + activation epilogue: fp16(act(acc + bias)); act in {"relu", "gelu", "silu"}; bias may be None."""
+    x = _c(x, np.float16)
+    q_raw = _c(q_raw, np.int8)
+    scales = _c(scales, np.float16)
+    M, K = x.shape
+    K2, N = q_raw.shape
+    assert K == K2 and scales.shape == (N,)
+    b = _c(bias, np.float16) if bias is not None else None
+    y = np.empty((M, N), np.float16)
+    lib().oracle_w8a16_gemm_bias_act(_p(x), _p(q_raw), _p(scales), _p(b) if b is not None else None,
+                                     {"relu": 1, "gelu": 2, "silu": 3}[act], _p(y), M, N, K)
+    return y
 
 
 def w8a16_gemm_f32acc(x, q_raw, scales):

@@ -67,3 +67,35 @@ def test_no_oracle_in_product():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(import|from)\s+oracle\b", text, flags=re.M), f
                 assert "eetq_oracle" not in text and "liboracle" not in text, f
+
+
+def test_compiled_operator_module_surface():
+    """The drop-in boundary is a COMPILED module named EETQ with the reference's six functions (csrc/eetpy.cpp:9-19):
+    same names, positional order, keyword names and defaults."""
+    import inspect
+    from eetq_amd import _ext
+    mod = _ext.load()
+    assert mod.__name__ == "EETQ" and mod.__file__.endswith(".so")
+    import EETQ
+    assert EETQ is mod
+    for name in ("w8_a16_gemm", "w8_a16_gemm_", "preprocess_weights", "quant_weights", "rotary_embedding_neox",
+                 "layernorm_forward"):
+        assert type(getattr(EETQ, name)).__name__ == "builtin_function_or_method", name
+    doc = EETQ.quant_weights.__doc__
+    assert "origin_weight" in doc and "quant_type" in doc and "return_unprocessed_quantized_tensor: bool = False" in doc
+    doc = EETQ.preprocess_weights.__doc__
+    assert "origin_weight" in doc and "is_int4: bool = False" in doc
+    assert EETQ.w8_a16_gemm.__doc__.startswith("w8_a16_gemm(input: torch.Tensor, weight: torch.Tensor, scale: torch.Tensor")
+    # errors are RuntimeError, raised before any GPU work
+    import torch
+    with pytest.raises(RuntimeError, match="int4 or int8"):
+        EETQ.quant_weights(torch.zeros(64, 64, dtype=torch.float16), torch.float16)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        EETQ.w8_a16_gemm(torch.zeros(1, 64, dtype=torch.float16), torch.zeros(64, 64, dtype=torch.int8),
+                         torch.zeros(64, dtype=torch.float16))
+    with pytest.raises(TypeError):
+        EETQ.w8_a16_gemm(torch.zeros(1, 64))           # wrong arity is a TypeError, as with the reference's pybind module
+    from eetq_amd import ops
+    if os.environ.get("EETQ_AMD_BOUNDARY", "") != "ctypes":
+        assert ops.BOUNDARY == "ext" and ops.w8_a16_gemm is EETQ.w8_a16_gemm
+    del inspect

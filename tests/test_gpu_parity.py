@@ -446,6 +446,32 @@ def test_fused_residual_is_bit_identical_to_separate_adds(ops, oracle, M, path):
         ops.w8_a16_gemm(xd, processed, scales, residual=res[:, :-16].contiguous())
 
 
+@pytest.mark.parametrize("M,path", [(1, "auto"), (3, "gemv"), (8, "auto"), (33, "stream"), (64, "mid"), (100, "mid"),
+                                    (200, "mfma"), (1024, "auto")])
+@pytest.mark.parametrize("act", ["relu", "gelu", "silu"])
+def test_activation_epilogues_vs_oracle(ops, oracle, M, path, act):
+    """Bias + activation epilogue (FT family: fpA_intB_gemm.cu:35-62, epilogue_helpers.h:20-71) in every kernel:
+    fp16(act(acc + bias)), sum and activation in fp32, against the oracle's restatement; plus no-bias and + residual."""
+    K, N = 1024, 320
+    w, x = _rand_case(K, N, M, seed=M + len(act), wscale=0.05)
+    x = (x - 0.5).astype(np.float16)                 # both signs, so every activation sees its whole domain
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    bias = (np.random.default_rng(5).standard_normal(N) * 0.5).astype(np.float16)
+    xd, bd = torch.from_numpy(x).to(DEV), torch.from_numpy(bias).to(DEV)
+    y = ops.w8_a16_gemm(xd, processed, scales, path=path, bias=bd, activation=act).cpu().numpy()
+    ref = oracle.w8a16_gemm_bias_act(x, q, s, bias, act)
+    assert _tier_a(y, ref).all(), np.abs(y.astype(np.float32) - ref.astype(np.float32)).max()
+    y0 = ops.w8_a16_gemm(xd, processed, scales, path=path, activation=act).cpu().numpy()
+    assert _tier_a(y0, oracle.w8a16_gemm_bias_act(x, q, s, None, act)).all()
+    if act == "relu":
+        assert (y >= 0).all() and (y == 0).any()
+    res = torch.from_numpy((np.random.default_rng(6).standard_normal((M, N))).astype(np.float16)).to(DEV)
+    yr = ops.w8_a16_gemm(xd, processed, scales, path=path, bias=bd, residual=res, activation=act)
+    assert torch.equal(yr, torch.from_numpy(y).to(DEV) + res)     # residual: an fp16 add after the activation
+
+
 def test_fuse_w8a16_linears_qkv(ops):
     """one launch over concatenated output channels == the three separate launches, bit for bit."""
     from eetq_amd.modules.qlinear import W8A16Linear

@@ -289,3 +289,25 @@ def test_rotary_against_torch(oracle):
         return torch.cat([x * c - y * s, y * c + x * s], -1)
     assert np.allclose(qo.astype(np.float32), rot(q).numpy(), atol=4e-3, rtol=4e-3)
     assert np.allclose(ko.astype(np.float32), rot(k).numpy(), atol=4e-3, rtol=4e-3)
+
+
+def test_activation_epilogue_restatement(oracle):
+    """fp16(act(acc + bias)) against numpy: ReLU exact, GELU (tanh form) and SiLU to fp16 rounding; with act applied to a
+    value the fp16 identity epilogue would have rounded first, the two differ -- that is the point of the fp32 epilogue."""
+    rng = np.random.default_rng(21)
+    K, N, M = 256, 64, 5
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float16)
+    q, s = oracle.quantize(w)
+    x = rng.standard_normal((M, K)).astype(np.float16)
+    bias = rng.standard_normal(N).astype(np.float16)
+    acc = x.astype(np.float64) @ oracle.dequant(q, s).astype(np.float64)
+    z = acc.astype(np.float32) + bias.astype(np.float32)[None, :]
+    z64 = z.astype(np.float64)
+    want = {"relu": np.maximum(z64, 0.0),
+            "gelu": 0.5 * z64 * (1.0 + np.tanh(0.7978845608028654 * z64 * (1.0 + 0.044715 * z64 * z64))),
+            "silu": z64 / (1.0 + np.exp(-z64))}
+    for act, ref in want.items():
+        got = oracle.w8a16_gemm_bias_act(x, q, s, bias, act)
+        assert np.array_equal(got, ref.astype(np.float32).astype(np.float16)), act
+    nob = oracle.w8a16_gemm_bias_act(x, q, s, None, "relu")
+    assert np.array_equal(nob, np.maximum(acc.astype(np.float32), 0).astype(np.float16))
