@@ -274,6 +274,7 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
         case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_MID: return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
+        case EETQ_PATH_SPLITK: return launch_gemm_splitk(xp, wp, sp, bp, yp, M, N, K, s);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] unknown or unimplemented GEMM path");
     }
 }

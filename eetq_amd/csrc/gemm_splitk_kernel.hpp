@@ -1,0 +1,319 @@
+// Kernel template of the split-K medium-batch (17 <= M <= 128) MFMA dequant-GEMM (included by gemm_splitk.hip and
+// tools/kbench.hip).
+//
+// Why split K.  At these M the time of gemm_mid_kernel is not the weight stream but what ONE compute unit can pull in
+// through its vector memory path (~57 B/clk = ~120 GB/s): a workgroup that owns BN columns re-reads all of x (M x K fp16)
+// next to its BN x K weight bytes, and only N / BN workgroups exist.  N = K = 4096, M = 64, BN = 32: 128 workgroups pull
+// 512 + 128 KiB each (5.3 us at 120 GB/s) while half the chip idles.  The bytes every CU must ingest are
+//     ((N / BN) * M * K * 2  +  N * K) / CUs in use,
+// so the lever is wider column blocks (fewer re-reads of x) TOGETHER with enough workgroups to use every CU: BN = 64 and
+// the K range cut into S slices gives (N / 64) * S workgroups that ingest (M * 2 + 64) * K / S bytes each -- 192 KiB at
+// S = 4 for the shape above (1.6 us), below the time the 16 MiB weight stream takes.
+//
+// Structure (per workgroup, 4 waves): the medium-batch tile of gemm_mid_kernel.hpp with NB column blocks of 32 --
+// (32*MT rows) x (32*NB columns) x 256-deep K step, wave j owns k tile j of the step for all rows and columns
+// (v_mfma_f32_32x32x16_f16, weights as the A operand: 4*MT*NB MFMAs per wave per step, every dequantised fragment feeds
+// MT MFMAs, every activation fragment NB); x and the weight tiles go L2/HBM -> LDS by LDS-DMA through a 2- or 3-deep ring,
+// x XOR-swizzled through the source address; the four k quarters are added through LDS at the end.
+//
+// The cross-workgroup reduction is in-launch and deterministic (no float atomics; replicas stay bit-identical):
+//   * every slice writes its fp32 partial tile (a "slab", 4*MT*NB KiB) with WRITE-THROUGH 16-byte stores
+//     (buffer_store_dwordx4 ... sc1), every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier,
+//     one lane takes a ticket with a relaxed agent-scope atomic add on the tile's counter;
+//   * the slice that draws the last ticket reads ALL S slabs of the tile back (sc1 loads: served below the per-CU L1,
+//     and the XCD's L2 cannot hold an older copy -- slab lines are only ever written in a launch before they are read, and
+//     kernel boundaries invalidate) and adds them in slice order 0..S-1, whichever slice it is itself and whatever the
+//     arrival order was: the sum is a function of the data alone.  Then the usual epilogue.
+//   * counters are monotonic: a tile's counter grows by exactly S per launch, "last" is (old & (S-1)) == S-1; they are
+//     zeroed once when the scratch buffer is created and never reset.
+// This is the hand-off of cdna_hip_programming.md (section 5, "in-launch split-K reduction", write-through form): no
+// placement or dispatch-order assumption; the block-id -> (tile, slice) map below only makes a tile's slices neighbours
+// on one XCD when the dispatcher places block b on XCD b % 8 (a speed matter).
+#pragma once
+#include "common.hpp"
+#include "gemm_kernel.hpp"
+
+namespace eetq {
+namespace gemm_splitk {
+
+constexpr int kBK      = 256;
+constexpr int kThreads = 256;
+constexpr int kMaxSlices = 4;
+
+template <int MT, int NB, int STAGES>
+struct Cfg {
+    static constexpr int kRows   = 32 * MT;
+    static constexpr int kBN     = 32 * NB;
+    static constexpr int kABytes = kRows * kBK * 2;
+    static constexpr int kBBytes = kBN * kBK;
+    static constexpr int kStage  = kABytes + kBBytes;
+    static constexpr int kStages = STAGES;
+    static constexpr int kRed    = 4 * MT * NB * 16 * 64 * 4;           // end-of-kernel cross-wave reduction area
+    static constexpr int kSmem   = kStages * kStage;                     // >= kRed + 16 for every MT, NB, STAGES >= 2
+    static_assert(kStages * kStage >= kRed + 16, "the reduction area and the ticket word must fit the ring");
+    static constexpr int kAPW    = kABytes / 1024 / 4;                   // A pieces (2 rows of 512 B) per wave and stage
+    static constexpr int kBPW    = kBBytes / 1024 / 4;                   // B pieces (native 1 KiB tiles) per wave and stage
+    static constexpr int kPieces = kAPW + kBPW;
+    static constexpr int kSlabFloats = kRows * kBN;                      // fp32 partial tile of one slice
+};
+
+// grid = tiles_n * S workgroups (all of M in one row tile: M <= 32*MT).  slabs: [tiles_n][S][kSlabFloats] floats,
+// counters: [tiles_n] unsigned (both unused when S == 1).
+template <int MT, int NB, int STAGES, bool KFULL>
+__global__ __launch_bounds__(kThreads, (Cfg<MT, NB, STAGES>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
+    int N, int K, int S, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
+{
+    using C = Cfg<MT, NB, STAGES>;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int tid  = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = tid & 63;
+    const int KT   = K >> 6;
+    const int steps_total = (KT + 3) >> 2;
+
+    // ---- block id -> (column tile, K slice): a tile's slices are consecutive ids on one XCD when tiles_n % 8 == 0 ----
+    const int tiles_n = (N + C::kBN - 1) / C::kBN;
+    int       tile, slice;
+    if ((tiles_n & 7) == 0) {
+        const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+        slice = j % S;
+        tile  = (j / S) * 8 + xcd;
+    } else {
+        slice = blockIdx.x % S;
+        tile  = blockIdx.x / S;
+    }
+    const int n0 = tile * C::kBN;
+    // K steps of this slice: [s0, s1); slices differ by at most one step
+    const int s0 = (int)(((long)steps_total * slice) / S), s1 = (int)(((long)steps_total * (slice + 1)) / S);
+    const int n_tiles_total = N >> 4;
+
+    const __amdgpu_buffer_rsrc_t x_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, (int)((size_t)M * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(w), 0, (int)((size_t)N * K), 0x00020000);
+
+    // ---- DMA pieces of this wave (roles fixed per index: no run-time branch per piece) ----
+    //   i < kAPW : A piece p = wave*kAPW + i  -> rows 2p, 2p+1 (512 B each)
+    //   else     : B piece b = wave*kBPW + (i - kAPW) -> 16-column tile b>>2, k tile b&3 of the step
+    int dma_voff[C::kPieces];
+#pragma unroll
+    for (int i = 0; i < C::kPieces; ++i) {
+        if (i < C::kAPW) {
+            const int p    = wave * C::kAPW + i;
+            const int row  = 2 * p + (lane >> 5);
+            const int slot = (lane & 31) ^ (row & 15);  // source slot for this LDS slot
+            int       gm   = row;
+            gm             = gm < M ? gm : M - 1;
+            dma_voff[i]    = (gm * K + slot * 8) * 2;
+        } else {
+            const int b  = wave * C::kBPW + (i - C::kAPW);
+            int       nt = (n0 >> 4) + (b >> 2);
+            nt           = nt < n_tiles_total ? nt : n_tiles_total - 1;
+            dma_voff[i]  = (nt * KT + (b & 3)) * kTileBytes + lane * 16;  // + step*4 tiles
+        }
+    }
+    auto issue_stage = [&](int buf, int step) {
+        uint8_t* sa = smem + buf * C::kStage;
+#pragma unroll
+        for (int i = 0; i < C::kPieces; ++i) {
+            if (i < C::kAPW) {
+                // the last step of a K that is not a multiple of 256 reads past the row end into the next row (or is
+                // zero-filled by the descriptor bounds check at the very end): those k tiles are never multiplied
+                gemm::dma16(x_rsrc, dma_voff[i], step * kBK * 2, sa + (wave * C::kAPW + i) * 1024);
+            } else {
+                const int b    = wave * C::kBPW + (i - C::kAPW);
+                const int kt   = step * 4 + (b & 3);
+                const int back = kt < KT ? 0 : (kt - (KT - 1)) * kTileBytes;  // clamp to the last valid k tile
+                gemm::dma16(w_rsrc, dma_voff[i] - back, step * 4 * kTileBytes, sa + C::kABytes + b * 1024);
+            }
+        }
+    };
+
+    // ---- fragment addressing: lane (fn, fh); this wave owns k tile `wave` of every step ----
+    const int fn = lane & 31, fh = lane >> 5;
+    // weight fragment of column block nb: 16-column tile (2*nb + (fn >> 4)), k tile `wave`
+    const int b_off = C::kABytes + ((fn >> 4) * 4 + wave) * 1024 + (fn & 15) * 16 + fh * 256;  // + nb*8192 + s*512
+    const int a_key = fn & 15;
+    int       a_slot[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int e = 0; e < 2; ++e) a_slot[s][e] = ((8 * wave + 4 * s + 2 * fh + e) ^ a_key) << 4;
+    const int a_row_off = fn * 512;
+
+    f16x2 scale2[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) {
+        const int ncol = n0 + 32 * nb + fn;
+        const f16 sc   = scales[ncol < N ? ncol : N - 1];
+        scale2[nb]     = f16x2{sc, sc};
+    }
+
+    f32x16 acc[MT][NB];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[mt][nb][i] = 0.f;
+
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(scale2[nb]));
+    if (s0 < s1) issue_stage(0, s0);
+    if (C::kStages == 3 && s0 + 1 < s1) issue_stage(1, s0 + 1);
+    int buf = 0;
+    for (int step = s0; step < s1; ++step) {
+        // this wave's pieces of the current stage have landed (a younger stage may stay in flight with a 3-deep ring)
+        if (C::kStages == 3 && step + 1 < s1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::kPieces) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... everyone's have; everyone is done with the buffer refilled below
+        const bool     active = KFULL || step * 4 + wave < KT;  // wave-uniform: k tile beyond K on the last step
+        const uint8_t* sa     = smem + buf * C::kStage;
+        // order inside a step as in gemm_mid_kernel: all fragment reads, then this wave's DMA pieces of the stage
+        // kStages-1 steps ahead (they run under the LDS read latency), then dequant + MFMA
+        u32x4 wq[NB][2];
+        f16x8 xa[2][2][MT];
+        if (active) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) wq[nb][s] = *reinterpret_cast<const u32x4*>(sa + b_off + nb * 8192 + s * 512);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        xa[s][e][mt] = *reinterpret_cast<const f16x8*>(sa + mt * 32 * 512 + a_row_off + a_slot[s][e]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (step + C::kStages - 1 < s1) {
+            int nbuf = buf + C::kStages - 1;
+            nbuf     = nbuf >= C::kStages ? nbuf - C::kStages : nbuf;
+            issue_stage(nbuf, step + C::kStages - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(wq[nb][0]), "+v"(wq[nb][1]));  // reads stay above the dequant
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f16x2 wd[8];
+                    dequant_16(wq[nb][s], scale2[nb], wd);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const f16x8 wf = gemm::make_frag(wd[4 * e], wd[4 * e + 1], wd[4 * e + 2], wd[4 * e + 3]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xa[s][e][mt], acc[mt][nb], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        buf = buf + 1 == C::kStages ? 0 : buf + 1;
+    }
+
+    // ---- add the four k quarters through LDS; wave q then owns accumulator registers 4q..4q+3 of every block ----
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(smem);  // [wave][mt][nb][reg][lane]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(((wave * MT + mt) * NB + nb) * 16 + r) * 64 + lane] = acc[mt][nb][r];
+    __syncthreads();
+    // s4[mt][nb][i] = partial y[32*mt + fn][n0 + 32*nb + 8*wave + 4*fh + i]
+    float s4[MT][NB][4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float s = 0.f;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s += red[(((q * MT + mt) * NB + nb) * 16 + 4 * wave + i) * 64 + lane];
+                s4[mt][nb][i] = s;
+            }
+
+    if (S > 1) {
+        // ---- publish this slice's partial tile (write-through), take a ticket ----
+        const size_t tile_floats = (size_t)S * C::kSlabFloats;
+        const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            slabs + (size_t)tile * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
+        // float4 index inside a slab: ((mt*NB + nb)*4 + wave)*64 + lane
+        const int lane_off = (wave * 64 + lane) * 16;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const u32x4 v = {__builtin_bit_cast(u32, s4[mt][nb][0]), __builtin_bit_cast(u32, s4[mt][nb][1]),
+                                 __builtin_bit_cast(u32, s4[mt][nb][2]), __builtin_bit_cast(u32, s4[mt][nb][3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, s_rsrc, (mt * NB + nb) * 4096 + lane_off,
+                                                       slice * C::kSlabFloats * 4, /*sc1*/ 16);
+            }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores
+        __syncthreads();
+        unsigned* flag = reinterpret_cast<unsigned*>(smem + C::kSmem - 16);  // inside the one dynamic LDS array
+        if (tid == 0)
+            *flag = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const unsigned ticket = *flag;
+        if ((ticket & (unsigned)(S - 1)) != (unsigned)(S - 1)) return;  // not the last slice of this tile
+        // ---- last arriver: all S slabs, summed in slice order (its own one read back like the others) ----
+        u32x4 part[kMaxSlices][MT][NB];
+#pragma unroll
+        for (int s = 0; s < kMaxSlices; ++s) {
+            const int ss = s < S ? s : S - 1;  // clamped, predicated use: no load behind a branch
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb)
+                    part[s][mt][nb] = __builtin_amdgcn_raw_buffer_load_b128(s_rsrc, (mt * NB + nb) * 4096 + lane_off,
+                                                                            ss * C::kSlabFloats * 4, /*sc1*/ 16);
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float t = __builtin_bit_cast(float, (u32)part[0][mt][nb][i]);
+#pragma unroll
+                    for (int s = 1; s < kMaxSlices; ++s) {
+                        const float v = __builtin_bit_cast(float, (u32)part[s][mt][nb][i]);
+                        t             = s < S ? t + v : t;
+                    }
+                    s4[mt][nb][i] = t;
+                }
+    }
+
+    // ---- epilogue ----
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 32 * mt + fn;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const int ncol = n0 + 32 * nb + 8 * wave + 4 * fh;
+            if (m < M && ncol < N) {
+                f16x2 lo, hi;
+                finish_quad(s4[mt][nb], ep, ncol, lo, hi);
+                if (ep.residual) {
+                    const u32x2 r = *reinterpret_cast<const u32x2*>(ep.residual + (size_t)m * N + ncol);
+                    lo            = lo + as_f16x2(r.x);
+                    hi            = hi + as_f16x2(r.y);
+                }
+                *reinterpret_cast<u32x2*>(y + (size_t)m * N + ncol) = u32x2{as_u32(lo), as_u32(hi)};
+            }
+        }
+    }
+}
+
+}  // namespace gemm_splitk
+}  // namespace eetq

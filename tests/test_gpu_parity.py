@@ -176,6 +176,59 @@ def test_mid_tile_vs_oracle(ops, oracle, M, K, N):
                                           np.argwhere(~ok)[:4])
 
 
+@pytest.mark.parametrize("M", [1, 17, 32, 33, 48, 64, 65, 100, 128])
+@pytest.mark.parametrize("K,N", [(256, 32), (512, 80), (1024, 256), (4096, 512), (4096, 4096), (11008, 64), (2048, 48),
+                                 (2112, 144), (5120, 5120), (1280, 11008)])
+def test_splitk_tile_vs_oracle(ops, oracle, M, K, N):
+    """Split-K medium-batch kernel (planned column-block width / slice count per shape): ragged N and K, every row-tile
+    count, shapes that plan to 1, 2 and 4 slices; against the oracle (sampled columns for the big shapes)."""
+    w, x = _rand_case(K, N, M, seed=M * 13 + K + N)
+    cols = np.arange(N) if N <= 512 else np.unique(np.concatenate([np.arange(48), np.arange(N - 48, N),
+                                                                    np.random.default_rng(N).integers(0, N, 160)]))
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    y = ops.w8_a16_gemm(torch.from_numpy(x).to(DEV), processed, torch.from_numpy(s).to(DEV), path="splitk").cpu().numpy()
+    ref = oracle.w8a16_gemm(x, np.ascontiguousarray(q[:, cols]), np.ascontiguousarray(s[cols]))
+    assert y.shape == (M, N)
+    assert _tier_a(y[:, cols], ref).all(), np.abs(y[:, cols].astype(np.float32) - ref.astype(np.float32)).max()
+
+
+def test_splitk_is_deterministic_and_back_to_back_safe(ops, oracle):
+    """The in-launch reduction adds the slices' partial tiles in slice order whatever the arrival order: 200 back-to-back
+    launches (tickets are monotonic and never reset) on two shapes give bit-identical results every time, also when
+    interleaved with other kernels and replayed from a HIP graph."""
+    w, x = _rand_case(4096, 4096, 64, seed=7)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    first = ops.w8_a16_gemm(xd, processed, scales, path="splitk")
+    ref = oracle.w8a16_gemm(x[:4], q, s)
+    assert _tier_a(first[:4].cpu().numpy(), ref).all()
+    x2 = xd[:40, :2048].contiguous()
+    p2 = ops.preprocess_weights(torch.from_numpy(np.ascontiguousarray(q[:2048, :1024])).to(DEV))
+    first2 = ops.w8_a16_gemm(x2, p2, scales[:1024].contiguous(), path="splitk")
+    for i in range(200):
+        assert torch.equal(ops.w8_a16_gemm(xd, processed, scales, path="splitk"), first), i
+        if i % 3 == 0:
+            assert torch.equal(ops.w8_a16_gemm(x2, p2, scales[:1024].contiguous(), path="splitk"), first2), i
+    y = torch.empty_like(first)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.w8_a16_gemm_(xd, processed, scales, y, 64, 4096, 4096)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(5):
+            ops.w8_a16_gemm_(xd, processed, scales, y, 64, 4096, 4096)
+    for _ in range(20):
+        y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, ops.w8_a16_gemm(xd, processed, scales))
+
+
 @pytest.mark.parametrize("M,K,N", [(5, 64, 16), (8, 256, 128), (17, 128, 144), (64, 1024, 256), (128, 512, 128),
                                    (130, 192, 272), (300, 2048, 384), (8, 4096, 4096), (64, 4096, 1024),
                                    # narrow (128 x 64) and wide tiles with ragged edges: N below / not a multiple of the

@@ -18,6 +18,7 @@
 #include "../eetq_amd/csrc/gemm_kernel.hpp"
 #include "../eetq_amd/csrc/streamk_kernel.hpp"
 #include "../eetq_amd/csrc/gemm_mid_kernel.hpp"
+#include "../eetq_amd/csrc/gemm_splitk_kernel.hpp"
 
 namespace eetq {  // stubs for the error plumbing declared in common.hpp (unused by the kernels)
 void set_error(const std::string&) {}
@@ -258,6 +259,33 @@ static void bench_mid(const char* name, int M, int N, int K, const std::vector<u
            st.mean, st.med, st.mn, bytes / st.med / 1e3, 2.0 * M * N * K / st.med / 1e6);
 }
 
+
+template <int MT, int NB, int STAGES>
+static void bench_splitk(const char* name, int M, int N, int K, int S, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
+                         const eetq::f16* scales, eetq::f16* y, float* slabs, unsigned* tickets)
+{
+    using namespace eetq::gemm_splitk;
+    using C   = Cfg<MT, NB, STAGES>;
+    auto kern = gemm_splitk_kernel<MT, NB, STAGES, true>;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    const int    tiles = (N + C::kBN - 1) / C::kBN;
+    const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
+    auto st = time_dispatch(
+        [&](int i, hipEvent_t a, hipEvent_t b) {
+            hipExtLaunchKernelGGL(kern, dim3(tiles * S), dim3(kThreads), C::kSmem, 0, a, b, 0, x,
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, S, slabs, tickets, eetq::Epilogue{});
+        },
+        200);
+    const double g = time_graph(
+        [&](int i, hipStream_t s) {
+            hipLaunchKernelGGL(kern, dim3(tiles * S), dim3(kThreads), C::kSmem, s, x, (const uint8_t*)bufs[i % bufs.size()],
+                               scales, y, M, N, K, S, slabs, tickets, eetq::Epilogue{});
+        },
+        200);
+    printf("%-26s N=%5d K=%5d M=%3d BN=%2d S=%d st=%d wg=%4d | disp mean %6.2f med %6.2f min %6.2f | graph step %6.2f us -> %6.0f GB/s(med) %6.1f TF\n",
+           name, N, K, M, 32 * NB, S, STAGES, tiles * S, st.mean, st.med, st.mn, g, bytes / st.med / 1e3,
+           2.0 * M * N * K / st.med / 1e6);
+}
 
 // ---- data-path probe: how many bytes per second can one CU pull from L2 (a) into LDS by LDS-DMA, (b) into registers?
 // Every workgroup streams PER_WG bytes out of a `region`-byte window (window <= 4 MiB: L2-resident after the first pass;
@@ -731,6 +759,55 @@ int main(int argc, char** argv)
             hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
                                (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{}, eetq::Prologue{});
         CK(hipDeviceSynchronize());
+    }
+    if (!strcmp(what, "splitk")) {
+        printf("--- split-K medium-batch kernel vs the unsplit tile ---\n");
+        eetq::f16 *xs, *ys;
+        CK(hipMalloc(&xs, 128ull * 13824 * 2));
+        CK(hipMalloc(&ys, 128ull * 13824 * 2));
+        {
+            std::vector<uint16_t> h(128ull * 13824);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
+            CK(hipMemcpy(xs, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        float*    slabs;
+        unsigned* tickets;
+        CK(hipMalloc(&slabs, 64ull << 20));
+        CK(hipMalloc(&tickets, 4096 * 4));
+        CK(hipMemset(tickets, 0, 4096 * 4));
+        bench_mid<2, 3>("mid MT2 (round 1)", 64, 4096, 4096, bufs, xs, scales, ys);
+        bench_splitk<2, 1, 3>("splitk", 64, 4096, 4096, 1, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 3>("splitk", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 2>("splitk", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 2>("splitk", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3>("splitk", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3>("splitk", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2>("splitk", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        printf("\n");
+        bench_mid<1, 3>("mid MT1 (round 1)", 32, 4096, 4096, bufs, xs, scales, ys);
+        bench_splitk<1, 1, 3>("splitk", 32, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 2, 3>("splitk", 32, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 2, 3>("splitk", 32, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 2, 2>("splitk", 17, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        printf("\n");
+        bench_mid<4, 2>("mid MT4 (round 1)", 128, 4096, 4096, bufs, xs, scales, ys);
+        bench_splitk<4, 1, 2>("splitk", 128, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 2, 2>("splitk", 128, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 2, 2>("splitk", 128, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<3, 2, 2>("splitk", 96, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        printf("\n");
+        bench_mid<2, 3>("mid MT2 K=11008 (r1)", 64, 4096, 11008, bufs_big, xs, scales, ys);
+        bench_splitk<2, 1, 2>("splitk K=11008", 64, 4096, 11008, 2, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3>("splitk K=11008", 64, 4096, 11008, 4, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2>("splitk K=11008", 64, 4096, 11008, 4, bufs_big, xs, scales, ys, slabs, tickets);
+        printf("\n");
+        bench_mid<2, 2>("mid MT2 N=11008 (r1)", 64, 11008, 4096, bufs_big, xs, scales, ys);
+        bench_splitk<2, 1, 2>("splitk N=11008", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2>("splitk N=11008", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2>("splitk N=11008", 64, 11008, 4096, 2, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3>("splitk N=11008", 64, 11008, 4096, 2, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 2, 2>("splitk N=11008 M=128", 128, 11008, 4096, 2, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 2, 2>("splitk N=11008 M=128", 128, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
     }
     if (!strcmp(what, "all") || !strcmp(what, "mid")) {
         printf("--- medium-batch tile kernel (32-column tiles, 256-deep K steps) ---\n");
