@@ -57,12 +57,12 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
     return EETQ_OK;
 }
 
-template <int MT, int NB, int STAGES, bool KFULL>
+template <int MT, int NB, int D, bool KFULL>
 int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    using C   = gemm_splitk::Cfg<MT, NB, STAGES>;
-    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, STAGES, KFULL>;
+    using C   = gemm_splitk::Cfg<MT, NB, D>;
+    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, D, KFULL>;
     if (C::kSmem > 64 * 1024) {
         static std::atomic<unsigned long long> opted{0};
         int st = opt_in_large_lds(kern, opted);
@@ -83,28 +83,22 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     return check_hip(hipGetLastError(), "gemm_splitk_kernel launch");
 }
 
-template <int MT, int NB, int STAGES>
+template <int MT, int NB, int D>
 int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    return K % gemm_splitk::kBK == 0 ? launch_full<MT, NB, STAGES, true>(x, w, scales, ep, y, M, N, K, S, stream)
-                                     : launch_full<MT, NB, STAGES, false>(x, w, scales, ep, y, M, N, K, S, stream);
+    return K % 256 == 0 ? launch_full<MT, NB, D, true>(x, w, scales, ep, y, M, N, K, S, stream)
+                        : launch_full<MT, NB, D, false>(x, w, scales, ep, y, M, N, K, S, stream);
 }
 
+// steps in flight per wave: as many as the LDS ring (16*MT KiB per step and workgroup) and the 6-bit vmcnt allow
 template <int MT>
 int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int nb, int S,
-              int stages, hipStream_t stream)
+              hipStream_t stream)
 {
-    if (nb == 2) {
-        if constexpr (MT <= 2) {
-            if (stages == 3) return launch_inst<MT, 2, 3>(x, w, scales, ep, y, M, N, K, S, stream);
-        }
-        return launch_inst<MT, 2, 2>(x, w, scales, ep, y, M, N, K, S, stream);
-    }
-    if constexpr (MT <= 2) {
-        if (stages == 3) return launch_inst<MT, 1, 3>(x, w, scales, ep, y, M, N, K, S, stream);
-    }
-    return launch_inst<MT, 1, 2>(x, w, scales, ep, y, M, N, K, S, stream);
+    constexpr int D = MT == 1 ? 4 : MT == 2 ? 4 : MT == 3 ? 3 : 2;
+    if (nb == 2) return launch_inst<MT, 2, D>(x, w, scales, ep, y, M, N, K, S, stream);
+    return launch_inst<MT, 1, D>(x, w, scales, ep, y, M, N, K, S, stream);
 }
 
 }  // namespace
@@ -113,7 +107,7 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
 // ~57 B/clk vector memory path bounds these shapes, so the plan minimises the busiest CU's bytes:
 //     rounds(workgroups / CUs) * ((32*MT*2 + 32*NB) * K / S)        [+ the reduction's slab traffic when S > 1]
 // subject to >= 2 K steps per slice.  Measured on MI355X: profiles/r02_kbench_splitk.txt.
-void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out)
+void splitk_plan(int M, int N, int K, int* nb_out, int* s_out)
 {
     const int  MT    = (M + 31) / 32;
     const int  ncu   = device_cu_count();
@@ -141,9 +135,6 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out)
     }
     *nb_out = bnb;
     *s_out  = bs;
-    // ring depth: 3 when one workgroup per CU is all there is (deeper prefetch), else 2 (two workgroups can share a CU)
-    const int tiles = (N + 32 * bnb - 1) / (32 * bnb);
-    *stages_out     = (MT <= 2 && tiles * bs <= ncu) ? 3 : 2;
 }
 
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
@@ -152,17 +143,16 @@ int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilog
     if (M < 1 || M > kMidMaxM) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] split-K tile path supports 1 <= M <= 128");
     EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31),
                  "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
-    int nb, s, stages;
-    splitk_plan(M, N, K, &nb, &s, &stages);
+    int nb, s;
+    splitk_plan(M, N, K, &nb, &s);
     if (force_nb) nb = force_nb;
     if (force_s) s = force_s;
-    if (force_nb || force_s) stages = ((M + 31) / 32 <= 2 && ((N + 32 * nb - 1) / (32 * nb)) * s <= device_cu_count()) ? 3 : 2;
     EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4), "invalid split-K plan");
     switch ((M + 31) / 32) {
-        case 1: return launch_mt<1>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
-        case 2: return launch_mt<2>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
-        case 3: return launch_mt<3>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
-        default: return launch_mt<4>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
+        case 1: return launch_mt<1>(x, w, scales, ep, y, M, N, K, nb, s, stream);
+        case 2: return launch_mt<2>(x, w, scales, ep, y, M, N, K, nb, s, stream);
+        case 3: return launch_mt<3>(x, w, scales, ep, y, M, N, K, nb, s, stream);
+        default: return launch_mt<4>(x, w, scales, ep, y, M, N, K, nb, s, stream);
     }
 }
 
