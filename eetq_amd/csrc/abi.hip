@@ -1,6 +1,7 @@
 // extern "C" boundary of libeetq_amd.so (declarations + reference citations: include/eetq_amd.h).
 // Stateless apart from (a) the thread-local last-error string and (b) a per-device scratch buffer for the
 // quantiser's column maxima (N floats), so the reference's "no workspace argument" signature is kept.
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -267,6 +268,14 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
                 // activations once per 64 columns instead of once per 32 (N = 11008: M = 64 17.5 vs 20.2 us, M = 128
                 // 21.9 vs 40.4 us; N = 4096: 15.9 vs 11.1 us the other way; profiles/r01_kbench_tile_shapes.txt)
                 if (M >= 33 && (N + 63) / 64 >= 160 && K >= 320) return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
+                // narrower N: the split-K tile (K slices + in-launch deterministic reduction; N = K = 4096: M = 64 8.8 vs
+                // 11.2 us, M = 128 14.0 vs 20.2, K = 11008 16.3 vs 28.0; profiles/r02_kbench_splitk.txt).  EETQ_AMD_SPLITK=0
+                // keeps the unsplit tile (the split form owns per-stream scratch; see gemm_splitk.hip)
+                static const bool use_splitk = [] {
+                    const char* e = getenv("EETQ_AMD_SPLITK");
+                    return !(e && e[0] == '0');
+                }();
+                if (use_splitk) return launch_gemm_splitk(xp, wp, sp, bp, yp, M, N, K, s);
                 return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
             }
             return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);

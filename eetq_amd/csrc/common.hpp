@@ -220,6 +220,6 @@ int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, Epilogue 
 // split-K form of the medium-batch tile (gemm_splitk.hip); force_nb / force_s (0 = planned) are tuning hooks
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                        hipStream_t stream, int force_nb = 0, int force_s = 0);
-void splitk_plan(int M, int N, int K, int* nb, int* s);
+void splitk_plan(int M, int N, int K, int* nb, int* s, int* stages);
 
 }  // namespace eetq

@@ -17,7 +17,7 @@ namespace {
 // on one stream but replayed concurrently on several, set EETQ_AMD_SPLITK=0 (the dispatcher then uses the unsplit kernels).
 constexpr int    kRegions       = 16;
 constexpr size_t kRegionSlabs   = 40ull << 20;  // bytes of fp32 partial tiles per region (largest plan: ~33 MiB)
-constexpr size_t kRegionTickets = 4096;         // tiles per launch (N <= 4096 * 32 columns)
+constexpr size_t kRegionTickets = 4096;         // tiles per launch (N <= 4096 * 32 columns); one ticket array PER slice count
 
 struct Arena {
     uint8_t*    base = nullptr;
@@ -33,7 +33,9 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
     EETQ_TRY_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_mutex);
     Arena&                      a = g_arena[dev & 63];
-    const size_t region_bytes = kRegionSlabs + kRegionTickets * sizeof(unsigned);
+    // a tile's ticket grows by S per launch and "last" is (old & (S-1)) == S-1: that only works if every launch that
+    // touches a ticket uses the same S, so S = 2 and S = 4 launches keep separate ticket arrays
+    const size_t region_bytes = kRegionSlabs + 2 * kRegionTickets * sizeof(unsigned);
     if (!a.base) {
         // not capturable: the first split-K launch on a device must happen outside graph capture (any eager warm-up does it)
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -57,12 +59,12 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
     return EETQ_OK;
 }
 
-template <int MT, int NB, int D, bool KFULL>
+template <int MT, int NB, int STAGES, bool KFULL>
 int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    using C   = gemm_splitk::Cfg<MT, NB, D>;
-    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, D, KFULL>;
+    using C   = gemm_splitk::Cfg<MT, NB, STAGES>;
+    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, STAGES, KFULL>;
     if (C::kSmem > 64 * 1024) {
         static std::atomic<unsigned long long> opted{0};
         int st = opt_in_large_lds(kern, opted);
@@ -75,7 +77,9 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         if ((size_t)tiles > kRegionTickets || (size_t)tiles * S * C::kSlabFloats * 4 > kRegionSlabs) S = 1;
         else {
             int st = region_for(stream, &slabs, &tickets);
-            if (st != EETQ_OK) return st;
+            if (st == EETQ_ERR_UNSUPPORTED) S = 1;  // scratch cannot be created while capturing: run this launch unsplit
+            else if (st != EETQ_OK) return st;
+            else if (S == 4) tickets += kRegionTickets;
         }
     }
     launch_kernel(kern, dim3(tiles * S), dim3(gemm_splitk::kThreads), C::kSmem, stream, x, w, scales, y, M, N, K, S, slabs,
@@ -83,58 +87,72 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     return check_hip(hipGetLastError(), "gemm_splitk_kernel launch");
 }
 
-template <int MT, int NB, int D>
+template <int MT, int NB, int STAGES>
 int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    return K % 256 == 0 ? launch_full<MT, NB, D, true>(x, w, scales, ep, y, M, N, K, S, stream)
-                        : launch_full<MT, NB, D, false>(x, w, scales, ep, y, M, N, K, S, stream);
+    return K % gemm_splitk::kBK == 0 ? launch_full<MT, NB, STAGES, true>(x, w, scales, ep, y, M, N, K, S, stream)
+                                     : launch_full<MT, NB, STAGES, false>(x, w, scales, ep, y, M, N, K, S, stream);
 }
 
-// steps in flight per wave: as many as the LDS ring (16*MT KiB per step and workgroup) and the 6-bit vmcnt allow
 template <int MT>
 int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int nb, int S,
-              hipStream_t stream)
+              int stages, hipStream_t stream)
 {
-    constexpr int D = MT == 1 ? 4 : MT == 2 ? 4 : MT == 3 ? 3 : 2;
-    if (nb == 2) return launch_inst<MT, 2, D>(x, w, scales, ep, y, M, N, K, S, stream);
-    return launch_inst<MT, 1, D>(x, w, scales, ep, y, M, N, K, S, stream);
+    if (nb == 2) {
+        if constexpr (MT <= 2) {
+            if (stages == 3) return launch_inst<MT, 2, 3>(x, w, scales, ep, y, M, N, K, S, stream);
+        }
+        return launch_inst<MT, 2, 2>(x, w, scales, ep, y, M, N, K, S, stream);
+    }
+    if constexpr (MT <= 2) {
+        if (stages == 3) return launch_inst<MT, 1, 3>(x, w, scales, ep, y, M, N, K, S, stream);
+    }
+    return launch_inst<MT, 1, 2>(x, w, scales, ep, y, M, N, K, S, stream);
 }
 
 }  // namespace
 
-// Plan (column blocks per workgroup, K slices, ring depth) for a shape.  What a compute unit must ingest through its
-// ~57 B/clk vector memory path bounds these shapes, so the plan minimises the busiest CU's bytes:
-//     rounds(workgroups / CUs) * ((32*MT*2 + 32*NB) * K / S)        [+ the reduction's slab traffic when S > 1]
-// subject to >= 2 K steps per slice.  Measured on MI355X: profiles/r02_kbench_splitk.txt.
-void splitk_plan(int M, int N, int K, int* nb_out, int* s_out)
+// Plan (column blocks per workgroup, K slices, ring depth) for a shape, from the measurements in
+// profiles/r02_kbench_splitk.txt (MI355X, N = K = 4096 unless noted; round-1 unsplit tile in brackets):
+//   M = 32: BN 32, S 2: 7.0 us [8.3];  M = 64: BN 32, S 2: 8.8 [11.2] (BN 64, S 4: 9.4);  M = 128: BN 64, S 4: 14.0 [20.2];
+//   K = 11008, M = 64: BN 64, S 4: 16.3 [28.0] (BN 32, S 2: 24.5);  N = 11008, M = 64: BN 64, S 1: 17.1 [20.0].
+// Reading: a slice costs about (its K steps) x (16*MT + 8*NB KiB per step at ~70 GB/s per CU) plus ~2 us for a 2-way and
+// ~3 us for a 4-way in-launch reduction, on top of ~2.3 us of launch + first-data latency; wide column blocks pay off when
+// the K loop is long (fewer re-reads of x) or the row tile is tall, narrow ones when the loop is short.
+void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out)
 {
-    const int  MT    = (M + 31) / 32;
-    const int  ncu   = device_cu_count();
-    const int  steps = (K / 64 + 3) / 4;
-    double     best  = 1e30;
-    int        bnb = 1, bs = 1;
+    const int MT    = (M + 31) / 32;
+    const int ncu   = device_cu_count();
+    const int steps = (K / 64 + 3) / 4;
+    double    best  = 1e30;
+    int       bnb = 1, bs = 1, bst = 2;
     for (int nb = 1; nb <= 2; ++nb) {
-        if (nb == 2 && N % 64 != 0 && N < 2048) continue;
         const int tiles = (N + 32 * nb - 1) / (32 * nb);
         for (int s = 1; s <= gemm_splitk::kMaxSlices; s *= 2) {
-            if (steps / s < 2 && s > 1) continue;
-            const int    wgs    = tiles * s;
-            const int    rounds = (wgs + ncu - 1) / ncu;
-            const double bytes  = (double)(32 * MT * 2 + 32 * nb) * K / s;
-            // per-workgroup fixed cost (prologue, barriers, cross-wave reduction; + publish / ticket / slab reads when split),
-            // in units of ingest bytes (~120 B/ns per CU)
-            const double fixed = 40e3 + (s > 1 ? 60e3 + 4096.0 * MT * nb * (s + 1) : 0.0);
-            const double cost  = rounds * (bytes + fixed);
-            if (cost < best) {
-                best = cost;
+            if (s > 1 && steps / s < 2) continue;
+            const int wgs = tiles * s;
+            // ring depth 3 (120..144 KiB: one workgroup per CU) when that many workgroups fit anyway, else depth 2 (two per CU at MT <= 2)
+            const int stages  = (MT <= 2 && wgs <= ncu) ? 3 : 2;
+            const int per_cu  = (stages == 2 && MT <= 2 && (16 * MT + 8 * nb) * 2 <= 80) ? 2 : 1;
+            const int rounds  = (wgs + ncu * per_cu - 1) / (ncu * per_cu);
+            const int my_steps = (steps + s - 1) / s;
+            // microseconds: per-step ingest at ~70 GB/s per CU (shared by the workgroups on the CU), shallower ring ~15 % slower
+            double t = my_steps * (16.0 * MT + 8.0 * nb) * 0.014 * per_cu * (stages == 3 ? 1.0 : 1.15);
+            t += s == 1 ? 0.0 : (s == 2 ? 2.0 : 3.6) + 0.05 * MT * nb * s;   // reduction: publish + ticket + slab reads
+            t = 2.3 + rounds * t;
+            if (wgs * 2 <= ncu) t *= 1.25;                                      // half the chip idle: the weight stream thins out
+            if (t < best) {
+                best = t;
                 bnb  = nb;
                 bs   = s;
+                bst  = stages;
             }
         }
     }
-    *nb_out = bnb;
-    *s_out  = bs;
+    *nb_out     = bnb;
+    *s_out      = bs;
+    *stages_out = bst;
 }
 
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
@@ -143,16 +161,17 @@ int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilog
     if (M < 1 || M > kMidMaxM) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] split-K tile path supports 1 <= M <= 128");
     EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31),
                  "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
-    int nb, s;
-    splitk_plan(M, N, K, &nb, &s);
+    int nb, s, stages;
+    splitk_plan(M, N, K, &nb, &s, &stages);
     if (force_nb) nb = force_nb;
     if (force_s) s = force_s;
+    if (force_nb || force_s) stages = ((M + 31) / 32 <= 2 && ((N + 32 * nb - 1) / (32 * nb)) * s <= device_cu_count()) ? 3 : 2;
     EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4), "invalid split-K plan");
     switch ((M + 31) / 32) {
-        case 1: return launch_mt<1>(x, w, scales, ep, y, M, N, K, nb, s, stream);
-        case 2: return launch_mt<2>(x, w, scales, ep, y, M, N, K, nb, s, stream);
-        case 3: return launch_mt<3>(x, w, scales, ep, y, M, N, K, nb, s, stream);
-        default: return launch_mt<4>(x, w, scales, ep, y, M, N, K, nb, s, stream);
+        case 1: return launch_mt<1>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
+        case 2: return launch_mt<2>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
+        case 3: return launch_mt<3>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
+        default: return launch_mt<4>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
     }
 }
 

@@ -1,23 +1,20 @@
 // Kernel template of the split-K medium-batch (17 <= M <= 128) MFMA dequant-GEMM (included by gemm_splitk.hip and
 // tools/kbench.hip).
 //
-// Why split K.  At these M the time of the round-1 medium-batch tile (gemm_mid_kernel.hpp) is neither the weight stream nor
-// the matrix cores: a workgroup that owns BN columns re-reads all of x (M x K fp16) next to its BN x K weight bytes, only
-// N / BN workgroups exist, and each of them walks K in barrier-separated steps with one or two stages in flight -- a chain
-// of L2/HBM latencies (N = K = 4096, M = 64: 128 workgroups, 16 steps, 10.9 us; the weights alone stream in ~3 us).
-// Two levers, used together:
-//   * wider column blocks + K slices: (N / BN) * S workgroups, each ingesting (M * 2 + BN) * K / S bytes -- BN = 64, S = 4
-//     gives 256 workgroups of 192 KiB for the shape above instead of 128 of 640 KiB;
-//   * no barriers and everything in flight: the four waves of a workgroup are INDEPENDENT streams.  Wave j owns k tile
-//     4*step + j of every 256-deep step for all rows and columns, so it needs only that k tile of x: it fetches those
-//     128-byte row segments itself by LDS-DMA into a wave-private LDS ring (eight rows x 128 B per 1 KiB piece, full
-//     lines; 16-byte slots XOR-swizzled by (row >> 1) & 7 through the source address so the MFMA operand reads are
-//     conflict-free) and loads its weight tiles straight into registers in fragment order (the native layout makes a
-//     wave-wide 16 B/lane load two contiguous 512-byte runs).  D steps are in flight per wave, counted with s_waitcnt
-//     vmcnt; nothing but the issuing wave's own vmcnt orders its ds_reads behind its DMA, so the main loop has no
-//     s_barrier at all.  With K / S <= D * 256 the whole slice is requested at kernel entry: one memory latency, like the GEMV.
-// MFMA: v_mfma_f32_32x32x16_f16, weights as the A operand (4*MT*NB MFMAs per wave per step; every dequantised fragment
-// feeds MT MFMAs, every activation fragment NB).  The four k quarters are added through LDS at the end.
+// Why split K.  At these M the time of gemm_mid_kernel is not the weight stream but what ONE compute unit can pull in
+// through its vector memory path (~57 B/clk = ~120 GB/s): a workgroup that owns BN columns re-reads all of x (M x K fp16)
+// next to its BN x K weight bytes, and only N / BN workgroups exist.  N = K = 4096, M = 64, BN = 32: 128 workgroups pull
+// 512 + 128 KiB each (5.3 us at 120 GB/s) while half the chip idles.  The bytes every CU must ingest are
+//     ((N / BN) * M * K * 2  +  N * K) / CUs in use,
+// so the lever is wider column blocks (fewer re-reads of x) TOGETHER with enough workgroups to use every CU: BN = 64 and
+// the K range cut into S slices gives (N / 64) * S workgroups that ingest (M * 2 + 64) * K / S bytes each -- 192 KiB at
+// S = 4 for the shape above (1.6 us), below the time the 16 MiB weight stream takes.
+//
+// Structure (per workgroup, 4 waves): the medium-batch tile of gemm_mid_kernel.hpp with NB column blocks of 32 --
+// (32*MT rows) x (32*NB columns) x 256-deep K step, wave j owns k tile j of the step for all rows and columns
+// (v_mfma_f32_32x32x16_f16, weights as the A operand: 4*MT*NB MFMAs per wave per step, every dequantised fragment feeds
+// MT MFMAs, every activation fragment NB); x and the weight tiles go L2/HBM -> LDS by LDS-DMA through a 2- or 3-deep ring,
+// x XOR-swizzled through the source address; the four k quarters are added through LDS at the end.
 //
 // The cross-workgroup reduction is in-launch and deterministic (no float atomics; replicas stay bit-identical):
 //   * every slice writes its fp32 partial tile (a "slab", 4*MT*NB KiB) with WRITE-THROUGH 16-byte stores
@@ -29,6 +26,10 @@
 //     arrival order was: the sum is a function of the data alone.  Then the usual epilogue.
 //   * counters are monotonic: a tile's counter grows by exactly S per launch, "last" is (old & (S-1)) == S-1; they are
 //     zeroed once when the scratch buffer is created and never reset.
+// A barrier-free variant (wave-private x ring filled by each wave's own LDS-DMA, weights straight to registers, hand-counted
+// vmcnt, no s_barrier in the main loop) was built and measured in round 2: within +-5 % of this kernel at N = K = 4096 and
+// slower at K = 11008 (19.1 vs 16.3 us) -- with four waves per CU the time goes to a chain of ~1 us phases (first data,
+// per-step issue, cross-wave reduction, publish + ticket, slab read), not to the barriers.  profiles/r02_kbench_splitk.txt.
 // This is the hand-off of cdna_hip_programming.md (section 5, "in-launch split-K reduction", write-through form): no
 // placement or dispatch-order assumption; the block-id -> (tile, slice) map below only makes a tile's slices neighbours
 // on one XCD when the dispatcher places block b on XCD b % 8 (a speed matter).
@@ -39,44 +40,37 @@
 namespace eetq {
 namespace gemm_splitk {
 
-constexpr int kThreads   = 256;
+constexpr int kBK      = 256;
+constexpr int kThreads = 256;
 constexpr int kMaxSlices = 4;
 
-// 16-byte non-temporal global load that hipcc does NOT see as a memory operation.  Needed because hipcc's s_waitcnt
-// bookkeeping does not count LDS-DMA operations (buffer_load ... lds) as vmcnt events next to ordinary loads: for a register
-// load issued between DMA pieces it emits "vmcnt(number of younger REGISTER loads)", which on the hardware counter -- that
-// counts the DMA pieces too -- drains every DMA in flight.  With the weight loads hidden, all waiting in the main loop is
-// the hand-counted "s_waitcnt vmcnt((D-1) * group)" at the top of a step, followed by a sched_barrier so that no consumer of
-// `dst` is scheduled above it (cdna_hip_programming.md 5.7, item 1, form iii).
-__device__ __forceinline__ void load16_nt_uncounted(u32x4& dst, const void* p)
-{
-    asm volatile("global_load_dwordx4 %0, %1, off nt" : "=v"(dst) : "v"(p) : "memory");
-}
-
-template <int MT, int NB, int D>
+template <int MT, int NB, int STAGES>
 struct Cfg {
     static constexpr int kRows   = 32 * MT;
     static constexpr int kBN     = 32 * NB;
-    static constexpr int kXPW    = 4 * MT;                    // x pieces (8 rows x 128 B) per wave and step
-    static constexpr int kWPW    = 2 * NB;                    // weight loads (16 B/lane) per wave and step
-    static constexpr int kGroup  = kXPW + kWPW;               // vector memory operations per wave and step
-    static constexpr int kStageW = kXPW * 1024;               // bytes of one wave's ring slot
-    static constexpr int kRing   = 4 * D * kStageW;           // all four waves
-    static constexpr int kRed    = 4 * MT * NB * 16 * 64 * 4; // end-of-kernel cross-wave reduction area
-    static constexpr int kSmem   = (kRing > kRed ? kRing : kRed) + 16;
-    static constexpr int kSlabFloats = kRows * kBN;           // fp32 partial tile of one slice
-    static_assert((D - 1) * kGroup <= 63, "vmcnt is a 6-bit counter");
+    static constexpr int kABytes = kRows * kBK * 2;
+    static constexpr int kBBytes = kBN * kBK;
+    static constexpr int kStage  = kABytes + kBBytes;
+    static constexpr int kStages = STAGES;
+    static constexpr int kRed    = 4 * MT * NB * 16 * 64 * 4;           // end-of-kernel cross-wave reduction area
+    static constexpr int kSmem   = kStages * kStage;                     // >= kRed + 16 for every MT, NB, STAGES >= 2
+    static_assert(kStages * kStage >= kRed + 16, "the reduction area and the ticket word must fit the ring");
+    static constexpr int kAPW    = kABytes / 1024 / 4;                   // A pieces (2 rows of 512 B) per wave and stage
+    static constexpr int kBPW    = kBBytes / 1024 / 4;                   // B pieces (native 1 KiB tiles) per wave and stage
+    static constexpr int kPieces = kAPW + kBPW;
+    static constexpr int kSlabFloats = kRows * kBN;                      // fp32 partial tile of one slice
 };
 
 // grid = tiles_n * S workgroups (all of M in one row tile: M <= 32*MT).  slabs: [tiles_n][S][kSlabFloats] floats,
 // counters: [tiles_n] unsigned (both unused when S == 1).
-template <int MT, int NB, int D, bool KFULL>
-__global__ __launch_bounds__(kThreads, (Cfg<MT, NB, D>::kSmem <= 80 * 1024 && MT * NB <= 2) ? 2 : 1) void gemm_splitk_kernel(
+template <int MT, int NB, int STAGES, bool KFULL>
+__global__ __launch_bounds__(kThreads, (Cfg<MT, NB, STAGES>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
     int N, int K, int S, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
 {
-    using C = Cfg<MT, NB, D>;
+    using C = Cfg<MT, NB, STAGES>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const int lds0 = (int)(uint32_t)(uintptr_t)(gemm::lds_void*)smem;
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
@@ -101,59 +95,57 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, D>::kSmem <= 80 * 1024 && MT
 
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, (int)((size_t)M * K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t w_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(w), 0, (int)((size_t)N * K), 0x00020000);
 
-    // ---- this wave's x pieces: piece i = rows 8i .. 8i+7, the 128-byte segment of the wave's k tile ----
-    // LDS image of a piece is lane-linear (row 8i + (lane >> 3), physical slot lane & 7); physical slot p of row r holds
-    // logical slot p ^ ((r >> 1) & 7): the permutation goes on the source address, the same XOR on the fragment read.
-    int x_voff[C::kXPW];
+    // ---- DMA pieces of this wave (roles fixed per index: no run-time branch per piece) ----
+    //   i < kAPW : A piece p = wave*kAPW + i  -> rows 2p, 2p+1 (512 B each)
+    //   else     : B piece b = wave*kBPW + (i - kAPW) -> 16-column tile b>>2, k tile b&3 of the step
+    int dma_voff[C::kPieces];
 #pragma unroll
-    for (int i = 0; i < C::kXPW; ++i) {
-        const int row     = 8 * i + (lane >> 3);
-        const int logical = (lane & 7) ^ ((row >> 1) & 7);
-        const int gm      = row < M ? row : M - 1;
-        x_voff[i]         = (gm * K + logical * 8) * 2;  // + k tile * 128 bytes
+    for (int i = 0; i < C::kPieces; ++i) {
+        if (i < C::kAPW) {
+            const int p    = wave * C::kAPW + i;
+            const int row  = 2 * p + (lane >> 5);
+            const int slot = (lane & 31) ^ (row & 15);  // source slot for this LDS slot
+            int       gm   = row;
+            gm             = gm < M ? gm : M - 1;
+            dma_voff[i]    = (gm * K + slot * 8) * 2;
+        } else {
+            const int b  = wave * C::kBPW + (i - C::kAPW);
+            int       nt = (n0 >> 4) + (b >> 2);
+            nt           = nt < n_tiles_total ? nt : n_tiles_total - 1;
+            dma_voff[i]  = (nt * KT + (b & 3)) * kTileBytes + lane * 16;  // + step*4 tiles
+        }
     }
-    uint8_t* ring = smem + wave * (D * C::kStageW);  // this wave's ring: D slots of kStageW bytes
-    // fragment reads go through integer LDS addresses (gemm::lds_read16): with a pointer hipcc can trace back to the LDS
-    // array it orders every ds_read behind the most recent LDS-DMA (s_waitcnt vmcnt of nearly everything in flight)
-    const int ring_addr = (int)(uint32_t)(uintptr_t)(gemm::lds_void*)smem + wave * (D * C::kStageW);
-
-    // ---- this wave's weight fragments: lane (fn, fh), column block nb: 16-column tile 2*nb + (fn >> 4), k tile of the
-    // wave; two 16-byte loads (s = 0, 1) at ((2s + fh) * 16 + (fn & 15)) * 16 inside the tile ----
-    const int      fn = lane & 31, fh = lane >> 5;
-    const uint8_t* w_lane[NB];
+    auto issue_stage = [&](int buf, int step) {
+        uint8_t* sa = smem + buf * C::kStage;
 #pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        int nt = (n0 >> 4) + 2 * nb + (fn >> 4);
-        nt     = nt < n_tiles_total ? nt : n_tiles_total - 1;
-        w_lane[nb] = w + (size_t)nt * KT * kTileBytes + (fh * 16 + (fn & 15)) * 16;  // + kt * 1024 + s * 512
-    }
-
-    u32x4 wreg[D][NB][2];
-    // one group = the wave's vector memory traffic of one step: kXPW DMA pieces, then kWPW register loads.  Steps beyond
-    // the slice are clamped to its last step (redundant, cache-resident, never used): no load sits behind a branch and the
-    // number of operations in flight is a compile-time constant.
-    auto issue_group = [&](int slot, int step) {
-        const int st = step < s1 ? step : s1 - 1;
-        int       kt = 4 * st + wave;
-        kt           = kt < KT ? kt : KT - 1;  // the k tile beyond a ragged K is fetched from the last valid one, never used
-        const int x_soff = kt * 128;  // byte offset of k tile kt inside a row
-#pragma unroll
-        for (int i = 0; i < C::kXPW; ++i) gemm::dma16(x_rsrc, x_voff[i], x_soff, ring + slot * C::kStageW + i * 1024);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb)
-#pragma unroll
-            for (int s = 0; s < 2; ++s)
-                load16_nt_uncounted(wreg[slot][nb][s], w_lane[nb] + (size_t)kt * kTileBytes + s * 512);
+        for (int i = 0; i < C::kPieces; ++i) {
+            if (i < C::kAPW) {
+                // the last step of a K that is not a multiple of 256 reads past the row end into the next row (or is
+                // zero-filled by the descriptor bounds check at the very end): those k tiles are never multiplied
+                gemm::dma16(x_rsrc, dma_voff[i], step * kBK * 2, sa + (wave * C::kAPW + i) * 1024);
+            } else {
+                const int b    = wave * C::kBPW + (i - C::kAPW);
+                const int kt   = step * 4 + (b & 3);
+                const int back = kt < KT ? 0 : (kt - (KT - 1)) * kTileBytes;  // clamp to the last valid k tile
+                gemm::dma16(w_rsrc, dma_voff[i] - back, step * 4 * kTileBytes, sa + C::kABytes + b * 1024);
+            }
+        }
     };
 
-    // fragment reads: row 32*mt + fn, logical slot 4s + 2fh + e
-    int a_off[2][2];
+    // ---- fragment addressing: lane (fn, fh); this wave owns k tile `wave` of every step ----
+    const int fn = lane & 31, fh = lane >> 5;
+    // weight fragment of column block nb: 16-column tile (2*nb + (fn >> 4)), k tile `wave`
+    const int b_off = C::kABytes + ((fn >> 4) * 4 + wave) * 1024 + (fn & 15) * 16 + fh * 256;  // + nb*8192 + s*512
+    const int a_key = fn & 15;
+    int       a_slot[2][2];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) a_off[s][e] = fn * 128 + (((4 * s + 2 * fh + e) ^ ((fn >> 1) & 7)) << 4);
-    // (rows 32*mt + fn: (row >> 1) & 7 == (fn >> 1) & 7 because 32*mt is a multiple of 16)
+        for (int e = 0; e < 2; ++e) a_slot[s][e] = ((8 * wave + 4 * s + 2 * fh + e) ^ a_key) << 4;
+    const int a_row_off = fn * 512;
 
     f16x2 scale2[NB];
 #pragma unroll
@@ -173,52 +165,65 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, D>::kSmem <= 80 * 1024 && MT
 
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(scale2[nb]));
+    if (s0 < s1) issue_stage(0, s0);
+    if (C::kStages == 3 && s0 + 1 < s1) issue_stage(1, s0 + 1);
+    int buf = 0;
+    for (int step = s0; step < s1; ++step) {
+        // this wave's pieces of the current stage have landed (a younger stage may stay in flight with a 3-deep ring)
+        if (C::kStages == 3 && step + 1 < s1)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::kPieces) : "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // ... everyone's have; everyone is done with the buffer refilled below
+        const bool     active = KFULL || step * 4 + wave < KT;  // wave-uniform: k tile beyond K on the last step
+        const int sa = lds0 + buf * C::kStage;  // integer LDS address: see gemm::lds_read16
+        // order inside a step as in gemm_mid_kernel: all fragment reads, then this wave's DMA pieces of the stage
+        // kStages-1 steps ahead (they run under the LDS read latency), then dequant + MFMA
+        u32x4 wq[NB][2];
+        f16x8 xa[2][2][MT];
+        if (active) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) issue_group(d, s0 + d);
-
-    for (int base = s0; base < s1; base += D) {
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            const int step = base + d;
-            // the group of `step` has landed: exactly D-1 younger groups are in flight behind it
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * C::kGroup) : "memory");
-            __builtin_amdgcn_sched_barrier(0);
-            const bool active = step < s1 && (KFULL || 4 * step + wave < KT);  // wave-uniform
-            if (active) {
-                const int sa = ring_addr + d * C::kStageW;
-                f16x8     xa[2][2][MT];
+                for (int s = 0; s < 2; ++s) wq[nb][s] = gemm::lds_read16(sa + b_off + nb * 8192 + s * 512);
 #pragma unroll
-                for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < 2; ++s)
 #pragma unroll
-                    for (int e = 0; e < 2; ++e)
+                for (int e = 0; e < 2; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        xa[s][e][mt] = __builtin_bit_cast(f16x8, gemm::lds_read16(sa + mt * 32 * 512 + a_row_off + a_slot[s][e]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (step + C::kStages - 1 < s1) {
+            int nbuf = buf + C::kStages - 1;
+            nbuf     = nbuf >= C::kStages ? nbuf - C::kStages : nbuf;
+            issue_stage(nbuf, step + C::kStages - 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (active) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(wq[nb][0]), "+v"(wq[nb][1]));  // reads stay above the dequant
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    f16x2 wd[8];
+                    dequant_16(wq[nb][s], scale2[nb], wd);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const f16x8 wf = gemm::make_frag(wd[4 * e], wd[4 * e + 1], wd[4 * e + 2], wd[4 * e + 3]);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
-                            xa[s][e][mt] = __builtin_bit_cast(f16x8, gemm::lds_read16(sa + mt * 4096 + a_off[s][e]));
-#pragma unroll
-                for (int s = 0; s < 2; ++s) {
-#pragma unroll
-                    for (int nb = 0; nb < NB; ++nb) {
-                        f16x2 wd[8];
-                        dequant_16(wreg[d][nb][s], scale2[nb], wd);
-#pragma unroll
-                        for (int e = 0; e < 2; ++e) {
-                            const f16x8 wf = gemm::make_frag(wd[4 * e], wd[4 * e + 1], wd[4 * e + 2], wd[4 * e + 3]);
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-                                acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xa[s][e][mt], acc[mt][nb], 0, 0, 0);
-                        }
+                            acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xa[s][e][mt], acc[mt][nb], 0, 0, 0);
                     }
                 }
             }
-            // the fragment reads of this slot have returned (their MFMAs consumed them): refill it
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            issue_group(d, step + D);
         }
+        buf = buf + 1 == C::kStages ? 0 : buf + 1;
     }
 
     // ---- add the four k quarters through LDS; wave q then owns accumulator registers 4q..4q+3 of every block ----
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the clamped tail groups still target the ring
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [wave][mt][nb][reg][lane]
 #pragma unroll

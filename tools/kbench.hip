@@ -260,13 +260,13 @@ static void bench_mid(const char* name, int M, int N, int K, const std::vector<u
 }
 
 
-template <int MT, int NB, int D>
+template <int MT, int NB, int STAGES>
 static void bench_splitk(const char* name, int M, int N, int K, int S, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
-                         const eetq::f16* scales, eetq::f16* y, float* slabs, unsigned* tickets)
+                              const eetq::f16* scales, eetq::f16* y, float* slabs, unsigned* tickets)
 {
     using namespace eetq::gemm_splitk;
-    using C   = Cfg<MT, NB, D>;
-    auto kern = gemm_splitk_kernel<MT, NB, D, true>;
+    using C   = Cfg<MT, NB, STAGES>;
+    auto kern = gemm_splitk_kernel<MT, NB, STAGES, true>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int    tiles = (N + C::kBN - 1) / C::kBN;
     const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
@@ -282,8 +282,8 @@ static void bench_splitk(const char* name, int M, int N, int K, int S, const std
                                scales, y, M, N, K, S, slabs, tickets, eetq::Epilogue{});
         },
         200);
-    printf("%-26s N=%5d K=%5d M=%3d BN=%2d S=%d D=%d wg=%4d | disp mean %6.2f med %6.2f min %6.2f | graph step %6.2f us -> %6.0f GB/s(med) %6.1f TF\n",
-           name, N, K, M, 32 * NB, S, D, tiles * S, st.mean, st.med, st.mn, g, bytes / st.med / 1e3,
+    printf("%-26s N=%5d K=%5d M=%3d BN=%2d S=%d st=%d wg=%4d | disp mean %6.2f med %6.2f min %6.2f | graph step %6.2f us -> %6.0f GB/s(med) %6.1f TF\n",
+           name, N, K, M, 32 * NB, S, STAGES, tiles * S, st.mean, st.med, st.mn, g, bytes / st.med / 1e3,
            2.0 * M * N * K / st.med / 1e6);
 }
 
@@ -776,39 +776,20 @@ int main(int argc, char** argv)
         CK(hipMalloc(&tickets, 4096 * 4));
         CK(hipMemset(tickets, 0, 4096 * 4));
         bench_mid<2, 3>("mid MT2 (round 1)", 64, 4096, 4096, bufs, xs, scales, ys);
-        bench_splitk<2, 1, 4>("splitk", 64, 4096, 4096, 1, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<2, 1, 4>("splitk", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<2, 1, 4>("splitk", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<2, 2, 4>("splitk", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<2, 2, 4>("splitk", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<2, 2, 2>("splitk", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
-        printf("\n");
-        bench_mid<1, 3>("mid MT1 (round 1)", 32, 4096, 4096, bufs, xs, scales, ys);
-        bench_splitk<1, 1, 4>("splitk", 32, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<1, 1, 7>("splitk", 32, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<1, 2, 4>("splitk", 32, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<1, 2, 4>("splitk", 32, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<1, 2, 4>("splitk", 17, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<1, 1, 4>("splitk", 8, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
-        printf("\n");
-        bench_mid<4, 2>("mid MT4 (round 1)", 128, 4096, 4096, bufs, xs, scales, ys);
-        bench_splitk<4, 1, 2>("splitk", 128, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<4, 2, 2>("splitk", 128, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<4, 2, 2>("splitk", 128, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<3, 2, 3>("splitk", 96, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
-        bench_splitk<3, 2, 2>("splitk", 96, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
-        printf("\n");
-        bench_mid<2, 3>("mid MT2 K=11008 (r1)", 64, 4096, 11008, bufs_big, xs, scales, ys);
-        bench_splitk<2, 1, 4>("splitk K=11008", 64, 4096, 11008, 2, bufs_big, xs, scales, ys, slabs, tickets);
-        bench_splitk<2, 2, 4>("splitk K=11008", 64, 4096, 11008, 4, bufs_big, xs, scales, ys, slabs, tickets);
-        bench_splitk<2, 2, 4>("splitk K=11008", 64, 4096, 11008, 2, bufs_big, xs, scales, ys, slabs, tickets);
-        printf("\n");
-        bench_mid<2, 2>("mid MT2 N=11008 (r1)", 64, 11008, 4096, bufs_big, xs, scales, ys);
-        bench_splitk<2, 1, 4>("splitk N=11008", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
-        bench_splitk<2, 2, 4>("splitk N=11008", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
-        bench_splitk<2, 2, 4>("splitk N=11008", 64, 11008, 4096, 2, bufs_big, xs, scales, ys, slabs, tickets);
-        bench_splitk<4, 2, 2>("splitk N=11008 M=128", 128, 11008, 4096, 2, bufs_big, xs, scales, ys, slabs, tickets);
-        bench_splitk<4, 2, 2>("splitk N=11008 M=128", 128, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 3>("ring", 64, 4096, 4096, 1, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 3>("ring", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 2>("ring", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3>("ring", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3>("ring", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2>("ring", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 1, 3>("ring", 32, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 2, 3>("ring", 32, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 1, 2>("ring", 128, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 2, 2>("ring", 128, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3>("ring K=11008", 64, 4096, 11008, 4, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3>("ring N=11008", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2>("ring N=11008", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 2, 2>("ring N=11008 M=128", 128, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
     }
     if (!strcmp(what, "all") || !strcmp(what, "mid")) {
         printf("--- medium-batch tile kernel (32-column tiles, 256-deep K steps) ---\n");

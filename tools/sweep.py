@@ -37,6 +37,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=None)
     ap.add_argument("--extra", action="store_true", help="also Llama-2-13B shapes")
+    ap.add_argument("--ms", default="1,8,64,1024", help="comma-separated batch sizes M")
     args = ap.parse_args()
     dev = "cuda:0"
     shapes = [(4096, 4096), (4096, 11008), (11008, 4096)]
@@ -55,7 +56,7 @@ def main():
                 raw0 = ops.quant_weights(w, torch.int8, True)[0]
             del w
         wdq = (raw0.float() * sets[0][1].float()[None, :]).half().float()   # fp16(q*s) exactly as the contract
-        for M in (1, 8, 64, 1024):
+        for M in [int(v) for v in args.ms.split(",")]:
             x = (torch.rand(M, K, device=dev, generator=g) - 0.25).half()
             y = torch.empty(M, N, dtype=torch.float16, device=dev)
             iters = 200 if M <= 64 else 60
