@@ -2,15 +2,22 @@
 
 Host-side mirror of /root/reference/python/eetq/modules/qlinear.py: ``quantize_and_preprocess_weights``
 (:14-24), ``W8A16Linear`` (:27-62), ``EetqLinearMMFunction`` (:64-94) and ``EetqLinear`` (:96-124) keep
-their names, constructor arguments, buffer names/shapes/dtypes and forward semantics so state dicts and
-callers (transformers' EETQ integration, TGI) are interchangeable.  ``W8A16LoraLinear`` (:127-186) is dead
-code in the reference (never constructed successfully) and is not carried over.
+their names, constructor arguments, buffer names/shapes/dtypes and forward semantics.  ``W8A16LoraLinear``
+(:127-186) is dead code in the reference (never constructed successfully) and is not carried over.
+
+Layouts.  In memory the int8 buffer (``qweight`` / ``weight``) holds this library's ``gfx950`` layout -- NOT the bytes a
+CUDA build of the reference keeps there.  State dicts are interchangeable all the same: every module re-encodes its int8
+buffer to the reference's processed layout (``sm80``) when ``state_dict()`` is taken and back when ``load_state_dict()``
+runs (eetq_amd/checkpoint.py), so a checkpoint written here loads in CUDA-EETQ and an NVIDIA-written one loads
+here.  Code that copies tensors straight into the buffers (bypassing ``load_state_dict``) must convert them itself:
+``eetq_amd.utils.convert_model_layout_(model, "sm80")``.
 """
 import torch
 import torch.nn as nn
 from torch.autograd import Function
 
 from ..ops import preprocess_weights, quant_weights, w8_a16_gemm
+from ..checkpoint import install_layout_hooks
 
 __all__ = ["quantize_and_preprocess_weights", "W8A16Linear", "EetqLinearMMFunction", "EetqLinear"]
 
@@ -46,6 +53,9 @@ class W8A16Linear(nn.Module):
             self.register_buffer("bias", torch.zeros((out_features,), dtype=torch.float16, device=dev))
         else:
             self.bias = None
+        # state dicts carry the reference's layout: re-encode on save / load (see the module docstring)
+        self.checkpoint_layout = None   # None = the process-wide wire layout; "sm80" / "gfx950" pins what load expects
+        install_layout_hooks(self, "qweight")
 
     @classmethod
     def from_torch(cls, linear, scales=None, init_only=False):
@@ -107,6 +117,8 @@ class EetqLinear(nn.Module):
             self.register_buffer("bias", torch.zeros((out_features,), dtype=torch.float16, device=device))
         else:
             self.bias = None
+        self.checkpoint_layout = None
+        install_layout_hooks(self, "weight")
 
     def register(self, buffer_name, tensor):
         self.register_buffer(buffer_name, tensor)

@@ -5,3 +5,5 @@ from .accelerator import (eet_accelerator, replace_with_eet_fp16_fused_attn, rep
                           replace_with_eet_fused_residual, replace_with_eet_qlinear, replace_with_eet_quant_fused_attn,
                           replace_with_eet_rmsnorm)
 from .graph_decoder import GraphDecoder  # noqa: F401,E402
+from ..checkpoint import (checkpoint_layout, convert_checkpoint, convert_model_layout_, get_wire_layout,  # noqa: F401,E402
+                         quantization_config, set_wire_layout, wire_layout)
