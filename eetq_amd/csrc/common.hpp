@@ -178,6 +178,7 @@ int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_ra
                     int layout, void* scales, float* colmax, hipStream_t stream);
 int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
 int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
+int launch_colmax(const void* w, int w_dtype, size_t K, size_t N, float* colmax, hipStream_t stream);
 // int4 (W4A16): int4.hip
 int launch_quantize_i4(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
                        void* scales, float* colmax, hipStream_t stream);

@@ -253,6 +253,26 @@ int launch_tile_pack(const T* src, size_t K, size_t N, const float* colmax, int8
 
 }  // namespace
 
+// per-column max |w| (fp32, NaN ignored like std::max) into colmax[N]; shared by the int8 and int4 quantisers
+int launch_colmax(const void* w, int w_dtype, size_t K, size_t N, float* colmax, hipStream_t stream)
+{
+    EETQ_REQUIRE(w && colmax, "null pointer");
+    EETQ_REQUIRE(N % 8 == 0, "the number of columns (N) must be a multiple of 8");
+    EETQ_TRY_HIP(hipMemsetAsync(colmax, 0, N * sizeof(float), stream));
+    // 32 rows per workgroup: K/32 x N/2048 workgroups (256 at 4096^2)
+    const int rows_per_block = 32;
+    if (w_dtype == EETQ_DTYPE_F16) {
+        dim3 grid((unsigned)((N / 8 + 255) / 256), (unsigned)((K + rows_per_block - 1) / rows_per_block));
+        colmax_kernel<f16, 8><<<grid, 256, 0, stream>>>(static_cast<const f16*>(w), K, N,
+                                                        reinterpret_cast<u32*>(colmax), rows_per_block);
+    } else {
+        dim3 grid((unsigned)((N / 4 + 255) / 256), (unsigned)((K + rows_per_block - 1) / rows_per_block));
+        colmax_kernel<float, 4><<<grid, 256, 0, stream>>>(static_cast<const float*>(w), K, N,
+                                                          reinterpret_cast<u32*>(colmax), rows_per_block);
+    }
+    return check_hip(hipGetLastError(), "colmax_kernel launch");
+}
+
 int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
                     void* scales, float* colmax, hipStream_t stream)
 {
@@ -272,19 +292,8 @@ int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_ra
             raw_copy = q_packed;
         packed_out = nullptr;
     }
-    EETQ_TRY_HIP(hipMemsetAsync(colmax, 0, N * sizeof(float), stream));
-    // 32 rows per workgroup: K/32 x N/2048 workgroups (256 at 4096^2)
-    const int rows_per_block = 32;
-    if (w_dtype == EETQ_DTYPE_F16) {
-        dim3 grid((unsigned)((N / 8 + 255) / 256), (unsigned)((K + rows_per_block - 1) / rows_per_block));
-        colmax_kernel<f16, 8><<<grid, 256, 0, stream>>>(static_cast<const f16*>(w), K, N,
-                                                        reinterpret_cast<u32*>(colmax), rows_per_block);
-    } else {
-        dim3 grid((unsigned)((N / 4 + 255) / 256), (unsigned)((K + rows_per_block - 1) / rows_per_block));
-        colmax_kernel<float, 4><<<grid, 256, 0, stream>>>(static_cast<const float*>(w), K, N,
-                                                          reinterpret_cast<u32*>(colmax), rows_per_block);
-    }
-    EETQ_TRY_HIP(hipGetLastError());
+    st = launch_colmax(w, w_dtype, K, N, colmax, stream);
+    if (st != EETQ_OK) return st;
     if (w_dtype == EETQ_DTYPE_F16)
         st = launch_tile_pack<f16>(static_cast<const f16*>(w), K, N, colmax, raw_out, packed_out, layout, scales, 0,
                                    stream);

@@ -19,7 +19,7 @@ from torch.autograd import Function
 from ..ops import preprocess_weights, quant_weights, w8_a16_gemm
 from ..checkpoint import install_layout_hooks
 
-__all__ = ["quantize_and_preprocess_weights", "W8A16Linear", "EetqLinearMMFunction", "EetqLinear"]
+__all__ = ["quantize_and_preprocess_weights", "W8A16Linear", "W4A16Linear", "EetqLinearMMFunction", "EetqLinear"]
 
 
 def quantize_and_preprocess_weights(weight, scales=None):
@@ -82,6 +82,46 @@ class W8A16Linear(nn.Module):
     def extra_repr(self):
         return "in_features={}, out_features={}, bias={}".format(self.in_features, self.out_features,
                                                                  self.bias is not None)
+
+
+class W4A16Linear(nn.Module):
+    """int4 weight-only linear layer (extension; the reference binds int4 quantisation -- ``quant_weights(w, torch.quint4x2)``
+    -- but no int4 GEMM): packed ``qweight`` int8 [in, out / 2] (two values per byte) in the gfx950 int4 layout, fp16
+    ``weight_scales`` [out].  Needs in_features % 128 == 0 and out_features % 16 == 0."""
+
+    def __init__(self, in_features, out_features, bias=True, dev="cuda:0"):
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.register_buffer("qweight", torch.zeros((in_features, out_features // 2), dtype=torch.int8, device=dev))
+        self.register_buffer("weight_scales", torch.zeros((out_features,), dtype=torch.float16, device=dev))
+        if bias:
+            self.register_buffer("bias", torch.zeros((out_features,), dtype=torch.float16, device=dev))
+        else:
+            self.bias = None
+
+    @classmethod
+    def from_torch(cls, linear, init_only=False):
+        dev = linear.weight.device
+        mod = cls(linear.in_features, linear.out_features, bias=linear.bias is not None, dev=dev)
+        if init_only:
+            return mod
+        if linear.weight.dtype != torch.float16:
+            raise ValueError("Unsupported data type: {}".format(linear.weight.dtype))
+        if linear.bias is not None:
+            mod.bias = linear.bias.clone().half()
+        qweight, scales = quant_weights(torch.t(linear.weight).contiguous(), torch.quint4x2, False)
+        mod.qweight = qweight.to(dev)
+        mod.weight_scales = scales.half().to(dev)
+        return mod
+
+    @torch.no_grad()
+    def forward(self, input, residual=None):
+        return w8_a16_gemm(input, self.qweight, self.weight_scales, bias=self.bias, residual=residual)
+
+    def extra_repr(self):
+        return "in_features={}, out_features={}, bias={}, bits=4".format(self.in_features, self.out_features,
+                                                                        self.bias is not None)
 
 
 class EetqLinearMMFunction(Function):

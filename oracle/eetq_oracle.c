@@ -448,6 +448,252 @@ int oracle_ref_gemv_sm80(const uint16_t* x, const int8_t* packed, const uint16_t
     return 0;
 }
 
+/* ================================================================== int4 (W4A16) ==========================================
+ * quint4x2 branch of the reference: quantise (cutlass_preprocessors.cc:581-678 with PACKED_INT4_WEIGHT_ONLY), processed
+ * layout (:137-195 row permute with 32-row groups, :201-335 sub-byte transpose, :432-495 column interleave with
+ * ColumnsInterleaved = 4 from mixed_gemm_B_layout.h:73-85, :360-418 +8 bias and nibble interleave), and -- second source
+ * for the layout -- the reference GEMV's Int4b reader (weightOnlyBatchedGemv/kernel.h:68-116, 169-214, 233-292, 294-376) with
+ * the int4 converter (interleaved_numeric_conversion.h:215-280).
+ * A raw int4 tensor is [K][N/2] bytes: byte j of a row holds column 2j in its low nibble and column 2j+1 in its high nibble,
+ * two's complement (:655-668). */
+
+static inline int  i4_get(const int8_t* row_bytes, size_t n)
+{
+    const uint8_t b = (uint8_t)row_bytes[n >> 1];
+    const int     v = (n & 1) ? (b >> 4) : (b & 0xF);
+    return v >= 8 ? v - 16 : v;
+}
+static inline void i4_set(int8_t* row_bytes, size_t n, int v)
+{
+    uint8_t* b = (uint8_t*)row_bytes + (n >> 1);
+    if (n & 1) *b = (uint8_t)((*b & 0x0F) | ((v & 0xF) << 4));
+    else *b = (uint8_t)((*b & 0xF0) | (v & 0xF));
+}
+
+/* :605-674 for bits = 4: quant_range_scale = 1/8; q = max(-8, min(7, int(round(w / scale)))).  Note the int() BEFORE the
+ * clamp (:660-661): for an all-zero column w / scale = 0/0 = NaN, round(NaN) = NaN, and int(NaN) is the x86 "integer
+ * indefinite" value INT_MIN (cvttss2si) on the hosts the reference runs on -> clamps to -8.  Same for +-inf / scale. */
+static void quantize_i4_core(const float* (*row_loader)(const void*, size_t, size_t, float*), const void* w, size_t K,
+                             size_t N, int8_t* q_packed, float* col_scale_f32)
+{
+    float* rowbuf = (float*)malloc(N * sizeof(float));
+    for (size_t j = 0; j < N; ++j) col_scale_f32[j] = 0.f;
+    for (size_t i = 0; i < K; ++i) {
+        const float* r = row_loader(w, i, N, rowbuf);
+        for (size_t j = 0; j < N; ++j) col_scale_f32[j] = ref_max(col_scale_f32[j], fabsf(r[j]));
+    }
+    for (size_t j = 0; j < N; ++j) col_scale_f32[j] *= 1.f / 8.f;
+    memset(q_packed, 0, K * (N / 2));
+    for (size_t i = 0; i < K; ++i) {
+        const float* r = row_loader(w, i, N, rowbuf);
+        for (size_t j = 0; j < N; ++j) {
+            const float scaled = roundf(r[j] / col_scale_f32[j]);
+            long        iw;
+            if (scaled != scaled || scaled >= 2147483648.f || scaled < -2147483648.f) iw = -2147483647L - 1;  /* INT_MIN */
+            else iw = (long)scaled;
+            const long c = iw < -8 ? -8 : (iw > 7 ? 7 : iw);
+            i4_set(q_packed + i * (N / 2), j, (int)c);
+        }
+    }
+    free(rowbuf);
+}
+
+void oracle_quantize_i4_f16(const uint16_t* w, size_t K, size_t N, int8_t* q_packed, uint16_t* scales)
+{
+    float* s32 = (float*)malloc(N * sizeof(float));
+    quantize_i4_core(load_row_f16, w, K, N, q_packed, s32);
+    for (size_t j = 0; j < N; ++j) scales[j] = f2h(s32[j]);
+    free(s32);
+}
+void oracle_quantize_i4_f32(const float* w, size_t K, size_t N, int8_t* q_packed, float* scales)
+{
+    quantize_i4_core(load_row_f32, w, K, N, q_packed, scales);
+}
+
+/* unpacked int4 values <-> the packed raw tensor */
+void oracle_i4_unpack_values(const int8_t* q_packed, size_t K, size_t N, int8_t* q)
+{
+    for (size_t k = 0; k < K; ++k)
+        for (size_t n = 0; n < N; ++n) q[k * N + n] = (int8_t)i4_get(q_packed + k * (N / 2), n);
+}
+void oracle_i4_pack_values(const int8_t* q, size_t K, size_t N, int8_t* q_packed)
+{
+    memset(q_packed, 0, K * (N / 2));
+    for (size_t k = 0; k < K; ++k)
+        for (size_t n = 0; n < N; ++n) i4_set(q_packed + k * (N / 2), n, q[k * N + n]);
+}
+
+/* The four steps on a packed [K][N/2] tensor, restated step by step (arch in [75, 90)).  Requires K % 64 == 0 (unchecked
+ * in the reference, as for int8), N % 64 == 0 (:455). */
+int oracle_sm80_pack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* out)
+{
+    if (K == 0 || N == 0 || K % 64 || N % 64) return -1;
+    const size_t bytes = K * N / 2;
+    int8_t*      a     = (int8_t*)calloc(bytes, 1);
+    int8_t*      b     = (int8_t*)calloc(bytes, 1);
+    /* P1 (:137-195, BITS = 4: B_ROWS_PER_MMA = 32, ELTS_PER_REG = 8): row t of every 32 <- row 8*((t%8)/2) + t%2 + 2*(t/8) */
+    const size_t row_bytes = N / 2;
+    for (size_t base = 0; base < K; base += 32)
+        for (size_t t = 0; t < 32; ++t) {
+            const size_t rr = 8 * ((t % 8) / 2) + t % 2 + 2 * (t / 8);
+            memcpy(a + (base + t) * row_bytes, q_packed + (base + rr) * row_bytes, row_bytes);
+        }
+    /* P2 (:201-335): element (k, n) -> (n, k); the transposed tensor is [N][K/2] bytes, k even in the low nibble */
+    for (size_t k = 0; k < K; ++k)
+        for (size_t n = 0; n < N; ++n) i4_set(b + n * (K / 2), k, i4_get(a + k * row_bytes, n));
+    /* P3 (:432-495, rows_per_column_tile = 64, columns_interleaved = 4): uint32 units of 8 nibbles along k;
+     * num_vec_rows = K/8, vec_rows_per_tile = 8: read column c, vec row v (base bb = v - v%8) ->
+     * write row 4*bb + 8*(c%4) + v%8 of output column c/4, whose length is 4 * num_vec_rows */
+    {
+        const uint32_t* in  = (const uint32_t*)b;
+        uint32_t*       o32 = (uint32_t*)a;
+        const size_t    nvr = K / 8;
+        for (size_t c = 0; c < N; ++c)
+            for (size_t v = 0; v < nvr; ++v) {
+                const size_t bb = v - v % 8;
+                const size_t wr = 4 * bb + 8 * (c % 4) + v % 8;
+                o32[(c / 4) * nvr * 4 + wr] = in[c * nvr + v];
+            }
+    }
+    /* P4 (:360-418): every nibble + 8 (to unsigned 0..15), then inside each uint32 nibble d <- source nibble
+     * (d < 4 ? 2d : 2(d-4)+1): [e0 e2 e4 e6 e1 e3 e5 e7] */
+    {
+        uint32_t* r32 = (uint32_t*)a;
+        for (size_t i = 0; i < bytes / 4; ++i) {
+            uint32_t cur = r32[i], biased = 0, outw = 0;
+            for (int e = 0; e < 8; ++e) {
+                int v = (int)((cur >> (4 * e)) & 0xF);
+                v     = (v >= 8 ? v - 16 : v) + 8;
+                biased |= (uint32_t)(v & 0xF) << (4 * e);
+            }
+            for (int d = 0; d < 8; ++d) {
+                const int src = d < 4 ? 2 * d : 2 * (d - 4) + 1;
+                outw |= ((biased >> (4 * src)) & 0xF) << (4 * d);
+            }
+            r32[i] = outw;
+        }
+    }
+    memcpy(out, a, bytes);
+    free(a);
+    free(b);
+    return 0;
+}
+
+/* Inverse of oracle_sm80_pack_i4, built by pushing an index pattern through the forward steps: position p of the processed
+ * nibble stream holds raw element map[p]. */
+int oracle_sm80_unpack_i4(const int8_t* packed, size_t K, size_t N, int8_t* q_packed)
+{
+    if (K == 0 || N == 0 || K % 64 || N % 64) return -1;
+    /* closed form of the forward map (checked against the 4-step restatement by the tests): processed nibble stream index
+     *   P(k', n) = (n/4) * 4K + (k'/64) * 256 + (n%4) * 64 + (k'%64),   k' = written row after P1,
+     * then inside its aligned group of 8 nibbles position e moves to dest d with src(d) = e. */
+    memset(q_packed, 0, K * (N / 2));
+    const uint8_t* pb = (const uint8_t*)packed;
+    for (size_t kw = 0; kw < K; ++kw) {
+        const size_t t = kw % 32, src_k = kw - t + (8 * ((t % 8) / 2) + t % 2 + 2 * (t / 8));
+        for (size_t n = 0; n < N; ++n) {
+            const size_t P = (n / 4) * 4 * K + (kw / 64) * 256 + (n % 4) * 64 + (kw % 64);
+            const size_t e = P % 8, g = P - e;
+            const size_t d = (e % 2 == 0) ? e / 2 : 4 + (e - 1) / 2;  /* dest nibble holding source nibble e */
+            const size_t pos = g + d;
+            const int    v   = (int)((pb[pos >> 1] >> (4 * (pos & 1))) & 0xF) - 8;
+            i4_set(q_packed + src_k * (N / 2), n, v);
+        }
+    }
+    return 0;
+}
+
+/* interleaved_numeric_conversion.h:215-280 on one register of 8 biased nibbles n0..n7 (n0 = bits 0..3): lop3 + sub / fma
+ * produce, in order, n0-8, n4-8, n1-8, n5-8, n2-8, n6-8, n3-8, n7-8 (exact in fp16: 1024 + n - 1032, (1024 + 16 n)/16 - 72). */
+static void ref_convert8_i4(uint32_t i4s, int* out8)
+{
+    static const int order[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+    for (int j = 0; j < 8; ++j) {
+        const uint32_t nib = (i4s >> (4 * order[j])) & 0xF;
+        float          f;
+        if ((order[j] & 1) == 0 ? 1 : 0) f = h2f((uint16_t)(0x6400u | nib)) - 1032.f; /* elt_01 / elt_45: sub 1032 */
+        else f = h2f(f2h(h2f((uint16_t)(0x6400u | (nib << 4))) * 0.0625f - 72.f));    /* elt_23 / elt_67: fma 1/16, -72 */
+        out8[j] = (int)f;
+    }
+}
+
+/* The reference GEMV's Int4b addressing run for every block / thread / k iteration (kernel.h:68-116: kInterleave 4, kStride
+ * 64, shuffle constants 2 / 4 / 4; :169-214: 32 elements per 128-bit access, kThreadsNumPerTile 2, kThreadsNumPerInterleave 8;
+ * :233-292 scale-loader offset; :294-376 load, convert, un-shuffle).  NPerBlock = 2, BlockSize = 256 as for int8. */
+int oracle_sm80_reader_unpack_i4(const int8_t* packed, size_t K, size_t N, int8_t* q_packed)
+{
+    enum { EPT = 32, IL = 4, STRIDE = 64, NPB = 2, BLOCK = 256, TPT = STRIDE / EPT, TPI = TPT * IL };
+    if (K == 0 || N == 0 || K % 64 || N % (NPB * IL)) return -1;
+    memset(q_packed, 0, K * (N / 2));
+    const uint8_t* base = (const uint8_t*)packed;
+    const size_t   grid = N / NPB / IL;
+    for (size_t bid = 0; bid < grid; ++bid) {
+        const size_t   n_start = bid * NPB * IL;
+        const uint8_t* qw      = base + n_start * K / 2;  /* :316, kElemsPerByte = 2 */
+        for (size_t tid = 0; tid < BLOCK; ++tid) {
+            const size_t inter_n = (tid / TPT) % IL;
+            size_t       off     = tid / TPI * STRIDE + (tid % TPT) * EPT;
+            for (size_t local_k = tid * EPT; local_k < K * IL; local_k += BLOCK * EPT) {
+                for (size_t idx = 0; idx < NPB; ++idx) {
+                    const uint8_t* src = qw + idx * IL * K / 2 + local_k / 2;  /* 16 bytes = 32 nibbles */
+                    int            vec[32], w32[32];
+                    for (int i = 0; i < 4; ++i) {
+                        uint32_t reg;
+                        memcpy(&reg, src + 4 * i, 4);
+                        ref_convert8_i4(reg, vec + 8 * i);
+                    }
+                    /* un-shuffle (:355-376): out[(i*4*2) + j*2 + t] = vec[i*2 + j*4*2 + t], i < 4, j < 4 */
+                    for (int i = 0; i < 4; ++i)
+                        for (int j = 0; j < 4; ++j)
+                            for (int t = 0; t < 2; ++t) w32[i * 8 + j * 2 + t] = vec[i * 2 + j * 8 + t];
+                    const size_t n = n_start + inter_n + idx * IL;
+                    for (int y = 0; y < 32; ++y) i4_set(q_packed + (off + (size_t)y) * (N / 2), n, w32[y]);
+                }
+                off += BLOCK * EPT / IL;
+            }
+        }
+    }
+    return 0;
+}
+
+/* This repo's native int4 layout: tile = 16 output columns x 128 k = 1024 bytes, tiles ordered [n/16][k/128];
+ * 64 lanes of 16 bytes, lane = ((k >> 5) & 3) * 16 + (n & 15) holds the 32 k values 32g .. 32g+31 of its column; dword d of
+ * a lane holds k = 8d .. 8d+7 as unsigned nibbles q + 8 at nibble positions [0, 4, 1, 5, 2, 6, 3, 7] (k-local j sits at
+ * nibble (j >> 1) + 4 * (j & 1)): (w & 0x000f000f) | 0x64006400 is then the fp16 pair (1024 + q_2j+8 .. ) of two
+ * consecutive k, the same extraction the reference's converter uses. */
+static inline size_t gfx950_i4_nibble(size_t k, size_t n, size_t K)
+{
+    const size_t tile = (n >> 4) * (K >> 7) + (k >> 7);
+    const size_t lane = ((k >> 5) & 3) * 16 + (n & 15);
+    const size_t d = (k >> 3) & 3, j = k & 7;
+    return (tile * 1024 + lane * 16 + d * 4) * 2 + ((j >> 1) + 4 * (j & 1));
+}
+int oracle_gfx950_pack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* out)
+{
+    if (K == 0 || N == 0 || K % 128 || N % 16) return -1;
+    memset(out, 0, K * N / 2);
+    uint8_t* o = (uint8_t*)out;
+    for (size_t k = 0; k < K; ++k)
+        for (size_t n = 0; n < N; ++n) {
+            const size_t  p = gfx950_i4_nibble(k, n, K);
+            const uint8_t v = (uint8_t)(i4_get(q_packed + k * (N / 2), n) + 8);
+            o[p >> 1] |= (uint8_t)(v << (4 * (p & 1)));
+        }
+    return 0;
+}
+int oracle_gfx950_unpack_i4(const int8_t* packed, size_t K, size_t N, int8_t* q_packed)
+{
+    if (K == 0 || N == 0 || K % 128 || N % 16) return -1;
+    memset(q_packed, 0, K * (N / 2));
+    const uint8_t* pb = (const uint8_t*)packed;
+    for (size_t k = 0; k < K; ++k)
+        for (size_t n = 0; n < N; ++n) {
+            const size_t p = gfx950_i4_nibble(k, n, K);
+            i4_set(q_packed + k * (N / 2), n, (int)((pb[p >> 1] >> (4 * (p & 1))) & 0xF) - 8);
+        }
+    return 0;
+}
+
 /* ------------------------------------------------------------------ gfx950 native layout (this repo's)
  * Not a reference algorithm: this is the CPU statement of the layout the HIP pack kernel must produce
  * (DESIGN.md "HBM layout").  Tile = 16 output columns x 64 k = 1 KiB, tiles ordered [n/16][k/64];

@@ -10,7 +10,8 @@ _LIB_PATH = os.path.join(_HERE, "libeetq_oracle.so")
 
 __all__ = [
     "build", "lib", "quantize", "sm80_pack", "sm80_pack_closed_form", "sm80_unpack", "gfx950_pack",
-    "gfx950_unpack", "sm80_reader_unpack", "ref_gemv_sm80", "w8a16_gemm", "w8a16_gemm_bias_act", "w8a16_gemm_f32acc", "dequant", "rmsnorm_f16", "rotary_neox_f16",
+    "gfx950_unpack", "sm80_reader_unpack", "ref_gemv_sm80", "quantize_i4", "i4_values", "i4_from_values", "sm80_pack_i4",
+    "sm80_unpack_i4", "sm80_reader_unpack_i4", "gfx950_pack_i4", "gfx950_unpack_i4", "w8a16_gemm", "w8a16_gemm_bias_act", "w8a16_gemm_f32acc", "dequant", "rmsnorm_f16", "rotary_neox_f16",
     "f32_to_f16_bits", "f16_bits_to_f32",
 ]
 
@@ -38,6 +39,14 @@ def lib():
             getattr(L, name).argtypes = [vp, sz, sz, vp]
             getattr(L, name).restype = i32
         L.oracle_w8a16_gemm.argtypes = [vp, vp, vp, vp, sz, sz, sz]
+        L.oracle_quantize_i4_f16.argtypes = [vp, sz, sz, vp, vp]
+        L.oracle_quantize_i4_f32.argtypes = [vp, sz, sz, vp, vp]
+        L.oracle_i4_unpack_values.argtypes = [vp, sz, sz, vp]
+        L.oracle_i4_pack_values.argtypes = [vp, sz, sz, vp]
+        for name in ("oracle_sm80_pack_i4", "oracle_sm80_unpack_i4", "oracle_sm80_reader_unpack_i4", "oracle_gfx950_pack_i4",
+                     "oracle_gfx950_unpack_i4"):
+            getattr(L, name).argtypes = [vp, sz, sz, vp]
+            getattr(L, name).restype = i32
         L.oracle_w8a16_gemm_bias_act.argtypes = [vp, vp, vp, vp, i32, vp, sz, sz, sz]
         L.oracle_ref_gemv_sm80.argtypes = [vp, vp, vp, vp, sz, sz, sz]
         L.oracle_ref_gemv_sm80.restype = i32
@@ -130,6 +139,67 @@ def ref_gemv_sm80(x, packed_sm80, scales):
     if rc != 0:
         raise ValueError("oracle_ref_gemv_sm80 failed: %d" % rc)
     return y
+
+
+def quantize_i4(w):
+    """w: [K, N] float16/float32 -> (packed raw int4 [K, N/2] int8, scales [N])."""
+    assert w.ndim == 2 and w.shape[1] % 2 == 0
+    K, N = w.shape
+    q = np.empty((K, N // 2), np.int8)
+    if w.dtype == np.float16:
+        s = np.empty(N, np.float16)
+        lib().oracle_quantize_i4_f16(_p(_c(w, np.float16)), K, N, _p(q), _p(s))
+    else:
+        s = np.empty(N, np.float32)
+        lib().oracle_quantize_i4_f32(_p(_c(w, np.float32)), K, N, _p(q), _p(s))
+    return q, s
+
+
+def i4_values(q_packed):
+    """packed raw int4 [K, N/2] -> int8 [K, N] holding the values -8..7."""
+    q_packed = _c(q_packed, np.int8)
+    K, half = q_packed.shape
+    q = np.empty((K, half * 2), np.int8)
+    lib().oracle_i4_unpack_values(_p(q_packed), K, half * 2, _p(q))
+    return q
+
+
+def i4_from_values(q):
+    q = _c(q, np.int8)
+    K, N = q.shape
+    out = np.empty((K, N // 2), np.int8)
+    lib().oracle_i4_pack_values(_p(q), K, N, _p(out))
+    return out
+
+
+def _layout_call_i4(fn, src):
+    src = _c(src, np.int8)
+    K, half = src.shape
+    out = np.empty((K, half), np.int8)
+    rc = fn(_p(src), K, half * 2, _p(out))
+    if rc != 0:
+        raise ValueError("unsupported int4 shape K=%d N=%d" % (K, half * 2))
+    return out
+
+
+def sm80_pack_i4(q_packed):
+    return _layout_call_i4(lib().oracle_sm80_pack_i4, q_packed)
+
+
+def sm80_unpack_i4(packed):
+    return _layout_call_i4(lib().oracle_sm80_unpack_i4, packed)
+
+
+def sm80_reader_unpack_i4(packed):
+    return _layout_call_i4(lib().oracle_sm80_reader_unpack_i4, packed)
+
+
+def gfx950_pack_i4(q_packed):
+    return _layout_call_i4(lib().oracle_gfx950_pack_i4, q_packed)
+
+
+def gfx950_unpack_i4(packed):
+    return _layout_call_i4(lib().oracle_gfx950_unpack_i4, packed)
 
 
 def gfx950_pack(q_raw):

@@ -1,0 +1,137 @@
+"""W4A16 (int4 weight-only): the quint4x2 branch of quant_weights / preprocess_weights bit-exact against the oracle's
+restatement of cutlass_preprocessors.cc (writer) pinned by the reference GEMV's Int4b reader, and the W4A16 GEMM
+(extension) against the same numerics contract as W8A16: y = fp16(sum_k fp32(x) * fp32(fp16(q4 * s)))."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import eetq_amd.ops as _ops
+    assert _ops.BOUNDARY == "ext", "int4 goes through the compiled module"
+    return _ops
+
+
+def _tier_a(y, ref):
+    y, ref = y.astype(np.float32), ref.astype(np.float32)
+    return np.abs(y - ref) <= 1e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref)
+
+
+@pytest.mark.parametrize("K,N,dtype", [(128, 16, np.float16), (128, 64, np.float32), (256, 192, np.float16),
+                                       (4096, 4096, np.float16), (1024, 11008, np.float16)])
+def test_quant_weights_int4_bit_exact(ops, oracle, K, N, dtype):
+    rng = np.random.default_rng(K + N)
+    w = (rng.standard_normal((K, N)) * 0.05).astype(dtype)
+    w[:, 5] = 0                                        # all-zero column: scale 0, q = -8
+    w[3, 7] = np.abs(w[:, 7]).max() * 2                # +amax -> +8 -> clipped to 7
+    raw, processed, scales = ops.quant_weights(torch.from_numpy(w), torch.quint4x2, True)
+    assert raw.shape == (K, N // 2) and processed.shape == (K, N // 2) and raw.dtype == torch.int8 and raw.device.type == "cpu"
+    q, s = oracle.quantize_i4(w)
+    assert np.array_equal(raw.numpy(), q)
+    assert scales.numpy().tobytes() == s.tobytes()
+    assert np.array_equal(processed.numpy(), oracle.gfx950_pack_i4(q))
+    two = ops.quant_weights(torch.from_numpy(w).to(DEV), torch.quint4x2, False)
+    assert len(two) == 2 and torch.equal(two[0].cpu(), processed) and two[0].is_cuda
+    if N % 64 == 0:
+        sm = ops.quant_weights(torch.from_numpy(w), torch.quint4x2, False, layout="sm80")[0]
+        assert np.array_equal(sm.numpy(), oracle.sm80_pack_i4(q))     # the bytes the reference would have produced
+
+
+@pytest.mark.parametrize("layout", ["gfx950", "sm80"])
+@pytest.mark.parametrize("K,N", [(128, 64), (384, 256), (4096, 4096)])
+def test_preprocess_unprocess_int4(ops, oracle, layout, K, N):
+    rng = np.random.default_rng(K * 3 + N)
+    q = oracle.i4_from_values(rng.integers(-8, 8, (K, N), dtype=np.int8))
+    want = oracle.gfx950_pack_i4(q) if layout == "gfx950" else oracle.sm80_pack_i4(q)
+    got = ops.preprocess_weights(torch.from_numpy(q), True, layout)
+    assert np.array_equal(got.numpy(), want)
+    assert np.array_equal(ops.unprocess_weights(got, layout, True).numpy(), q)
+    d = ops.preprocess_weights(torch.from_numpy(q).to(DEV), True, layout)
+    assert d.is_cuda and np.array_equal(d.cpu().numpy(), want)
+    if layout == "sm80":   # checkpoint interop: reference bytes -> native
+        assert np.array_equal(ops.convert_layout(torch.from_numpy(want), "sm80", "gfx950", is_int4=True).numpy(),
+                              oracle.gfx950_pack_i4(q))
+
+
+def test_int4_shape_errors(ops):
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        ops.preprocess_weights(torch.zeros(64, 32, dtype=torch.int8), True)
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.preprocess_weights(torch.zeros(128, 16, dtype=torch.int8), True, "sm80")
+    with pytest.raises(RuntimeError):
+        ops.quant_weights(torch.zeros(128, 15, dtype=torch.float16), torch.quint4x2)
+
+
+@pytest.mark.parametrize("M", [1, 2, 3, 4])
+@pytest.mark.parametrize("K,N", [(128, 16), (256, 48), (1024, 256), (4096, 512), (11008, 64), (2176, 32)])
+def test_w4a16_gemv_vs_oracle(ops, oracle, M, K, N):
+    rng = np.random.default_rng(M + K + N)
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float16)
+    x = (rng.random((M, K)) - 0.3).astype(np.float16)
+    qp, s = oracle.quantize_i4(w)
+    processed = torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV)
+    y = ops.w8_a16_gemm(torch.from_numpy(x).to(DEV), processed, torch.from_numpy(s).to(DEV)).cpu().numpy()
+    ref = oracle.w8a16_gemm(x, oracle.i4_values(qp), s)      # same contract on the int4 values
+    assert y.shape == (M, N) and _tier_a(y, ref).all(), np.abs(y.astype(np.float32) - ref.astype(np.float32)).max()
+
+
+def test_w4a16_identity_is_exact_dequant(ops, oracle):
+    """x = I selects single products: the GEMM must return fp16(q4 * s) exactly, for every nibble value and k position
+    (GEMV path for the first rows, the expanded-int8 route for the whole identity)."""
+    K, N = 256, 64
+    rng = np.random.default_rng(1)
+    q = rng.integers(-8, 8, (K, N), dtype=np.int8)
+    q[:16, 0] = np.arange(-8, 8)
+    qp = oracle.i4_from_values(q)
+    s = (rng.random(N) * 0.02 + 0.001).astype(np.float16)
+    processed = torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV)
+    want = oracle.dequant(q, s)
+    eye = torch.eye(K, dtype=torch.float16, device=DEV)
+    full = ops.w8_a16_gemm(eye, processed, torch.from_numpy(s).to(DEV)).cpu().numpy()
+    assert np.array_equal(full, want)
+    for r in (0, 1, 7, 31, 32, 100, 255):
+        one = ops.w8_a16_gemm(eye[r:r + 1], processed, torch.from_numpy(s).to(DEV)).cpu().numpy()
+        assert np.array_equal(one[0], want[r]), r
+
+
+@pytest.mark.parametrize("M", [5, 8, 33, 64, 200, 1024])
+def test_w4a16_larger_batches_via_int8_kernels(ops, oracle, M):
+    K, N = 1024, 384
+    rng = np.random.default_rng(M)
+    w = (rng.standard_normal((K, N)) * 0.05).astype(np.float16)
+    x = (rng.random((M, K)) - 0.3).astype(np.float16)
+    qp, s = oracle.quantize_i4(w)
+    processed = torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV)
+    bias = torch.randn(N, dtype=torch.float16, device=DEV)
+    res = torch.randn(M, N, dtype=torch.float16, device=DEV)
+    xd, sd = torch.from_numpy(x).to(DEV), torch.from_numpy(s).to(DEV)
+    y = ops.w8_a16_gemm(xd, processed, sd)
+    rows = sorted(set([0, M // 2, M - 1]))
+    ref = oracle.w8a16_gemm(x[rows], oracle.i4_values(qp), s)
+    assert _tier_a(y.cpu().numpy()[rows], ref).all()
+    # the expanded weight is exactly the int8 tile image of the same integers: bit-identical to W8A16 on them
+    p8 = torch.from_numpy(oracle.gfx950_pack(oracle.i4_values(qp))).to(DEV)
+    assert torch.equal(y, ops.w8_a16_gemm(xd, p8, sd))
+    assert torch.equal(ops.w8_a16_gemm(xd, processed, sd, bias=bias, residual=res), y + bias + res)
+
+
+def test_w4a16_linear_module(ops, oracle):
+    from eetq_amd.modules.qlinear import W4A16Linear
+    torch.manual_seed(2)
+    lin = torch.nn.Linear(512, 256, bias=True, dtype=torch.float16, device=DEV)
+    mod = W4A16Linear.from_torch(lin)
+    assert mod.qweight.shape == (512, 128) and mod.weight_scales.shape == (256,)
+    x = torch.rand(3, 512, dtype=torch.float16, device=DEV)
+    with torch.no_grad():
+        ref = lin(x)
+    y = mod(x)
+    assert y.shape == ref.shape
+    # 4-bit per-channel quantisation of a U(+-1/sqrt(512)) layer: error ~ scale/2 * sqrt(K) * E|x|
+    assert (y - ref).abs().max().item() < 0.12
+    qp, s = oracle.quantize_i4(lin.weight.detach().t().contiguous().cpu().numpy())
+    want = oracle.w8a16_gemm(x.cpu().numpy(), oracle.i4_values(qp), s).astype(np.float32) + lin.bias.detach().cpu().numpy().astype(np.float32)
+    assert np.abs(y.cpu().numpy().astype(np.float32) - want).max() < 3e-3

@@ -311,3 +311,74 @@ def test_activation_epilogue_restatement(oracle):
         assert np.array_equal(got, ref.astype(np.float32).astype(np.float16)), act
     nob = oracle.w8a16_gemm_bias_act(x, q, s, None, "relu")
     assert np.array_equal(nob, np.maximum(acc.astype(np.float32), 0).astype(np.float16))
+
+
+# ---------------------------------------------------------------- int4 (W4A16)
+
+def test_int4_quantise_restatement(oracle):
+    """cutlass_preprocessors.cc:605-674 with PACKED_INT4_WEIGHT_ONLY: scale = amax / 8, q = clamp(int(round(w / s)), -8, 7),
+    two values per byte along N (even column in the low nibble); +amax -> 8 -> clipped to 7, -amax -> -8; an all-zero
+    column has scale 0 and q = -8 (int(NaN) is INT_MIN on x86, clamped)."""
+    rng = np.random.default_rng(3)
+    K, N = 64, 8
+    w = rng.standard_normal((K, N)).astype(np.float16)
+    w[:, 3] = 0
+    w[0, 0], w[1, 0] = 7.0, -7.0                # column 0: amax 7 -> scale 0.875
+    w[2:, 0] = (np.arange(K - 2) % 15 - 7) * np.float16(0.4375)   # exact ties at half-integers of w / s
+    qp, s = oracle.quantize_i4(w)
+    q = oracle.i4_values(qp)
+    assert qp.shape == (K, N // 2) and q.min() >= -8 and q.max() <= 7
+    assert s[0] == np.float16(0.875) and q[0, 0] == 7 and q[1, 0] == -8
+    ties = [int(v) for v in q[2:17, 0]]          # w/s = -3.5, -3, -2.5, ... : half away from zero
+    assert ties == [-4, -3, -3, -2, -2, -1, -1, 0, 1, 1, 2, 2, 3, 3, 4]
+    assert s[3] == 0 and np.all(q[:, 3] == -8)
+    s32 = np.abs(w.astype(np.float32)).max(axis=0) * np.float32(0.125)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        r = w.astype(np.float32) / s32
+    ref = np.sign(r) * np.floor(np.abs(r) + np.float32(0.5))
+    ref = np.where(np.isnan(ref), -8, np.clip(ref, -8, 7)).astype(np.int8)
+    assert np.array_equal(q, ref)
+    assert np.array_equal(oracle.i4_from_values(q), qp)
+    assert (qp.view(np.uint8)[5, 1] & 0xF) == (int(q[5, 2]) & 0xF) and (qp.view(np.uint8)[5, 1] >> 4) == (int(q[5, 3]) & 0xF)
+    q32, s32b = oracle.quantize_i4(w.astype(np.float32))
+    assert np.array_equal(q32, qp) and s32b.dtype == np.float32
+
+
+def test_int4_sm80_layout_writer_reader_and_inverse(oracle):
+    """The int4 processed layout from both reference sides: the writer (cutlass_preprocessors.cc P1..P4 for int4) and the
+    reader (the GEMV's Int4b addressing + the int4 converter); reader(writer(q)) == q for every nibble value and position,
+    and the closed-form inverse agrees."""
+    rng = np.random.default_rng(8)
+    for K, N in [(64, 64), (128, 64), (192, 256), (2048 + 64, 128)]:
+        q = rng.integers(-8, 8, (K, N), dtype=np.int8)
+        q[:16, 1] = np.arange(-8, 8, dtype=np.int8)
+        qp = oracle.i4_from_values(q)
+        packed = oracle.sm80_pack_i4(qp)
+        assert np.array_equal(oracle.sm80_reader_unpack_i4(packed), qp), (K, N)
+        assert np.array_equal(oracle.sm80_unpack_i4(packed), qp), (K, N)
+    K, N = 128, 64
+    for k in range(0, K, 5):
+        for n in range(0, N, 7):
+            q = np.zeros((K, N), np.int8)
+            q[k, n] = -5
+            qp = oracle.i4_from_values(q)
+            assert np.array_equal(oracle.sm80_reader_unpack_i4(oracle.sm80_pack_i4(qp)), qp)
+    with pytest.raises(ValueError):
+        oracle.sm80_pack_i4(np.zeros((64, 16), np.int8))       # N = 32
+
+
+def test_int4_native_layout_definition(oracle):
+    K, N = 256, 32
+    rng = np.random.default_rng(2)
+    q = rng.integers(-8, 8, (K, N), dtype=np.int8)
+    qp = oracle.i4_from_values(q)
+    packed = oracle.gfx950_pack_i4(qp).reshape(-1).view(np.uint8)
+    for k, n in [(0, 0), (1, 0), (2, 0), (7, 3), (8, 3), (31, 15), (32, 0), (127, 15), (128, 16), (255, 31), (77, 9)]:
+        tile = (n >> 4) * (K >> 7) + (k >> 7)
+        lane = ((k >> 5) & 3) * 16 + (n & 15)
+        d, j = (k >> 3) & 3, k & 7
+        nib = (tile * 1024 + lane * 16 + d * 4) * 2 + (j >> 1) + 4 * (j & 1)
+        assert (packed[nib >> 1] >> (4 * (nib & 1))) & 0xF == int(q[k, n]) + 8
+    assert np.array_equal(oracle.gfx950_unpack_i4(oracle.gfx950_pack_i4(qp)), qp)
+    with pytest.raises(ValueError):
+        oracle.gfx950_pack_i4(np.zeros((64, 16), np.int8))     # K % 128
