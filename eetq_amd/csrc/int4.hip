@@ -1,7 +1,7 @@
 // W4A16 (int4 weight-only) path: quantise, pack / unpack, the decode GEMV (M <= 4) and the route to the int8 kernels for
 // larger M.
 //
-// Reference behaviour restated (paths relative to /root/reference; CPU restatement: oracle/eetq_oracle.c "int4"):
+// Reference behaviour restated (paths relative to /root/reference):
 //   quantise      csrc/cutlass_kernels/cutlass_preprocessors.cc:581-678 with PACKED_INT4_WEIGHT_ONLY (scale = amax / 8,
 //                 q = clamp(int(round(w / scale)), -8, 7), two values per byte along N, even column in the low nibble)
 //   sm80 layout   cutlass_preprocessors.cc:137-195 (32-row permute), :201-335 (sub-byte transpose), :432-495 (column
@@ -43,7 +43,7 @@ __device__ __forceinline__ void gfx950_i4_inv(size_t pos, size_t K, size_t& k, s
     k = (tile % ktiles) * 128 + (lane >> 4) * 32 + d * 8 + j;
     n = (tile / ktiles) * 16 + (lane & 15);
 }
-// reference layout (closed form of P1..P4 for int4; oracle_sm80_unpack_i4): written row kw <- source row perm32(kw);
+// reference layout (closed form of P1..P4 for int4): written row kw <- source row perm32(kw);
 // stream index P = (n/4)*4K + (kw/64)*256 + (n%4)*64 + kw%64; inside an aligned group of 8 nibbles source e sits at dest
 // (e even ? e/2 : 4 + e/2)
 __device__ __forceinline__ size_t perm32(size_t kw)
