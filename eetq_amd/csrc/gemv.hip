@@ -117,6 +117,49 @@ int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16
     return launch_lds<M, 1, 1, false, 1>(x, w, scales, ep, y, N, K, stream, pro);
 }
 
+// ---- int4 tiles (W4A16): the same kernel template with BITS = 4 (128 k per tile, 32 k per lane) ----
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int OCC>
+int launch_inst_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
+{
+    auto         kern = gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC, 0, 4>;
+    const size_t smem = gemv::gemv_smem_bytes(M, K, WAVES, XREG);
+    if (smem > 64 * 1024) {
+        static std::atomic<unsigned long long> opted{0};
+        int st = opt_in_large_lds(kern, opted);
+        if (st != EETQ_OK) return st;
+    }
+    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep, Prologue{});
+    return check_hip(hipGetLastError(), "gemv_kernel (int4) launch");
+}
+
+template <int M, int WAVES, int D, int OCC>
+int launch_lds_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
+{
+    const int xvecs = M * K / 8, threads = WAVES * 64;
+    const int need  = (xvecs + threads - 1) / threads;
+    if (gemv::gemv_smem_bytes(M, K, WAVES, false) > 160 * 1024 || need > 8)
+        return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16 GEMV: M*K too large for LDS staging");
+    if (need <= 1) return launch_inst_i4<M, WAVES, D, false, false, 1, OCC>(x, w, scales, ep, y, N, K, stream);
+    if (need <= 2) return launch_inst_i4<M, WAVES, D, false, false, 2, OCC>(x, w, scales, ep, y, N, K, stream);
+    if (need <= 4) return launch_inst_i4<M, WAVES, D, false, false, 4, OCC>(x, w, scales, ep, y, N, K, stream);
+    return launch_inst_i4<M, WAVES, D, false, false, 8, OCC>(x, w, scales, ep, y, N, K, stream);
+}
+
+template <int M>
+int launch_m_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
+{
+    const int KT = K / 128;
+    if constexpr (M <= 2) {
+        // whole tile row in flight, activations straight to registers (the K = 4096 / 8192 decode shapes)
+        if (KT == 32) return launch_inst_i4<M, 16, 2, true, true, 1, 4>(x, w, scales, ep, y, N, K, stream);
+        if (KT == 64) return launch_inst_i4<M, 16, 4, true, true, 1, 2>(x, w, scales, ep, y, N, K, stream);
+    }
+    if (KT >= 32) return launch_lds_i4<M, 16, 2, 4>(x, w, scales, ep, y, N, K, stream);
+    if (KT >= 16) return launch_lds_i4<M, 8, 2, 2>(x, w, scales, ep, y, N, K, stream);
+    if (KT >= 4) return launch_lds_i4<M, 4, 1, 1>(x, w, scales, ep, y, N, K, stream);
+    return launch_lds_i4<M, 1, 1, 1>(x, w, scales, ep, y, N, K, stream);
+}
+
 }  // namespace
 
 int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
@@ -131,4 +174,18 @@ int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     }
 }
 
+}  // namespace eetq
+
+namespace eetq {
+int launch_gemv_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
+                   hipStream_t stream)
+{
+    switch (M) {
+        case 1: return launch_m_i4<1>(x, w, scales, ep, y, N, K, stream);
+        case 2: return launch_m_i4<2>(x, w, scales, ep, y, N, K, stream);
+        case 3: return launch_m_i4<3>(x, w, scales, ep, y, N, K, stream);
+        case 4: return launch_m_i4<4>(x, w, scales, ep, y, N, K, stream);
+        default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16 GEMV path only supports M <= 4");
+    }
+}
 }  // namespace eetq

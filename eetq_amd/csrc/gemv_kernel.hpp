@@ -113,20 +113,83 @@ __device__ __forceinline__ void silu_mul_staged(u32x4 (&xv)[XV], const u32x4 (&u
     }
 }
 
-// One 1 KiB tile: this lane's 16 k of column c against the matching 16 activations of every batch row.
+// int4 tiles (DESIGN.md "int4 layout"): one dword = 8 consecutive k as unsigned nibbles q + 8 at nibble positions
+// [0, 4, 1, 5, 2, 6, 3, 7]; the mask / shift extractions of the reference's converter
+// (cutlass_extensions/.../interleaved_numeric_conversion.h:215-280: (w & 0x000f000f) | 0x64006400, - 1032; (w & 0x00f000f0) |
+// 0x64006400, * 1/16 - 72) give the exact integers as fp16 pairs (k0,k1) (k2,k3) (k4,k5) (k6,k7); one rounding by the scale.
+__device__ __forceinline__ void dequant_dword_i4(u32 w, f16x2 scale2, f16x2 (&out)[4])
+{
+    const f16x2 c1032 = {(f16)1032.0f, (f16)1032.0f};
+    const f16x2 c16th = {(f16)0.0625f, (f16)0.0625f};
+    const f16x2 c72   = {(f16)72.0f, (f16)72.0f};
+    const u32   top   = w >> 8;
+    const f16x2 p0 = as_f16x2((w & 0x000f000fu) | 0x64006400u);
+    const f16x2 p1 = as_f16x2((w & 0x00f000f0u) | 0x64006400u);
+    const f16x2 p2 = as_f16x2((top & 0x000f000fu) | 0x64006400u);
+    const f16x2 p3 = as_f16x2((top & 0x00f000f0u) | 0x64006400u);
+    out[0] = (p0 - c1032) * scale2;
+    out[1] = (p1 * c16th - c72) * scale2;
+    out[2] = (p2 - c1032) * scale2;
+    out[3] = (p3 * c16th - c72) * scale2;
+}
+
+// weight bits -> k values per 1 KiB tile (16 columns x kTileK<BITS>) and per lane (16 bytes)
+template <int BITS>
+struct Codec {
+    static constexpr int kTileK = BITS == 8 ? 64 : 128;
+    static constexpr int kLaneK = BITS == 8 ? 16 : 32;
+    static constexpr int kXQ    = kLaneK / 8;  // 16-byte activation vectors per lane and tile
+};
+
+// One lane's 16 weight bytes against the matching activations of one batch row (xq: kXQ 16-byte vectors of x).
+template <int BITS>
+__device__ __forceinline__ float dot_lane(const u32x4& wv, f16x2 scale2, const u32x4* xq, float acc)
+{
+    if constexpr (BITS == 8) {
+        f16x2 wq[8];
+        dequant_16(wv, scale2, wq);
+        const u32 xd[8] = {xq[0].x, xq[0].y, xq[0].z, xq[0].w, xq[1].x, xq[1].y, xq[1].z, xq[1].w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc, false);
+    } else {
+        const u32 wd[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            f16x2 wq[4];
+            dequant_dword_i4(wd[d], scale2, wq);
+            acc = __builtin_amdgcn_fdot2(wq[0], as_f16x2(xq[d].x), acc, false);
+            acc = __builtin_amdgcn_fdot2(wq[1], as_f16x2(xq[d].y), acc, false);
+            acc = __builtin_amdgcn_fdot2(wq[2], as_f16x2(xq[d].z), acc, false);
+            acc = __builtin_amdgcn_fdot2(wq[3], as_f16x2(xq[d].w), acc, false);
+        }
+    }
+    return acc;
+}
+
+// One 1 KiB tile: this lane's k values of column c against the matching activations of every batch row.
 // xs = this lane's window of the LDS copy of x (row m at xs + m*K halfs).
-template <int M>
+template <int M, int BITS = 8>
 __device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, const f16* xs, int K, float (&acc)[M])
 {
-    f16x2 wq[8];
-    dequant_16(wv, scale2, wq);
+    if constexpr (BITS == 8) {
+        f16x2 wq[8];
+        dequant_16(wv, scale2, wq);
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const u32x4 xa    = *reinterpret_cast<const u32x4*>(xs + m * K);
-        const u32x4 xb    = *reinterpret_cast<const u32x4*>(xs + m * K + 8);
-        const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+        for (int m = 0; m < M; ++m) {
+            const u32x4 xa    = *reinterpret_cast<const u32x4*>(xs + m * K);
+            const u32x4 xb    = *reinterpret_cast<const u32x4*>(xs + m * K + 8);
+            const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc[m] = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc[m], false);
+            for (int i = 0; i < 8; ++i) acc[m] = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc[m], false);
+        }
+    } else {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            u32x4 xq[4];
+#pragma unroll
+            for (int d = 0; d < 4; ++d) xq[d] = *reinterpret_cast<const u32x4*>(xs + m * K + 8 * d);
+            acc[m] = dot_lane<4>(wv, scale2, xq, acc[m]);
+        }
     }
 }
 
@@ -142,7 +205,7 @@ __device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, cons
 //           retire at L2 latency; no LDS, no barrier before the math.
 //   else  : activations are staged once per workgroup in LDS (XV 16-byte loads per thread, clamped).
 // Dynamic LDS: [M*K fp16 activations unless XREG] + WAVES*M*16 floats (cross-wave reduction).
-template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0>
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
@@ -160,22 +223,24 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane  = tid & 63;
     const int g = lane >> 4, c = lane & 15;
-    const int KT = K >> 6;
+    using CD = Codec<BITS>;
+    constexpr int TK = CD::kTileK, LK = CD::kLaneK, XQ = CD::kXQ;
+    const int KT = K / TK;
 
     // Memory queue order matters (returns are in order): the tiny scale + activation loads go first so they
     // retire at L2 latency while the weight stream is already queued right behind them.
     u32 sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
 
-    u32x4 xr[XREG ? M * D * 2 : 1];  // XREG: this lane's 16 activations for each of its D tiles, per batch row
+    u32x4 xr[XREG ? M * D * XQ : 1];  // XREG: this lane's activations for each of its D tiles, per batch row
     u32x4 xv[XREG ? 1 : XV];
     if constexpr (XREG) {
 #pragma unroll
         for (int m = 0; m < M; ++m)
 #pragma unroll
             for (int d = 0; d < D; ++d) {
-                const u32x4* p       = reinterpret_cast<const u32x4*>(x + (size_t)m * K + (wave + d * WAVES) * 64 + 16 * g);
-                xr[(m * D + d) * 2]     = p[0];
-                xr[(m * D + d) * 2 + 1] = p[1];
+                const u32x4* p = reinterpret_cast<const u32x4*>(x + (size_t)m * K + (wave + d * WAVES) * TK + LK * g);
+#pragma unroll
+                for (int q = 0; q < XQ; ++q) xr[(m * D + d) * XQ + q] = p[q];
             }
     } else {
         const int    xvecs = (M * K) >> 3;  // 16-byte vectors of x
@@ -224,28 +289,33 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     if constexpr (XREG) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            f16x2 wq[8];
-            dequant_16(buf[d], scale2, wq);
+            if constexpr (BITS == 8) {
+                f16x2 wq[8];
+                dequant_16(buf[d], scale2, wq);
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const u32x4 xa = xr[(m * D + d) * 2], xb = xr[(m * D + d) * 2 + 1];
-                const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+                for (int m = 0; m < M; ++m) {
+                    const u32x4 xa = xr[(m * D + d) * 2], xb = xr[(m * D + d) * 2 + 1];
+                    const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) acc[m] = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc[m], false);
+                    for (int i = 0; i < 8; ++i) acc[m] = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc[m], false);
+                }
+            } else {
+#pragma unroll
+                for (int m = 0; m < M; ++m) acc[m] = dot_lane<BITS>(buf[d], scale2, &xr[(m * D + d) * XQ], acc[m]);
             }
         }
     } else {
-        const f16* xl = xs + wave * 64 + 16 * g;  // + 64*WAVES halfs per tile step
+        const f16* xl = xs + wave * TK + LK * g;  // + TK*WAVES halfs per tile step
         if constexpr (EXACT) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) consume_tile<M>(buf[d], scale2, xl + (size_t)d * 64 * WAVES, K, acc);
+            for (int d = 0; d < D; ++d) consume_tile<M, BITS>(buf[d], scale2, xl + (size_t)d * TK * WAVES, K, acc);
         } else {
             const int n = (KT - wave + WAVES - 1) / WAVES;  // tiles of this wave (>= D by launch contract)
             int       i = 0;
             for (; i + 2 * D <= n; i += D) {
 #pragma unroll
                 for (int d = 0; d < D; ++d) {
-                    consume_tile<M>(buf[d], scale2, xl + (size_t)(i + d) * 64 * WAVES, K, acc);
+                    consume_tile<M, BITS>(buf[d], scale2, xl + (size_t)(i + d) * TK * WAVES, K, acc);
                     buf[d] = load_w<true>(wp + (size_t)(i + d + D) * stride);
                 }
             }
@@ -258,10 +328,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
                 tail[d]     = load_w<true>(wp + (size_t)(t < n ? t : n - 1) * stride);
             }
 #pragma unroll
-            for (int d = 0; d < D; ++d) consume_tile<M>(buf[d], scale2, xl + (size_t)(i + d) * 64 * WAVES, K, acc);
+            for (int d = 0; d < D; ++d) consume_tile<M, BITS>(buf[d], scale2, xl + (size_t)(i + d) * TK * WAVES, K, acc);
 #pragma unroll
             for (int d = 0; d < D - 1; ++d)
-                if (d < r) consume_tile<M>(tail[d], scale2, xl + (size_t)(i + D + d) * 64 * WAVES, K, acc);
+                if (d < r) consume_tile<M, BITS>(tail[d], scale2, xl + (size_t)(i + D + d) * TK * WAVES, K, acc);
         }
     }
 

@@ -1,5 +1,5 @@
-// W4A16 (int4 weight-only) path: quantise, pack / unpack, the decode GEMV (M <= 4) and the route to the int8 kernels for
-// larger M.
+// W4A16 (int4 weight-only) path: quantise, pack / unpack, and the GEMM dispatch (decode GEMV on int4 tiles for M <= 4 --
+// gemv_kernel.hpp with BITS = 4 -- and the route to the int8 kernels for larger M).
 //
 // Reference behaviour restated (paths relative to /root/reference):
 //   quantise      csrc/cutlass_kernels/cutlass_preprocessors.cc:581-678 with PACKED_INT4_WEIGHT_ONLY (scale = amax / 8,
@@ -162,119 +162,6 @@ int check_i4_shape(size_t K, size_t N, int layout)
     return EETQ_OK;
 }
 
-// ---- dequant helpers: one dword (8 k) -> four fp16 pairs fp16(q * s), the reference converter's arithmetic ---------------
-__device__ __forceinline__ void dequant_dword_i4(u32 w, f16x2 scale2, f16x2 (&out)[4])
-{
-    const f16x2 c1032 = {(f16)1032.0f, (f16)1032.0f};
-    const f16x2 c16th = {(f16)0.0625f, (f16)0.0625f};
-    const f16x2 c72   = {(f16)72.0f, (f16)72.0f};
-    const u32   top   = w >> 8;
-    const f16x2 p0 = as_f16x2((w & 0x000f000fu) | 0x64006400u);     // (1024 + u0, 1024 + u1)
-    const f16x2 p1 = as_f16x2((w & 0x00f000f0u) | 0x64006400u);     // (1024 + 16 u2, 1024 + 16 u3)
-    const f16x2 p2 = as_f16x2((top & 0x000f000fu) | 0x64006400u);
-    const f16x2 p3 = as_f16x2((top & 0x00f000f0u) | 0x64006400u);
-    out[0] = (p0 - c1032) * scale2;                                  // exact integers q, then one rounding by the scale
-    out[1] = (p1 * c16th - c72) * scale2;                            // (1024 + 16u)/16 - 72 = u - 8: both steps exact
-    out[2] = (p2 - c1032) * scale2;
-    out[3] = (p3 * c16th - c72) * scale2;
-}
-
-// ---- W4A16 decode GEMV, M <= 4 ----------------------------------------------------------------------------------------------
-// grid = N/16 workgroups (one per 16-column tile row: a contiguous K*8-byte stream), 16 waves; wave w takes tiles w,
-// w+16, ...; two tiles (16 B/lane each) in flight per wave, loads never behind a branch (clamped index, predicated use).
-// Activations are staged once per workgroup in LDS.  fp32 accumulation (v_dot2), lane-swap + LDS reduction as in the int8 GEMV.
-template <int M, int XV>
-__global__ __launch_bounds__(1024) void w4a16_gemv_kernel(const f16* __restrict__ x, const uint8_t* __restrict__ w,
-                                                          const f16* __restrict__ scales, f16* __restrict__ y, int N, int K,
-                                                          Epilogue ep)
-{
-    constexpr int WAVES = 16;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    f16*   xs  = reinterpret_cast<f16*>(smem);
-    float* red = reinterpret_cast<float*>(smem + (size_t)M * K * 2);
-    const int tid = threadIdx.x, ntile = blockIdx.x;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, c = lane & 15;
-    const int KT = K >> 7;
-
-    u32 sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
-    u32x4        xv[XV];
-    const int    xvecs = (M * K) >> 3;
-    const u32x4* xg    = reinterpret_cast<const u32x4*>(x);
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-        const int v = tid + i * WAVES * 64;
-        xv[i]       = xg[v < xvecs ? v : xvecs - 1];
-    }
-    const u32x4* wp = reinterpret_cast<const u32x4*>(w + (size_t)ntile * KT * kTileBytes) + lane;
-    const int    n  = (KT - wave + WAVES - 1) / WAVES;  // tiles of this wave (may be 0)
-    auto tile_ptr = [&](int i) {
-        int t = wave + (i < n ? i : (n > 0 ? n - 1 : 0)) * WAVES;
-        t     = t < KT ? t : KT - 1;
-        return wp + (size_t)t * 64;
-    };
-    u32x4 buf0 = __builtin_nontemporal_load(tile_ptr(0));
-    u32x4 buf1 = __builtin_nontemporal_load(tile_ptr(1));
-#pragma unroll
-    for (int i = 0; i < XV; ++i) {
-        const int v = tid + i * WAVES * 64;
-        if (v < xvecs) reinterpret_cast<u32x4*>(xs)[v] = xv[i];
-    }
-    asm volatile("" : "+v"(sraw));
-    const f16x2 scale2 = as_f16x2(sraw | (sraw << 16));
-    __syncthreads();
-
-    float acc[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) acc[m] = 0.f;
-    auto consume = [&](const u32x4& wv, int i) {
-        const f16* xl = xs + (size_t)(wave + i * WAVES) * 128 + 32 * g;  // this lane's 32 activations of the tile
-        const u32  wd[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            f16x2 wq[4];
-            dequant_dword_i4(wd[d], scale2, wq);
-#pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const u32x4 xa = *reinterpret_cast<const u32x4*>(xl + (size_t)m * K + 8 * d);
-                acc[m] = __builtin_amdgcn_fdot2(wq[0], as_f16x2(xa.x), acc[m], false);
-                acc[m] = __builtin_amdgcn_fdot2(wq[1], as_f16x2(xa.y), acc[m], false);
-                acc[m] = __builtin_amdgcn_fdot2(wq[2], as_f16x2(xa.z), acc[m], false);
-                acc[m] = __builtin_amdgcn_fdot2(wq[3], as_f16x2(xa.w), acc[m], false);
-            }
-        }
-    };
-    for (int i = 0; i < n; i += 2) {
-        const u32x4 a = buf0, b = buf1;
-        buf0 = __builtin_nontemporal_load(tile_ptr(i + 2));
-        buf1 = __builtin_nontemporal_load(tile_ptr(i + 3));
-        consume(a, i);
-        if (i + 1 < n) consume(b, i + 1);
-    }
-
-    // reduction: 4 k-groups of the wave (xor 16, xor 32), then across waves via LDS
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-        float v = acc[m];
-        v += __shfl_xor(v, 16, 64);
-        v += __shfl_xor(v, 32, 64);
-        acc[m] = v;
-    }
-    if (lane < 16) {
-#pragma unroll
-        for (int m = 0; m < M; ++m) red[(wave * M + m) * 16 + lane] = acc[m];
-    }
-    __syncthreads();
-    if (tid < 16 * M) {
-        const int m = tid >> 4, cc = tid & 15;
-        float     s = 0.f;
-#pragma unroll
-        for (int wv = 0; wv < WAVES; ++wv) s += red[(wv * M + m) * 16 + cc];
-        f16 v = finish_element(s, ep, ntile * 16 + cc);
-        if (ep.residual) v = v + ep.residual[(size_t)m * N + ntile * 16 + cc];
-        y[(size_t)m * N + ntile * 16 + cc] = v;
-    }
-}
-
 // ---- expand int4 tiles to int8 gfx950 tiles (same integers, same scales): the route to the MFMA kernels for M > 4 --------
 // one thread per int4 lane chunk (16 bytes = 32 k of one column) -> two int8 lane chunks (16 k each) of one int8 tile
 __global__ __launch_bounds__(256) void expand_i4_to_i8_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t chunks,
@@ -331,33 +218,6 @@ int expanded_scratch(size_t bytes, hipStream_t stream, uint8_t** out)
     }
     *out = s.p;
     return EETQ_OK;
-}
-
-template <int M, int XV>
-int launch_gemv_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, size_t smem,
-                   hipStream_t stream)
-{
-    auto kern = w4a16_gemv_kernel<M, XV>;
-    if (smem > 64 * 1024) {
-        static std::atomic<unsigned long long> opted{0};
-        int st = opt_in_large_lds(kern, opted);
-        if (st != EETQ_OK) return st;
-    }
-    launch_kernel(kern, dim3(N / 16), dim3(1024), smem, stream, x, w, scales, y, N, K, ep);
-    return check_hip(hipGetLastError(), "w4a16_gemv_kernel launch");
-}
-
-template <int M>
-int launch_gemv_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
-{
-    const size_t smem = (size_t)M * K * 2 + 16 * M * 16 * 4;
-    if (smem > 160 * 1024) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16 GEMV: M*K too large for LDS staging");
-    const int need = ((M * K / 8) + 1023) / 1024;
-    if (need <= 1) return launch_gemv_xv<M, 1>(x, w, scales, ep, y, N, K, smem, stream);
-    if (need <= 2) return launch_gemv_xv<M, 2>(x, w, scales, ep, y, N, K, smem, stream);
-    if (need <= 4) return launch_gemv_xv<M, 4>(x, w, scales, ep, y, N, K, smem, stream);
-    if (need <= 8) return launch_gemv_xv<M, 8>(x, w, scales, ep, y, N, K, smem, stream);
-    return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16 GEMV: M*K too large");
 }
 
 }  // namespace
@@ -430,13 +290,8 @@ int launch_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, 
 
 int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, hipStream_t stream)
 {
-    switch (M) {
-        case 1: return launch_gemv_m<1>(x, w, scales, ep, y, N, K, stream);
-        case 2: return launch_gemv_m<2>(x, w, scales, ep, y, N, K, stream);
-        case 3: return launch_gemv_m<3>(x, w, scales, ep, y, N, K, stream);
-        case 4: return launch_gemv_m<4>(x, w, scales, ep, y, N, K, stream);
-        default: break;
-    }
+    // decode: the wave-reduction GEMV on int4 tiles (gemv_kernel<..., BITS = 4>)
+    if (M <= kGemvMaxM) return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
     // larger batches: expand the nibbles to the int8 tile layout once per call (K*N/2 bytes read, K*N written; the GEMM that
     // follows is MFMA- or x-bound at these M) and run the W8A16 kernels on it -- same integers, same scales, same contract
     uint8_t* w8 = nullptr;

@@ -484,6 +484,13 @@ int main(int argc, char** argv)
         bench_gemv<1, 16, 8, false, false, 2, 4>("M1 loop lds 16x8 o4", 4096, 11008, bufs_big, x, scales, y);
         bench_gemv<4, 16, 4, false, false, 8, 4>("M4 loop lds 16x4 o4", 4096, 11008, bufs_big, x, scales, y);
     }
+    if (!strcmp(what, "gemv_geom")) {  // wave count x tiles-in-flight at equal bytes in flight (64 KiB per workgroup)
+        bench_gemv<1, 16, 4, true, true, 1, 8>("M1 xreg 16 waves x 4 (shipping)", 4096, 4096, bufs, x, scales, y);
+        bench_gemv<1, 8, 8, true, true, 1, 2>("M1 xreg  8 waves x 8", 4096, 4096, bufs, x, scales, y);
+        bench_gemv<1, 4, 16, true, true, 1, 1>("M1 xreg  4 waves x 16", 4096, 4096, bufs, x, scales, y);
+        bench_gemv<1, 16, 4, true, true, 1, 8>("M1 xreg 16 waves x 4 (again)", 4096, 4096, bufs, x, scales, y);
+        bench_gemv<1, 16, 4, true, false, 1, 4>("M1 lds  16 waves x 4", 4096, 4096, bufs, x, scales, y);
+    }
     if (!strcmp(what, "all") || !strcmp(what, "gemm")) {
         printf("--- MFMA dequant-GEMM (128 x 128 x 64 tile, 4 waves) ---\n");
         eetq::f16 *xg, *yg;
