@@ -154,6 +154,7 @@ int launch_m_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         if (KT == 32) return launch_inst_i4<M, 16, 2, true, true, 1, 4>(x, w, scales, ep, y, N, K, stream);
         if (KT == 64) return launch_inst_i4<M, 16, 4, true, true, 1, 2>(x, w, scales, ep, y, N, K, stream);
     }
+    if (KT >= 64) return launch_lds_i4<M, 16, 4, 4>(x, w, scales, ep, y, N, K, stream);  // every wave owns >= 4 tiles
     if (KT >= 32) return launch_lds_i4<M, 16, 2, 4>(x, w, scales, ep, y, N, K, stream);
     if (KT >= 16) return launch_lds_i4<M, 8, 2, 2>(x, w, scales, ep, y, N, K, stream);
     if (KT >= 4) return launch_lds_i4<M, 4, 1, 1>(x, w, scales, ep, y, N, K, stream);

@@ -298,8 +298,8 @@ int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
     int      st = expanded_scratch((size_t)K * N, stream, &w8);
     if (st != EETQ_OK) return st;
     const size_t chunks = (size_t)K * N / 2 / 16;
-    expand_i4_to_i8_kernel<<<(unsigned)((chunks + 255) / 256), 256, 0, stream>>>(reinterpret_cast<const u32x4*>(w),
-                                                                                  reinterpret_cast<u32x4*>(w8), chunks, (size_t)K >> 7);
+    launch_kernel(expand_i4_to_i8_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream,
+                  reinterpret_cast<const u32x4*>(w), reinterpret_cast<u32x4*>(w8), chunks, (size_t)K >> 7);
     EETQ_TRY_HIP(hipGetLastError());
     return eetq_w8a16_gemm_act(x, reinterpret_cast<const int8_t*>(w8), scales, ep.bias, ep.residual, y, M, N, K, EETQ_PATH_AUTO,
                                ep.act, stream);
