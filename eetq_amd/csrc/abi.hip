@@ -429,6 +429,21 @@ int eetq_rotary_neox_kvcache_f16(const int64_t* positions, const int64_t* slots,
                                  max_positions, static_cast<hipStream_t>(stream));
 }
 
+int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slots, int slot_stride, const void* query,
+                                   const void* key, const void* value, const void* cos_sin_cache, void* k_cache,
+                                   void* v_cache, const void* mask, void* out, float* workspace, unsigned* tickets,
+                                   int batch, int heads, int kv_heads, int max_positions, int head_dim, int splits,
+                                   float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
+                                   int64_t* advance, void* stream)
+{
+    return launch_rope_attn_decode(positions, slots, slot_stride, static_cast<const f16*>(query),
+                                   static_cast<const f16*>(key), static_cast<const f16*>(value),
+                                   static_cast<const f16*>(cos_sin_cache), static_cast<f16*>(k_cache),
+                                   static_cast<f16*>(v_cache), static_cast<const f16*>(mask), static_cast<f16*>(out),
+                                   workspace, tickets, batch, heads, kv_heads, max_positions, head_dim, splits, scaling,
+                                   strides, kv_len, kv_len_bias, advance, static_cast<hipStream_t>(stream));
+}
+
 int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* mask, void* out,
                               float* workspace, int batch, int heads, int kv_heads, int positions, int head_dim,
                               int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,

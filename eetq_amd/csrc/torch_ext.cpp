@@ -139,6 +139,74 @@ Tensor unprocess_weights(const Tensor& processed_weight, const std::string& layo
 
 // ---- fused dequant + GEMM ---------------------------------------------------------------------------------------------
 void layernorm_forward(const Tensor& input, const Tensor& gamma, Tensor& out, double eps);
+// eetq_rotary_neox_kvcache_f16 + eetq_decode_attention_f16 as one launch (the decode step of a static cache)
+Tensor rope_decode_attention(const Tensor& positions, const Tensor& query, const Tensor& key, const Tensor& value,
+                             const Tensor& cos_sin_cache, Tensor& key_cache, Tensor& value_cache, Tensor& tickets,
+                             const OptTensor& slots, const OptTensor& mask, std::optional<double> scaling,
+                             std::optional<int64_t> splits_in, const OptTensor& kv_len, int64_t kv_len_bias,
+                             const OptTensor& advance)
+{
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&query, &key, &value, &cos_sin_cache, &key_cache, &value_cache})
+        TORCH_CHECK(t->scalar_type() == at::kHalf, "rope_decode_attention: float16 tensors expected");
+    TORCH_CHECK(positions.scalar_type() == at::kLong && positions.is_contiguous(),
+                "rope_decode_attention: positions must be contiguous int64");
+    TORCH_CHECK(query.dim() == 3 && key.dim() == 3 && value.dim() == 3 && key_cache.dim() == 4 &&
+                    value_cache.sizes() == key_cache.sizes(),
+                "rope_decode_attention: expected query [B, H, D], key / value [B, Hkv, D], caches [B, Hkv, S, D]");
+    const int64_t B = query.size(0), H = query.size(1), D = query.size(2), Hkv = key.size(1), S = key_cache.size(2);
+    TORCH_CHECK(key.size(0) == B && key.size(2) == D && value.sizes() == key.sizes() && key_cache.size(0) == B &&
+                    key_cache.size(1) == Hkv && key_cache.size(3) == D && H % Hkv == 0 && positions.numel() == B,
+                "rope_decode_attention: shape mismatch");
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&query, &key, &value})
+        TORCH_CHECK(t->stride(-1) == 1 && t->stride(-2) == D, "rope_decode_attention: [heads, head_size] must be dense");
+    TORCH_CHECK(key_cache.stride(-1) == 1 && value_cache.stride(-1) == 1 && cos_sin_cache.is_contiguous() &&
+                    cos_sin_cache.size(-1) == D,
+                "rope_decode_attention: cache rows must be dense and the rotation must cover the whole head (rot_dim == D)");
+    TORCH_CHECK(tickets.scalar_type() == at::kInt && tickets.is_contiguous() && tickets.numel() >= B * H + 1 &&
+                    tickets.device() == query.device(),
+                "rope_decode_attention: tickets must be a zeroed int32 tensor of at least B * H + 1 elements on the device");
+    int slot_stride = 0;
+    if (slots) {
+        const Tensor& s = *slots;
+        TORCH_CHECK(s.scalar_type() == at::kLong && s.device() == query.device() && (s.numel() == 1 || s.numel() == B) &&
+                        s.is_contiguous(),
+                    "rope_decode_attention: slots must be contiguous int64 on the device, 1 or B elements");
+        slot_stride = (s.numel() == B && B > 1) ? 1 : 0;
+    }
+    Tensor  mrow;
+    int64_t m_sb = 0;
+    if (mask) {
+        mrow = mask->dim() != 2 ? mask->reshape({mask->size(0), -1}) : *mask;
+        TORCH_CHECK(mrow.scalar_type() == at::kHalf && mrow.size(-1) >= S && mrow.stride(-1) == 1 && mrow.device() == query.device(),
+                    "rope_decode_attention: mask must be additive float16 with a dense last dimension >= S");
+        TORCH_CHECK(mrow.size(0) == 1 || mrow.size(0) == B,
+                    "rope_decode_attention: the mask needs one row per batch entry (or a single shared row)");
+        m_sb = (mrow.size(0) == B && B > 1) ? mrow.stride(0) : 0;
+    }
+    for (const OptTensor* t : std::initializer_list<const OptTensor*>{&kv_len, &advance})
+        if (*t)
+            TORCH_CHECK((*t)->scalar_type() == at::kLong && (*t)->numel() == 1 && (*t)->device() == query.device(),
+                        "rope_decode_attention: kv_len / advance must be a one-element int64 tensor on the query's device");
+    const double sc = scaling ? *scaling : 1.0 / std::sqrt((double)D);
+    int64_t      splits = splits_in ? *splits_in
+                                    : std::max<int64_t>(1, std::min<int64_t>((S + 63) / 64, std::max<int64_t>(1, 1024 / (B * H))));
+    Tensor       out = torch::empty({B, H, D}, query.options());
+    Tensor       ws  = torch::empty({B * H * splits * (D + 2)}, query.options().dtype(at::kFloat));
+    const long   strides[12] = {(long)query.stride(0),       (long)key.stride(0),         (long)value.stride(0),
+                                (long)key_cache.stride(0),   (long)key_cache.stride(1),   (long)key_cache.stride(2),
+                                (long)value_cache.stride(0), (long)value_cache.stride(1), (long)value_cache.stride(2),
+                                (long)m_sb,                  (long)out.stride(0),         (long)out.stride(1)};
+    c10::DeviceGuard guard(query.device());
+    check(eetq_rope_decode_attention_f16(
+        positions.data_ptr<int64_t>(), slots ? slots->data_ptr<int64_t>() : nullptr, slot_stride, query.data_ptr(),
+        key.data_ptr(), value.data_ptr(), cos_sin_cache.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(),
+        mrow.defined() ? mrow.data_ptr() : nullptr, out.data_ptr(), ws.data_ptr<float>(),
+        reinterpret_cast<unsigned*>(tickets.data_ptr<int32_t>()), (int)B, (int)H, (int)Hkv, (int)S, (int)D, (int)splits,
+        (float)sc, strides, kv_len ? kv_len->data_ptr<int64_t>() : nullptr, (int)kv_len_bias,
+        advance ? advance->data_ptr<int64_t>() : nullptr, stream_of(query)));
+    return out;
+}
+
 Tensor silu_mul(const Tensor& gate_up);
 
 void check_epilogue(const Tensor& input, const OptTensor& bias, const OptTensor& residual, int64_t m, int64_t n)
@@ -463,6 +531,11 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("cos_sin_cache"), py::arg("key_cache"), py::arg("value_cache"), py::arg("slots") = py::none());
     m.def("decode_attention", &decode_attention, "single-query attention over a KV cache", py::arg("query"),
           py::arg("key_cache"), py::arg("value_cache"), py::arg("mask") = py::none(), py::arg("scaling") = py::none(),
+          py::arg("splits") = py::none(), py::arg("kv_len") = py::none(), py::arg("kv_len_bias") = 0,
+          py::arg("advance") = py::none());
+    m.def("rope_decode_attention", &rope_decode_attention, py::arg("positions"), py::arg("query"), py::arg("key"),
+          py::arg("value"), py::arg("cos_sin_cache"), py::arg("key_cache"), py::arg("value_cache"), py::arg("tickets"),
+          py::arg("slots") = py::none(), py::arg("mask") = py::none(), py::arg("scaling") = py::none(),
           py::arg("splits") = py::none(), py::arg("kv_len") = py::none(), py::arg("kv_len_bias") = 0,
           py::arg("advance") = py::none());
     m.def("silu_mul", &silu_mul, "silu(gate) * up on a fused gate|up block", py::arg("gate_up"));

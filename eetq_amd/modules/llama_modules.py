@@ -73,6 +73,8 @@ class _EETAttentionBase(nn.Module):
         self.attention_dropout = 0.0
         self.is_causal = True
         self.decode_math_attention = True
+        self.fused_decode_step = True   # rotary + cache write + attention of a static-cache decode step as one launch
+        self._tickets = None            # that launch's arrival counters (zero between launches)
         self.rotary_emb = EETRotaryEmbedding(self.head_dim, max_position_embeddings=max_position_embeddings,
                                              base=rope_theta, device=dev)
 
@@ -251,10 +253,21 @@ class EETLlamaAttention(_EETAttentionBase):
             # counter + 1 are never attended, mask or no mask, and the kernel's last launch advances the counter (the
             # cache's bookkeeping: the next step's positions and mask come from it).
             counter = layer.cumulative_length
-            ops.rotary_embedding_neox_kvcache(positions[:, 0].contiguous(), q[:, 0], k[:, 0], v[:, 0], self.head_dim,
-                                              self.rotary_emb.cos_sin_cache, layer.keys, layer.values, slots=counter)
-            out = ops.decode_attention(q[:, 0], layer.keys, layer.values, mask=add, scaling=self.scaling, kv_len=counter,
-                                       kv_len_bias=1, advance=counter).reshape(bsz, q_len, -1)
+            pos = positions[:, 0].contiguous()
+            table = self.rotary_emb.cos_sin_cache
+            if self.fused_decode_step and table.shape[-1] == self.head_dim:
+                # ... and both as ONE launch: q and k rotated in registers, the new row taken from registers, the chunk
+                # merge done by the last workgroup of each head (bit-identical to the pair of launches below)
+                if self._tickets is None or self._tickets.numel() < bsz * h + 1 or self._tickets.device != q.device:
+                    self._tickets = torch.zeros(bsz * h + 1, dtype=torch.int32, device=q.device)
+                out = ops.rope_decode_attention(pos, q[:, 0], k[:, 0], v[:, 0], table, layer.keys, layer.values,
+                                                self._tickets, slots=counter, mask=add, scaling=self.scaling,
+                                                kv_len=counter, kv_len_bias=1, advance=counter).reshape(bsz, q_len, -1)
+            else:
+                ops.rotary_embedding_neox_kvcache(pos, q[:, 0], k[:, 0], v[:, 0], self.head_dim, table, layer.keys,
+                                                  layer.values, slots=counter)
+                out = ops.decode_attention(q[:, 0], layer.keys, layer.values, mask=add, scaling=self.scaling,
+                                           kv_len=counter, kv_len_bias=1, advance=counter).reshape(bsz, q_len, -1)
             weights = None
         else:
             self.rotary_emb(q, k, positions)

@@ -37,16 +37,18 @@ if _C is not None:
     rotary_embedding_neox_strided = _C.rotary_embedding_neox_strided
     rotary_embedding_neox_kvcache = _C.rotary_embedding_neox_kvcache
     decode_attention = _C.decode_attention
+    rope_decode_attention = _C.rope_decode_attention
     silu_mul = _C.silu_mul
 else:
     BOUNDARY = "ctypes"
     from .ops_ctypes import (decode_attention, layernorm_forward, preprocess_weights, quant_weights,  # noqa: F401
-                             rotary_embedding_neox, rotary_embedding_neox_kvcache, rotary_embedding_neox_strided, silu_mul,
+                             rope_decode_attention, rotary_embedding_neox, rotary_embedding_neox_kvcache,
+                             rotary_embedding_neox_strided, silu_mul,
                              unprocess_weights, w8_a16_gemm, w8_a16_gemm_)
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_", "layernorm_forward",
            "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention",
-           "silu_mul", "convert_layout", "BOUNDARY"]
+           "rope_decode_attention", "silu_mul", "convert_layout", "BOUNDARY"]
 
 
 def convert_layout(weight, src_layout, dst_layout, is_int4=False):

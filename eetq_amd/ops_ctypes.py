@@ -25,7 +25,7 @@ from ._lib import (ACT_GELU, ACT_IDENTITY, ACT_RELU, ACT_SILU, DTYPE_F16, DTYPE_
                    LAYOUT_SM80, PATH_AUTO, PATH_GEMV, PATH_MFMA, check)
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_",
-           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention", "silu_mul", "convert_layout"]
+           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout"]
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
@@ -402,6 +402,72 @@ def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, spl
                                                    Hkv, S, D, int(splits), float(scaling), strides,
                                                    _ptr(kv_len) if kv_len is not None else None, int(kv_len_bias),
                                                    _ptr(advance) if advance is not None else None, _stream_ptr()))
+    return out
+
+
+@_eager_only
+def rope_decode_attention(positions, query, key, value, cos_sin_cache, key_cache, value_cache, tickets, slots=None,
+                          mask=None, scaling=None, splits=None, kv_len=None, kv_len_bias=0, advance=None):
+    """``rotary_embedding_neox_kvcache`` followed by ``decode_attention`` as ONE launch (extension; the decode step of a
+    static KV cache).  Bit-identical to that pair in the cache rows written and in the returned [B, H, D] output; the
+    rotated query is not written back.  ``tickets``: an int32 device tensor of at least B * H + 1 zeros that the launch
+    leaves zeroed (launches that may overlap need their own).  The rotation must cover the whole head."""
+    for t in (query, key, value, cos_sin_cache, key_cache, value_cache):
+        if t.dtype != torch.float16:
+            raise RuntimeError("rope_decode_attention: float16 tensors expected")
+    if positions.dtype != torch.int64 or not positions.is_contiguous():
+        raise RuntimeError("rope_decode_attention: positions must be contiguous int64")
+    if query.dim() != 3 or key.dim() != 3 or value.dim() != 3 or key_cache.dim() != 4 or value_cache.shape != key_cache.shape:
+        raise RuntimeError("rope_decode_attention: expected query [B, H, D], key / value [B, Hkv, D], caches [B, Hkv, S, D]")
+    B, H, D = query.shape
+    Hkv, S = key.shape[1], key_cache.shape[2]
+    if (key.shape[0] != B or key.shape[2] != D or value.shape != key.shape or key_cache.shape[0] != B
+            or key_cache.shape[1] != Hkv or key_cache.shape[3] != D or H % Hkv or positions.numel() != B):
+        raise RuntimeError("rope_decode_attention: shape mismatch")
+    for t in (query, key, value):
+        if t.stride(-1) != 1 or t.stride(-2) != D:
+            raise RuntimeError("rope_decode_attention: [heads, head_size] must be dense")
+    if (key_cache.stride(-1) != 1 or value_cache.stride(-1) != 1 or not cos_sin_cache.is_contiguous()
+            or cos_sin_cache.shape[-1] != D):
+        raise RuntimeError("rope_decode_attention: cache rows must be dense and the rotation must cover the whole head "
+                           "(rot_dim == D)")
+    if (tickets.dtype != torch.int32 or not tickets.is_contiguous() or tickets.numel() < B * H + 1
+            or tickets.device != query.device):
+        raise RuntimeError("rope_decode_attention: tickets must be a zeroed int32 tensor of at least B * H + 1 elements "
+                           "on the device")
+    slot_stride = 0
+    if slots is not None:
+        if (slots.dtype != torch.int64 or slots.device != query.device or slots.numel() not in (1, B)
+                or not slots.is_contiguous()):
+            raise RuntimeError("rope_decode_attention: slots must be contiguous int64 on the device, 1 or B elements")
+        slot_stride = 1 if (slots.numel() == B and B > 1) else 0
+    mrow, m_sb = None, 0
+    if mask is not None:
+        mrow = mask.reshape(mask.shape[0], -1) if mask.dim() != 2 else mask
+        if mrow.dtype != torch.float16 or mrow.shape[-1] < S or mrow.stride(-1) != 1 or mrow.device != query.device:
+            raise RuntimeError("rope_decode_attention: mask must be additive float16 with a dense last dimension >= S")
+        if mrow.shape[0] not in (1, B):
+            raise RuntimeError("rope_decode_attention: the mask needs one row per batch entry (or a single shared row)")
+        m_sb = mrow.stride(0) if mrow.shape[0] == B and B > 1 else 0
+    for name, t in (("kv_len", kv_len), ("advance", advance)):
+        if t is not None and (t.dtype != torch.int64 or t.numel() != 1 or t.device != query.device):
+            raise RuntimeError("rope_decode_attention: %s must be a one-element int64 tensor on the query's device" % name)
+    if scaling is None:
+        scaling = D ** -0.5
+    if splits is None:
+        splits = max(1, min((S + 63) // 64, max(1, 1024 // (B * H))))
+    out = torch.empty((B, H, D), dtype=torch.float16, device=query.device)
+    ws = torch.empty((B * H * splits * (D + 2),), dtype=torch.float32, device=query.device)
+    strides = (ctypes.c_long * 12)(query.stride(0), key.stride(0), value.stride(0), key_cache.stride(0),
+                                   key_cache.stride(1), key_cache.stride(2), value_cache.stride(0), value_cache.stride(1),
+                                   value_cache.stride(2), m_sb, out.stride(0), out.stride(1))
+    with torch.cuda.device(query.device):
+        check(_lib.lib().eetq_rope_decode_attention_f16(
+            _ptr(positions), _ptr(slots) if slots is not None else None, slot_stride, _ptr(query), _ptr(key), _ptr(value),
+            _ptr(cos_sin_cache), _ptr(key_cache), _ptr(value_cache), _ptr(mrow) if mrow is not None else None, _ptr(out),
+            _ptr(ws), _ptr(tickets), B, H, Hkv, S, D, int(splits), float(scaling), strides,
+            _ptr(kv_len) if kv_len is not None else None, int(kv_len_bias),
+            _ptr(advance) if advance is not None else None, _stream_ptr()))
     return out
 
 

@@ -201,6 +201,23 @@ int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_
                               int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
                               int64_t* advance, void* stream);
 
+/* Decode step of a pre-allocated KV cache as ONE launch (extension): eetq_rotary_neox_kvcache_f16 followed by
+ * eetq_decode_attention_f16, bit-identical to that pair in the cache rows written and in the output.  The new token's q
+ * [batch][heads][head_dim] and k [batch][kv_heads][head_dim] are rotated by cos_sin_cache[positions[b]] (rot_dim =
+ * head_dim; q is NOT written back), the rotated k and v go to cache row slots[b * slot_stride] (slots NULL: positions[b]),
+ * and the rows j < min(max_positions, *kv_len + kv_len_bias) are attended, the new row among them if it is in that range.
+ * strides (elements): {q_b, k_b, v_b, kcache_b, kcache_head, kcache_pos, vcache_b, vcache_head, vcache_pos, mask_b,
+ * out_b, out_head}.  workspace: batch * heads * splits * (head_dim + 2) floats (contents irrelevant).  tickets: batch *
+ * heads + 1 unsigned, ZERO before the first launch that uses them; the launch leaves them zero.  Launches that may run
+ * concurrently need distinct workspaces and tickets.  advance: see eetq_decode_attention_f16 (may alias kv_len and slots:
+ * it is written after every workgroup of the launch has read them). */
+int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slots, int slot_stride, const void* query,
+                                   const void* key, const void* value, const void* cos_sin_cache, void* k_cache,
+                                   void* v_cache, const void* mask, void* out, float* workspace, unsigned* tickets,
+                                   int batch, int heads, int kv_heads, int max_positions, int head_dim, int splits,
+                                   float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
+                                   int64_t* advance, void* stream);
+
 /* ---- profiling hook (no reference counterpart; used by bench.py) -------------------------------------
  * Between eetq_prof_begin(n) and eetq_prof_end() every kernel this library launches from the calling thread
  * carries a start/stop event pair on its dispatch packet; eetq_prof_end synchronises the device and returns
