@@ -36,6 +36,9 @@ __device__ __forceinline__ void attn_chunk(const float (&qf)[8], const f16* __re
                                            const f16x8& knew, const f16x8& vnew, float* sm_m, float* sm_l, float* sm_o,
                                            float& M, float& L, float& O)
 {
+    // every multiply-add below is an explicit fmaf and contraction is off: the two launch forms instantiate this code
+    // separately and must round identically
+#pragma clang fp contract(off)
     constexpr int LPP  = D / 8;               // lanes per position
     constexpr int PPW  = 64 / LPP;            // positions per wave instruction
     constexpr int SETS = (kAttnThreads / 64) * PPW;
@@ -69,7 +72,7 @@ __device__ __forceinline__ void attn_chunk(const float (&qf)[8], const f16* __re
             }
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s += qf[i] * (float)kv[u][i];
+            for (int i = 0; i < 8; ++i) s = fmaf(qf[i], (float)kv[u][i], s);
 #pragma unroll
             for (int off = 1; off < LPP; off <<= 1) s += __shfl_xor(s, off, 64);
             if (mrow) s += (float)mrow[jj[u]];
@@ -77,9 +80,9 @@ __device__ __forceinline__ void attn_chunk(const float (&qf)[8], const f16* __re
             const float mn = fmaxf(m, s);
             if (mn > -INFINITY) {  // group-uniform
                 const float sc = __expf(m - mn), p = __expf(s - mn);
-                l = l * sc + p;
+                l = fmaf(l, sc, p);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = o[i] * sc + p * (float)vv[u][i];
+                for (int i = 0; i < 8; ++i) o[i] = fmaf(p, (float)vv[u][i], o[i] * sc);
                 m = mn;
             }
         }
@@ -100,8 +103,8 @@ __device__ __forceinline__ void attn_chunk(const float (&qf)[8], const f16* __re
 #pragma unroll
             for (int s2 = 0; s2 < SETS; ++s2) {
                 const float w = __expf(sm_m[s2] - M);  // exp(-inf) = 0 for empty sets
-                L += sm_l[s2] * w;
-                O += sm_o[s2 * D + tid] * w;
+                L = fmaf(sm_l[s2], w, L);
+                O = fmaf(sm_o[s2 * D + tid], w, O);
             }
         }
     }
@@ -155,6 +158,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
 template <int D, int NT, typename Load>
 __device__ __forceinline__ float attn_merge(const float* p, int splits, int d, float* sm_w, Load load)
 {
+#pragma clang fp contract(off)
     float M = -INFINITY;
     for (int s = d; s < splits; s += NT) M = fmaxf(M, load(p + s * (D + 2)));
 #pragma unroll
@@ -174,8 +178,8 @@ __device__ __forceinline__ float attn_merge(const float* p, int splits, int d, f
 #pragma unroll 8
     for (int s = 0; s < splits; ++s) {
         const float w = sm_w[s];
-        L += load(p + s * (D + 2) + 1) * w;
-        O += load(p + s * (D + 2) + 2 + d) * w;
+        L = fmaf(load(p + s * (D + 2) + 1), w, L);
+        O = fmaf(load(p + s * (D + 2) + 2 + d), w, O);
     }
     return L > 0.f ? O / L : 0.f;
 }

@@ -504,6 +504,39 @@ Tensor silu_mul(const Tensor& gate_up)
 
 }  // namespace
 
+// One decode step (one new token per batch row) of an accelerated Llama decoder layer over a pre-allocated KV cache, as ONE
+// call: the six launches the Python blocks issue (eetq_amd/modules/llama_modules.py: EETLlamaAttention.forward +
+// EETLlamaMLP.forward under replace_with_eet_fused_residual), in the same order with the same arguments -- so the result is
+// bit-identical -- without ~100 us of interpreter time per layer.  Host-side only; nothing here touches the device directly.
+//   qkv  = W8A16(rmsnorm(hidden))                      (norm inside the GEMV launch for a single row)
+//   attn = rope_decode_attention(qkv)                  (rotary + cache write + attention, advances `counter`)
+//   h    = hidden + W8A16_o(attn)                      (residual in the epilogue)
+//   out  = h + W8A16_down(silu(gate) * up),  gate|up = W8A16(rmsnorm(h))
+using NormArg = std::tuple<Tensor, double>;
+Tensor llama_decode_layer(const Tensor& hidden, const NormArg& input_norm, const Tensor& qkv_w, const Tensor& qkv_s,
+                          const OptTensor& qkv_b, const Tensor& positions, const Tensor& cos_sin_cache, Tensor& key_cache,
+                          Tensor& value_cache, Tensor& tickets, Tensor& counter, const OptTensor& mask, double scaling,
+                          int64_t heads, int64_t kv_heads, const Tensor& o_w, const Tensor& o_s, const OptTensor& o_b,
+                          const NormArg& post_norm, const Tensor& gu_w, const Tensor& gu_s, const OptTensor& gu_b,
+                          const Tensor& down_w, const Tensor& down_s, const OptTensor& down_b)
+{
+    TORCH_CHECK(hidden.dim() == 3 && hidden.size(1) == 1, "llama_decode_layer: hidden must be [B, 1, C]");
+    const int64_t B = hidden.size(0), total = heads + 2 * kv_heads;
+    const std::string autop = "auto", none;
+    const std::optional<NormArg> n1(input_norm), n2(post_norm), no_norm;
+    const OptTensor no_tensor;
+    Tensor qkv = w8_a16_gemm(hidden, qkv_w, qkv_s, autop, qkv_b, no_tensor, n1, false, none);  // [B, 1, (H + 2 Hkv) D]
+    TORCH_CHECK(total > 0 && qkv.size(-1) % total == 0, "llama_decode_layer: the QKV width is not (heads + 2 kv_heads) * D");
+    const int64_t D = qkv.size(-1) / total;
+    Tensor rows = qkv.view({B, total, D});
+    Tensor attn = rope_decode_attention(positions, rows.narrow(1, 0, heads), rows.narrow(1, heads, kv_heads),
+                                        rows.narrow(1, heads + kv_heads, kv_heads), cos_sin_cache, key_cache, value_cache,
+                                        tickets, counter, mask, scaling, std::nullopt, counter, 1, counter);
+    Tensor h  = w8_a16_gemm(attn.view({B, 1, heads * D}), o_w, o_s, autop, o_b, hidden, no_norm, false, none);
+    Tensor gu = w8_a16_gemm(h, gu_w, gu_s, autop, gu_b, no_tensor, n2, false, none);
+    return w8_a16_gemm(silu_mul(gu), down_w, down_s, autop, down_b, h, no_norm, false, none);
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "EETQ operator module on libeetq_amd.so (MI355X / gfx950)";
@@ -538,6 +571,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("slots") = py::none(), py::arg("mask") = py::none(), py::arg("scaling") = py::none(),
           py::arg("splits") = py::none(), py::arg("kv_len") = py::none(), py::arg("kv_len_bias") = 0,
           py::arg("advance") = py::none());
+    m.def("llama_decode_layer", &llama_decode_layer, "one decode step of an accelerated Llama decoder layer (six launches, one call)",
+          py::arg("hidden"), py::arg("input_norm"), py::arg("qkv_weight"), py::arg("qkv_scale"), py::arg("qkv_bias"),
+          py::arg("positions"), py::arg("cos_sin_cache"), py::arg("key_cache"), py::arg("value_cache"), py::arg("tickets"),
+          py::arg("counter"), py::arg("mask"), py::arg("scaling"), py::arg("heads"), py::arg("kv_heads"), py::arg("o_weight"),
+          py::arg("o_scale"), py::arg("o_bias"), py::arg("post_norm"), py::arg("gate_up_weight"), py::arg("gate_up_scale"),
+          py::arg("gate_up_bias"), py::arg("down_weight"), py::arg("down_scale"), py::arg("down_bias"));
     m.def("silu_mul", &silu_mul, "silu(gate) * up on a fused gate|up block", py::arg("gate_up"));
     m.attr("__eetq_amd_version__") = eetq_version();
 }

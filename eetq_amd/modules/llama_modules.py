@@ -133,6 +133,38 @@ class _EETAttentionBase(nn.Module):
         add = memo[1]
         return add[..., :s_len] if add.shape[-1] != s_len else add
 
+    def _grow_table(self, need):
+        """The rotation indexes the cos|sin cache by position: grow it (host-side, never during graph capture -- the first
+        eager pass already sees the same lengths) when the cache or the sequence is longer than the table."""
+        if need > self.rotary_emb.max_seq_len_cached:
+            self.rotary_emb._set_cos_sin_cache(max(need, 2 * self.rotary_emb.max_seq_len_cached),
+                                               self.rotary_emb.cos_sin_cache.device)
+
+    def _step_tickets(self, batch, device):
+        if self._tickets is None or self._tickets.numel() < batch * self.num_heads + 1 or self._tickets.device != device:
+            self._tickets = torch.zeros(batch * self.num_heads + 1, dtype=torch.int32, device=device)
+        return self._tickets
+
+    def decode_step_state(self, hidden_states, attention_mask, position_ids, past_key_values):
+        """What the one-call decoder-layer step (ops.llama_decode_layer) needs beyond the weights, or None when this step
+        is not a single-token step on an initialised static cache with a mask this path understands:
+        (positions [B] int64, cos|sin table, the cache layer, ticket buffer, additive mask rows or None)."""
+        layer = self._static_cache_layer(past_key_values)
+        if layer is None or self.decode_math_attention is not True or not hidden_states.is_cuda:
+            return None
+        bsz = hidden_states.shape[0]
+        add = self._decode_mask_rows(attention_mask, bsz, layer.keys.shape[2], hidden_states.dtype, hidden_states.device)
+        if add is False:
+            return None
+        self._grow_table(layer.keys.shape[2])
+        table = self.rotary_emb.cos_sin_cache
+        if table.shape[-1] != self.head_dim:
+            return None
+        positions = self._positions(position_ids, past_key_values, bsz, 1, hidden_states.device)[:, 0]
+        if not positions.is_contiguous():
+            positions = positions.contiguous()
+        return positions, table, layer, self._step_tickets(bsz, hidden_states.device), add
+
     def _attend(self, q, k, v, attention_mask, past_key_values, input_shape, kwargs):
         """q [B, T, H, D], k/v [B, T, Hkv, D] (views into the projection output) -> [B, T, H*D]"""
         q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
@@ -230,8 +262,6 @@ class EETLlamaAttention(_EETAttentionBase):
         positions = self._positions(position_ids, past_key_values, bsz, q_len, hidden_states.device)
         kwargs.pop("use_cache", None)
         layer = self._static_cache_layer(past_key_values) if q_len == 1 else None
-        # the rotation indexes the cos|sin cache by position: grow it (host-side, never during graph capture -- the first
-        # eager pass already sees the same lengths) when the cache or the sequence is longer than the table
         need = q_len
         if layer is not None:
             need = layer.keys.shape[2]
@@ -239,9 +269,7 @@ class EETLlamaAttention(_EETAttentionBase):
             seen = past_key_values.get_seq_length(self.layer_idx)
             if isinstance(seen, int):
                 need = seen + q_len
-        if need > self.rotary_emb.max_seq_len_cached:
-            self.rotary_emb._set_cos_sin_cache(max(need, 2 * self.rotary_emb.max_seq_len_cached),
-                                               self.rotary_emb.cos_sin_cache.device)
+        self._grow_table(need)
         add = False
         if layer is not None and self.decode_math_attention is True and not kwargs.get("output_attentions", False):
             add = self._decode_mask_rows(attention_mask, bsz, layer.keys.shape[2], hidden_states.dtype, hidden_states.device)
@@ -258,10 +286,8 @@ class EETLlamaAttention(_EETAttentionBase):
             if self.fused_decode_step and table.shape[-1] == self.head_dim:
                 # ... and both as ONE launch: q and k rotated in registers, the new row taken from registers, the chunk
                 # merge done by the last workgroup of each head (bit-identical to the pair of launches below)
-                if self._tickets is None or self._tickets.numel() < bsz * h + 1 or self._tickets.device != q.device:
-                    self._tickets = torch.zeros(bsz * h + 1, dtype=torch.int32, device=q.device)
                 out = ops.rope_decode_attention(pos, q[:, 0], k[:, 0], v[:, 0], table, layer.keys, layer.values,
-                                                self._tickets, slots=counter, mask=add, scaling=self.scaling,
+                                                self._step_tickets(bsz, q.device), slots=counter, mask=add, scaling=self.scaling,
                                                 kv_len=counter, kv_len_bias=1, advance=counter).reshape(bsz, q_len, -1)
             else:
                 ops.rotary_embedding_neox_kvcache(pos, q[:, 0], k[:, 0], v[:, 0], self.head_dim, table, layer.keys,

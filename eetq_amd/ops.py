@@ -39,12 +39,14 @@ if _C is not None:
     decode_attention = _C.decode_attention
     rope_decode_attention = _C.rope_decode_attention
     silu_mul = _C.silu_mul
+    llama_decode_layer = _C.llama_decode_layer   # compiled boundary only: its point is the interpreter time it saves
 else:
     BOUNDARY = "ctypes"
     from .ops_ctypes import (decode_attention, layernorm_forward, preprocess_weights, quant_weights,  # noqa: F401
                              rope_decode_attention, rotary_embedding_neox, rotary_embedding_neox_kvcache,
                              rotary_embedding_neox_strided, silu_mul,
                              unprocess_weights, w8_a16_gemm, w8_a16_gemm_)
+    llama_decode_layer = None
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_", "layernorm_forward",
            "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention",

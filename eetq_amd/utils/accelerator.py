@@ -120,21 +120,39 @@ def replace_with_eet_fused_residual(model):
     """Extension: decoder layers whose attention and MLP are the EET blocks add their residuals inside the o_proj /
     down_proj epilogues (``eetq_w8a16_gemm_fused``) instead of two elementwise kernels per layer, and hand their two RMS-norms
     to the QKV and gate/up projections (inside the GEMV launch for single-token steps, ``eetq_w8a16_gemv_rmsnorm``)."""
+    from .. import ops
     from ..modules.llama_modules import EETLlamaAttention
+    layer_step = ops.llama_decode_layer   # None under the ctypes binding
 
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
                 position_embeddings=None, **kwargs):
         n1, n2 = self.input_layernorm, self.post_attention_layernorm
-        h, _ = self.self_attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
-                              past_key_values=past_key_values, use_cache=use_cache, position_embeddings=position_embeddings,
-                              residual=hidden_states, input_norm=(n1.weight, n1.variance_epsilon), **kwargs)
-        return self.mlp(h, residual=h, norm=(n2.weight, n2.variance_epsilon))
+        attn, mlp = self.self_attn, self.mlp
+        if (hidden_states.shape[1] == 1 and layer_step is not None and attn.fused_decode_step and self.fused_layer_step
+                and not mlp.fuse_activation and not kwargs.get("output_attentions", False)):
+            # single-token step on a static cache: the whole layer (six launches) as one call into the compiled module
+            ready = attn.decode_step_state(hidden_states, attention_mask, position_ids, past_key_values)
+            if ready is not None:
+                positions, table, cache, tickets, add = ready
+                qkv, o, gu, down = attn.qkv_proj, attn.o_proj, mlp.gate_up_proj, mlp.down_proj
+                return layer_step(hidden_states, (n1.weight, n1.variance_epsilon), qkv.qweight, qkv.weight_scales, qkv.bias,
+                                  positions, table, cache.keys, cache.values, tickets, cache.cumulative_length, add,
+                                  attn.scaling, attn.num_heads, attn.num_key_value_heads, o.qweight, o.weight_scales, o.bias,
+                                  (n2.weight, n2.variance_epsilon), gu.qweight, gu.weight_scales, gu.bias, down.qweight,
+                                  down.weight_scales, down.bias)
+        h, _ = attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
+                    past_key_values=past_key_values, use_cache=use_cache, position_embeddings=position_embeddings,
+                    residual=hidden_states, input_norm=(n1.weight, n1.variance_epsilon), **kwargs)
+        return mlp(h, residual=h, norm=(n2.weight, n2.variance_epsilon))
 
     n = 0
     for m in model.modules():
         if (type(m).__name__ == "LlamaDecoderLayer" and isinstance(m.self_attn, EETLlamaAttention)
                 and isinstance(m.mlp, EETLlamaMLP) and isinstance(m.self_attn.o_proj, W8A16Linear)
                 and m.input_layernorm.weight.dtype == torch.float16 and hasattr(m.input_layernorm, "variance_epsilon")):
+            eligible = (isinstance(m.self_attn.qkv_proj, W8A16Linear) and isinstance(m.mlp.down_proj, W8A16Linear)
+                        and m.mlp.intermediate_size % 8 == 0)
+            m.fused_layer_step = bool(eligible)
             m.forward = types.MethodType(forward, m)
             n += 1
     return n

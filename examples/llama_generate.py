@@ -110,6 +110,8 @@ def main():
     ap.add_argument("--gated-fusion", action="store_true", help="silu*mul inside the down GEMV launch instead of its own launch")
     ap.add_argument("--two-launch-step", action="store_true",
                     help="decode step as rotary+cache-write launch and two attention launches instead of the one-launch form")
+    ap.add_argument("--python-layer-step", action="store_true",
+                    help="decode step of a layer through the Python blocks instead of one call into the compiled module")
     ap.add_argument("--graph", action="store_true",
                     help="greedy decode with a static KV cache and ONE captured HIP graph per token (launch-bound "
                          "inner loop -> hipGraph) instead of transformers' eager generate()")
@@ -128,6 +130,7 @@ def main():
             layer.self_attn.decode_math_attention = {"kernel": True, "math": "always", "off": False}[args.decode_attn]
             layer.mlp.fuse_activation = args.gated_fusion
             layer.self_attn.fused_decode_step = not args.two_launch_step
+            layer.fused_layer_step = layer.fused_layer_step and not args.python_layer_step
     elif not args.no_quant:
         eet_quantize(model)
     if args.fuse_norm:
@@ -174,7 +177,8 @@ def main():
                            ("hipGraph decode" if args.graph else "transformers eager generate") +
                            (", fused rmsnorm" if args.fuse_norm else "") + (", fused qkv + gate/up" if args.fuse_proj else "") +
                            (", eet_accelerator(fused_attn, fused_mlp, fused_norm)" if args.accelerate else "") +
-                           (", two-launch decode step" if args.two_launch_step else "")),
+                           (", two-launch decode step" if args.two_launch_step else "") +
+                           (", python layer step" if args.python_layer_step else "")),
                 "n_gpus": grp.world_size, "end_to_end_s": round(secs, 4), "prefill_s": round(t_prefill, 4),
                 "tokens_per_s_per_replica": round(new_tokens / secs, 2),
                 "tokens_per_s_aggregate": round(grp.world_size * new_tokens / secs, 2),

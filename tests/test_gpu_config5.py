@@ -156,3 +156,53 @@ def test_config5_batches(ops):
             assert out.shape == (B, P + NEW)
             for b in range(1, B):
                 assert torch.equal(out[b], out[0])   # identical rows -> identical tokens (deterministic kernels)
+
+
+@pytest.mark.parametrize("width", ["13b", "gqa"])
+def test_compiled_layer_step_equals_python_blocks(ops, width):
+    """Decode steps on a static cache three ways -- one call per layer into the compiled module (llama_decode_layer), the
+    Python blocks with the one-launch attention step, the Python blocks with the two-launch step -- issue the same launches
+    with the same arguments: the greedy tokens of every step must be identical, batch 1 and batch 2."""
+    transformers = pytest.importorskip("transformers")
+    from eetq_amd.utils import GraphDecoder, eet_accelerator
+    if ops.BOUNDARY != "ext":
+        pytest.skip("llama_decode_layer lives in the compiled module")
+    if width == "13b":
+        model = _model_13b_width()
+    else:
+        cfg = transformers.LlamaConfig(hidden_size=1024, intermediate_size=2816, num_hidden_layers=3, num_attention_heads=16,
+                                       num_key_value_heads=4, vocab_size=1000, max_position_embeddings=512)
+        torch.manual_seed(3)
+        model = transformers.LlamaForCausalLM(cfg).half().to(DEV).eval()
+    model = eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True, fused_residual=True)
+    layers = model.model.layers
+    assert all(l.fused_layer_step for l in layers)
+    vocab = model.config.vocab_size
+    P, NEW = 96, 10
+
+    def run(batch, layer_step, one_launch):
+        for l in layers:
+            l.fused_layer_step = layer_step
+            l.self_attn.fused_decode_step = one_launch
+        g = torch.Generator().manual_seed(5)
+        prompt = torch.randint(1, vocab, (batch, P), generator=g).to(DEV)
+        with torch.no_grad():
+            return GraphDecoder(model, batch, P + NEW + 8, capture=False).generate(prompt, NEW)
+
+    for batch in (1, 2):
+        a = run(batch, True, True)
+        b = run(batch, False, True)
+        c = run(batch, False, False)
+        assert torch.equal(a, b) and torch.equal(b, c), batch
+    # stock eager generate with a static cache takes the same decode path (its prefill differs: it builds a mask)
+    for l in layers:
+        l.fused_layer_step = True
+        l.self_attn.fused_decode_step = True
+    g = torch.Generator().manual_seed(5)
+    prompt = torch.randint(1, vocab, (1, P), generator=g).to(DEV)
+    with torch.no_grad():
+        ref = GraphDecoder(model, 1, P + NEW + 8, capture=False).generate(prompt, NEW)
+        out = model.generate(prompt, max_new_tokens=NEW, min_new_tokens=NEW, do_sample=False, pad_token_id=0,
+                             cache_implementation="static")
+    assert out.shape == ref.shape and torch.equal(out[:, :P + 1], ref[:, :P + 1])
+    assert (out[:, P:] == ref[:, P:]).float().mean().item() > 0.5
