@@ -112,6 +112,9 @@ def main():
                     help="decode step as rotary+cache-write launch and two attention launches instead of the one-launch form")
     ap.add_argument("--python-layer-step", action="store_true",
                     help="decode step of a layer through the Python blocks instead of one call into the compiled module")
+    ap.add_argument("--static-cache", action="store_true",
+                    help="eager generate(cache_implementation='static', disable_compile=True): pre-allocated cache, so the "
+                         "accelerated blocks take their one-launch decode step / the compiled layer step")
     ap.add_argument("--graph", action="store_true",
                     help="greedy decode with a static KV cache and ONE captured HIP graph per token (launch-bound "
                          "inner loop -> hipGraph) instead of transformers' eager generate()")
@@ -145,6 +148,8 @@ def main():
     prompt = torch.randint(0, 32000, (args.batch, args.prompt), generator=g).to(dev)
     grp.fan_out(prompt)
     kw = dict(max_new_tokens=args.new, min_new_tokens=args.new, do_sample=False, pad_token_id=0)
+    if args.static_cache:
+        kw.update(cache_implementation="static", disable_compile=True)
 
     with torch.no_grad():
         out = model.generate(prompt[:, :64], max_new_tokens=4, min_new_tokens=4, do_sample=False, pad_token_id=0)  # warm-up
@@ -174,7 +179,7 @@ def main():
         new_tokens = args.batch * args.new
         line = {"config": "Llama-2-13B shapes, random init fp16, %s, prompt=%d new=%d batch=%d, %s" %
                           ("fp16 nn.Linear" if args.no_quant else "eet_quantize (W8A16)", args.prompt, args.new, args.batch,
-                           ("hipGraph decode" if args.graph else "transformers eager generate") +
+                           ("hipGraph decode" if args.graph else "transformers eager generate" + (" (static cache)" if args.static_cache else "")) +
                            (", fused rmsnorm" if args.fuse_norm else "") + (", fused qkv + gate/up" if args.fuse_proj else "") +
                            (", eet_accelerator(fused_attn, fused_mlp, fused_norm)" if args.accelerate else "") +
                            (", two-launch decode step" if args.two_launch_step else "") +
