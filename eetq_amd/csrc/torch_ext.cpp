@@ -522,6 +522,76 @@ Tensor llama_decode_layer(const Tensor& hidden, const NormArg& input_norm, const
 {
     TORCH_CHECK(hidden.dim() == 3 && hidden.size(1) == 1, "llama_decode_layer: hidden must be [B, 1, C]");
     const int64_t B = hidden.size(0), total = heads + 2 * kv_heads;
+    if (B == 1) {
+        // batch 1: straight onto the C ABI -- one device guard, one stream query, one scratch allocation; the same six
+        // launches with the same arguments as the generic composition below (bit-identical by construction)
+        const int64_t C = hidden.size(2), NQ = qkv_s.numel(), I2 = gu_s.numel(), I = I2 / 2;
+        const Tensor &g1 = std::get<0>(input_norm), &g2 = std::get<0>(post_norm);
+        TORCH_CHECK(total > 0 && NQ % total == 0, "llama_decode_layer: the QKV width is not (heads + 2 kv_heads) * D");
+        const int64_t D = NQ / total, S = key_cache.size(2);
+        for (const Tensor* t : std::initializer_list<const Tensor*>{&hidden, &g1, &g2, &qkv_s, &o_s, &gu_s, &down_s, &cos_sin_cache,
+                                                                    &key_cache, &value_cache})
+            TORCH_CHECK(t->scalar_type() == at::kHalf && t->is_cuda() && t->is_contiguous() && t->device() == hidden.device(),
+                        "llama_decode_layer: float16 contiguous tensors on the hidden state's device expected");
+        for (const Tensor* t : std::initializer_list<const Tensor*>{&qkv_w, &o_w, &gu_w, &down_w})
+            TORCH_CHECK(t->scalar_type() == at::kChar && t->is_contiguous() && t->dim() == 2 && t->device() == hidden.device(),
+                        "llama_decode_layer: weights must be contiguous int8 [K, N] on the hidden state's device");
+        for (const OptTensor* t : std::initializer_list<const OptTensor*>{&qkv_b, &o_b, &gu_b, &down_b})
+            TORCH_CHECK(!*t || ((*t)->scalar_type() == at::kHalf && (*t)->is_contiguous() && (*t)->device() == hidden.device()),
+                        "llama_decode_layer: biases must be contiguous float16 on the hidden state's device");
+        TORCH_CHECK(qkv_w.size(0) == C && qkv_w.size(1) == NQ && g1.numel() == C && g2.numel() == C && o_w.size(0) == heads * D &&
+                        o_w.size(1) == C && o_s.numel() == C && gu_w.size(0) == C && gu_w.size(1) == I2 && I2 == 2 * I &&
+                        I % 8 == 0 && down_w.size(0) == I && down_w.size(1) == C && down_s.numel() == C &&
+                        (!qkv_b || qkv_b->numel() == NQ) && (!o_b || o_b->numel() == C) && (!gu_b || gu_b->numel() == I2) &&
+                        (!down_b || down_b->numel() == C),
+                    "llama_decode_layer: weight shapes do not match the hidden size / head geometry");
+        TORCH_CHECK(key_cache.dim() == 4 && key_cache.size(0) == 1 && key_cache.size(1) == kv_heads && key_cache.size(3) == D &&
+                        value_cache.sizes() == key_cache.sizes() && cos_sin_cache.size(-1) == D && heads % kv_heads == 0,
+                    "llama_decode_layer: cache [1, kv_heads, S, D] / rotation table [positions, D] expected");
+        TORCH_CHECK(positions.scalar_type() == at::kLong && positions.numel() == 1 && positions.device() == hidden.device() &&
+                        counter.scalar_type() == at::kLong && counter.numel() == 1 && counter.device() == hidden.device() &&
+                        tickets.scalar_type() == at::kInt && tickets.is_contiguous() && tickets.numel() >= heads + 1 &&
+                        tickets.device() == hidden.device(),
+                    "llama_decode_layer: positions / counter must be one-element int64, tickets int32 [>= heads + 1], on the device");
+        const void* mrow = nullptr;
+        if (mask) {
+            TORCH_CHECK(mask->scalar_type() == at::kHalf && mask->size(-1) >= S && mask->stride(-1) == 1 &&
+                            mask->numel() == mask->size(-1) && mask->device() == hidden.device(),
+                        "llama_decode_layer: mask must be one additive float16 row of at least S entries");
+            mrow = mask->data_ptr();
+        }
+        const int64_t splits = std::max<int64_t>(1, std::min<int64_t>((S + 63) / 64, std::max<int64_t>(1, 1024 / heads)));
+        // fp16 scratch: qkv | attention output | gate|up | activation ; fp32 scratch: the attention chunk records
+        const int64_t n16 = NQ + heads * D + I2 + I, n32 = heads * splits * (D + 2);
+        Tensor  scratch = torch::empty({n16 * 2 + n32 * 4 + 16}, hidden.options().dtype(at::kByte));
+        Tensor  h = torch::empty_like(hidden), out = torch::empty_like(hidden);
+        char*   base = static_cast<char*>(scratch.data_ptr());
+        void *  qkv = base, *att = base + NQ * 2, *gu = base + (NQ + heads * D) * 2, *act = base + (NQ + heads * D + I2) * 2;
+        float*  ws  = reinterpret_cast<float*>(base + ((n16 * 2 + 15) / 16) * 16);
+        const long st[12] = {(long)NQ, (long)NQ, (long)NQ, (long)key_cache.stride(0), (long)key_cache.stride(1),
+                             (long)key_cache.stride(2), (long)value_cache.stride(0), (long)value_cache.stride(1),
+                             (long)value_cache.stride(2), 0, (long)(heads * D), (long)D};
+        auto optp = [](const OptTensor& t) -> const void* { return t ? t->data_ptr() : nullptr; };
+        c10::DeviceGuard guard(hidden.device());
+        void*            stream = stream_of(hidden);
+        int64_t*         cnt    = counter.data_ptr<int64_t>();
+        check(eetq_w8a16_gemv_rmsnorm(hidden.data_ptr(), g1.data_ptr(), (float)std::get<1>(input_norm), qkv_w.data_ptr<int8_t>(),
+                                      qkv_s.data_ptr(), optp(qkv_b), nullptr, qkv, (int)NQ, (int)C, stream));
+        const char* q = static_cast<const char*>(qkv);
+        check(eetq_rope_decode_attention_f16(positions.data_ptr<int64_t>(), cnt, 0, q, q + heads * D * 2,
+                                             q + (heads + kv_heads) * D * 2, cos_sin_cache.data_ptr(), key_cache.data_ptr(),
+                                             value_cache.data_ptr(), mrow, att, ws,
+                                             reinterpret_cast<unsigned*>(tickets.data_ptr<int32_t>()), 1, (int)heads,
+                                             (int)kv_heads, (int)S, (int)D, (int)splits, (float)scaling, st, cnt, 1, cnt, stream));
+        check(eetq_w8a16_gemm_act(att, o_w.data_ptr<int8_t>(), o_s.data_ptr(), optp(o_b), hidden.data_ptr(), h.data_ptr(), 1,
+                                  (int)C, (int)(heads * D), EETQ_PATH_AUTO, EETQ_ACT_IDENTITY, stream));
+        check(eetq_w8a16_gemv_rmsnorm(h.data_ptr(), g2.data_ptr(), (float)std::get<1>(post_norm), gu_w.data_ptr<int8_t>(),
+                                      gu_s.data_ptr(), optp(gu_b), nullptr, gu, (int)I2, (int)C, stream));
+        check(eetq_silu_mul_f16(gu, act, 1, (int)I, stream));
+        check(eetq_w8a16_gemm_act(act, down_w.data_ptr<int8_t>(), down_s.data_ptr(), optp(down_b), h.data_ptr(), out.data_ptr(),
+                                  1, (int)C, (int)I, EETQ_PATH_AUTO, EETQ_ACT_IDENTITY, stream));
+        return out;
+    }
     const std::string autop = "auto", none;
     const std::optional<NormArg> n1(input_norm), n2(post_norm), no_norm;
     const OptTensor no_tensor;

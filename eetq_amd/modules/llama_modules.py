@@ -145,24 +145,38 @@ class _EETAttentionBase(nn.Module):
             self._tickets = torch.zeros(batch * self.num_heads + 1, dtype=torch.int32, device=device)
         return self._tickets
 
+    # what every layer of a model derives from the step's position_ids / attention_mask, computed by the first layer of the
+    # step and reused by the others: [position_ids, its version, attention_mask, its version, batch, rows, positions, add].
+    # The tensors themselves are held (an id() could be recycled) and their version counters checked (in-place updates).
+    _step_memo = [None] * 8
+
     def decode_step_state(self, hidden_states, attention_mask, position_ids, past_key_values):
         """What the one-call decoder-layer step (ops.llama_decode_layer) needs beyond the weights, or None when this step
         is not a single-token step on an initialised static cache with a mask this path understands:
         (positions [B] int64, cos|sin table, the cache layer, ticket buffer, additive mask rows or None)."""
         layer = self._static_cache_layer(past_key_values)
-        if layer is None or self.decode_math_attention is not True or not hidden_states.is_cuda:
+        if layer is None or self.decode_math_attention is not True or position_ids is None or not hidden_states.is_cuda:
             return None
-        bsz = hidden_states.shape[0]
-        add = self._decode_mask_rows(attention_mask, bsz, layer.keys.shape[2], hidden_states.dtype, hidden_states.device)
+        bsz, rows = hidden_states.shape[0], layer.keys.shape[2]
+        memo = _EETAttentionBase._step_memo
+        if not (memo[0] is position_ids and memo[1] == position_ids._version and memo[2] is attention_mask
+                and (attention_mask is None or memo[3] == attention_mask._version) and memo[4] == bsz and memo[5] == rows):
+            add = self._decode_mask_rows(attention_mask, bsz, rows, hidden_states.dtype, hidden_states.device)
+            positions = None
+            if add is not False:
+                positions = self._positions(position_ids, past_key_values, bsz, 1, hidden_states.device)[:, 0]
+                if not positions.is_contiguous():
+                    positions = positions.contiguous()
+            memo[:] = [position_ids, position_ids._version, attention_mask,
+                       None if attention_mask is None else attention_mask._version, bsz, rows, positions, add]
+        positions, add = memo[6], memo[7]
         if add is False:
             return None
-        self._grow_table(layer.keys.shape[2])
+        if rows > self.rotary_emb.max_seq_len_cached:
+            self._grow_table(rows)
         table = self.rotary_emb.cos_sin_cache
-        if table.shape[-1] != self.head_dim:
+        if table.shape[-1] != self.head_dim or positions.device != hidden_states.device:
             return None
-        positions = self._positions(position_ids, past_key_values, bsz, 1, hidden_states.device)[:, 0]
-        if not positions.is_contiguous():
-            positions = positions.contiguous()
         return positions, table, layer, self._step_tickets(bsz, hidden_states.device), add
 
     def _attend(self, q, k, v, attention_mask, past_key_values, input_shape, kwargs):

@@ -124,22 +124,33 @@ def replace_with_eet_fused_residual(model):
     from ..modules.llama_modules import EETLlamaAttention
     layer_step = ops.llama_decode_layer   # None under the ctypes binding
 
+    def step_weights(self, attn, mlp, n1, n2):
+        """The layer's tensors in llama_decode_layer's order, gathered once (module attribute lookups cost more than the call
+        itself otherwise); rebuilt when a projection's weight buffer has been replaced (.to(), load_state_dict(assign=True))."""
+        qkv, o, gu, down = attn.qkv_proj, attn.o_proj, mlp.gate_up_proj, mlp.down_proj
+        cached = self._step_weights
+        if (cached is not None and cached[0][2] is qkv._buffers["qweight"] and cached[1][0] is o._buffers["qweight"]
+                and cached[1][5] is gu._buffers["qweight"] and cached[1][8] is down._buffers["qweight"]
+                and cached[0][0][0] is n1.weight):
+            return cached
+        cached = (((n1.weight, n1.variance_epsilon), qkv.qweight, qkv.weight_scales, qkv.bias),
+                  (o.qweight, o.weight_scales, o.bias, (n2.weight, n2.variance_epsilon), gu.qweight, gu.weight_scales, gu.bias,
+                   down.qweight, down.weight_scales, down.bias))
+        self._step_weights = cached
+        return cached
+
     def forward(self, hidden_states, attention_mask=None, position_ids=None, past_key_values=None, use_cache=False,
                 position_embeddings=None, **kwargs):
-        n1, n2 = self.input_layernorm, self.post_attention_layernorm
-        attn, mlp = self.self_attn, self.mlp
-        if (hidden_states.shape[1] == 1 and layer_step is not None and attn.fused_decode_step and self.fused_layer_step
+        attn, mlp, n1, n2 = self._eet_blocks
+        if (hidden_states.shape[1] == 1 and layer_step is not None and self.fused_layer_step and attn.fused_decode_step
                 and not mlp.fuse_activation and not kwargs.get("output_attentions", False)):
             # single-token step on a static cache: the whole layer (six launches) as one call into the compiled module
             ready = attn.decode_step_state(hidden_states, attention_mask, position_ids, past_key_values)
             if ready is not None:
                 positions, table, cache, tickets, add = ready
-                qkv, o, gu, down = attn.qkv_proj, attn.o_proj, mlp.gate_up_proj, mlp.down_proj
-                return layer_step(hidden_states, (n1.weight, n1.variance_epsilon), qkv.qweight, qkv.weight_scales, qkv.bias,
-                                  positions, table, cache.keys, cache.values, tickets, cache.cumulative_length, add,
-                                  attn.scaling, attn.num_heads, attn.num_key_value_heads, o.qweight, o.weight_scales, o.bias,
-                                  (n2.weight, n2.variance_epsilon), gu.qweight, gu.weight_scales, gu.bias, down.qweight,
-                                  down.weight_scales, down.bias)
+                head, tail = step_weights(self, attn, mlp, n1, n2)
+                return layer_step(hidden_states, *head, positions, table, cache.keys, cache.values, tickets,
+                                  cache.cumulative_length, add, attn.scaling, attn.num_heads, attn.num_key_value_heads, *tail)
         h, _ = attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                     past_key_values=past_key_values, use_cache=use_cache, position_embeddings=position_embeddings,
                     residual=hidden_states, input_norm=(n1.weight, n1.variance_epsilon), **kwargs)
@@ -153,6 +164,8 @@ def replace_with_eet_fused_residual(model):
             eligible = (isinstance(m.self_attn.qkv_proj, W8A16Linear) and isinstance(m.mlp.down_proj, W8A16Linear)
                         and m.mlp.intermediate_size % 8 == 0)
             m.fused_layer_step = bool(eligible)
+            m._eet_blocks = (m.self_attn, m.mlp, m.input_layernorm, m.post_attention_layernorm)  # plain attribute: no __getattr__
+            m._step_weights = None
             m.forward = types.MethodType(forward, m)
             n += 1
     return n
