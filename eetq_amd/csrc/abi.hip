@@ -409,6 +409,29 @@ int eetq_w8a16_gemv_silu_gated(const void* gate_up, const int8_t* w_packed, cons
                        pro);
 }
 
+int eetq_w8a16_gemv_glu8(const void* x, const void* gamma, float eps, const int8_t* w_packed, const void* scales,
+                         const void* bias, void* y, int N, int K, void* stream)
+{
+    int st = check_gemm_args(x, w_packed, scales, y, 1, N, K);
+    if (st != EETQ_OK) return st;
+    EETQ_REQUIRE(gamma == nullptr || (uintptr_t)gamma % 16 == 0, "gamma must be 16-byte aligned");
+    Epilogue ep;
+    ep.bias = static_cast<const f16*>(bias);
+    ep.act  = kActGlu8;
+    Prologue pro;
+    pro.gamma = static_cast<const f16*>(gamma);
+    pro.eps   = eps;
+    return launch_gemv(static_cast<const f16*>(x), reinterpret_cast<const uint8_t*>(w_packed),
+                       static_cast<const f16*>(scales), ep, static_cast<f16*>(y), 1, N, K, static_cast<hipStream_t>(stream),
+                       pro);
+}
+
+int eetq_silu_mul_glu8_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream)
+{
+    return launch_silu_mul(static_cast<const f16*>(gate_up), static_cast<f16*>(out), rows, intermediate,
+                           static_cast<hipStream_t>(stream), true);
+}
+
 int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream)
 {
     return launch_silu_mul(static_cast<const f16*>(gate_up), static_cast<f16*>(out), rows, intermediate,

@@ -75,8 +75,21 @@ __device__ __forceinline__ void dequant_16(const u32x4& w, f16x2 scale2, f16x2 (
 struct Epilogue {
     const f16* bias     = nullptr;  // [N]
     const f16* residual = nullptr;  // [M][N], row stride N; must not alias y unless it is y itself element for element
-    int        act      = 0;        // EETQ_ACT_*: 0 = identity (the Python-level `output + bias` above)
+    int        act      = 0;        // EETQ_ACT_*: 0 = identity (the Python-level `output + bias` above); kActGlu8: see below
 };
+
+// Gated-MLP epilogue of the M = 1 GEMV (internal value of Epilogue::act, reached through eetq_w8a16_gemv_glu8 only): the
+// weight's columns come in groups of 16 = 8 gate columns followed by the 8 matching up columns, and the kernel writes
+// y[8 t + c] = silu_mul(gate, up) for its tile t -- N/2 outputs, the silu_mul launch saved.
+constexpr int kActGlu8 = 16;
+
+// silu(g) * u in the roundings of the separate torch ops (silu in fp32 rounded to fp16, then an fp16 multiply); the one
+// definition every kernel that fuses or performs the gated activation uses, so they all produce the same bits
+__device__ __forceinline__ f16 silu_mul_f16(f16 g, f16 u)
+{
+    const float x = (float)g;
+    return (f16)(x / (1.0f + expf(-x))) * u;
+}
 
 // Activation epilogues (EETQ_ACT_RELU / GELU / SILU): FT's bias + activation family, which the reference compiles but never
 // reaches from Python (cutlass_kernels/fpA_intB_gemm.cu:35-97 -> fpA_intB_gemm_template.h:492-537 -> epilogue_helpers.h:20-71:
@@ -209,7 +222,7 @@ int launch_rotary_kvcache(const int64_t* pos, const int64_t* slots, int slot_str
                           const f16* cache, f16* kcache, f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,
                           long k_stride, long v_stride, long c_sb, long c_sh, long c_ss, int max_pos, hipStream_t stream);
 
-int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t stream);
+int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t stream, bool glu8 = false);
 
 // compute units of the current device (cached per device); 256 on MI355X
 int device_cu_count();

@@ -99,7 +99,7 @@ int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16
     const int KT = K / kTileK;
     if constexpr (M == 1) {
         // N = 5120: 320 tile rows on 256 CUs -> 640 half rows, 3 instead of 4 eight-column units on the busiest CU
-        if (half_units_pay(N, K)) return launch_half(x, w, scales, ep, y, N, K, stream, pro);
+        if (ep.act != kActGlu8 && half_units_pay(N, K)) return launch_half(x, w, scales, ep, y, N, K, stream, pro);
     }
     // Tuned on MI355X with tools/kbench (profiles/r01_kbench_gemv.txt):
     if (KT == 64) {  // K = 4096: 16 waves x 4 tiles, straight-line; <= 64 VGPRs so two workgroups fit a CU

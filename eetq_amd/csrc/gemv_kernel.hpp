@@ -356,9 +356,18 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
             }
             s = sum_xor32(sum_xor16(s));
             if (lane < 16) {
-                f16 v = finish_element(s, ep, ntile * 16 + c);  // identity: fp16 add after the fp16 rounding == the reference's separate `+ bias`
-                if (ep.residual) v = v + ep.residual[(size_t)m * N + ntile * 16 + c];
-                y[(size_t)m * N + ntile * 16 + c] = v;
+                if (ep.act == kActGlu8) {
+                    // columns 0..7 of the tile are gate, 8..15 the matching up columns: N/2 outputs per row
+                    Epilogue lin = ep;
+                    lin.act      = 0;
+                    const f16 v  = finish_element(s, lin, ntile * 16 + c);
+                    const f16 up = __builtin_bit_cast(f16, (unsigned short)__shfl_xor((int)__builtin_bit_cast(unsigned short, v), 8, 64));
+                    if (c < 8) y[(size_t)m * (N >> 1) + ntile * 8 + c] = silu_mul_f16(v, up);
+                } else {
+                    f16 v = finish_element(s, ep, ntile * 16 + c);  // identity: fp16 add after the fp16 rounding == the reference's separate `+ bias`
+                    if (ep.residual) v = v + ep.residual[(size_t)m * N + ntile * 16 + c];
+                    y[(size_t)m * N + ntile * 16 + c] = v;
+                }
             }
         }
     }

@@ -106,10 +106,21 @@ __global__ void silu_mul_kernel(const f16* __restrict__ gu, f16* __restrict__ ou
     const f16x8 u = *reinterpret_cast<const f16x8*>(gu + r * 2 * inter + inter + i);
     f16x8       o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        const float x = (float)g[j];
-        o[j]          = (f16)(x / (1.0f + expf(-x))) * u[j];
-    }
+    for (int j = 0; j < 8; ++j) o[j] = silu_mul_f16(g[j], u[j]);
+    *reinterpret_cast<f16x8*>(out + idx) = o;
+}
+
+// the same on the "glu8" column order of a fused gate|up projection (groups of 16 = 8 gate + the 8 matching up columns):
+// out[r][8 t + c] = silu_mul(gu[r][16 t + c], gu[r][16 t + 8 + c])
+__global__ void silu_mul_glu8_kernel(const f16* __restrict__ gu, f16* __restrict__ out, long rows_x_inter)
+{
+    const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;   // = r * inter + 8 t
+    if (idx >= rows_x_inter) return;
+    const f16x8 g = *reinterpret_cast<const f16x8*>(gu + 2 * idx);
+    const f16x8 u = *reinterpret_cast<const f16x8*>(gu + 2 * idx + 8);
+    f16x8       o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = silu_mul_f16(g[j], u[j]);
     *reinterpret_cast<f16x8*>(out + idx) = o;
 }
 
@@ -180,13 +191,16 @@ int launch_rotary_kvcache(const int64_t* pos, const int64_t* slots, int slot_str
     return check_hip(hipGetLastError(), "rotary_neox_kvcache_kernel launch");
 }
 
-int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t stream)
+int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t stream, bool glu8)
 {
     EETQ_REQUIRE(gu && out, "null pointer");
     EETQ_REQUIRE(rows >= 0 && inter > 0 && inter % 8 == 0, "silu_mul: the intermediate size must be a multiple of 8");
     if (rows == 0) return EETQ_OK;
     const long n = (long)rows * inter;
-    silu_mul_kernel<<<(unsigned)((n / 8 + 255) / 256), 256, 0, stream>>>(gu, out, inter, n);
+    if (glu8)
+        silu_mul_glu8_kernel<<<(unsigned)((n / 8 + 255) / 256), 256, 0, stream>>>(gu, out, n);
+    else
+        silu_mul_kernel<<<(unsigned)((n / 8 + 255) / 256), 256, 0, stream>>>(gu, out, inter, n);
     return check_hip(hipGetLastError(), "silu_mul_kernel launch");
 }
 

@@ -207,7 +207,7 @@ Tensor rope_decode_attention(const Tensor& positions, const Tensor& query, const
     return out;
 }
 
-Tensor silu_mul(const Tensor& gate_up);
+Tensor silu_mul(const Tensor& gate_up, bool glu8 = false);
 
 void check_epilogue(const Tensor& input, const OptTensor& bias, const OptTensor& residual, int64_t m, int64_t n)
 {
@@ -259,7 +259,7 @@ int act_id(const std::string& name)
     if (name == "relu") return EETQ_ACT_RELU;
     if (name == "gelu") return EETQ_ACT_GELU;
     if (name == "silu") return EETQ_ACT_SILU;
-    throw std::runtime_error("unknown activation '" + name + "' (identity, relu, gelu, silu)");
+    throw std::runtime_error("unknown activation '" + name + "' (identity, relu, gelu, silu; silu_glu8 for gated weights)");
 }
 
 std::vector<int64_t> out_shape(const Tensor& input, int64_t n)
@@ -278,6 +278,31 @@ Tensor w8_a16_gemm(const Tensor& input_in, const Tensor& weight, const Tensor& s
     int64_t n     = scale.numel();  // [N]; for packed int4 weights the byte tensor is [K, N/2]
     TORCH_CHECK(input.dim() >= 1 && weight.dim() == 2, "w8_a16_gemm: expected input [..., K] and weight [K, N]");
     const int64_t kw = weight.size(0);
+    if (activation == "silu_glu8") {
+        // gated MLP over a weight in "glu8" column order: [..., N/2] = silu_mul of the column pairs.  One launch for a single
+        // row (activation in the GEMV epilogue, RMS-norm in its prologue); projection + eetq_silu_mul_glu8_f16 otherwise.
+        TORCH_CHECK(!gated && !residual && n % 16 == 0 && weight.size(1) == n,
+                    "w8_a16_gemm: silu_glu8 takes an int8 [K, N] weight with N % 16 == 0, no residual");
+        const int64_t rows = kw ? input.numel() / kw : 0;
+        const bool    fusable_norm = !norm || (std::get<0>(*norm).scalar_type() == at::kHalf &&
+                                            std::get<0>(*norm).is_contiguous() && std::get<0>(*norm).numel() == kw &&
+                                            std::get<0>(*norm).device() == input.device());
+        if (rows == 1 && path == "auto" && input.size(-1) == kw && input.is_cuda() && input.scalar_type() == at::kHalf &&
+            fusable_norm) {
+            TORCH_CHECK(weight.scalar_type() == at::kChar && scale.scalar_type() == at::kHalf && weight.is_contiguous() &&
+                            weight.device() == input.device() && scale.device() == input.device(),
+                        "w8_a16_gemm: weight must be contiguous int8 and scale float16, on the input's device");
+            check_epilogue(input, bias, residual, 1, n);
+            Tensor           x = input.contiguous();
+            Tensor           output = torch::empty(out_shape(input, n / 2), input.options());
+            c10::DeviceGuard guard(input.device());
+            check(eetq_w8a16_gemv_glu8(x.data_ptr(), norm ? std::get<0>(*norm).data_ptr() : nullptr,
+                                       norm ? (float)std::get<1>(*norm) : 0.f, weight.data_ptr<int8_t>(), scale.data_ptr(),
+                                       bias ? bias->data_ptr() : nullptr, output.data_ptr(), (int)n, (int)kw, stream_of(input)));
+            return output;
+        }
+        return silu_mul(w8_a16_gemm(input_in, weight, scale, path, bias, residual, norm, false, std::string()), true);
+    }
     if (gated) {
         TORCH_CHECK(input.size(-1) == 2 * kw, "w8_a16_gemm: gated input must be [..., 2K] for a [K, N] weight");
         const int64_t rows = input.numel() / input.size(-1);
@@ -489,7 +514,7 @@ Tensor decode_attention(const Tensor& query, const Tensor& key_cache, const Tens
     return out;
 }
 
-Tensor silu_mul(const Tensor& gate_up)
+Tensor silu_mul(const Tensor& gate_up, bool glu8)
 {
     TORCH_CHECK(gate_up.scalar_type() == at::kHalf && gate_up.is_cuda() && gate_up.is_contiguous(),
                 "silu_mul: expected a contiguous float16 CUDA tensor");
@@ -498,7 +523,10 @@ Tensor silu_mul(const Tensor& gate_up)
     Tensor        out  = torch::empty(out_shape(gate_up, inter), gate_up.options());
     const int64_t rows = inter ? out.numel() / inter : 0;
     c10::DeviceGuard guard(gate_up.device());
-    check(eetq_silu_mul_f16(gate_up.data_ptr(), out.data_ptr(), (int)rows, (int)inter, stream_of(gate_up)));
+    if (glu8)
+        check(eetq_silu_mul_glu8_f16(gate_up.data_ptr(), out.data_ptr(), (int)rows, (int)inter, stream_of(gate_up)));
+    else
+        check(eetq_silu_mul_f16(gate_up.data_ptr(), out.data_ptr(), (int)rows, (int)inter, stream_of(gate_up)));
     return out;
 }
 
@@ -518,7 +546,7 @@ Tensor llama_decode_layer(const Tensor& hidden, const NormArg& input_norm, const
                           Tensor& value_cache, Tensor& tickets, Tensor& counter, const OptTensor& mask, double scaling,
                           int64_t heads, int64_t kv_heads, const Tensor& o_w, const Tensor& o_s, const OptTensor& o_b,
                           const NormArg& post_norm, const Tensor& gu_w, const Tensor& gu_s, const OptTensor& gu_b,
-                          const Tensor& down_w, const Tensor& down_s, const OptTensor& down_b)
+                          const Tensor& down_w, const Tensor& down_s, const OptTensor& down_b, bool glu8)
 {
     TORCH_CHECK(hidden.dim() == 3 && hidden.size(1) == 1, "llama_decode_layer: hidden must be [B, 1, C]");
     const int64_t B = hidden.size(0), total = heads + 2 * kv_heads;
@@ -585,9 +613,14 @@ Tensor llama_decode_layer(const Tensor& hidden, const NormArg& input_norm, const
                                              (int)kv_heads, (int)S, (int)D, (int)splits, (float)scaling, st, cnt, 1, cnt, stream));
         check(eetq_w8a16_gemm_act(att, o_w.data_ptr<int8_t>(), o_s.data_ptr(), optp(o_b), hidden.data_ptr(), h.data_ptr(), 1,
                                   (int)C, (int)(heads * D), EETQ_PATH_AUTO, EETQ_ACT_IDENTITY, stream));
-        check(eetq_w8a16_gemv_rmsnorm(h.data_ptr(), g2.data_ptr(), (float)std::get<1>(post_norm), gu_w.data_ptr<int8_t>(),
-                                      gu_s.data_ptr(), optp(gu_b), nullptr, gu, (int)I2, (int)C, stream));
-        check(eetq_silu_mul_f16(gu, act, 1, (int)I, stream));
+        if (glu8) {  // gate|up in "glu8" column order: the activation rides in the projection's epilogue
+            check(eetq_w8a16_gemv_glu8(h.data_ptr(), g2.data_ptr(), (float)std::get<1>(post_norm), gu_w.data_ptr<int8_t>(),
+                                       gu_s.data_ptr(), optp(gu_b), act, (int)I2, (int)C, stream));
+        } else {
+            check(eetq_w8a16_gemv_rmsnorm(h.data_ptr(), g2.data_ptr(), (float)std::get<1>(post_norm), gu_w.data_ptr<int8_t>(),
+                                          gu_s.data_ptr(), optp(gu_b), nullptr, gu, (int)I2, (int)C, stream));
+            check(eetq_silu_mul_f16(gu, act, 1, (int)I, stream));
+        }
         check(eetq_w8a16_gemm_act(act, down_w.data_ptr<int8_t>(), down_s.data_ptr(), optp(down_b), h.data_ptr(), out.data_ptr(),
                                   1, (int)C, (int)I, EETQ_PATH_AUTO, EETQ_ACT_IDENTITY, stream));
         return out;
@@ -603,8 +636,9 @@ Tensor llama_decode_layer(const Tensor& hidden, const NormArg& input_norm, const
                                         rows.narrow(1, heads + kv_heads, kv_heads), cos_sin_cache, key_cache, value_cache,
                                         tickets, counter, mask, scaling, std::nullopt, counter, 1, counter);
     Tensor h  = w8_a16_gemm(attn.view({B, 1, heads * D}), o_w, o_s, autop, o_b, hidden, no_norm, false, none);
-    Tensor gu = w8_a16_gemm(h, gu_w, gu_s, autop, gu_b, no_tensor, n2, false, none);
-    return w8_a16_gemm(silu_mul(gu), down_w, down_s, autop, down_b, h, no_norm, false, none);
+    Tensor act = glu8 ? w8_a16_gemm(h, gu_w, gu_s, autop, gu_b, no_tensor, n2, false, std::string("silu_glu8"))
+                      : silu_mul(w8_a16_gemm(h, gu_w, gu_s, autop, gu_b, no_tensor, n2, false, none));
+    return w8_a16_gemm(act, down_w, down_s, autop, down_b, h, no_norm, false, none);
 }
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
@@ -646,7 +680,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("positions"), py::arg("cos_sin_cache"), py::arg("key_cache"), py::arg("value_cache"), py::arg("tickets"),
           py::arg("counter"), py::arg("mask"), py::arg("scaling"), py::arg("heads"), py::arg("kv_heads"), py::arg("o_weight"),
           py::arg("o_scale"), py::arg("o_bias"), py::arg("post_norm"), py::arg("gate_up_weight"), py::arg("gate_up_scale"),
-          py::arg("gate_up_bias"), py::arg("down_weight"), py::arg("down_scale"), py::arg("down_bias"));
-    m.def("silu_mul", &silu_mul, "silu(gate) * up on a fused gate|up block", py::arg("gate_up"));
+          py::arg("gate_up_bias"), py::arg("down_weight"), py::arg("down_scale"), py::arg("down_bias"), py::arg("glu8") = false);
+    m.def("silu_mul", &silu_mul, "silu(gate) * up on a fused gate|up block (glu8: columns in groups of 8 gate + 8 up)",
+          py::arg("gate_up"), py::arg("glu8") = false);
     m.attr("__eetq_amd_version__") = eetq_version();
 }

@@ -336,13 +336,18 @@ class EETQuantLlamaAttention(EETLlamaAttention):
 
 
 class EETLlamaMLP(nn.Module):
-    """down(silu(gate(x)) * up(x)) with gate and up as ONE W8A16 launch over concatenated channels."""
+    """down(silu(gate(x)) * up(x)) with gate and up as ONE W8A16 launch over concatenated channels.
 
-    def __init__(self, gate_proj, up_proj, down_proj):
+    ``glu8`` (default): the fused weight's columns are interleaved in groups of 8 gate + 8 up, so for a single token the
+    activation is computed in that launch's epilogue (``eetq_w8a16_gemv_glu8``) and the block is two launches; larger inputs
+    run the projection and one ``silu_mul`` launch on the interleaved output.  Bit-identical to the plain order."""
+
+    def __init__(self, gate_proj, up_proj, down_proj, glu8=True):
         super().__init__()
         from ..utils.fuse import fuse_w8a16_linears
-        self.gate_up_proj = fuse_w8a16_linears([gate_proj, up_proj]).fused
         self.intermediate_size = gate_proj.out_features
+        self.glu8 = bool(glu8) and self.intermediate_size % 16 == 0 and gate_proj.in_features % 64 == 0
+        self.gate_up_proj = fuse_w8a16_linears([gate_proj, up_proj], glu8=self.glu8).fused
         self.down_proj = down_proj
         # silu(gate) * up inside the down projection's GEMV launch (eetq_w8a16_gemv_silu_gated) is available but off: every
         # workgroup recomputes the activation of the whole vector, which costs more than the one launch it saves
@@ -350,7 +355,13 @@ class EETLlamaMLP(nn.Module):
         self.fuse_activation = False
 
     def forward(self, x, residual=None, norm=None):
+        if self.glu8 and x.is_cuda:
+            return self.down_proj(self.gate_up_proj(x, norm=norm, activation="silu_glu8"), residual=residual)
         gu = self.gate_up_proj(x, norm=norm)
+        if self.glu8:   # (CPU tensors never get here through the operators; kept for shape-only uses)
+            gu = gu.unflatten(-1, (-1, 2, 8))
+            return self.down_proj(torch.nn.functional.silu(gu[..., 0, :]).flatten(-2) * gu[..., 1, :].flatten(-2),
+                                  residual=residual)
         if self.intermediate_size % 8 == 0 and gu.is_cuda:
             if self.fuse_activation:
                 # silu(gate) * up inside the down projection's launch for a single token, one silu_mul launch otherwise

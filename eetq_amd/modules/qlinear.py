@@ -71,13 +71,14 @@ class W8A16Linear(nn.Module):
         return mod
 
     @torch.no_grad()
-    def forward(self, input, residual=None, norm=None, gated=False):
+    def forward(self, input, residual=None, norm=None, gated=False, activation=""):
         # bias is fused into the kernel epilogue: same bits as the reference's `output + self.bias` (qlinear.py:61);
         # `residual` (extension) is added after it in the same epilogue: the decoder block's `residual + proj(x)`
         # `norm=(gamma, eps)` (extension): RMS-norm of the input, fused into the launch for single-row inputs
         # `gated=True` (extension): input is a fused gate|up block and the projection runs on silu(gate) * up
+        # `activation` (extension): "relu" / "gelu" / "silu" epilogues, "silu_glu8" for a gate|up weight in glu8 column order
         return w8_a16_gemm(input, self.qweight, self.weight_scales, bias=self.bias, residual=residual, norm=norm,
-                           gated=gated)
+                           gated=gated, activation=activation)
 
     def extra_repr(self):
         return "in_features={}, out_features={}, bias={}".format(self.in_features, self.out_features,

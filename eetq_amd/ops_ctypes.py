@@ -200,8 +200,21 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, nor
     ``activation`` ("relu" | "gelu" | "silu"; extension): FT's bias + activation epilogue, ``fp16(act(acc + bias))``
     (csrc/cutlass_kernels/fpA_intB_gemm.cu:35-62), which the reference compiles but never binds.
     """
+    if activation == "silu_glu8":
+        # gated MLP over a weight in "glu8" column order (groups of 16 = 8 gate + the 8 matching up columns): one launch for
+        # a single row (activation in the GEMV epilogue, RMS-norm in its prologue), projection + silu_mul(glu8) otherwise
+        k, n = weight.shape[-2], scale.numel()
+        if gated or residual is not None or n % 16 or weight.shape[-1] != n:
+            raise RuntimeError("w8_a16_gemm: silu_glu8 takes an int8 [K, N] weight with N % 16 == 0, no residual")
+        rows = input.numel() // k if k else 0
+        gamma = norm[0] if norm is not None else None
+        if (rows == 1 and path == "auto" and input.shape[-1] == k and input.is_cuda and input.dtype == torch.float16
+                and (gamma is None or (gamma.dtype == torch.float16 and gamma.is_contiguous() and gamma.numel() == k
+                                       and gamma.device == input.device))):
+            return _gemv_glu8_launch(input, gamma, norm[1] if norm is not None else 0.0, weight, scale, bias, n, k)
+        return silu_mul(w8_a16_gemm(input, weight, scale, path, bias, None, norm), glu8=True)
     if activation not in _ACTS:
-        raise RuntimeError("unknown activation %r (identity, relu, gelu, silu)" % (activation,))
+        raise RuntimeError("unknown activation %r (identity, relu, gelu, silu; silu_glu8 for gated weights)" % (activation,))
     act = _ACTS[activation]
     if gated:
         k2 = input.shape[-1]
@@ -232,6 +245,24 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, nor
         layernorm_forward(input if input.is_contiguous() else input.contiguous(), gamma, normed, eps)
         input = normed
     return _gemm_launch(input, weight, scale, output, m, n, k, _PATHS[path], bias, residual, act)
+
+
+@_eager_only
+def _gemv_glu8_launch(input, gamma, eps, weight, scale, bias, n, k):
+    if weight.dtype != torch.int8 or scale.dtype != torch.float16 or not weight.is_contiguous():
+        raise RuntimeError("w8_a16_gemm: weight must be contiguous int8 and scale float16")
+    for t in (weight, scale) + ((bias,) if bias is not None else ()):
+        if t.device != input.device:
+            raise RuntimeError("w8_a16_gemm: all tensors must be on the input's device")
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != n or not bias.is_contiguous()):
+        raise RuntimeError("w8_a16_gemm: bias must be a contiguous float16 [N] tensor")
+    x = input if input.is_contiguous() else input.contiguous()
+    output = torch.empty(tuple(input.shape[:-1]) + (n // 2,), dtype=input.dtype, device=input.device)
+    with torch.cuda.device(input.device):
+        check(_lib.lib().eetq_w8a16_gemv_glu8(_ptr(x), _ptr(gamma) if gamma is not None else None, float(eps), _ptr(weight),
+                                              _ptr(scale), _ptr(bias) if bias is not None else None, _ptr(output), n, k,
+                                              _stream_ptr()))
+    return output
 
 
 @_eager_only
@@ -513,8 +544,9 @@ def rotary_embedding_neox_kvcache(positions, query, key, value, head_size, cos_s
 
 
 @_eager_only
-def silu_mul(gate_up):
-    """``silu(gate) * up`` on a fused gate|up projection output [..., 2*I] -> [..., I] in one launch (extension)."""
+def silu_mul(gate_up, glu8=False):
+    """``silu(gate) * up`` on a fused gate|up projection output [..., 2*I] -> [..., I] in one launch (extension).
+    ``glu8``: the columns come in groups of 16 = 8 gate + the 8 matching up columns instead of [all gate | all up]."""
     if gate_up.dtype != torch.float16 or not gate_up.is_cuda or not gate_up.is_contiguous():
         raise RuntimeError("silu_mul: expected a contiguous float16 CUDA tensor")
     inter = gate_up.shape[-1] // 2
@@ -523,5 +555,6 @@ def silu_mul(gate_up):
     out = torch.empty(tuple(gate_up.shape[:-1]) + (inter,), dtype=torch.float16, device=gate_up.device)
     rows = out.numel() // inter if inter else 0
     with torch.cuda.device(gate_up.device):
-        check(_lib.lib().eetq_silu_mul_f16(_ptr(gate_up), _ptr(out), rows, inter, _stream_ptr()))
+        fn = _lib.lib().eetq_silu_mul_glu8_f16 if glu8 else _lib.lib().eetq_silu_mul_f16
+        check(fn(_ptr(gate_up), _ptr(out), rows, inter, _stream_ptr()))
     return out

@@ -86,13 +86,14 @@ def replace_with_eet_qlinear(model, init_only=False, target_model="llama", devic
     return model
 
 
-def replace_with_eet_fused_mlp(model):
-    """Extension: every Llama MLP whose projections are W8A16Linear -> EETLlamaMLP (gate/up in one launch)."""
+def replace_with_eet_fused_mlp(model, glu8=True):
+    """Extension: every Llama MLP whose projections are W8A16Linear -> EETLlamaMLP (gate/up in one launch; ``glu8``: with the
+    activation in that launch's epilogue for single-token steps)."""
     n = 0
     for name, m in list(model.named_modules()):
         if type(m).__name__ == "LlamaMLP" and all(isinstance(getattr(m, p, None), W8A16Linear)
                                                    for p in ("gate_proj", "up_proj", "down_proj")):
-            set_op_by_name(model, name, EETLlamaMLP(m.gate_proj, m.up_proj, m.down_proj))
+            set_op_by_name(model, name, EETLlamaMLP(m.gate_proj, m.up_proj, m.down_proj, glu8=glu8))
             n += 1
     return n
 
@@ -129,9 +130,9 @@ def replace_with_eet_fused_residual(model):
         itself otherwise); rebuilt when a projection's weight buffer has been replaced (.to(), load_state_dict(assign=True))."""
         qkv, o, gu, down = attn.qkv_proj, attn.o_proj, mlp.gate_up_proj, mlp.down_proj
         cached = self._step_weights
-        if (cached is not None and cached[0][2] is qkv._buffers["qweight"] and cached[1][0] is o._buffers["qweight"]
-                and cached[1][5] is gu._buffers["qweight"] and cached[1][8] is down._buffers["qweight"]
-                and cached[0][0][0] is n1.weight):
+        if (cached is not None and cached[0][1] is qkv._buffers["qweight"] and cached[1][0] is o._buffers["qweight"]
+                and cached[1][4] is gu._buffers["qweight"] and cached[1][7] is down._buffers["qweight"]
+                and cached[0][0][0] is n1._parameters["weight"]):
             return cached
         cached = (((n1.weight, n1.variance_epsilon), qkv.qweight, qkv.weight_scales, qkv.bias),
                   (o.qweight, o.weight_scales, o.bias, (n2.weight, n2.variance_epsilon), gu.qweight, gu.weight_scales, gu.bias,
@@ -150,7 +151,8 @@ def replace_with_eet_fused_residual(model):
                 positions, table, cache, tickets, add = ready
                 head, tail = step_weights(self, attn, mlp, n1, n2)
                 return layer_step(hidden_states, *head, positions, table, cache.keys, cache.values, tickets,
-                                  cache.cumulative_length, add, attn.scaling, attn.num_heads, attn.num_key_value_heads, *tail)
+                                  cache.cumulative_length, add, attn.scaling, attn.num_heads, attn.num_key_value_heads, *tail,
+                                  mlp.glu8)
         h, _ = attn(hidden_states=hidden_states, attention_mask=attention_mask, position_ids=position_ids,
                     past_key_values=past_key_values, use_cache=use_cache, position_embeddings=position_embeddings,
                     residual=hidden_states, input_norm=(n1.weight, n1.variance_epsilon), **kwargs)
@@ -172,17 +174,23 @@ def replace_with_eet_fused_residual(model):
 
 
 def eet_accelerator(model, quantize=False, fused_attn=False, dev="cuda:0", fused_mlp=False, fused_norm=False,
-                    fused_residual=False):
+                    fused_residual=False, static_cache=False, glu8=True):
     """Reference semantics (accelerator.py:15-19): ``fused_attn`` first builds fp16 fused-QKV attention blocks, then
-    ``quantize`` turns every decoder nn.Linear -- the fused QKV included -- into W8A16."""
+    ``quantize`` turns every decoder nn.Linear -- the fused QKV included -- into W8A16.  ``static_cache`` (extension): make
+    ``model.generate`` default to a pre-allocated KV cache without torch.compile (``cache_implementation="static"``,
+    ``disable_compile=True`` in the model's generation config), the form on which the accelerated blocks run a decode
+    step as one launch per attention / one call per layer.  ``glu8``: see ``replace_with_eet_fused_mlp``."""
     if fused_attn:
         replace_with_eet_fp16_fused_attn(model)
     if quantize:
         replace_with_eet_qlinear(model, init_only=False, target_model="llama", device=dev)
     if fused_mlp:
-        replace_with_eet_fused_mlp(model)
+        replace_with_eet_fused_mlp(model, glu8=glu8)
     if fused_norm:
         replace_with_eet_rmsnorm(model)
     if fused_residual:
         replace_with_eet_fused_residual(model)
+    if static_cache and getattr(model, "generation_config", None) is not None:
+        model.generation_config.cache_implementation = "static"
+        model.generation_config.disable_compile = True
     return model

@@ -28,8 +28,26 @@ class FusedW8A16Linear(nn.Module):
         return torch.split(self.fused(x), self.splits, dim=-1)
 
 
-def fuse_w8a16_linears(parts):
-    """parts: W8A16Linear modules with the same in_features, device and bias-ness -> FusedW8A16Linear."""
+def _glu8_interleave_columns(gate, up):
+    """[.., I] x 2 -> [.., 2I] in "glu8" order: groups of 16 = 8 gate entries followed by the 8 matching up entries."""
+    return torch.stack([gate.unflatten(-1, (-1, 8)), up.unflatten(-1, (-1, 8))], dim=-2).flatten(-3)
+
+
+def _glu8_interleave_tiles(gate, up, k):
+    """The same for two processed (gfx950) int8 weights [K, I]: tile row t' of a part = 16 columns x K = K/64 tiles of
+    [4 k groups][16 columns][16 bytes]; output tile row 2t' + h takes columns 8h..8h+7 of gate's and of up's tile row t'."""
+    def split(w):   # -> [tile rows, K/64, 4, half, 8, 16]
+        return w.contiguous().reshape(-1, k // 64, 4, 2, 8, 16)
+    g, u = split(gate), split(up)
+    both = torch.stack([g, u], dim=4)                      # [t', kt, grp, half, gate|up, 8, 16]
+    return both.permute(0, 3, 1, 2, 4, 5, 6).contiguous()  # [t', half, kt, grp, gate|up, 8, 16] = tile rows 2t' + half
+
+
+def fuse_w8a16_linears(parts, glu8=False):
+    """parts: W8A16Linear modules with the same in_features, device and bias-ness -> FusedW8A16Linear.
+    ``glu8`` (two parts = gate and up of a gated MLP, out_features % 16 == 0): columns interleaved in groups of 8 + 8 so one
+    16-column tile carries both operands of 8 outputs and the activation can ride in the projection's epilogue
+    (``w8_a16_gemm(..., activation="silu_glu8")``); the fused module then has ``glu8 = True``."""
     parts = list(parts)
     if not parts or not all(isinstance(p, W8A16Linear) for p in parts):
         raise TypeError("fuse_w8a16_linears expects W8A16Linear modules")
@@ -43,6 +61,16 @@ def fuse_w8a16_linears(parts):
             raise ValueError("every part's out_features must be a multiple of 16")
     n = sum(p.out_features for p in parts)
     fused = W8A16Linear(k, n, bias=has_bias, dev=dev)
+    fused.glu8 = bool(glu8)
+    if glu8:
+        if len(parts) != 2 or parts[0].out_features != parts[1].out_features or k % 64:
+            raise ValueError("glu8 fuses exactly two parts (gate, up) of equal width")
+        gate, up = parts
+        fused.qweight = _glu8_interleave_tiles(gate.qweight, up.qweight, k).reshape(k, n)
+        fused.weight_scales = _glu8_interleave_columns(gate.weight_scales, up.weight_scales)
+        if has_bias:
+            fused.bias = _glu8_interleave_columns(gate.bias, up.bias)
+        return FusedW8A16Linear(fused, [n])
     # [K, N_i] int8 tensors hold N_i/16 tile rows of K*16 bytes each: concatenate the raw bytes
     flat = torch.cat([p.qweight.contiguous().reshape(-1) for p in parts])
     fused.qweight = flat.reshape(k, n)

@@ -112,6 +112,7 @@ def main():
                     help="decode step as rotary+cache-write launch and two attention launches instead of the one-launch form")
     ap.add_argument("--python-layer-step", action="store_true",
                     help="decode step of a layer through the Python blocks instead of one call into the compiled module")
+    ap.add_argument("--no-glu8", action="store_true", help="gate|up in plain column order: silu*mul as its own launch")
     ap.add_argument("--static-cache", action="store_true",
                     help="eager generate(cache_implementation='static', disable_compile=True): pre-allocated cache, so the "
                          "accelerated blocks take their one-launch decode step / the compiled layer step")
@@ -128,7 +129,8 @@ def main():
     t0 = time.perf_counter()
     if args.accelerate:
         from eetq_amd.utils import eet_accelerator
-        eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True, fused_residual=True)
+        eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True, fused_residual=True,
+                        glu8=not args.no_glu8)
         for layer in model.model.layers:
             layer.self_attn.decode_math_attention = {"kernel": True, "math": "always", "off": False}[args.decode_attn]
             layer.mlp.fuse_activation = args.gated_fusion
@@ -183,7 +185,7 @@ def main():
                            (", fused rmsnorm" if args.fuse_norm else "") + (", fused qkv + gate/up" if args.fuse_proj else "") +
                            (", eet_accelerator(fused_attn, fused_mlp, fused_norm)" if args.accelerate else "") +
                            (", two-launch decode step" if args.two_launch_step else "") +
-                           (", python layer step" if args.python_layer_step else "")),
+                           (", python layer step" if args.python_layer_step else "") + (", no glu8" if args.no_glu8 else "")),
                 "n_gpus": grp.world_size, "end_to_end_s": round(secs, 4), "prefill_s": round(t_prefill, 4),
                 "tokens_per_s_per_replica": round(new_tokens / secs, 2),
                 "tokens_per_s_aggregate": round(grp.world_size * new_tokens / secs, 2),

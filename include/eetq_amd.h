@@ -173,6 +173,18 @@ int eetq_w8a16_gemv_silu_gated(const void* gate_up, const int8_t* w_packed, cons
  * then an fp16 multiply. */
 int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream);
 
+/* Gated MLP with the activation in the projection's epilogue (extension).  "glu8" column order of a fused gate|up weight:
+ * columns in groups of 16 = gate columns 8t..8t+7 followed by up columns 8t..8t+7 (scales and bias in the same order), so
+ * one 16-column tile holds both operands of 8 outputs.
+ *   eetq_w8a16_gemv_glu8: M = 1; y[8t + c] = silu_mul(g, u) with g, u the projection's fp16 outputs (+ bias) for the pair,
+ *     i.e. exactly eetq_w8a16_gemm (+ bias) followed by eetq_silu_mul_glu8_f16; y has N / 2 entries; gamma non-NULL adds
+ *     the RMS-norm prologue of eetq_w8a16_gemv_rmsnorm.
+ *   eetq_silu_mul_glu8_f16: out[r][8t + c] = silu_mul(gate_up[r][16t + c], gate_up[r][16t + 8 + c]) for the M > 1 GEMMs over
+ *     such a weight; gate_up [rows][2 * intermediate] dense, intermediate % 8 == 0. */
+int eetq_w8a16_gemv_glu8(const void* x, const void* gamma, float eps, const int8_t* w_packed, const void* scales,
+                         const void* bias, void* y, int N, int K, void* stream);
+int eetq_silu_mul_glu8_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream);
+
 /* Decode-step rotary + KV-cache write (extension for the EET attention blocks): one new token per batch row b, rotated
  * by cos_sin_cache[positions[b]]; q [batch][q_heads][head_size] is rotated in place, k is rotated and written to
  * k_cache[b][head][slot][:], v is copied to v_cache[b][head][slot][:] (caches [batch][k_heads][max_positions][head_size]).

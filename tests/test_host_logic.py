@@ -233,3 +233,23 @@ def test_error_behaviour_matches_the_reference_python_layer():
         assert ours[key] is not None and ours[key][0] == etype, (key, ours[key], etype)
         if msg:
             assert ours[key][1] == msg, (key, ours[key][1], msg)
+
+
+def test_glu8_fuse_layout_matches_packing_the_interleaved_matrix():
+    """fuse_w8a16_linears(glu8=True) permutes the PROCESSED bytes of gate and up; the result must be the processed form of
+    the raw [K, 2I] matrix whose columns are interleaved in groups of 8 gate + 8 up (oracle packer), scales likewise."""
+    import numpy as np
+    import oracle
+    from eetq_amd.utils.fuse import _glu8_interleave_columns, _glu8_interleave_tiles
+    rng = np.random.default_rng(0)
+    for K, I in ((64, 16), (192, 48), (256, 160)):
+        G = rng.integers(-128, 128, (K, I), dtype=np.int8)
+        U = rng.integers(-128, 128, (K, I), dtype=np.int8)
+        fused = _glu8_interleave_tiles(torch.from_numpy(oracle.gfx950_pack(G)), torch.from_numpy(oracle.gfx950_pack(U)), K)
+        raw = _glu8_interleave_columns(torch.from_numpy(G), torch.from_numpy(U)).numpy()
+        for t in range(I // 8):
+            assert np.array_equal(raw[:, 16 * t: 16 * t + 8], G[:, 8 * t: 8 * t + 8])
+            assert np.array_equal(raw[:, 16 * t + 8: 16 * t + 16], U[:, 8 * t: 8 * t + 8])
+        assert np.array_equal(fused.reshape(K, 2 * I).numpy(), oracle.gfx950_pack(np.ascontiguousarray(raw)))
+    s = _glu8_interleave_columns(torch.arange(32.), 100 + torch.arange(32.))
+    assert s[:16].tolist() == list(range(8)) + list(range(100, 108))
