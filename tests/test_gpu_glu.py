@@ -24,7 +24,7 @@ def _mlp_parts(K, I, bias, seed):
     return mk(K, I), mk(K, I), mk(I, K)
 
 
-@pytest.mark.parametrize("K,I,bias", [(4096, 11008, False), (5120, 13824, False), (1024, 2816, True), (512, 48, True),
+@pytest.mark.parametrize("K,I,bias", [(4096, 11008, False), (5120, 13824, False), (1024, 2816, True), (512, 192, True),
                                       (4096, 4096, False), (2048, 5120, False)])
 def test_glu8_gemv_equals_projection_then_silu_mul(ops, K, I, bias):
     """M = 1 (one launch, with and without the RMS-norm prologue), M = 2..4 (GEMV path), 8, 64, 300 (MFMA kernels + the glu8
