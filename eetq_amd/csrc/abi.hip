@@ -467,6 +467,12 @@ int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slot
                                    strides, kv_len, kv_len_bias, advance, static_cast<hipStream_t>(stream));
 }
 
+int eetq_diag_attn_stamps(unsigned long long* stamps)
+{
+    set_attn_stamps(stamps);
+    return EETQ_OK;
+}
+
 int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* mask, void* out,
                               float* workspace, int batch, int heads, int kv_heads, int positions, int head_dim,
                               int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,

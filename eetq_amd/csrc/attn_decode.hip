@@ -27,14 +27,43 @@ namespace {
 
 constexpr int kAttnThreads = 256;
 
+// One "trip" of a wave through the cache: U position groups, i.e. 2U independent 16-byte loads per lane in flight (the
+// loop is latency-bound otherwise).  The FIRST trip of a workgroup is loaded by the caller before anything else it has to
+// do (scalar setup, the rotation of the new token), so the cache rows are in flight while that runs.
+constexpr int kTripU = 4;
+template <int D>
+struct KvTrip {
+    f16x8 k[kTripU], v[kTripU];
+    int   jj[kTripU];
+    bool  valid[kTripU];
+};
+
+template <int D>
+__device__ __forceinline__ void load_trip(KvTrip<D>& t, const f16* __restrict__ kbase, const f16* __restrict__ vbase, long k_ss,
+                                          long v_ss, int jb, int j1)
+{
+    constexpr int LPP = D / 8, STEP = (kAttnThreads / 64) * (64 / LPP);
+    const int     grp = (threadIdx.x & 63) / LPP;
+#pragma unroll
+    for (int u = 0; u < kTripU; ++u) {
+        const int j = jb + u * STEP + grp;
+        t.valid[u]  = j < j1;
+        t.jj[u]     = t.valid[u] ? j : max(j1 - 1, 0);  // clamped, predicated use: no load behind a branch
+        t.k[u]      = *reinterpret_cast<const f16x8*>(kbase + (long)t.jj[u] * k_ss);
+    }
+#pragma unroll
+    for (int u = 0; u < kTripU; ++u) t.v[u] = *reinterpret_cast<const f16x8*>(vbase + (long)t.jj[u] * v_ss);
+}
+
 // The chunk [j0, j1) of one (batch row, head): online softmax over its positions, merged across the workgroup.  On return
 // threads tid < D hold (M, L, O) = the chunk's running maximum, its sum of exp(s - M) and channel tid of sum exp(s - M) v.
+// `t` holds the wave's first trip (load_trip at jb = j0 + wave * PPW).
 // SUBST: position `slot` is taken from registers (knew, vnew: this lane's 8 channels of the new token) instead of the cache.
 template <int D, bool SUBST>
-__device__ __forceinline__ void attn_chunk(const float (&qf)[8], const f16* __restrict__ kbase, const f16* __restrict__ vbase,
-                                           long k_ss, long v_ss, const f16* __restrict__ mrow, int j0, int j1, int slot,
-                                           const f16x8& knew, const f16x8& vnew, float* sm_m, float* sm_l, float* sm_o,
-                                           float& M, float& L, float& O)
+__device__ __forceinline__ void attn_chunk(const float (&qf)[8], KvTrip<D>& t, const f16* __restrict__ kbase,
+                                           const f16* __restrict__ vbase, long k_ss, long v_ss, const f16* __restrict__ mrow,
+                                           int j0, int j1, int slot, const f16x8& knew, const f16x8& vnew, float* sm_m,
+                                           float* sm_l, float* sm_o, float& M, float& L, float& O)
 {
     // every multiply-add below is an explicit fmaf and contraction is off: the two launch forms instantiate this code
     // separately and must round identically
@@ -49,43 +78,33 @@ __device__ __forceinline__ void attn_chunk(const float (&qf)[8], const f16* __re
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = 0.f;
 
-    // U position groups per trip: 2U independent 16-byte loads per lane in flight (the loop is latency-bound otherwise)
-    constexpr int U = 4, STEP = (kAttnThreads / 64) * PPW;
-    for (int jb = j0 + wave * PPW; jb < j1; jb += U * STEP) {
-        f16x8 kv[U], vv[U];
-        int   jj[U];
-        bool  valid[U];
+    constexpr int STEP = (kAttnThreads / 64) * PPW;
+    for (int jb = j0 + wave * PPW;;) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = jb + u * STEP + grp;
-            valid[u]    = j < j1;
-            jj[u]       = valid[u] ? j : j1 - 1;  // clamped, predicated use: no load behind a branch
-            kv[u]       = *reinterpret_cast<const f16x8*>(kbase + (long)jj[u] * k_ss);
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) vv[u] = *reinterpret_cast<const f16x8*>(vbase + (long)jj[u] * v_ss);
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (SUBST && jj[u] == slot) {
-                kv[u] = knew;
-                vv[u] = vnew;
+        for (int u = 0; u < kTripU; ++u) {
+            if (SUBST && t.jj[u] == slot) {
+                t.k[u] = knew;
+                t.v[u] = vnew;
             }
             float s = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s = fmaf(qf[i], (float)kv[u][i], s);
+            for (int i = 0; i < 8; ++i) s = fmaf(qf[i], (float)t.k[u][i], s);
 #pragma unroll
             for (int off = 1; off < LPP; off <<= 1) s += __shfl_xor(s, off, 64);
-            if (mrow) s += (float)mrow[jj[u]];
-            if (!valid[u]) s = -INFINITY;
+            if (mrow) s += (float)mrow[t.jj[u]];
+            if (!t.valid[u]) s = -INFINITY;
             const float mn = fmaxf(m, s);
             if (mn > -INFINITY) {  // group-uniform
                 const float sc = __expf(m - mn), p = __expf(s - mn);
                 l = fmaf(l, sc, p);
 #pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = fmaf(p, (float)vv[u][i], o[i] * sc);
+                for (int i = 0; i < 8; ++i) o[i] = fmaf(p, (float)t.v[u][i], o[i] * sc);
                 m = mn;
             }
         }
+        jb += kTripU * STEP;
+        if (jb >= j1) break;  // wave-uniform
+        load_trip<D>(t, kbase, vbase, k_ss, v_ss, jb, j1);
     }
     const int set = wave * PPW + grp;
     if (li == 0) {
@@ -132,6 +151,9 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
     const int chunk = (Sv + (int)gridDim.x - 1) / (int)gridDim.x;
     const int j0 = split * chunk, j1 = min(Sv, j0 + chunk);
 
+    const f16 *kbase = kc + b * k_sb + hk * k_sh + d0, *vbase = vc + b * v_sb + hk * v_sh + d0;
+    KvTrip<D>  trip;
+    load_trip<D>(trip, kbase, vbase, k_ss, v_ss, j0 + (tid >> 6) * (64 / (D / 8)), j1);
     float qf[8];
     {
         const f16x8 qv = *reinterpret_cast<const f16x8*>(q + b * q_sb + h * q_sh + d0);
@@ -140,8 +162,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
     }
     float       M, L, O;
     const f16x8 none = {};
-    attn_chunk<D, false>(qf, kc + b * k_sb + hk * k_sh + d0, vc + b * v_sb + hk * v_sh + d0, k_ss, v_ss,
-                         mask ? mask + b * m_sb : nullptr, j0, j1, -1, none, none, sm_m, sm_l, sm_o, M, L, O);
+    attn_chunk<D, false>(qf, trip, kbase, vbase, k_ss, v_ss, mask ? mask + b * m_sb : nullptr, j0, j1, -1, none, none, sm_m,
+                         sm_l, sm_o, M, L, O);
     if (tid < D) {
         float* out = ws + (((size_t)b * gridDim.y + h) * gridDim.x + split) * (D + 2);
         out[2 + tid] = O;
@@ -153,33 +175,51 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
 }
 
 // Merge of a head's `splits` chunk records p[s] = (m, l, o[D]) by a workgroup of NT threads (all of them call; thread
-// d < D returns channel d); LOAD fetches one float.  sm_w: splits + NT/64 floats of LDS.  A fully masked row yields zeros,
-// not NaN.  Sums run in chunk order whatever NT is: the two launch forms give the same bits.
+// d < D returns channel d); LOAD fetches one float.  sm_w: 2 * splits + NT/64 floats of LDS.  Two dependent memory phases:
+// every (m, l) at once, then the chunk outputs with 16 loads in flight per thread.  A fully masked row yields zeros, not
+// NaN.  Sums run in chunk order whatever NT is: the two launch forms give the same bits.
 template <int D, int NT, typename Load>
 __device__ __forceinline__ float attn_merge(const float* p, int splits, int d, float* sm_w, Load load)
 {
 #pragma clang fp contract(off)
-    float M = -INFINITY;
-    for (int s = d; s < splits; s += NT) M = fmaxf(M, load(p + s * (D + 2)));
+    float* sm_l    = sm_w + splits;
+    float* sm_part = sm_w + 2 * splits;
+    float  M       = -INFINITY;
+    for (int s = d; s < splits; s += NT) {
+        const float ms = load(p + s * (D + 2)), ls = load(p + s * (D + 2) + 1);
+        sm_w[s] = ms;
+        sm_l[s] = ls;
+        M       = fmaxf(M, ms);
+    }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
     if (NT > 64) {
-        float* sm_part = sm_w + splits;
         if ((d & 63) == 0) sm_part[d >> 6] = M;
         __syncthreads();
         M = sm_part[0];
 #pragma unroll
         for (int i = 1; i < NT / 64; ++i) M = fmaxf(M, sm_part[i]);
     }
-    for (int s = d; s < splits; s += NT) sm_w[s] = M > -INFINITY ? __expf(load(p + s * (D + 2)) - M) : 0.f;
+    for (int s = d; s < splits; s += NT) sm_w[s] = M > -INFINITY ? __expf(sm_w[s] - M) : 0.f;  // own entries: no barrier needed yet
     __syncthreads();
     if (d >= D) return 0.f;
     float L = 0.f, O = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < splits; ++s) {
-        const float w = sm_w[s];
-        L = fmaf(load(p + s * (D + 2) + 1), w, L);
-        O = fmaf(load(p + s * (D + 2) + 2 + d), w, O);
+    for (int s = 0; s < splits; ++s) L = fmaf(sm_l[s], sm_w[s], L);
+    int s = 0;
+    for (; s + 16 <= splits; s += 16) {
+        float o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = load(p + (s + i) * (D + 2) + 2 + d);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) O = fmaf(o[i], sm_w[s + i], O);
+    }
+    {
+        float o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[i] = load(p + min(s + i, splits - 1) * (D + 2) + 2 + d);  // clamped, predicated use
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (s + i < splits) O = fmaf(o[i], sm_w[s + i], O);
     }
     return L > 0.f ? O / L : 0.f;
 }
@@ -190,7 +230,7 @@ template <int D>
 __global__ __launch_bounds__(D) void attn_decode_merge_kernel(const float* __restrict__ ws, f16* __restrict__ out,
                                                              int splits, long o_sb, long o_sh, int64_t* advance)
 {
-    extern __shared__ float sm_w[];  // [splits] weights exp(m_s - M), then D/64 wave maxima
+    extern __shared__ float sm_w[];  // attn_merge's scratch: 2 * splits + D/64 floats
     const int    h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
     const float* p = ws + ((size_t)b * gridDim.x + h) * splits * (D + 2);
     out[b * o_sb + h * o_sh + d] = (f16)attn_merge<D, D>(p, splits, d, sm_w, [](const float* a) { return *a; });
@@ -200,26 +240,33 @@ __global__ __launch_bounds__(D) void attn_decode_merge_kernel(const float* __res
 }
 
 struct RopeAttnArgs {
-    const int64_t* positions;
-    const int64_t* slots;
-    int            slot_stride;
     const f16 *    q, *k, *v;  // the new token: [batch][heads][D] with q_sb / k_sb / v_sb elements between batch rows
+    int            S, groups, kv_len_bias, slot_stride;
+    long           kc_sb, kc_sh, kc_ss, vc_sb, vc_sh, vc_ss;
     long           q_sb, k_sb, v_sb;
     const f16*     cos_sin;
-    f16 *          kc, *vc;
-    long           kc_sb, kc_sh, kc_ss, vc_sb, vc_sh, vc_ss;
     const f16*     mask;
     long           m_sb;
     f16*           out;
     long           o_sb, o_sh;
     float*         ws;
     unsigned*      tickets;  // [batch * heads] per-head arrival counts + [1] finished heads; zero between launches
-    const int64_t* kv_len;
-    int            kv_len_bias;
     int64_t*       advance;
-    int            S, groups;
     float          scaling;
+    unsigned long long* stamps;  // diagnostics (eetq_diag_attn_stamps): [workgroup][8] device-clock stamps, or null
 };
+
+// device clock (100 MHz) into slot i of this workgroup's stamp row, ordered behind everything issued so far
+#define ATTN_STAMP(i)                                                                                                  \
+    do {                                                                                                               \
+        if (a.stamps) {                                                                                                \
+            unsigned long long t_;                                                                                     \
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+            if (threadIdx.x == 0)                                                                                      \
+                a.stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + (i)] = t_;     \
+        }                                                                                                              \
+    } while (0)
+
 
 // NeoX rotation of this lane's 8 channels [d0, d0 + 8) of one head (rot_dim = D: channel d < D/2 pairs with d + D/2).
 // own / other: the lane's channels and the paired ones; cs: the position's cos|sin row.  fp16 arithmetic, one rounding per
@@ -252,29 +299,51 @@ __device__ __forceinline__ void store_sc1(float* p, float v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
 }
 
-// grid (splits, heads, batch), 256 threads; see the file header.
+// grid (splits, heads, batch), 256 threads; see the file header.  The five leading pointers are preloaded into SGPRs at
+// launch (-amdgpu-kernarg-preload-count): the three scalar reads the chunk bounds depend on go out with the first
+// instructions, together with the fetch of the argument block, and nothing else stands before the first cache loads.
 template <int D>
-__global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const RopeAttnArgs a)
+__global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const int64_t* __restrict__ kv_len,
+                                                                        const int64_t* __restrict__ slots,
+                                                                        const int64_t* __restrict__ positions,
+                                                                        f16* __restrict__ kc, f16* __restrict__ vc,
+                                                                        const RopeAttnArgs a)
 {
     constexpr int LPP = D / 8, SETS = (kAttnThreads / 64) * (64 / LPP);
-    extern __shared__ float sm_w[];  // merge weights [splits] + one maximum per wave
+    extern __shared__ float sm_w[];  // attn_merge's scratch: 2 * splits + one maximum per wave
     __shared__ float    sm_m[SETS], sm_l[SETS];
     __shared__ float    sm_o[SETS * D];
     __shared__ unsigned sm_ticket;
 
+    ATTN_STAMP(0);
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z, hk = h / a.groups;
     const int splits = gridDim.x, H = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, li = lane % LPP, d0 = li * 8;
     const int d1 = d0 < D / 2 ? d0 + D / 2 : d0 - D / 2;  // the paired channels of the rotation
 
-    const int64_t rpos = a.positions[b];
-    const int64_t slot64 = a.slots ? a.slots[(long)b * a.slot_stride] : rpos;
+    // three independent scalar reads, every one from a valid address (no branch before the loads): a missing `slots`
+    // reads the position instead, a missing `kv_len` reads the position and ignores it
+    // (issued as one batch with one wait: left to itself the compiler waits after each of them)
+    const int64_t* p_pos  = positions + b;
+    const int64_t* p_slot = slots ? slots + (long)b * a.slot_stride : positions + b;
+    const int64_t* p_len  = kv_len ? kv_len : positions;
+    int64_t        rpos, slot64, filled;
+    asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dwordx2 %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(rpos), "=&s"(slot64), "=&s"(filled)
+                 : "s"(p_pos), "s"(p_slot), "s"(p_len)
+                 : "memory");
+    ATTN_STAMP(1);
     // a slot outside the cache is neither written nor attended, and (like the two-launch form) nothing is rotated then
     const bool have_new = slot64 >= 0 && slot64 < a.S && rpos >= 0;
     const int  slot = have_new ? (int)slot64 : -1;
-    const int  Sv = valid_len(a.S, a.kv_len, a.kv_len_bias);
+    const int  Sv = kv_len ? max(0, (int)min((int64_t)a.S, filled + a.kv_len_bias)) : a.S;
     const int  chunk = (Sv + splits - 1) / splits;
     const int  j0 = split * chunk, j1 = min(Sv, j0 + chunk);
+
+    // the cache rows of the first trip go in flight before anything else is touched
+    const f16 *kbase = kc + b * a.kc_sb + hk * a.kc_sh + d0, *vbase = vc + b * a.vc_sb + hk * a.vc_sh + d0;
+    KvTrip<D>  trip;
+    load_trip<D>(trip, kbase, vbase, a.kc_ss, a.vc_ss, j0 + (tid >> 6) * (64 / LPP), j1);
 
     const f16* qp = a.q + b * a.q_sb + (long)h * D;
     const f16* kp = a.k + b * a.k_sb + (long)hk * D;
@@ -288,18 +357,20 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const Ro
         knew = rope8<D>(knew, k2, cs, d0);
         // the cache row of the new token: once per kv head, by one position group of the head's first workgroup
         if (split == 0 && h == hk * a.groups && tid < LPP) {
-            *reinterpret_cast<f16x8*>(a.kc + b * a.kc_sb + hk * a.kc_sh + (long)slot * a.kc_ss + d0) = knew;
-            *reinterpret_cast<f16x8*>(a.vc + b * a.vc_sb + hk * a.vc_sh + (long)slot * a.vc_ss + d0) = vnew;
+            *reinterpret_cast<f16x8*>(kc + b * a.kc_sb + hk * a.kc_sh + (long)slot * a.kc_ss + d0) = knew;
+            *reinterpret_cast<f16x8*>(vc + b * a.vc_sb + hk * a.vc_sh + (long)slot * a.vc_ss + d0) = vnew;
         }
     }
     float qf[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) qf[i] = (float)qv[i] * a.scaling;
 
+    ATTN_STAMP(2);
     float M, L, O;
-    attn_chunk<D, true>(qf, a.kc + b * a.kc_sb + hk * a.kc_sh + d0, a.vc + b * a.vc_sb + hk * a.vc_sh + d0, a.kc_ss,
-                        a.vc_ss, a.mask ? a.mask + b * a.m_sb : nullptr, j0, j1, slot, knew, vnew, sm_m, sm_l, sm_o, M, L, O);
+    attn_chunk<D, true>(qf, trip, kbase, vbase, a.kc_ss, a.vc_ss, a.mask ? a.mask + b * a.m_sb : nullptr, j0, j1, slot, knew,
+                        vnew, sm_m, sm_l, sm_o, M, L, O);
 
+    ATTN_STAMP(3);
     float* head_ws = a.ws + ((size_t)b * H + h) * splits * (D + 2);
     if (splits > 1) {
         // ---- publish the chunk record (write-through), take a ticket; every storing wave drains its own stores ----
@@ -313,9 +384,11 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const Ro
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        ATTN_STAMP(4);
         if (tid == 0)
             sm_ticket = __hip_atomic_fetch_add(a.tickets + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        ATTN_STAMP(5);
         if (sm_ticket != (unsigned)(splits - 1)) return;  // not the head's last chunk
         if (tid == 0) __hip_atomic_store(a.tickets + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- last arriver: merge all chunk records of the head (its own one read back like the others) ----
@@ -323,7 +396,9 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const Ro
     } else if (tid < D) {
         O = L > 0.f ? O / L : 0.f;
     }
+    ATTN_STAMP(6);
     if (tid < D) a.out[b * a.o_sb + h * a.o_sh + tid] = (f16)O;
+    ATTN_STAMP(7);
     // ---- the last head to finish advances the token counter: by then every workgroup of the launch has read it ----
     if (a.advance && tid == 0) {
         const unsigned heads_total = (unsigned)(H * gridDim.z);
@@ -344,7 +419,7 @@ int launch_d(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out
         q, k, v, mask, ws, scaling, S, H / Hkv, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8],
         kv_len, kv_len_bias);
     EETQ_TRY_HIP(hipGetLastError());
-    attn_decode_merge_kernel<D><<<dim3(H, B), D, (splits + D / 64) * sizeof(float), stream>>>(ws, out, splits, st[9], st[10], advance);
+    attn_decode_merge_kernel<D><<<dim3(H, B), D, (2 * splits + D / 64) * sizeof(float), stream>>>(ws, out, splits, st[9], st[10], advance);
     return check_hip(hipGetLastError(), "attn_decode kernels launch");
 }
 
@@ -366,6 +441,9 @@ int launch_attn_decode(const f16* q, const f16* k, const f16* v, const f16* mask
     return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] decode attention supports head_dim 64 and 128");
 }
 
+static unsigned long long* g_attn_stamps = nullptr;  // process-wide diagnostic hook (not thread-safe by design)
+void set_attn_stamps(unsigned long long* buf) { g_attn_stamps = buf; }
+
 int launch_rope_attn_decode(const int64_t* positions, const int64_t* slots, int slot_stride, const f16* q, const f16* k,
                             const f16* v, const f16* cos_sin, f16* kc, f16* vc, const f16* mask, f16* out, float* ws,
                             unsigned* tickets, int B, int H, int Hkv, int S, int D, int splits, float scaling,
@@ -378,18 +456,19 @@ int launch_rope_attn_decode(const int64_t* positions, const int64_t* slots, int 
     EETQ_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)cos_sin) % 16 == 0,
                  "q, k, v, the caches and the cos|sin table must be 16-byte aligned");
     RopeAttnArgs a;
-    a.positions = positions, a.slots = slots, a.slot_stride = slot_stride;
+    a.slot_stride = slot_stride;
     a.q = q, a.k = k, a.v = v, a.q_sb = st[0], a.k_sb = st[1], a.v_sb = st[2];
-    a.cos_sin = cos_sin, a.kc = kc, a.vc = vc;
+    a.cos_sin = cos_sin;
     a.kc_sb = st[3], a.kc_sh = st[4], a.kc_ss = st[5], a.vc_sb = st[6], a.vc_sh = st[7], a.vc_ss = st[8];
     a.mask = mask, a.m_sb = st[9], a.out = out, a.o_sb = st[10], a.o_sh = st[11];
-    a.ws = ws, a.tickets = tickets, a.kv_len = kv_len, a.kv_len_bias = kv_len_bias, a.advance = advance;
+    a.ws = ws, a.tickets = tickets, a.kv_len_bias = kv_len_bias, a.advance = advance;
     a.S = S, a.groups = H / Hkv, a.scaling = scaling;
-    const size_t smem = (size_t)(splits + kAttnThreads / 64) * sizeof(float);
+    a.stamps = g_attn_stamps;
+    const size_t smem = (size_t)(2 * splits + kAttnThreads / 64) * sizeof(float);
     if (D == 128)
-        rope_attn_decode_kernel<128><<<dim3(splits, H, B), kAttnThreads, smem, stream>>>(a);
+        rope_attn_decode_kernel<128><<<dim3(splits, H, B), kAttnThreads, smem, stream>>>(kv_len, slots, positions, kc, vc, a);
     else if (D == 64)
-        rope_attn_decode_kernel<64><<<dim3(splits, H, B), kAttnThreads, smem, stream>>>(a);
+        rope_attn_decode_kernel<64><<<dim3(splits, H, B), kAttnThreads, smem, stream>>>(kv_len, slots, positions, kc, vc, a);
     else
         return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] decode attention supports head_dim 64 and 128");
     return check_hip(hipGetLastError(), "rope_attn_decode_kernel launch");

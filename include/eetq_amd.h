@@ -230,6 +230,12 @@ int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slot
                                    float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
                                    int64_t* advance, void* stream);
 
+/* Diagnostics: while `stamps` (DEVICE, batch * heads * splits * 8 uint64) is set, every eetq_rope_decode_attention_f16
+ * launch of this process records per workgroup the 100 MHz device clock at: 0 entry, 1 scalar reads done, 2 new token
+ * rotated, 3 chunk done, 4 chunk record published, 5 ticket drawn, 6 (last workgroup of a head) merge done, 7 output
+ * stored.  NULL switches it off.  Used by tools/attn_bench.py --stamps; not for production launches. */
+int eetq_diag_attn_stamps(unsigned long long* stamps);
+
 /* ---- profiling hook (no reference counterpart; used by bench.py) -------------------------------------
  * Between eetq_prof_begin(n) and eetq_prof_end() every kernel this library launches from the calling thread
  * carries a start/stop event pair on its dispatch packet; eetq_prof_end synchronises the device and returns

@@ -1,0 +1,118 @@
+"""Decode-step attention at Llama-2-13B shapes (40 heads x 128, one new token), as the graph decoder issues it: `layers`
+independent caches (together larger than the 256 MB Infinity Cache) stepped back to back inside one HIP graph.
+Prints microseconds per layer-step for the one-launch form (eetq_rope_decode_attention_f16) over a sweep of chunk counts,
+and for the two-launch pair.  usage: python tools/attn_bench.py [--filled 1024] [--rows 1082] [--batch 1]"""
+import argparse
+import json
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import eetq_amd.ops as ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--filled", type=int, default=1024)
+ap.add_argument("--rows", type=int, default=1082)
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--heads", type=int, default=40)
+ap.add_argument("--kv-heads", type=int, default=40)
+ap.add_argument("--layers", type=int, default=20)
+ap.add_argument("--splits", default="default,4,8,12,17,25,34")
+ap.add_argument("--stamps", action="store_true", help="per-phase device-clock decomposition of the one-launch form")
+args = ap.parse_args()
+dev = "cuda:0"
+B, H, Hkv, D, S, L = args.batch, args.heads, args.kv_heads, 128, args.rows, args.layers
+torch.manual_seed(0)
+inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+fr = torch.einsum("i,j->ij", torch.arange(S + 64).float(), inv)
+table = torch.cat([fr.cos(), fr.sin()], -1).half().to(dev)
+kc = [torch.randn(B, Hkv, S, D, dtype=torch.float16, device=dev) for _ in range(L)]
+vc = [torch.randn(B, Hkv, S, D, dtype=torch.float16, device=dev) for _ in range(L)]
+qkv = torch.randn(B, 1, (H + 2 * Hkv) * D, dtype=torch.float16, device=dev)
+q = qkv[..., : H * D].unflatten(-1, (H, D))[:, 0]
+k = qkv[..., H * D: (H + Hkv) * D].unflatten(-1, (Hkv, D))[:, 0]
+v = qkv[..., (H + Hkv) * D:].unflatten(-1, (Hkv, D))[:, 0]
+pos = torch.full((B,), args.filled, dtype=torch.int64, device=dev)
+tickets = [torch.zeros(B * H + 1, dtype=torch.int32, device=dev) for _ in range(L)]
+counters = [torch.tensor(args.filled, dtype=torch.int64, device=dev) for _ in range(L)]
+kv_mb = 2 * B * Hkv * (args.filled + 1) * D * 2 / 1e6
+
+
+def one_launch(i, splits):
+    return ops.rope_decode_attention(pos, q, k, v, table, kc[i], vc[i], tickets[i], slots=counters[i], splits=splits,
+                                     kv_len=counters[i], kv_len_bias=1)
+
+
+def two_launch(i, splits):
+    ops.rotary_embedding_neox_kvcache(pos, q, k, v, D, table, kc[i], vc[i], slots=counters[i])
+    return ops.decode_attention(q, kc[i], vc[i], splits=splits, kv_len=counters[i], kv_len_bias=1)
+
+
+def timed(fn, splits, reps=30):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(L):
+            fn(i, splits)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for i in range(L):
+                fn(i, splits)
+    torch.cuda.current_stream().wait_stream(side)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / (reps * L)
+
+
+if args.stamps:
+    import ctypes
+    from eetq_amd import _lib
+    lib = _lib.lib()
+    splits = max(1, min((S + 63) // 64, max(1, 1024 // (B * H))))
+    nwg = B * H * splits
+    buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
+    names = ["entry", "scalar reads", "q rotated + first trip landed", "chunk done", "record published", "ticket drawn",
+             "merge done (last of head)", "output stored (last of head)"]
+    rows = []
+    for it in range(12):
+        buf.zero_()
+        lib.eetq_diag_attn_stamps(ctypes.c_void_p(buf.data_ptr()))
+        one_launch(it % L, None)
+        torch.cuda.synchronize()
+        lib.eetq_diag_attn_stamps(None)
+        st = buf.view(nwg, 8).cpu().double()
+        t0 = st[:, 0].min()
+        rel = (st - t0) / 100.0                    # microseconds since the first workgroup's entry
+        rel[st == 0] = float("nan")
+        rows.append(rel)
+    rel = torch.stack(rows[2:]).nanmean(0)         # mean over launches, per workgroup
+    print("one-launch decode attention, %d workgroups (%d splits), device clock, us since the first workgroup entered:" % (nwg, splits))
+    for i, n in enumerate(names):
+        col = rel[:, i]
+        col = col[~col.isnan()]
+        print("  %-34s mean %6.2f   min %6.2f   max %6.2f   (n=%d)" % (n, col.mean(), col.min(), col.max(), col.numel()))
+    d = rel[:, 1:] - rel[:, :-1]
+    print("phase lengths (mean over workgroups that reach the phase):")
+    for i in range(7):
+        col = d[:, i]
+        col = col[~col.isnan()]
+        if col.numel():
+            print("  %-34s -> %-34s %6.2f us" % (names[i], names[i + 1], col.mean()))
+    sys.exit(0)
+
+for name, fn in (("one_launch", one_launch), ("two_launch", two_launch)):
+    for s in args.splits.split(","):
+        splits = None if s == "default" else int(s)
+        us = timed(fn, splits)
+        print(json.dumps({"form": name, "splits": s, "batch": B, "heads": H, "kv_heads": Hkv, "filled": args.filled,
+                          "rows": S, "us_per_layer_step": round(us, 2), "kv_MB": round(kv_mb, 1),
+                          "kv_GBps": round(kv_mb / us * 1e3, 0)}))
