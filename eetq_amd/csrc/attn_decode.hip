@@ -55,24 +55,48 @@ __device__ __forceinline__ void load_trip(KvTrip<D>& t, const f16* __restrict__ 
     for (int u = 0; u < kTripU; ++u) t.v[u] = *reinterpret_cast<const f16x8*>(vbase + (long)t.jj[u] * v_ss);
 }
 
+// Sum over the LPP = 8 or 16 consecutive lanes that share a position, by DPP (no LDS traffic): quad swaps, then the
+// mirrored half row, then the mirrored row.  Every lane of the group ends with the same bits (each step adds the same two
+// partial sums in both partners).
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int moved = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true);
+    return v + __builtin_bit_cast(float, moved);
+}
+template <int LPP>
+__device__ __forceinline__ float group_sum(float v)
+{
+    static_assert(LPP == 8 || LPP == 16, "a position is shared by 8 or 16 lanes");
+    v = dpp_add<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    if (LPP == 16) v = dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+
 // The chunk [j0, j1) of one (batch row, head): online softmax over its positions, merged across the workgroup.  On return
 // threads tid < D hold (M, L, O) = the chunk's running maximum, its sum of exp(s - M) and channel tid of sum exp(s - M) v.
-// `t` holds the wave's first trip (load_trip at jb = j0 + wave * PPW).
+// qv: this lane's 8 channels of the (rotated) query; scores are scaling * (q . k) with the products summed in fp32
+// (v_dot2_f32_f16).  `t` holds the wave's first trip (load_trip at jb = j0 + wave * PPW).  The running state is rescaled
+// once per trip (U positions), not once per position.
 // SUBST: position `slot` is taken from registers (knew, vnew: this lane's 8 channels of the new token) instead of the cache.
 template <int D, bool SUBST>
-__device__ __forceinline__ void attn_chunk(const float (&qf)[8], KvTrip<D>& t, const f16* __restrict__ kbase,
+__device__ __forceinline__ void attn_chunk(const f16x8& qv, float scaling, KvTrip<D>& t, const f16* __restrict__ kbase,
                                            const f16* __restrict__ vbase, long k_ss, long v_ss, const f16* __restrict__ mrow,
                                            int j0, int j1, int slot, const f16x8& knew, const f16x8& vnew, float* sm_m,
                                            float* sm_l, float* sm_o, float& M, float& L, float& O)
 {
-    // every multiply-add below is an explicit fmaf and contraction is off: the two launch forms instantiate this code
-    // separately and must round identically
+    // every multiply-add below is explicit and contraction is off: the two launch forms instantiate this code separately
+    // and must round identically
 #pragma clang fp contract(off)
     constexpr int LPP  = D / 8;               // lanes per position
     constexpr int PPW  = 64 / LPP;            // positions per wave instruction
     constexpr int SETS = (kAttnThreads / 64) * PPW;
+    constexpr int U    = kTripU;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int grp = lane / LPP, li = lane % LPP, d0 = li * 8;
+    const f16x2 q2[4] = {{qv[0], qv[1]}, {qv[2], qv[3]}, {qv[4], qv[5]}, {qv[6], qv[7]}};
 
     float m = -INFINITY, l = 0.f, o[8];
 #pragma unroll
@@ -80,29 +104,38 @@ __device__ __forceinline__ void attn_chunk(const float (&qf)[8], KvTrip<D>& t, c
 
     constexpr int STEP = (kAttnThreads / 64) * PPW;
     for (int jb = j0 + wave * PPW;;) {
+        float sc[U];
 #pragma unroll
-        for (int u = 0; u < kTripU; ++u) {
+        for (int u = 0; u < U; ++u) {
             if (SUBST && t.jj[u] == slot) {
                 t.k[u] = knew;
                 t.v[u] = vnew;
             }
-            float s = 0.f;
+            float a = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) s = fmaf(qf[i], (float)t.k[u][i], s);
-#pragma unroll
-            for (int off = 1; off < LPP; off <<= 1) s += __shfl_xor(s, off, 64);
-            if (mrow) s += (float)mrow[t.jj[u]];
-            if (!t.valid[u]) s = -INFINITY;
-            const float mn = fmaxf(m, s);
-            if (mn > -INFINITY) {  // group-uniform
-                const float sc = __expf(m - mn), p = __expf(s - mn);
-                l = fmaf(l, sc, p);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = fmaf(p, (float)t.v[u][i], o[i] * sc);
-                m = mn;
-            }
+            for (int i = 0; i < 4; ++i) a = __builtin_amdgcn_fdot2(f16x2{t.k[u][2 * i], t.k[u][2 * i + 1]}, q2[i], a, false);
+            a = group_sum<LPP>(a) * scaling;
+            if (mrow) a += (float)mrow[t.jj[u]];
+            sc[u] = t.valid[u] ? a : -INFINITY;
         }
-        jb += kTripU * STEP;
+        float mn = m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) mn = fmaxf(mn, sc[u]);
+        if (mn > -INFINITY) {  // group-uniform
+            const float keep = __expf(m - mn);
+            l *= keep;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] *= keep;
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const float p = __expf(sc[u] - mn);  // exp(-inf) = 0 for the positions beyond the chunk
+                l += p;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) o[i] = fmaf(p, (float)t.v[u][i], o[i]);
+            }
+            m = mn;
+        }
+        jb += U * STEP;
         if (jb >= j1) break;  // wave-uniform
         load_trip<D>(t, kbase, vbase, k_ss, v_ss, jb, j1);
     }
@@ -111,8 +144,8 @@ __device__ __forceinline__ void attn_chunk(const float (&qf)[8], KvTrip<D>& t, c
         sm_m[set] = m;
         sm_l[set] = l;
     }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) sm_o[set * D + d0 + i] = o[i];
+    *reinterpret_cast<f32x4*>(sm_o + set * D + d0)     = f32x4{o[0], o[1], o[2], o[3]};
+    *reinterpret_cast<f32x4*>(sm_o + set * D + d0 + 4) = f32x4{o[4], o[5], o[6], o[7]};
     __syncthreads();
     M = -INFINITY, L = 0.f, O = 0.f;
     if (tid < D) {
@@ -143,7 +176,7 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
 {
     constexpr int SETS = (kAttnThreads / 64) * (64 / (D / 8));
     __shared__ float sm_m[SETS], sm_l[SETS];
-    __shared__ float sm_o[SETS * D];
+    __shared__ __attribute__((aligned(16))) float sm_o[SETS * D];
 
     const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z, hk = h / groups;
     const int tid = threadIdx.x, d0 = ((tid & 63) % (D / 8)) * 8;
@@ -154,16 +187,11 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
     const f16 *kbase = kc + b * k_sb + hk * k_sh + d0, *vbase = vc + b * v_sb + hk * v_sh + d0;
     KvTrip<D>  trip;
     load_trip<D>(trip, kbase, vbase, k_ss, v_ss, j0 + (tid >> 6) * (64 / (D / 8)), j1);
-    float qf[8];
-    {
-        const f16x8 qv = *reinterpret_cast<const f16x8*>(q + b * q_sb + h * q_sh + d0);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) qf[i] = (float)qv[i] * scaling;
-    }
+    const f16x8 qv = *reinterpret_cast<const f16x8*>(q + b * q_sb + h * q_sh + d0);
     float       M, L, O;
     const f16x8 none = {};
-    attn_chunk<D, false>(qf, trip, kbase, vbase, k_ss, v_ss, mask ? mask + b * m_sb : nullptr, j0, j1, -1, none, none, sm_m,
-                         sm_l, sm_o, M, L, O);
+    attn_chunk<D, false>(qv, scaling, trip, kbase, vbase, k_ss, v_ss, mask ? mask + b * m_sb : nullptr, j0, j1, -1, none, none,
+                         sm_m, sm_l, sm_o, M, L, O);
     if (tid < D) {
         float* out = ws + (((size_t)b * gridDim.y + h) * gridDim.x + split) * (D + 2);
         out[2 + tid] = O;
@@ -175,21 +203,26 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
 }
 
 // Merge of a head's `splits` chunk records p[s] = (m, l, o[D]) by a workgroup of NT threads (all of them call; thread
-// d < D returns channel d); LOAD fetches one float.  sm_w: 2 * splits + NT/64 floats of LDS.  Two dependent memory phases:
-// every (m, l) at once, then the chunk outputs with 16 loads in flight per thread.  A fully masked row yields zeros, not
-// NaN.  Sums run in chunk order whatever NT is: the two launch forms give the same bits.
+// d < D returns channel d); LOAD fetches one float.  sm_w: 2 * splits + NT/64 floats of LDS.  ONE memory phase for up to 32
+// records: every (m, l) and the first 32 outputs of the thread's channel are requested before anything is waited for.
+// A fully masked row yields zeros, not NaN.  Sums run in chunk order whatever NT is: the two launch forms give the same bits.
 template <int D, int NT, typename Load>
 __device__ __forceinline__ float attn_merge(const float* p, int splits, int d, float* sm_w, Load load)
 {
 #pragma clang fp contract(off)
+    constexpr int R = 32;
     float* sm_l    = sm_w + splits;
     float* sm_part = sm_w + 2 * splits;
-    float  M       = -INFINITY;
+    const int dc   = d < D ? d : D - 1;  // threads beyond D only help with (m, l); their output loads are clamped duplicates
+    float o[R];
+#pragma unroll
+    for (int i = 0; i < R; ++i) o[i] = load(p + min(i, splits - 1) * (D + 2) + 2 + dc);
+    float M = -INFINITY;
     for (int s = d; s < splits; s += NT) {
-        const float ms = load(p + s * (D + 2)), ls = load(p + s * (D + 2) + 1);
-        sm_w[s] = ms;
-        sm_l[s] = ls;
-        M       = fmaxf(M, ms);
+        const float m1 = load(p + s * (D + 2)), l1 = load(p + s * (D + 2) + 1);
+        sm_w[s] = m1;
+        sm_l[s] = l1;
+        M       = fmaxf(M, m1);
     }
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
@@ -200,27 +233,15 @@ __device__ __forceinline__ float attn_merge(const float* p, int splits, int d, f
 #pragma unroll
         for (int i = 1; i < NT / 64; ++i) M = fmaxf(M, sm_part[i]);
     }
-    for (int s = d; s < splits; s += NT) sm_w[s] = M > -INFINITY ? __expf(sm_w[s] - M) : 0.f;  // own entries: no barrier needed yet
+    for (int s = d; s < splits; s += NT) sm_w[s] = M > -INFINITY ? __expf(sm_w[s] - M) : 0.f;  // the thread's own entries
     __syncthreads();
     if (d >= D) return 0.f;
     float L = 0.f, O = 0.f;
     for (int s = 0; s < splits; ++s) L = fmaf(sm_l[s], sm_w[s], L);
-    int s = 0;
-    for (; s + 16 <= splits; s += 16) {
-        float o[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] = load(p + (s + i) * (D + 2) + 2 + d);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) O = fmaf(o[i], sm_w[s + i], O);
-    }
-    {
-        float o[16];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] = load(p + min(s + i, splits - 1) * (D + 2) + 2 + d);  // clamped, predicated use
-#pragma unroll
-        for (int i = 0; i < 16; ++i)
-            if (s + i < splits) O = fmaf(o[i], sm_w[s + i], O);
-    }
+    for (int i = 0; i < R; ++i)
+        if (i < splits) O = fmaf(o[i], sm_w[i], O);
+    for (int s = R; s < splits; ++s) O = fmaf(load(p + s * (D + 2) + 2 + d), sm_w[s], O);
     return L > 0.f ? O / L : 0.f;
 }
 
@@ -312,7 +333,7 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
     constexpr int LPP = D / 8, SETS = (kAttnThreads / 64) * (64 / LPP);
     extern __shared__ float sm_w[];  // attn_merge's scratch: 2 * splits + one maximum per wave
     __shared__ float    sm_m[SETS], sm_l[SETS];
-    __shared__ float    sm_o[SETS * D];
+    __shared__ __attribute__((aligned(16))) float sm_o[SETS * D];
     __shared__ unsigned sm_ticket;
 
     ATTN_STAMP(0);
@@ -361,14 +382,10 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
             *reinterpret_cast<f16x8*>(vc + b * a.vc_sb + hk * a.vc_sh + (long)slot * a.vc_ss + d0) = vnew;
         }
     }
-    float qf[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) qf[i] = (float)qv[i] * a.scaling;
-
     ATTN_STAMP(2);
     float M, L, O;
-    attn_chunk<D, true>(qf, trip, kbase, vbase, a.kc_ss, a.vc_ss, a.mask ? a.mask + b * a.m_sb : nullptr, j0, j1, slot, knew,
-                        vnew, sm_m, sm_l, sm_o, M, L, O);
+    attn_chunk<D, true>(qv, a.scaling, trip, kbase, vbase, a.kc_ss, a.vc_ss, a.mask ? a.mask + b * a.m_sb : nullptr, j0, j1, slot,
+                        knew, vnew, sm_m, sm_l, sm_o, M, L, O);
 
     ATTN_STAMP(3);
     float* head_ws = a.ws + ((size_t)b * H + h) * splits * (D + 2);
