@@ -19,6 +19,8 @@
 // write-through stores, a ticket per head decides "last" (the in-launch hand-off of gemm_splitk_kernel.hpp), and the last
 // head to finish advances the cache's token counter.  Three launches and ~10 us per layer become one.  Both forms run the
 // same chunk code and the same merge arithmetic: their outputs are bit-identical.
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace eetq {
@@ -26,6 +28,9 @@ namespace eetq {
 namespace {
 
 constexpr int kAttnThreads = 256;
+// A chunk record: kRecPad + D floats = [m, l, -, -, o[D]] (o on a 16-byte boundary).
+constexpr int kRecPad = 4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // One "trip" of a wave through the cache: U position groups, i.e. 2U independent 16-byte loads per lane in flight (the
 // loop is latency-bound otherwise).  The FIRST trip of a workgroup is loaded by the caller before anything else it has to
@@ -193,8 +198,8 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
     attn_chunk<D, false>(qv, scaling, trip, kbase, vbase, k_ss, v_ss, mask ? mask + b * m_sb : nullptr, j0, j1, -1, none, none,
                          sm_m, sm_l, sm_o, M, L, O);
     if (tid < D) {
-        float* out = ws + (((size_t)b * gridDim.y + h) * gridDim.x + split) * (D + 2);
-        out[2 + tid] = O;
+        float* out = ws + (((size_t)b * gridDim.x + split) * gridDim.y + h) * (D + kRecPad);  // [batch][split][head][record]
+        out[kRecPad + tid] = O;
         if (tid == 0) {
             out[0] = M;
             out[1] = L;
@@ -202,62 +207,120 @@ __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
     }
 }
 
-// Merge of a head's `splits` chunk records p[s] = (m, l, o[D]) by a workgroup of NT threads (all of them call; thread
-// d < D returns channel d); LOAD fetches one float.  sm_w: 2 * splits + NT/64 floats of LDS.  ONE memory phase for up to 32
-// records: every (m, l) and the first 32 outputs of the thread's channel are requested before anything is waited for.
-// A fully masked row yields zeros, not NaN.  Sums run in chunk order whatever NT is: the two launch forms give the same bits.
-template <int D, int NT, typename Load>
-__device__ __forceinline__ float attn_merge(const float* p, int splits, int d, float* sm_w, Load load)
+
+// how the merge reads records: plain loads in the two-launch form (the records come from an earlier launch), loads served
+// below the per-CU L1 in the one-launch form (they come from other workgroups of this launch)
+struct PlainRecords {
+    const float* base;
+    __device__ f32x2 v2(long off) const { return *reinterpret_cast<const f32x2*>(base + off); }
+    __device__ f32x4 v4(long off) const { return *reinterpret_cast<const f32x4*>(base + off); }
+};
+struct CoherentRecords {
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ f32x2 v2(long off) const
+    {
+        return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(off * 4), 0, /*sc1*/ 16));
+    }
+    __device__ f32x4 v4(long off) const
+    {
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off * 4), 0, /*sc1*/ 16));
+    }
+};
+
+// Merge of a head's `splits` chunk records at offsets s * stride (floats) by a workgroup of NT threads (all of them call:
+// there is a barrier inside); thread d < D returns channel d, normalised.  The cost of this step is the number of memory
+// INSTRUCTIONS a wave issues (~90 cycles each: 51 of them per wave made an earlier form take 3.3 us at 17 records), so:
+// lane i of every wave fetches (m, l) of record i with one 8-byte load; a group of D/4 lanes owns a subset of the records
+// (every NS-th) and fetches four channels of each with one 16-byte load -- 1 + ceil(splits / NS) loads per wave; the subsets
+// are added through lane swaps and one LDS exchange (sm_x: NT/64 * D floats).  Sums run in a fixed order that depends only
+// on (D, NT, splits): both launch forms use NT = 256 and give the same bits.  A fully masked row yields zeros, not NaN.
+template <int D, int NT, typename Records>
+__device__ __forceinline__ float attn_merge(const Records& rec, long stride, int splits, int tid, float* sm_x)
 {
 #pragma clang fp contract(off)
-    constexpr int R = 32;
-    float* sm_l    = sm_w + splits;
-    float* sm_part = sm_w + 2 * splits;
-    const int dc   = d < D ? d : D - 1;  // threads beyond D only help with (m, l); their output loads are clamped duplicates
-    float o[R];
+    constexpr int G = D / 4, WS = 64 / G, NW = NT / 64, NS = NW * WS;  // lanes per record, subsets per wave / per workgroup
+    const int lane = tid & 63, wave = tid >> 6, cg = lane % G, rs = wave * WS + lane / G;
+    float M = -INFINITY, L = 0.f;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    // one block of up to 64 records, JN loads of this thread's records in flight (JN chosen by the caller from the block's
+    // record count: straight-line loads, no load behind a branch)
+    auto block = [&](int s0, int n, auto jn_tag) {
+        constexpr int JN = decltype(jn_tag)::value;
+        f32x4 o4[JN];
 #pragma unroll
-    for (int i = 0; i < R; ++i) o[i] = load(p + min(i, splits - 1) * (D + 2) + 2 + dc);
-    float M = -INFINITY;
-    for (int s = d; s < splits; s += NT) {
-        const float m1 = load(p + s * (D + 2)), l1 = load(p + s * (D + 2) + 1);
-        sm_w[s] = m1;
-        sm_l[s] = l1;
-        M       = fmaxf(M, m1);
+        for (int j = 0; j < JN; ++j) o4[j] = rec.v4((s0 + min(rs + NS * j, n - 1)) * stride + kRecPad + 4 * cg);
+        const f32x2 ml = rec.v2((s0 + min(lane, n - 1)) * stride);
+        const float mi = lane < n ? ml.x : -INFINITY, li = lane < n ? ml.y : 0.f;
+        float Mb = mi;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) Mb = fmaxf(Mb, __shfl_xor(Mb, off, 64));
+        Mb = fmaxf(Mb, M);
+        if (Mb > -INFINITY) {  // uniform
+            const float keep = __expf(M - Mb);   // 0 for the first block
+            const float wi   = __expf(mi - Mb);  // weight of record s0 + lane (exp(-inf) = 0 beyond the block and for empty chunks)
+            float x = li * wi;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off, 64);
+            L = fmaf(L, keep, x);
+            acc *= keep;
+#pragma unroll
+            for (int j = 0; j < JN; ++j) {
+                const int   idx = rs + NS * j;
+                const float w   = __shfl(wi, idx < n ? idx : 0, 64);
+                if (idx < n) {
+                    acc.x = fmaf(o4[j].x, w, acc.x);
+                    acc.y = fmaf(o4[j].y, w, acc.y);
+                    acc.z = fmaf(o4[j].z, w, acc.z);
+                    acc.w = fmaf(o4[j].w, w, acc.w);
+                }
+            }
+            M = Mb;
+        }
+    };
+    for (int s0 = 0; s0 < splits; s0 += 64) {
+        const int n = min(64, splits - s0);
+        if (n <= NS)
+            block(s0, n, std::integral_constant<int, 1>{});
+        else if (n <= 2 * NS)
+            block(s0, n, std::integral_constant<int, 2>{});
+        else if (n <= 3 * NS)
+            block(s0, n, std::integral_constant<int, 3>{});
+        else if (n <= 4 * NS)
+            block(s0, n, std::integral_constant<int, 4>{});
+        else
+            block(s0, n, std::integral_constant<int, (64 + NS - 1) / NS>{});
     }
+    // the wave's subsets (lanes G apart), then the waves (in order) through LDS
+    float part[4] = {acc.x, acc.y, acc.z, acc.w};
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) M = fmaxf(M, __shfl_xor(M, off, 64));
-    if (NT > 64) {
-        if ((d & 63) == 0) sm_part[d >> 6] = M;
-        __syncthreads();
-        M = sm_part[0];
-#pragma unroll
-        for (int i = 1; i < NT / 64; ++i) M = fmaxf(M, sm_part[i]);
+    for (int c = 0; c < 4; ++c) {
+        if (WS == 4) part[c] = sum_xor16(part[c]);
+        part[c] = sum_xor32(part[c]);
     }
-    for (int s = d; s < splits; s += NT) sm_w[s] = M > -INFINITY ? __expf(sm_w[s] - M) : 0.f;  // the thread's own entries
+    if (lane < G) *reinterpret_cast<f32x4*>(sm_x + wave * D + 4 * cg) = f32x4{part[0], part[1], part[2], part[3]};
     __syncthreads();
-    if (d >= D) return 0.f;
-    float L = 0.f, O = 0.f;
-    for (int s = 0; s < splits; ++s) L = fmaf(sm_l[s], sm_w[s], L);
+    if (tid >= D) return 0.f;
+    float O = sm_x[tid];
 #pragma unroll
-    for (int i = 0; i < R; ++i)
-        if (i < splits) O = fmaf(o[i], sm_w[i], O);
-    for (int s = R; s < splits; ++s) O = fmaf(load(p + s * (D + 2) + 2 + d), sm_w[s], O);
+    for (int w = 1; w < NW; ++w) O += sm_x[w * D + tid];
     return L > 0.f ? O / L : 0.f;
 }
 
 // one workgroup per (head, batch): thread t < splits fetches that chunk's (m, l) in parallel; D threads then sum the chunk
 // outputs with the loads of up to 8 chunks in flight
 template <int D>
-__global__ __launch_bounds__(D) void attn_decode_merge_kernel(const float* __restrict__ ws, f16* __restrict__ out,
-                                                             int splits, long o_sb, long o_sh, int64_t* advance)
+__global__ __launch_bounds__(kAttnThreads) void attn_decode_merge_kernel(const float* __restrict__ ws, f16* __restrict__ out,
+                                                                        int splits, long o_sb, long o_sh, int64_t* advance)
 {
-    extern __shared__ float sm_w[];  // attn_merge's scratch: 2 * splits + D/64 floats
-    const int    h = blockIdx.x, b = blockIdx.y, d = threadIdx.x;
-    const float* p = ws + ((size_t)b * gridDim.x + h) * splits * (D + 2);
-    out[b * o_sb + h * o_sh + d] = (f16)attn_merge<D, D>(p, splits, d, sm_w, [](const float* a) { return *a; });
+    __shared__ __attribute__((aligned(16))) float sm_x[(kAttnThreads / 64) * D];
+    const int h = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    // workspace [batch][split][head][record]: the records of one head are a row of heads apart
+    const PlainRecords rec{ws + ((size_t)b * splits * gridDim.x + h) * (D + kRecPad)};
+    const float        o = attn_merge<D, kAttnThreads>(rec, (long)gridDim.x * (D + kRecPad), splits, tid, sm_x);
+    if (tid < D) out[b * o_sb + h * o_sh + tid] = (f16)o;
     // the cache's token counter (every reader of it in this step -- the cache-write launch and the partial kernel -- has
     // completed: they are earlier launches on the stream)
-    if (advance && h == 0 && b == 0 && d == 0) *advance += 1;
+    if (advance && h == 0 && b == 0 && tid == 0) *advance += 1;
 }
 
 struct RopeAttnArgs {
@@ -331,7 +394,6 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
                                                                         const RopeAttnArgs a)
 {
     constexpr int LPP = D / 8, SETS = (kAttnThreads / 64) * (64 / LPP);
-    extern __shared__ float sm_w[];  // attn_merge's scratch: 2 * splits + one maximum per wave
     __shared__ float    sm_m[SETS], sm_l[SETS];
     __shared__ __attribute__((aligned(16))) float sm_o[SETS * D];
     __shared__ unsigned sm_ticket;
@@ -388,12 +450,13 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
                         knew, vnew, sm_m, sm_l, sm_o, M, L, O);
 
     ATTN_STAMP(3);
-    float* head_ws = a.ws + ((size_t)b * H + h) * splits * (D + 2);
+    float*     head_ws = a.ws + ((size_t)b * splits * H + h) * (D + kRecPad);  // [batch][split][head][record]
+    const long rec_stride = (long)H * (D + kRecPad);
     if (splits > 1) {
         // ---- publish the chunk record (write-through), take a ticket; every storing wave drains its own stores ----
         if (tid < D) {
-            float* rec = head_ws + (size_t)split * (D + 2);
-            store_sc1(rec + 2 + tid, O);
+            float* rec = head_ws + (size_t)split * rec_stride;
+            store_sc1(rec + kRecPad + tid, O);
             if (tid == 0) {
                 store_sc1(rec, M);
                 store_sc1(rec + 1, L);
@@ -409,7 +472,8 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
         if (sm_ticket != (unsigned)(splits - 1)) return;  // not the head's last chunk
         if (tid == 0) __hip_atomic_store(a.tickets + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // ---- last arriver: merge all chunk records of the head (its own one read back like the others) ----
-        O = attn_merge<D, kAttnThreads>(head_ws, splits, tid, sm_w, [](const float* p) { return load_sc1(p); });
+        const CoherentRecords recs{__builtin_amdgcn_make_buffer_rsrc(head_ws, 0, 0x7fffffff, 0x00020000)};
+        O = attn_merge<D, kAttnThreads>(recs, rec_stride, splits, tid, sm_o);  // sm_o is free again: reused for the exchange
     } else if (tid < D) {
         O = L > 0.f ? O / L : 0.f;
     }
@@ -436,7 +500,7 @@ int launch_d(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out
         q, k, v, mask, ws, scaling, S, H / Hkv, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8],
         kv_len, kv_len_bias);
     EETQ_TRY_HIP(hipGetLastError());
-    attn_decode_merge_kernel<D><<<dim3(H, B), D, (2 * splits + D / 64) * sizeof(float), stream>>>(ws, out, splits, st[9], st[10], advance);
+    attn_decode_merge_kernel<D><<<dim3(H, B), kAttnThreads, 0, stream>>>(ws, out, splits, st[9], st[10], advance);
     return check_hip(hipGetLastError(), "attn_decode kernels launch");
 }
 
@@ -481,11 +545,10 @@ int launch_rope_attn_decode(const int64_t* positions, const int64_t* slots, int 
     a.ws = ws, a.tickets = tickets, a.kv_len_bias = kv_len_bias, a.advance = advance;
     a.S = S, a.groups = H / Hkv, a.scaling = scaling;
     a.stamps = g_attn_stamps;
-    const size_t smem = (size_t)(2 * splits + kAttnThreads / 64) * sizeof(float);
     if (D == 128)
-        rope_attn_decode_kernel<128><<<dim3(splits, H, B), kAttnThreads, smem, stream>>>(kv_len, slots, positions, kc, vc, a);
+        rope_attn_decode_kernel<128><<<dim3(splits, H, B), kAttnThreads, 0, stream>>>(kv_len, slots, positions, kc, vc, a);
     else if (D == 64)
-        rope_attn_decode_kernel<64><<<dim3(splits, H, B), kAttnThreads, smem, stream>>>(kv_len, slots, positions, kc, vc, a);
+        rope_attn_decode_kernel<64><<<dim3(splits, H, B), kAttnThreads, 0, stream>>>(kv_len, slots, positions, kc, vc, a);
     else
         return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] decode attention supports head_dim 64 and 128");
     return check_hip(hipGetLastError(), "rope_attn_decode_kernel launch");

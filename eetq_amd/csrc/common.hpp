@@ -69,6 +69,22 @@ __device__ __forceinline__ void dequant_16(const u32x4& w, f16x2 scale2, f16x2 (
     dequant_dword(w.w, scale2, out[6], out[7]);
 }
 
+// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second;
+// v_permlane32_swap exchanges the upper half of the first with the lower half of the second.  Feeding the same
+// value twice yields (a', b') with a' + b' = v[lane] + v[lane ^ 16] (resp. ^ 32) in every lane.
+__device__ __forceinline__ float sum_xor16(float v)
+{
+    const u32 u = __builtin_bit_cast(u32, v);
+    auto      r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (u32)r[0]) + __builtin_bit_cast(float, (u32)r[1]);
+}
+__device__ __forceinline__ float sum_xor32(float v)
+{
+    const u32 u = __builtin_bit_cast(u32, v);
+    auto      r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (u32)r[0]) + __builtin_bit_cast(float, (u32)r[1]);
+}
+
 // ---- fused epilogue operands (either may be null).  y = fp16(acc) [+ bias[n]] [+ residual[m][n]], every step rounded to
 // fp16: bit-identical to the reference's separate `output + bias` (qlinear.py:61) and to a separate residual add
 // (FT's bias / residual epilogues, cutlass_kernels/fpA_intB_gemm.cu:35-97, are the reference's fused counterpart).

@@ -38,22 +38,6 @@ __device__ __forceinline__ u32x4 load_w(const u32x4* p)
 }
 
 // xor-16 / xor-32 butterfly sums with the gfx950 lane-swap instructions (VALU, no LDS round trip).
-// v_permlane16_swap exchanges the odd 16-lane rows of its first operand with the even rows of the second;
-// v_permlane32_swap exchanges the upper half of the first with the lower half of the second.  Feeding the same
-// value twice yields (a', b') with a' + b' = v[lane] + v[lane ^ 16] (resp. ^ 32) in every lane.
-__device__ __forceinline__ float sum_xor16(float v)
-{
-    const u32 u = __builtin_bit_cast(u32, v);
-    auto      r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (u32)r[0]) + __builtin_bit_cast(float, (u32)r[1]);
-}
-__device__ __forceinline__ float sum_xor32(float v)
-{
-    const u32 u = __builtin_bit_cast(u32, v);
-    auto      r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (u32)r[0]) + __builtin_bit_cast(float, (u32)r[1]);
-}
-
 // RMS-norm of the activation vector while it sits in the staging registers (M = 1): every thread holds XV 16-byte
 // vectors xv[i] of x (vector index tid + i*THREADS, valid below xvecs) and the matching gamma vectors.  Same arithmetic as
 // rmsnorm_kernel (norm_rope.hip): fp32 sum of squares, rsqrtf(mean + eps), ((x * s) * gamma) clamped to the fp16 range.

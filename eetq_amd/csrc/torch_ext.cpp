@@ -191,7 +191,7 @@ Tensor rope_decode_attention(const Tensor& positions, const Tensor& query, const
     int64_t      splits = splits_in ? *splits_in
                                     : std::max<int64_t>(1, std::min<int64_t>((S + 63) / 64, std::max<int64_t>(1, 1024 / (B * H))));
     Tensor       out = torch::empty({B, H, D}, query.options());
-    Tensor       ws  = torch::empty({B * H * splits * (D + 2)}, query.options().dtype(at::kFloat));
+    Tensor       ws  = torch::empty({B * H * splits * (D + 4)}, query.options().dtype(at::kFloat));
     const long   strides[12] = {(long)query.stride(0),       (long)key.stride(0),         (long)value.stride(0),
                                 (long)key_cache.stride(0),   (long)key_cache.stride(1),   (long)key_cache.stride(2),
                                 (long)value_cache.stride(0), (long)value_cache.stride(1), (long)value_cache.stride(2),
@@ -500,7 +500,7 @@ Tensor decode_attention(const Tensor& query, const Tensor& key_cache, const Tens
     int64_t       splits = splits_in ? *splits_in
                                      : std::max<int64_t>(1, std::min<int64_t>((S + 63) / 64, std::max<int64_t>(1, 1024 / (B * H))));
     Tensor        out = torch::empty({B, H, D}, query.options());
-    Tensor        ws  = torch::empty({B * H * splits * (D + 2)}, query.options().dtype(at::kFloat));
+    Tensor        ws  = torch::empty({B * H * splits * (D + 4)}, query.options().dtype(at::kFloat));
     const long    strides[11] = {(long)query.stride(0),       (long)query.stride(1),       (long)key_cache.stride(0),
                                  (long)key_cache.stride(1),   (long)key_cache.stride(2),   (long)value_cache.stride(0),
                                  (long)value_cache.stride(1), (long)value_cache.stride(2), (long)m_sb,
@@ -590,7 +590,7 @@ Tensor llama_decode_layer(const Tensor& hidden, const NormArg& input_norm, const
         }
         const int64_t splits = std::max<int64_t>(1, std::min<int64_t>((S + 63) / 64, std::max<int64_t>(1, 1024 / heads)));
         // fp16 scratch: qkv | attention output | gate|up | activation ; fp32 scratch: the attention chunk records
-        const int64_t n16 = NQ + heads * D + I2 + I, n32 = heads * splits * (D + 2);
+        const int64_t n16 = NQ + heads * D + I2 + I, n32 = heads * splits * (D + 4);
         Tensor  scratch = torch::empty({n16 * 2 + n32 * 4 + 16}, hidden.options().dtype(at::kByte));
         Tensor  h = torch::empty_like(hidden), out = torch::empty_like(hidden);
         char*   base = static_cast<char*>(scratch.data_ptr());

@@ -423,7 +423,7 @@ def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, spl
     if splits is None:  # enough workgroups to cover the chip a few times over, at least 64 positions per chunk
         splits = max(1, min((S + 63) // 64, max(1, 1024 // (B * H))))
     out = torch.empty((B, H, D), dtype=torch.float16, device=query.device)
-    ws = torch.empty((B * H * splits * (D + 2),), dtype=torch.float32, device=query.device)
+    ws = torch.empty((B * H * splits * (D + 4),), dtype=torch.float32, device=query.device)
     strides = (ctypes.c_long * 11)(query.stride(0), query.stride(1), key_cache.stride(0), key_cache.stride(1),
                                    key_cache.stride(2), value_cache.stride(0), value_cache.stride(1), value_cache.stride(2),
                                    m_sb, out.stride(0), out.stride(1))
@@ -488,7 +488,7 @@ def rope_decode_attention(positions, query, key, value, cos_sin_cache, key_cache
     if splits is None:
         splits = max(1, min((S + 63) // 64, max(1, 1024 // (B * H))))
     out = torch.empty((B, H, D), dtype=torch.float16, device=query.device)
-    ws = torch.empty((B * H * splits * (D + 2),), dtype=torch.float32, device=query.device)
+    ws = torch.empty((B * H * splits * (D + 4),), dtype=torch.float32, device=query.device)
     strides = (ctypes.c_long * 12)(query.stride(0), key.stride(0), value.stride(0), key_cache.stride(0),
                                    key_cache.stride(1), key_cache.stride(2), value_cache.stride(0), value_cache.stride(1),
                                    value_cache.stride(2), m_sb, out.stride(0), out.stride(1))

@@ -203,8 +203,8 @@ int eetq_rotary_neox_kvcache_f16(const int64_t* positions, const int64_t* slots,
  *   out[b][h][:] = softmax_j( scaling * q[b][h] . k[b][h / (heads/kv_heads)][j] + mask[b][j] ) @ v[...]   j < positions
  * fp16 operands, fp32 softmax/accumulation.  strides (in elements): {q_b, q_h, k_b, k_h, k_pos, v_b, v_h, v_pos, mask_b,
  * out_b, out_h}; head_dim (64 or 128) is the dense last dimension everywhere.  mask: additive fp16 [batch][positions]
- * rows (-inf = masked; mask_b may be 0 to share one row) or NULL.  workspace: batch * heads * splits * (head_dim + 2)
- * floats.  A fully masked row gives 0.
+ * rows (-inf = masked; mask_b may be 0 to share one row) or NULL.  workspace: batch * heads * splits * (head_dim + 4)
+ * floats, 16-byte aligned.  A fully masked row gives 0.
  * kv_len (DEVICE int64 scalar or NULL): only cache rows j < min(positions, *kv_len + kv_len_bias) are attended -- the
  * valid length of a pre-allocated cache whose tail holds zeros or stale tokens.  advance (DEVICE int64 scalar or NULL): incremented by one
  * when the call's last kernel finishes (the cache's token counter; may alias kv_len). */
@@ -219,7 +219,7 @@ int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_
  * head_dim; q is NOT written back), the rotated k and v go to cache row slots[b * slot_stride] (slots NULL: positions[b]),
  * and the rows j < min(max_positions, *kv_len + kv_len_bias) are attended, the new row among them if it is in that range.
  * strides (elements): {q_b, k_b, v_b, kcache_b, kcache_head, kcache_pos, vcache_b, vcache_head, vcache_pos, mask_b,
- * out_b, out_head}.  workspace: batch * heads * splits * (head_dim + 2) floats (contents irrelevant).  tickets: batch *
+ * out_b, out_head}.  workspace: batch * heads * splits * (head_dim + 4) floats, 16-byte aligned (contents irrelevant).  tickets: batch *
  * heads + 1 unsigned, ZERO before the first launch that uses them; the launch leaves them zero.  Launches that may run
  * concurrently need distinct workspaces and tickets.  advance: see eetq_decode_attention_f16 (may alias kv_len and slots:
  * it is written after every workgroup of the launch has read them). */

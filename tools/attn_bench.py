@@ -78,6 +78,8 @@ if args.stamps:
     from eetq_amd import _lib
     lib = _lib.lib()
     splits = max(1, min((S + 63) // 64, max(1, 1024 // (B * H))))
+    if args.splits.split(',')[0].isdigit():
+        splits = int(args.splits.split(',')[0])
     nwg = B * H * splits
     buf = torch.zeros(nwg * 8, dtype=torch.int64, device=dev)
     names = ["entry", "scalar reads", "q rotated + first trip landed", "chunk done", "record published", "ticket drawn",
@@ -86,7 +88,7 @@ if args.stamps:
     for it in range(12):
         buf.zero_()
         lib.eetq_diag_attn_stamps(ctypes.c_void_p(buf.data_ptr()))
-        one_launch(it % L, None)
+        one_launch(it % L, splits)
         torch.cuda.synchronize()
         lib.eetq_diag_attn_stamps(None)
         st = buf.view(nwg, 8).cpu().double()
@@ -94,19 +96,22 @@ if args.stamps:
         rel = (st - t0) / 100.0                    # microseconds since the first workgroup's entry
         rel[st == 0] = float("nan")
         rows.append(rel)
-    rel = torch.stack(rows[2:]).nanmean(0)         # mean over launches, per workgroup
-    print("one-launch decode attention, %d workgroups (%d splits), device clock, us since the first workgroup entered:" % (nwg, splits))
+    allr = torch.stack(rows[2:])                   # [launch, workgroup, stamp]
+    print("one-launch decode attention, %d workgroups (%d splits), device clock, us since the first workgroup entered" % (nwg, splits))
+    print("(mean over %d launches and the workgroups that reach the stamp):" % allr.shape[0])
     for i, n in enumerate(names):
-        col = rel[:, i]
+        col = allr[:, :, i]
         col = col[~col.isnan()]
         print("  %-34s mean %6.2f   min %6.2f   max %6.2f   (n=%d)" % (n, col.mean(), col.min(), col.max(), col.numel()))
-    d = rel[:, 1:] - rel[:, :-1]
-    print("phase lengths (mean over workgroups that reach the phase):")
+    d = allr[:, :, 1:] - allr[:, :, :-1]           # per launch and workgroup: no mixing of launches
+    print("phase lengths (same launch, same workgroup):")
     for i in range(7):
-        col = d[:, i]
+        col = d[:, :, i]
         col = col[~col.isnan()]
         if col.numel():
-            print("  %-34s -> %-34s %6.2f us" % (names[i], names[i + 1], col.mean()))
+            print("  %-34s -> %-34s mean %6.2f  min %6.2f  max %6.2f us" % (names[i], names[i + 1], col.mean(), col.min(), col.max()))
+    last = allr[:, :, 7]
+    print("kernel span (first entry -> last output stored), mean over launches: %.2f us" % torch.nan_to_num(last, nan=0.0).amax(1).mean())
     sys.exit(0)
 
 for name, fn in (("one_launch", one_launch), ("two_launch", two_launch)):
