@@ -103,7 +103,9 @@ int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16
     }
     // Tuned on MI355X with tools/kbench (profiles/r01_kbench_gemv.txt):
     if (KT == 64) {  // K = 4096: 16 waves x 4 tiles, straight-line; <= 64 VGPRs so two workgroups fit a CU
-        if constexpr (M <= 2) {
+        // (register-resident activations only for one row: at M = 2 they cost 32 more VGPRs and the second workgroup per CU --
+        // 14.5 instead of 5.9 us at N = 4096, tools/path_compare.py)
+        if constexpr (M == 1) {
             if (!pro.gamma && !pro.up) return launch_inst<M, 16, 4, true, true, 1, 8>(x, w, scales, ep, y, N, K, stream);
             return launch_lds<M, 16, 4, true, 4>(x, w, scales, ep, y, N, K, stream, pro);  // the prologue needs x in LDS
         } else {
