@@ -101,3 +101,36 @@ def test_compiled_module_uses_the_current_stream_and_device_guard(both):
     torch.cuda.synchronize()
     assert torch.equal(y, ref)
     del big
+
+
+def test_splitk_opt_out_env_var_uses_the_unsplit_tile():
+    """EETQ_AMD_SPLITK=0 (read once per process) makes AUTO run 17 <= M <= 128 on the unsplit medium tile: same results as the
+    explicit 'mid' path bit for bit, and within tolerance of the default split-K result."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.environ["GRAFT_ROOT"])
+import eetq_amd.ops as ops
+torch.manual_seed(0)
+K, N, M = 2048, 1024, 48
+w = torch.randn(K, N, dtype=torch.float16)
+_, wq, s = ops.quant_weights(w, torch.int8, True)
+x = torch.randn(M, K, dtype=torch.float16, device="cuda:0")
+wq, s = wq.cuda(), s.cuda()
+auto = ops.w8_a16_gemm(x, wq, s)
+mid = ops.w8_a16_gemm(x, wq, s, path="mid")
+split = ops.w8_a16_gemm(x, wq, s, path="splitk")
+print("AUTO_IS_MID", int(torch.equal(auto, mid)), "AUTO_IS_SPLIT", int(torch.equal(auto, split)),
+      "CLOSE", int(torch.allclose(auto.float(), split.float(), atol=2e-2, rtol=2e-3)))
+'''
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, EETQ_AMD_SPLITK=flag, GRAFT_ROOT=root)
+        res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert res.returncode == 0, res.stderr[-2000:]
+        outs[flag] = res.stdout.strip().splitlines()[-1].split()
+    assert outs["0"][1] == "1" and outs["0"][5] == "1", outs        # opted out: AUTO == mid
+    assert outs["1"][3] == "1", outs                                # default: AUTO == split-K
