@@ -10,6 +10,8 @@ projections as ONE launch over concatenated channels (bit-identical to three lau
 ``EETLlamaMLP`` (gate/up as one launch) has no counterpart in llama_modules.py; the reference fuses gate/up only in its
 offline export layer (python/eetq/models/llama.py:39-77).
 """
+import threading
+
 import torch
 import torch.nn as nn
 
@@ -98,7 +100,10 @@ class _EETAttentionBase(nn.Module):
             return None
         return layer
 
-    _mask_memo = [None, None]  # (key, additive rows) of the most recent conversion: the model hands every layer the same mask
+    # (key, additive rows, the mask itself) of the most recent conversion: the model hands every layer the same mask.  ONE
+    # immutable tuple, replaced whole: a reader in another thread sees the old entry or the new one, never a mixture; the
+    # entry keeps the mask alive, so its id() cannot be recycled while the entry stands.
+    _mask_memo = [(None, None, None)]
 
     @classmethod
     def _decode_mask_rows(cls, attention_mask, batch, s_len, dtype, device):
@@ -123,14 +128,14 @@ class _EETAttentionBase(nn.Module):
             return rows[..., :s_len] if rows.shape[-1] != s_len else rows
         key = (id(attention_mask), attention_mask._version, attention_mask.data_ptr(), tuple(attention_mask.shape),
                attention_mask.dtype, dtype)
-        memo = cls._mask_memo
-        if memo[0] != key:
+        entry = cls._mask_memo[0]
+        if entry[0] != key or entry[2] is not attention_mask:
             if rows.is_floating_point():
                 add = rows.to(dtype)
             else:  # bool / integer: non-zero = attend
                 add = torch.zeros(rows.shape, dtype=dtype, device=device).masked_fill_(rows == 0, float("-inf"))
-            memo[0], memo[1] = key, add
-        add = memo[1]
+            entry = cls._mask_memo[0] = (key, add, attention_mask)
+        add = entry[1]
         return add[..., :s_len] if add.shape[-1] != s_len else add
 
     def _grow_table(self, need):
@@ -148,7 +153,8 @@ class _EETAttentionBase(nn.Module):
     # what every layer of a model derives from the step's position_ids / attention_mask, computed by the first layer of the
     # step and reused by the others: [position_ids, its version, attention_mask, its version, batch, rows, positions, add].
     # The tensors themselves are held (an id() could be recycled) and their version counters checked (in-place updates).
-    _step_memo = [None] * 8
+    # Per thread: two models stepping in two threads must not read each other's entry between the check and the use.
+    _step_memo = threading.local()
 
     def decode_step_state(self, hidden_states, attention_mask, position_ids, past_key_values):
         """What the one-call decoder-layer step (ops.llama_decode_layer) needs beyond the weights, or None when this step
@@ -158,7 +164,9 @@ class _EETAttentionBase(nn.Module):
         if layer is None or self.decode_math_attention is not True or position_ids is None or not hidden_states.is_cuda:
             return None
         bsz, rows = hidden_states.shape[0], layer.keys.shape[2]
-        memo = _EETAttentionBase._step_memo
+        memo = getattr(_EETAttentionBase._step_memo, "entry", None)
+        if memo is None:
+            memo = _EETAttentionBase._step_memo.entry = [None] * 8
         if not (memo[0] is position_ids and memo[1] == position_ids._version and memo[2] is attention_mask
                 and (attention_mask is None or memo[3] == attention_mask._version) and memo[4] == bsz and memo[5] == rows):
             add = self._decode_mask_rows(attention_mask, bsz, rows, hidden_states.dtype, hidden_states.device)
