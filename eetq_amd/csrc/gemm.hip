@@ -43,9 +43,15 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         return EETQ_OK;
     }
     {   // > 64 KiB of dynamic LDS: one opt-in per kernel and device (common.hpp)
-        static std::atomic<unsigned long long> opted2{0}, opted1{0};
-        int st = opt_in_large_lds(gemm_tile_kernel<0, 2>, opted2);
-        if (st == EETQ_OK) st = opt_in_large_lds(gemm_tile_kernel<0, 1>, opted1);
+        static std::atomic<unsigned long long> opted2{0}, opted1{0}, opted2a{0}, opted1a{0};
+        int st = EETQ_OK;
+        if (ep.act == 0) {
+            st = opt_in_large_lds(gemm_tile_kernel<0, 2>, opted2);
+            if (st == EETQ_OK) st = opt_in_large_lds(gemm_tile_kernel<0, 1>, opted1);
+        } else {  // the activation epilogues are their own instantiation (gemm_kernel.hpp)
+            st = opt_in_large_lds(gemm_tile_kernel<0, 2, true>, opted2a);
+            if (st == EETQ_OK) st = opt_in_large_lds(gemm_tile_kernel<0, 1, true>, opted1a);
+        }
         if (st != EETQ_OK) return st;
     }
     // the LDS-DMA path addresses its operands with 32-bit buffer offsets
@@ -71,12 +77,14 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         if (e.residual) e.residual += (size_t)m * N + c0;
         const uint8_t* wc = w + (size_t)(c0 / kTileN) * (K / kTileK) * kTileBytes;
         const bool     narrow = force_j == 1 || (force_j == 0 && cost1 < cost2);
-        if (narrow)
-            launch_kernel(gemm_tile_kernel<0, 1>, dim3(tiles1), dim3(256), TileCfg<1>::SMEM_BYTES, stream, x + (size_t)m * K, wc,
-                          scales + c0, y + (size_t)m * N + c0, rows, cols, K, N, e);
-        else
-            launch_kernel(gemm_tile_kernel<0, 2>, dim3(tiles2), dim3(256), TileCfg<2>::SMEM_BYTES, stream, x + (size_t)m * K, wc,
-                          scales + c0, y + (size_t)m * N + c0, rows, cols, K, N, e);
+        auto go = [&](auto kern, int tiles, size_t smem) {
+            launch_kernel(kern, dim3(tiles), dim3(256), smem, stream, x + (size_t)m * K, wc, scales + c0, y + (size_t)m * N + c0,
+                          rows, cols, K, N, e);
+        };
+        if (narrow && e.act == 0) go(gemm_tile_kernel<0, 1>, tiles1, TileCfg<1>::SMEM_BYTES);
+        else if (narrow) go(gemm_tile_kernel<0, 1, true>, tiles1, TileCfg<1>::SMEM_BYTES);
+        else if (e.act == 0) go(gemm_tile_kernel<0, 2>, tiles2, TileCfg<2>::SMEM_BYTES);
+        else go(gemm_tile_kernel<0, 2, true>, tiles2, TileCfg<2>::SMEM_BYTES);
         return check_hip(hipGetLastError(), "gemm_tile_kernel launch");
     };
     for (int m = 0; m < M; m += max_rows) {

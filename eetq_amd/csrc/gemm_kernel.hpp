@@ -68,7 +68,11 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // An earlier schedule (all reads in gaps 0..3, DMA in gaps 0..5, dequant 6 ops per gap in gaps 4..11, bookkeeping after
 // the last MFMA) ran 3 % slower; see profiles/r01_kbench_ablation_gemm.txt.
 // ABLATE (kbench only): 1 = no DMA, 2 = no dequant, 4 = no LDS fragment reads, 8 = no MFMA, 16 = no barrier
-template <int ABLATE, int J>
+// ACT: the activation epilogues (ep.act != 0) are a separate instantiation.  With them inlined behind a run-time test the
+// kernel grew from 4.4 k to 21 k instructions (exp / tanh expanded for 128 accumulators) and the SAME main loop ran 11 %
+// slower (M = 1024, N = K = 4096: 40.8 vs 36.7 us, tools/kbench gemm, same box) -- instruction fetch, not registers (both
+// builds use 410).  The identity instantiation keeps the round-1 epilogue.
+template <int ABLATE, int J, bool ACT = false>
 __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
@@ -396,10 +400,20 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         if (nbase + 8 * q < N) {
-                            f16x2       lo, hi;
-                            const float a4[4] = {acc[mt][j][4 * q + 0], acc[mt][j][4 * q + 1], acc[mt][j][4 * q + 2],
-                                                 acc[mt][j][4 * q + 3]};
-                            finish_quad(a4, ep, nbase + 8 * q, lo, hi);
+                            f16x2 lo, hi;
+                            if constexpr (ACT) {
+                                const float a4[4] = {acc[mt][j][4 * q + 0], acc[mt][j][4 * q + 1], acc[mt][j][4 * q + 2],
+                                                     acc[mt][j][4 * q + 3]};
+                                finish_quad(a4, ep, nbase + 8 * q, lo, hi);
+                            } else {  // identity: round to fp16, then the fp16 bias add (the reference's `output + bias`)
+                                lo = f16x2{(f16)acc[mt][j][4 * q + 0], (f16)acc[mt][j][4 * q + 1]};
+                                hi = f16x2{(f16)acc[mt][j][4 * q + 2], (f16)acc[mt][j][4 * q + 3]};
+                                if (ep.bias) {
+                                    const u32x2 b = *reinterpret_cast<const u32x2*>(ep.bias + nbase + 8 * q);
+                                    lo            = lo + as_f16x2(b.x);
+                                    hi            = hi + as_f16x2(b.y);
+                                }
+                            }
                             if (ep.residual) {
                                 const u32x2 r =
                                     *reinterpret_cast<const u32x2*>(ep.residual + (size_t)m * ldc + nbase + 8 * q);
