@@ -243,7 +243,7 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
     int st = check_gemm_args(x, w_packed, scales, y, M, N, K);
     if (st != EETQ_OK) return st;
     EETQ_REQUIRE(!bias || (uintptr_t)bias % 8 == 0, "bias must be 8-byte aligned");
-    EETQ_REQUIRE(!residual || (uintptr_t)residual % 8 == 0, "residual must be 8-byte aligned");
+    EETQ_REQUIRE(!residual || (uintptr_t)residual % 16 == 0, "residual must be 16-byte aligned");
     const f16*     xp = static_cast<const f16*>(x);
     const uint8_t* wp = reinterpret_cast<const uint8_t*>(w_packed);
     const f16*     sp = static_cast<const f16*>(scales);

@@ -7,6 +7,21 @@
 namespace eetq {
 namespace gemm {
 
+// kbench-only instrumentation (tools/kbench_stamps gemmstamps): wave 0 of every workgroup records the 100 MHz device clock
+// at kernel entry (0), first stage landed (1), end of the steady loop (2), end of the drain steps (3), accumulators of the
+// second K half parked in LDS (4), output stored (5).
+#ifdef EETQ_KBENCH_STAMPS
+__device__ unsigned long long* g_gemm_stamps = nullptr;
+#define EETQ_GEMM_STAMP(i)                                                                                  \
+    do {                                                                                                    \
+        unsigned long long t_;                                                                              \
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                     \
+        if (g_gemm_stamps && threadIdx.x == 0) g_gemm_stamps[(size_t)blockIdx.x * 8 + (i)] = t_;            \
+    } while (0)
+#else
+#define EETQ_GEMM_STAMP(i) do { } while (0)
+#endif
+
 constexpr int BM = 128, BK = 64;
 constexpr int A_STAGE_BYTES = BM * BK * 2;  // 16 KiB of fp16 activations per K step
 constexpr int STAGES        = 6;
@@ -78,6 +93,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
 {
     // N = columns of THIS launch (w, scales, y, ep.* already point at its first column); ldc = row stride of y / residual
+    EETQ_GEMM_STAMP(0);
     using Cfg = TileCfg<J>;
     constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES;
     constexpr int WN_COLS = 32 * J, PIECES = 4 + J, NMFMA = 8 * J;
@@ -320,6 +336,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     }
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PIECES) : "memory");  // stage 0 landed
     __builtin_amdgcn_s_barrier();
+    EETQ_GEMM_STAMP(1);
     Frags f0, f1;
     WFrag w0, w1;
     {
@@ -359,6 +376,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
         k_step(Steady{}, w0, f0, w1, f1);
         k_step(Steady{}, w1, f1, w0, f0);
     }
+    EETQ_GEMM_STAMP(2);
     if (tail == 6) {
         k_step(std::integral_constant<int, 5>{}, w0, f0, w1, f1);
         k_step(std::integral_constant<int, 4>{}, w1, f1, w0, f0);
@@ -374,59 +392,81 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
         k_step(std::integral_constant<int, 0>{}, w0, f0, w1, f1);
     }
 
-    // ---- combine the two K halves: group 1 parks its accumulators in LDS, group 0 adds and stores ----
+    // ---- epilogue.  The two K halves are combined through LDS (group 1 parks its accumulators, 16-byte LDS accesses; group 0
+    // adds).  An MFMA accumulator lane holds ONE output row and 4 x 4 columns of it, so storing from registers means 8-byte
+    // writes scattered over 32 rows per instruction: 3.1 us of a 36.5 us kernel (tools/kbench_stamps gemmstamps).  Instead
+    // group 0 rounds to fp16 (+ bias / activation) into a row-major LDS image of the tile, and all four waves write it out 16
+    // bytes per lane, whole 256-byte rows (4 rows per wave instruction), adding the residual on the way. ----
+    EETQ_GEMM_STAMP(3);
     __builtin_amdgcn_s_barrier();
-    float* red = reinterpret_cast<float*>(smem) + (size_t)wn * (64 * J) * 64;  // [reg][lane]
+    f32x4* red4 = reinterpret_cast<f32x4*>(smem) + (size_t)wn * (16 * J) * 64;  // [block][quad][lane]
     if (grp == 1) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
             for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) red[((mt * J + j) * 16 + r) * 64 + lane] = acc[mt][j][r];
+                for (int q = 0; q < 4; ++q)
+                    red4[((mt * J + j) * 4 + q) * 64 + lane] =
+                        f32x4{acc[mt][j][4 * q], acc[mt][j][4 * q + 1], acc[mt][j][4 * q + 2], acc[mt][j][4 * q + 3]};
     }
     __syncthreads();
+    EETQ_GEMM_STAMP(4);
+    constexpr int kRowHalfs = BN + 8;                       // row stride of the image: 272 / 144 bytes (bank shift per row)
+    f16* image = reinterpret_cast<f16*>(smem + 2 * (16 * J) * 64 * 16);  // behind both column halves' parked accumulators
+    static_assert(2 * (16 * J) * 64 * 16 + BM * kRowHalfs * 2 <= SMEM_BYTES, "the output image must fit behind the parked halves");
     if (grp == 0) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
-            const int m = m0 + mt * 32 + fn;
 #pragma unroll
             for (int j = 0; j < J; ++j) {
+                const int ncol = wn * WN_COLS + 32 * j + 4 * fh;  // tile-local column of quad 0
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mt][j][r] += red[((mt * J + j) * 16 + r) * 64 + lane];
-                const int nbase = n0 + wn * WN_COLS + 32 * j + 4 * fh;
-                if (m < M) {
-                    f16* yrow = y + (size_t)m * ldc + nbase;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        if (nbase + 8 * q < N) {
-                            f16x2 lo, hi;
-                            if constexpr (ACT) {
-                                const float a4[4] = {acc[mt][j][4 * q + 0], acc[mt][j][4 * q + 1], acc[mt][j][4 * q + 2],
-                                                     acc[mt][j][4 * q + 3]};
-                                finish_quad(a4, ep, nbase + 8 * q, lo, hi);
-                            } else {  // identity: round to fp16, then the fp16 bias add (the reference's `output + bias`)
-                                lo = f16x2{(f16)acc[mt][j][4 * q + 0], (f16)acc[mt][j][4 * q + 1]};
-                                hi = f16x2{(f16)acc[mt][j][4 * q + 2], (f16)acc[mt][j][4 * q + 3]};
-                                if (ep.bias) {
-                                    const u32x2 b = *reinterpret_cast<const u32x2*>(ep.bias + nbase + 8 * q);
-                                    lo            = lo + as_f16x2(b.x);
-                                    hi            = hi + as_f16x2(b.y);
-                                }
-                            }
-                            if (ep.residual) {
-                                const u32x2 r =
-                                    *reinterpret_cast<const u32x2*>(ep.residual + (size_t)m * ldc + nbase + 8 * q);
-                                lo = lo + as_f16x2(r.x);
-                                hi = hi + as_f16x2(r.y);
-                            }
-                            *reinterpret_cast<u32x2*>(yrow + 8 * q) = u32x2{as_u32(lo), as_u32(hi)};
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 o  = red4[((mt * J + j) * 4 + q) * 64 + lane];
+                    const float a4[4] = {acc[mt][j][4 * q + 0] + o.x, acc[mt][j][4 * q + 1] + o.y, acc[mt][j][4 * q + 2] + o.z,
+                                         acc[mt][j][4 * q + 3] + o.w};
+                    f16x2      lo = {}, hi = {};
+                    const bool in_n = n0 + ncol + 8 * q < N;  // columns beyond a ragged launch edge: nothing to read or keep
+                    if constexpr (ACT) {
+                        if (in_n) finish_quad(a4, ep, n0 + ncol + 8 * q, lo, hi);
+                    } else {  // identity: round to fp16, then the fp16 bias add (the reference's `output + bias`)
+                        lo = f16x2{(f16)a4[0], (f16)a4[1]};
+                        hi = f16x2{(f16)a4[2], (f16)a4[3]};
+                        if (ep.bias && in_n) {
+                            const u32x2 b = *reinterpret_cast<const u32x2*>(ep.bias + n0 + ncol + 8 * q);
+                            lo            = lo + as_f16x2(b.x);
+                            hi            = hi + as_f16x2(b.y);
                         }
                     }
+                    *reinterpret_cast<u32x2*>(image + (mt * 32 + fn) * kRowHalfs + ncol + 8 * q) = u32x2{as_u32(lo), as_u32(hi)};
                 }
             }
         }
     }
+    __syncthreads();
+    {
+        constexpr int kLanesPerRow = BN / 8, kRowsPerWave = 64 / kLanesPerRow, kRowsPerRound = 4 * kRowsPerWave;
+        const int     c            = (lane % kLanesPerRow) * 8;
+#pragma unroll
+        for (int r0 = 0; r0 < BM; r0 += kRowsPerRound) {
+            const int r = r0 + wave * kRowsPerWave + lane / kLanesPerRow;
+            const int m = m0 + r;
+            if (m < M && n0 + c < N) {
+                u32x4 v = *reinterpret_cast<const u32x4*>(image + r * kRowHalfs + c);
+                if (ep.residual) {
+                    const u32x4 rr = *reinterpret_cast<const u32x4*>(ep.residual + (size_t)m * ldc + n0 + c);
+                    v.x = as_u32(as_f16x2(v.x) + as_f16x2(rr.x));
+                    v.y = as_u32(as_f16x2(v.y) + as_f16x2(rr.y));
+                    v.z = as_u32(as_f16x2(v.z) + as_f16x2(rr.z));
+                    v.w = as_u32(as_f16x2(v.w) + as_f16x2(rr.w));
+                }
+                *reinterpret_cast<u32x4*>(y + (size_t)m * ldc + n0 + c) = v;
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    EETQ_GEMM_STAMP(5);
 }
 
 }  // namespace gemm

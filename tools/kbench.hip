@@ -662,6 +662,64 @@ int main(int argc, char** argv)
     }
 #endif
 #ifdef EETQ_KBENCH_STAMPS
+    if (!strcmp(what, "gemmstamps")) {
+        // Where do the tile GEMM's microseconds go at M = 1024, N = K = 4096 (one tile per workgroup, 256 workgroups)?
+        // Device-clock stamps of wave 0 of every workgroup: 0 entry, 1 first stage landed, 2 steady loop done, 3 drain steps
+        // done, 4 second K half parked in LDS, 5 output stored.
+        using namespace eetq::gemm;
+        const int M = 1024, N = 4096, K = 4096, NWG = (M / 128) * (N / 128), ROUNDS = 40;
+        eetq::f16 *xg, *yg;
+        CK(hipMalloc(&xg, (size_t)M * K * 2));
+        CK(hipMalloc(&yg, (size_t)M * N * 2));
+        {
+            std::vector<uint16_t> hx((size_t)M * K);
+            for (auto& v : hx) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));  // +-[0.125, 0.5)
+            CK(hipMemcpy(xg, hx.data(), hx.size() * 2, hipMemcpyHostToDevice));
+        }
+        auto kern = gemm_tile_kernel<0, 2>;
+        CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<2>::SMEM_BYTES));
+        unsigned long long* stamps;
+        CK(hipMalloc(&stamps, (size_t)NWG * 8 * 8));
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(eetq::gemm::g_gemm_stamps), &stamps, sizeof(stamps)));
+        std::vector<unsigned long long> h((size_t)NWG * 8);
+        double sum[6] = {0, 0, 0, 0, 0, 0}, mx[6] = {0, 0, 0, 0, 0, 0}, span = 0;
+        hipEvent_t a, b;
+        CK(hipEventCreate(&a));
+        CK(hipEventCreate(&b));
+        double disp = 0;
+        for (int r = -5; r < ROUNDS; ++r) {
+            hipExtLaunchKernelGGL(kern, dim3(NWG), dim3(256), TileCfg<2>::SMEM_BYTES, 0, a, b, 0, xg,
+                                  (const uint8_t*)bufs[(r + 5) % bufs.size()], scales, yg, M, N, K, N, eetq::Epilogue{});
+            CK(hipDeviceSynchronize());
+            if (r < 0) continue;
+            float ms;
+            CK(hipEventElapsedTime(&ms, a, b));
+            disp += ms * 1e3;
+            CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
+            unsigned long long t0 = ~0ull, tend = 0;
+            for (int w = 0; w < NWG; ++w) t0 = std::min(t0, h[w * 8]);
+            for (int i = 0; i < 6; ++i) {
+                double s = 0, m = 0;
+                for (int w = 0; w < NWG; ++w) {
+                    const double v = (double)(h[w * 8 + i] - t0) / 100.0;
+                    s += v;
+                    m = std::max(m, v);
+                }
+                sum[i] += s / NWG;
+                mx[i] += m;
+            }
+            for (int w = 0; w < NWG; ++w) tend = std::max(tend, h[w * 8 + 5]);
+            span += (double)(tend - t0) / 100.0;
+        }
+        const char* names[6] = {"entry", "first stage landed", "steady loop done", "drain steps done", "K halves parked in LDS",
+                                "output stored"};
+        printf("tile GEMM M=%d N=%d K=%d, %d workgroups, %d launches: dispatch begin->end %.2f us, device span %.2f us\n", M, N, K,
+               NWG, ROUNDS, disp / ROUNDS, span / ROUNDS);
+        for (int i = 0; i < 6; ++i)
+            printf("  %-24s mean %6.2f us  latest workgroup %6.2f us   (+%.2f since the previous stamp)\n", names[i], sum[i] / ROUNDS,
+                   mx[i] / ROUNDS, i ? (sum[i] - sum[i - 1]) / ROUNDS : 0.0);
+        return 0;
+    }
     if (!strcmp(what, "decompose")) {
         // Where do the GEMV's microseconds go?  Same process, same buffers, interleaved rounds of
         //   E  empty kernel, GEMV launch geometry (256 x 1024)      -> what a dispatch costs with no work
