@@ -12,7 +12,8 @@ DEV = "cuda:0"
 @pytest.fixture(scope="module")
 def ops():
     import eetq_amd.ops as _ops
-    assert _ops.BOUNDARY == "ext", "int4 goes through the compiled module"
+    if _ops.BOUNDARY != "ext":
+        pytest.skip("int4 goes through the compiled module (EETQ_AMD_BOUNDARY=ctypes selects the twin binding)")
     return _ops
 
 
