@@ -1,0 +1,72 @@
+"""Soak test of the in-launch hand-offs (write-through records + tickets): thousands of launches of the split-K GEMM and of
+the one-launch decode attention on fixed inputs, interleaved with launches that dirty the caches, every result compared
+bit for bit with the first.  A lost or early-read record shows up as a mismatch.  usage: python tools/soak.py [iterations]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import eetq_amd.ops as ops  # noqa: E402
+
+dev = "cuda:0"
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+torch.manual_seed(0)
+t0 = time.time()
+
+# ---- split-K GEMM, several shapes / slice counts (AUTO picks S from its plan) ----
+bad = 0
+cases = []
+for M, K, N in ((64, 4096, 4096), (32, 4096, 4096), (128, 4096, 4096), (64, 11008, 4096), (48, 5120, 5120), (100, 2048, 1024)):
+    w = torch.randint(-128, 127, (K, N), dtype=torch.int8, device=dev)
+    s = torch.rand(N, dtype=torch.float16, device=dev) * 0.01
+    x = torch.randn(M, K, dtype=torch.float16, device=dev)
+    cases.append((x, w, s, ops.w8_a16_gemm(x, w, s, path="splitk").clone()))
+junk = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+streams = [torch.cuda.Stream() for _ in range(3)]
+for it in range(iters):
+    x, w, s, ref = cases[it % len(cases)]
+    st = streams[it % 3] if it % 5 == 0 else torch.cuda.current_stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        y = ops.w8_a16_gemm(x, w, s, path="splitk")
+    torch.cuda.current_stream().wait_stream(st)
+    if it % 7 == 0:
+        junk.add_(1)            # churn L2 / Infinity Cache between launches
+    if not torch.equal(y, ref):
+        bad += 1
+print("split-K: %d launches, %d mismatches" % (iters, bad))
+
+# ---- one-launch decode attention: fixed cache and token, the counter walks and is reset; tickets must stay zero ----
+B, H, Hkv, D, S = 2, 40, 8, 128, 600
+inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+fr = torch.einsum("i,j->ij", torch.arange(S + 8).float(), inv)
+table = torch.cat([fr.cos(), fr.sin()], -1).half().to(dev)
+kc = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=dev)
+vc = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=dev)
+qkv = torch.randn(B, 1, (H + 2 * Hkv) * D, dtype=torch.float16, device=dev)
+q = qkv[..., : H * D].unflatten(-1, (H, D))[:, 0]
+k = qkv[..., H * D: (H + Hkv) * D].unflatten(-1, (Hkv, D))[:, 0]
+v = qkv[..., (H + Hkv) * D:].unflatten(-1, (Hkv, D))[:, 0]
+pos = torch.tensor([500, 480], device=dev)
+tickets = torch.zeros(B * H + 1, dtype=torch.int32, device=dev)
+counter = torch.tensor(500, dtype=torch.int64, device=dev)
+refs, bad2 = {}, 0
+for it in range(iters):
+    splits = (None, 3, 9, 16)[it % 4]
+    counter.fill_(500)
+    out = ops.rope_decode_attention(pos, q, k, v, table, kc, vc, tickets, slots=counter, splits=splits, kv_len=counter,
+                                    kv_len_bias=1, advance=counter)
+    if it % 7 == 0:
+        junk.add_(1)
+    key = splits
+    if key not in refs:
+        refs[key] = out.clone()
+    elif not torch.equal(out, refs[key]):
+        bad2 += 1
+    if it % 97 == 0 and (int(counter.item()) != 501 or int(tickets.abs().sum().item()) != 0):
+        bad2 += 1000
+print("decode attention: %d launches, %d mismatches; tickets zero: %s" % (iters, bad2, int(tickets.abs().sum().item()) == 0))
+print("elapsed %.1f s" % (time.time() - t0))
+sys.exit(1 if bad or bad2 else 0)
