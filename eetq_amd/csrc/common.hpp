@@ -213,6 +213,8 @@ int launch_quantize_i4(const void* w, int w_dtype, size_t K, size_t N, int8_t* q
                        void* scales, float* colmax, hipStream_t stream);
 int launch_pack_i4(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
 int launch_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
+int launch_streamk_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
+                      hipStream_t stream);
 int launch_gemv_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                    hipStream_t stream);
 int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,

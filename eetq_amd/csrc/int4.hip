@@ -292,6 +292,9 @@ int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
 {
     // decode: the wave-reduction GEMV on int4 tiles (gemv_kernel<..., BITS = 4>)
     if (M <= kGemvMaxM) return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
+    // batched decode, 5 <= M <= 64: the register-streaming MFMA kernel on int4 tiles (streamk_kernel<..., BITS = 4>) -- the
+    // weight stream bounds these M, and it is half as long as the int8 one
+    if (M <= kStreamMaxM) return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
     // larger batches: expand the nibbles to the int8 tile layout once per call (K*N/2 bytes read, K*N written; the GEMM that
     // follows is MFMA- or x-bound at these M) and run the W8A16 kernels on it -- same integers, same scales, same contract
     uint8_t* w8 = nullptr;

@@ -15,7 +15,9 @@ namespace streamk {
 
 // grid.x = N / (16*NT); block = WAVES*64; wave w takes k tiles w, w+WAVES, ... (each >= D tiles by launch contract).
 // Dynamic LDS: WAVES * MT*NT*256 floats (cross-wave reduction only).
-template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD>
+// BITS = 4 (W4A16): the 1 KiB tile holds 16 columns x 128 k, a lane's 16 bytes are 32 k values of its column (the int4
+// layout of int4.hip / gemv_kernel.hpp): four MFMAs and four activation vectors per tile instead of two.
+template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD, int BITS = 8>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, Epilogue ep)
@@ -27,7 +29,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int g = lane >> 4, c = lane & 15;
-    const int KT     = K >> 6;
+    using CD = gemv::Codec<BITS>;
+    constexpr int XQ = CD::kXQ;          // 16-byte activation vectors per lane and tile
+    const int KT     = K / CD::kTileK;
     const int ntile0 = blockIdx.x * NT;
 
     u32 sraw[NT];
@@ -40,7 +44,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     for (int mt = 0; mt < MT; ++mt) {
         int r    = 16 * mt + c;
         r        = r < M ? r : M - 1;
-        xrow[mt] = reinterpret_cast<const u32x4*>(x + (size_t)r * K + 16 * g);  // + 8 u32x4 per k tile
+        xrow[mt] = reinterpret_cast<const u32x4*>(x + (size_t)r * K + CD::kLaneK * g);  // + kTileK / 8 u32x4 per k tile
     }
     const u32x4* wp[NT];
 #pragma unroll
@@ -49,16 +53,15 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
 
     struct Stage {
         u32x4 wq[NT];
-        u32x4 xa[MT][2];
+        u32x4 xa[MT][XQ];
     };
     auto load_stage = [&](int kt, Stage& s) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) s.wq[t] = gemv::load_w<true>(wp[t] + (size_t)kt * 64);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            s.xa[mt][0] = xrow[mt][(size_t)kt * 8];
-            s.xa[mt][1] = xrow[mt][(size_t)kt * 8 + 1];
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) s.xa[mt][q] = xrow[mt][(size_t)kt * (CD::kTileK / 8) + q];
     };
 
     f32x4 acc[MT][NT];
@@ -71,16 +74,30 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     auto  consume = [&](const Stage& s) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            f16x2 wq[8];
-            dequant_16(s.wq[t], scale2[t], wq);
-            const f16x8 b0 = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
-            const f16x8 b1 = {wq[4].x, wq[4].y, wq[5].x, wq[5].y, wq[6].x, wq[6].y, wq[7].x, wq[7].y};
+            if constexpr (BITS == 8) {
+                f16x2 wq[8];
+                dequant_16(s.wq[t], scale2[t], wq);
+                const f16x8 b0 = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
+                const f16x8 b1 = {wq[4].x, wq[4].y, wq[5].x, wq[5].y, wq[6].x, wq[6].y, wq[7].x, wq[7].y};
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s.xa[mt][0]), b0,
-                                                                    acc[mt][t], 0, 0, 0);
-                acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s.xa[mt][1]), b1,
-                                                                    acc[mt][t], 0, 0, 0);
+                for (int mt = 0; mt < MT; ++mt) {
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s.xa[mt][0]), b0,
+                                                                        acc[mt][t], 0, 0, 0);
+                    acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s.xa[mt][1]), b1,
+                                                                        acc[mt][t], 0, 0, 0);
+                }
+            } else {
+                const u32 wd[4] = {s.wq[t].x, s.wq[t].y, s.wq[t].z, s.wq[t].w};  // dword d = k values 8d .. 8d+7 of the lane
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    f16x2 wq[4];
+                    gemv::dequant_dword_i4(wd[d], scale2[t], wq);
+                    const f16x8 b = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s.xa[mt][d]), b,
+                                                                            acc[mt][t], 0, 0, 0);
+                }
             }
         }
     };
