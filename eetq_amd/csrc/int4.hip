@@ -291,10 +291,11 @@ int launch_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, 
 int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, hipStream_t stream)
 {
     // decode: the wave-reduction GEMV on int4 tiles (gemv_kernel<..., BITS = 4>)
-    if (M <= kGemvMaxM) return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
-    // batched decode, 5 <= M <= 64: the register-streaming MFMA kernel on int4 tiles (streamk_kernel<..., BITS = 4>) -- the
-    // weight stream bounds these M, and it is half as long as the int8 one
-    if (M <= kStreamMaxM) return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
+    if (M == 1) return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
+    // batched decode, 2 <= M <= 16: the register-streaming MFMA kernel on int4 tiles (streamk_kernel<..., BITS = 4>) -- the
+    // weight stream bounds these M, and it is half as long as the int8 one (M = 8, N = K = 4096: 4.5 vs 5.1 us; the dot2
+    // GEMV at M = 4 needs 6.9).  Larger M are bound by the activation traffic / the matrix cores, where int4 buys nothing.
+    if (M <= 16) return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
     // larger batches: expand the nibbles to the int8 tile layout once per call (K*N/2 bytes read, K*N written; the GEMM that
     // follows is MFMA- or x-bound at these M) and run the W8A16 kernels on it -- same integers, same scales, same contract
     uint8_t* w8 = nullptr;

@@ -48,18 +48,23 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
     return launch_inst<MT, 1, 1, 1, 1>(x, w, scales, ep, y, M, N, K, stream);
 }
 
-// W4A16: int4 tiles carry 128 k, so a wave needs K / 128 >= WAVES * D tiles; one tile row per workgroup keeps the register
-// budget of the four activation vectors per tile (MT * 16 VGPRs per stage)
-template <int MT>
+// W4A16, 2 <= M <= 16 (one row tile): int4 tiles carry 128 k, so a wave needs K / 128 >= WAVES * D tiles.  Two tile rows per
+// workgroup when that puts fewer loads on the busiest CU (per k tile: NT weight loads + 4 activation loads).
 int launch_mt_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, hipStream_t stream)
 {
     const int KT = K / 128;
-    if constexpr (MT <= 2) {  // (three and four row tiles spill at 16 waves: 128 VGPRs per lane; eight waves have 256)
-        if (KT >= 32) return launch_inst<MT, 1, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+    if (KT >= 32) {
+        if (N % (2 * kTileN) == 0) {
+            const int  ncu   = device_cu_count();
+            const long cost1 = (long)((N / kTileN + ncu - 1) / ncu) * 5;
+            const long cost2 = (long)((N / (2 * kTileN) + ncu - 1) / ncu) * 6;
+            if (cost2 < cost1) return launch_inst<1, 2, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+        }
+        return launch_inst<1, 1, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     }
-    if (KT >= 16) return launch_inst<MT, 1, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
-    if (KT >= 4) return launch_inst<MT, 1, 4, 1, 1, 4>(x, w, scales, ep, y, M, N, K, stream);
-    return launch_inst<MT, 1, 1, 1, 1, 4>(x, w, scales, ep, y, M, N, K, stream);
+    if (KT >= 16) return launch_inst<1, 1, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+    if (KT >= 4) return launch_inst<1, 1, 4, 1, 1, 4>(x, w, scales, ep, y, M, N, K, stream);
+    return launch_inst<1, 1, 1, 1, 1, 4>(x, w, scales, ep, y, M, N, K, stream);
 }
 
 }  // namespace
@@ -67,14 +72,9 @@ int launch_mt_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
 int launch_streamk_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                       hipStream_t stream)
 {
-    if (M < 1 || M > kStreamMaxM || K % 128)
-        return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16 stream-MFMA path supports 1 <= M <= 64, K % 128 == 0");
-    switch ((M + 15) / 16) {
-        case 1: return launch_mt_i4<1>(x, w, scales, ep, y, M, N, K, stream);
-        case 2: return launch_mt_i4<2>(x, w, scales, ep, y, M, N, K, stream);
-        case 3: return launch_mt_i4<3>(x, w, scales, ep, y, M, N, K, stream);
-        default: return launch_mt_i4<4>(x, w, scales, ep, y, M, N, K, stream);
-    }
+    if (M < 1 || M > 16 || K % 128)
+        return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16 stream-MFMA path supports 1 <= M <= 16, K % 128 == 0");
+    return launch_mt_i4(x, w, scales, ep, y, M, N, K, stream);
 }
 
 int launch_streamk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,

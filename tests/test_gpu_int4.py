@@ -101,7 +101,7 @@ def test_w4a16_identity_is_exact_dequant(ops, oracle):
 
 @pytest.mark.parametrize("M", [5, 8, 16, 17, 33, 64, 65, 200, 1024])
 def test_w4a16_larger_batches(ops, oracle, M):
-    """5 <= M <= 64: the register-streaming MFMA kernel on int4 tiles; above: nibbles expanded to int8 tiles + the W8A16
+    """2 <= M <= 16: the register-streaming MFMA kernel on int4 tiles; above: nibbles expanded to int8 tiles + the W8A16
     kernels.  Both against the oracle on the exact integers; the expansion route is bit-identical to W8A16 on them."""
     K, N = 1024, 384
     rng = np.random.default_rng(M)
@@ -118,15 +118,15 @@ def test_w4a16_larger_batches(ops, oracle, M):
     assert _tier_a(y.cpu().numpy()[rows], ref).all()
     p8 = torch.from_numpy(oracle.gfx950_pack(oracle.i4_values(qp))).to(DEV)
     y8 = ops.w8_a16_gemm(xd, p8, sd)
-    if M > 64:   # the expanded weight is exactly the int8 tile image of the same integers: bit-identical to W8A16 on them
+    if M > 16:   # the expanded weight is exactly the int8 tile image of the same integers: bit-identical to W8A16 on them
         assert torch.equal(y, y8)
     else:        # same dequantised values, another summation order
         assert _tier_a(y.cpu().numpy(), y8.float().cpu().numpy()).all()
     assert torch.equal(ops.w8_a16_gemm(xd, processed, sd, bias=bias, residual=res), y + bias + res)
 
 
-@pytest.mark.parametrize("K,N", [(4096, 4096), (5120, 15360), (13824, 5120), (512, 64), (128, 16), (2048, 1024)])
-@pytest.mark.parametrize("M", [5, 16, 40, 64])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (5120, 15360), (5120, 27648), (13824, 5120), (512, 64), (128, 16), (2048, 1024)])
+@pytest.mark.parametrize("M", [2, 5, 16])
 def test_w4a16_stream_kernel_shapes(ops, oracle, M, K, N):
     """The int4 stream kernel over the decode shapes (every wave-count / depth instantiation of its launcher), against the
     oracle GEMM on the exact integers (rows sampled)."""
