@@ -426,6 +426,22 @@ int eetq_w8a16_gemv_glu8(const void* x, const void* gamma, float eps, const int8
                        pro);
 }
 
+int eetq_w8a16_gemm_glu8(const void* x, const int8_t* w_packed, const void* scales, const void* bias, void* y, int M, int N,
+                         int K, void* stream)
+{
+    int st = check_gemm_args(x, w_packed, scales, y, M, N, K);
+    if (st != EETQ_OK) return st;
+    EETQ_REQUIRE(M >= 1 && M <= 16, "the gated epilogue is implemented for 1 <= M <= 16 rows");
+    Epilogue ep;
+    ep.bias = static_cast<const f16*>(bias);
+    ep.act  = kActGlu8;
+    const auto xp = static_cast<const f16*>(x);
+    const auto wp = reinterpret_cast<const uint8_t*>(w_packed);
+    const auto sp = static_cast<const f16*>(scales);
+    if (M == 1) return launch_gemv(xp, wp, sp, ep, static_cast<f16*>(y), 1, N, K, static_cast<hipStream_t>(stream));
+    return launch_streamk(xp, wp, sp, ep, static_cast<f16*>(y), M, N, K, static_cast<hipStream_t>(stream));
+}
+
 int eetq_silu_mul_glu8_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream)
 {
     return launch_silu_mul(static_cast<const f16*>(gate_up), static_cast<f16*>(out), rows, intermediate,

@@ -143,6 +143,28 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
             for (int j = 0; j < 4; ++j)
                 red[wave * kPerWave + ((mt * NT + t) * 16 + 4 * g + j) * 16 + c] = acc[mt][t][j];
     __syncthreads();
+    if (ep.act == kActGlu8) {
+        // "glu8" column order (8 gate + the 8 matching up columns per 16-column tile): N/2 outputs per row,
+        // y[m][8 tile + c] = silu_mul(gate, up) with both operands rounded (+ bias) like the plain epilogue
+        Epilogue lin = ep;
+        lin.act      = 0;
+        for (int o = tid; o < kPerWave; o += WAVES * 64) {
+            const int cc = o & 15, rr = (o >> 4) & 15, tt = (o >> 8) % NT, mt = (o >> 8) / NT;
+            const int m = 16 * mt + rr;
+            if (m < M && cc < 8) {
+                float sg = 0.f, su = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < WAVES; ++wv) {
+                    sg += red[wv * kPerWave + o];
+                    su += red[wv * kPerWave + o + 8];
+                }
+                const f16 gv = finish_element(sg, lin, (ntile0 + tt) * 16 + cc);
+                const f16 uv = finish_element(su, lin, (ntile0 + tt) * 16 + cc + 8);
+                y[(size_t)m * (N >> 1) + (ntile0 + tt) * 8 + cc] = silu_mul_f16(gv, uv);
+            }
+        }
+        return;
+    }
     for (int o = tid; o < kPerWave; o += WAVES * 64) {
         const int cc = o & 15, rr = (o >> 4) & 15, tt = (o >> 8) % NT, mt = (o >> 8) / NT;
         const int m = 16 * mt + rr;

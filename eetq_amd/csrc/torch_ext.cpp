@@ -301,6 +301,24 @@ Tensor w8_a16_gemm(const Tensor& input_in, const Tensor& weight, const Tensor& s
                                        bias ? bias->data_ptr() : nullptr, output.data_ptr(), (int)n, (int)kw, stream_of(input)));
             return output;
         }
+        if (rows >= 2 && rows <= 16 && path == "auto" && input.size(-1) == kw && input.is_cuda() &&
+            input.scalar_type() == at::kHalf && weight.scalar_type() == at::kChar && scale.scalar_type() == at::kHalf &&
+            weight.is_contiguous() && weight.device() == input.device() && scale.device() == input.device()) {
+            // batched decode: the activation in the stream kernel's epilogue (the norm, if any, as its own launch first)
+            Tensor xin = input.contiguous();
+            if (norm) {
+                Tensor normed = torch::empty_like(xin);
+                layernorm_forward(xin, std::get<0>(*norm), normed, std::get<1>(*norm));
+                xin = normed;
+            }
+            check_epilogue(input, bias, residual, rows, n);
+            Tensor           output = torch::empty(out_shape(input, n / 2), input.options());
+            c10::DeviceGuard guard(input.device());
+            check(eetq_w8a16_gemm_glu8(xin.data_ptr(), weight.data_ptr<int8_t>(), scale.data_ptr(),
+                                       bias ? bias->data_ptr() : nullptr, output.data_ptr(), (int)rows, (int)n, (int)kw,
+                                       stream_of(input)));
+            return output;
+        }
         return silu_mul(w8_a16_gemm(input_in, weight, scale, path, bias, residual, norm, false, std::string()), true);
     }
     if (gated) {

@@ -212,6 +212,8 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, nor
                 and (gamma is None or (gamma.dtype == torch.float16 and gamma.is_contiguous() and gamma.numel() == k
                                        and gamma.device == input.device))):
             return _gemv_glu8_launch(input, gamma, norm[1] if norm is not None else 0.0, weight, scale, bias, n, k)
+        if (2 <= rows <= 16 and path == "auto" and input.shape[-1] == k and input.is_cuda and input.dtype == torch.float16):
+            return _gemm_glu8_launch(input, norm, weight, scale, bias, rows, n, k)
         return silu_mul(w8_a16_gemm(input, weight, scale, path, bias, None, norm), glu8=True)
     if activation not in _ACTS:
         raise RuntimeError("unknown activation %r (identity, relu, gelu, silu; silu_glu8 for gated weights)" % (activation,))
@@ -245,6 +247,27 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, nor
         layernorm_forward(input if input.is_contiguous() else input.contiguous(), gamma, normed, eps)
         input = normed
     return _gemm_launch(input, weight, scale, output, m, n, k, _PATHS[path], bias, residual, act)
+
+
+@_eager_only
+def _gemm_glu8_launch(input, norm, weight, scale, bias, rows, n, k):
+    if weight.dtype != torch.int8 or scale.dtype != torch.float16 or not weight.is_contiguous():
+        raise RuntimeError("w8_a16_gemm: weight must be contiguous int8 and scale float16")
+    for t in (weight, scale) + ((bias,) if bias is not None else ()):
+        if t.device != input.device:
+            raise RuntimeError("w8_a16_gemm: all tensors must be on the input's device")
+    if bias is not None and (bias.dtype != torch.float16 or bias.numel() != n or not bias.is_contiguous()):
+        raise RuntimeError("w8_a16_gemm: bias must be a contiguous float16 [N] tensor")
+    x = input if input.is_contiguous() else input.contiguous()
+    if norm is not None:
+        normed = torch.empty_like(x)
+        layernorm_forward(x, norm[0], normed, norm[1])
+        x = normed
+    output = torch.empty(tuple(input.shape[:-1]) + (n // 2,), dtype=input.dtype, device=input.device)
+    with torch.cuda.device(input.device):
+        check(_lib.lib().eetq_w8a16_gemm_glu8(_ptr(x), _ptr(weight), _ptr(scale), _ptr(bias) if bias is not None else None,
+                                              _ptr(output), rows, n, k, _stream_ptr()))
+    return output
 
 
 @_eager_only

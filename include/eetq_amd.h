@@ -183,6 +183,9 @@ int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate
  *     such a weight; gate_up [rows][2 * intermediate] dense, intermediate % 8 == 0. */
 int eetq_w8a16_gemv_glu8(const void* x, const void* gamma, float eps, const int8_t* w_packed, const void* scales,
                          const void* bias, void* y, int N, int K, void* stream);
+/*   eetq_w8a16_gemm_glu8: the same for 1 <= M <= 16 rows (batched decode; no norm prologue): y [M][N / 2]. */
+int eetq_w8a16_gemm_glu8(const void* x, const int8_t* w_packed, const void* scales, const void* bias, void* y, int M, int N,
+                         int K, void* stream);
 int eetq_silu_mul_glu8_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream);
 
 /* Decode-step rotary + KV-cache write (extension for the EET attention blocks): one new token per batch row b, rotated
