@@ -489,6 +489,17 @@ int eetq_diag_attn_stamps(unsigned long long* stamps)
     return EETQ_OK;
 }
 
+int eetq_decode_attention_splits(int batch, int heads, int positions)
+{
+    if (batch <= 0 || heads <= 0 || positions <= 0) return 1;
+    const long bh     = (long)batch * heads;
+    const long target = (15L * device_cu_count() / 8 + bh / 2) / bh;  // round(1.875 * CUs / (batch * heads))
+    long       splits = target < 8 ? target : 8;
+    const long cap    = ((long)positions + 63) / 64;
+    if (splits > cap) splits = cap;
+    return (int)(splits < 1 ? 1 : splits);
+}
+
 int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_cache, const void* mask, void* out,
                               float* workspace, int batch, int heads, int kv_heads, int positions, int head_dim,
                               int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,

@@ -189,7 +189,7 @@ Tensor rope_decode_attention(const Tensor& positions, const Tensor& query, const
                         "rope_decode_attention: kv_len / advance must be a one-element int64 tensor on the query's device");
     const double sc = scaling ? *scaling : 1.0 / std::sqrt((double)D);
     int64_t      splits = splits_in ? *splits_in
-                                    : std::max<int64_t>(1, std::min<int64_t>((S + 63) / 64, std::max<int64_t>(1, 1024 / (B * H))));
+                                    : (int64_t)eetq_decode_attention_splits((int)B, (int)H, (int)S);
     Tensor       out = torch::empty({B, H, D}, query.options());
     Tensor       ws  = torch::empty({B * H * splits * (D + 4)}, query.options().dtype(at::kFloat));
     const long   strides[12] = {(long)query.stride(0),       (long)key.stride(0),         (long)value.stride(0),
@@ -516,7 +516,7 @@ Tensor decode_attention(const Tensor& query, const Tensor& key_cache, const Tens
                         "decode_attention: kv_len / advance must be a one-element int64 tensor on the query's device");
     const double  sc = scaling ? *scaling : 1.0 / std::sqrt((double)D);
     int64_t       splits = splits_in ? *splits_in
-                                     : std::max<int64_t>(1, std::min<int64_t>((S + 63) / 64, std::max<int64_t>(1, 1024 / (B * H))));
+                                     : (int64_t)eetq_decode_attention_splits((int)B, (int)H, (int)S);
     Tensor        out = torch::empty({B, H, D}, query.options());
     Tensor        ws  = torch::empty({B * H * splits * (D + 4)}, query.options().dtype(at::kFloat));
     const long    strides[11] = {(long)query.stride(0),       (long)query.stride(1),       (long)key_cache.stride(0),
@@ -606,7 +606,7 @@ Tensor llama_decode_layer(const Tensor& hidden, const NormArg& input_norm, const
                         "llama_decode_layer: mask must be one additive float16 row of at least S entries");
             mrow = mask->data_ptr();
         }
-        const int64_t splits = std::max<int64_t>(1, std::min<int64_t>((S + 63) / 64, std::max<int64_t>(1, 1024 / heads)));
+        const int64_t splits = eetq_decode_attention_splits(1, (int)heads, (int)S);
         // fp16 scratch: qkv | attention output | gate|up | activation ; fp32 scratch: the attention chunk records
         const int64_t n16 = NQ + heads * D + I2 + I, n32 = heads * splits * (D + 4);
         Tensor  scratch = torch::empty({n16 * 2 + n32 * 4 + 16}, hidden.options().dtype(at::kByte));

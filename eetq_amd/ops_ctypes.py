@@ -443,8 +443,8 @@ def decode_attention(query, key_cache, value_cache, mask=None, scaling=None, spl
             raise RuntimeError("decode_attention: %s must be a one-element int64 tensor on the query's device" % name)
     if scaling is None:
         scaling = D ** -0.5
-    if splits is None:  # enough workgroups to cover the chip a few times over, at least 64 positions per chunk
-        splits = max(1, min((S + 63) // 64, max(1, 1024 // (B * H))))
+    if splits is None:  # the library's tuned default (about two workgroups per CU, at most 8 chunks)
+        splits = _lib.lib().eetq_decode_attention_splits(B, H, S)
     out = torch.empty((B, H, D), dtype=torch.float16, device=query.device)
     ws = torch.empty((B * H * splits * (D + 4),), dtype=torch.float32, device=query.device)
     strides = (ctypes.c_long * 11)(query.stride(0), query.stride(1), key_cache.stride(0), key_cache.stride(1),
@@ -509,7 +509,7 @@ def rope_decode_attention(positions, query, key, value, cos_sin_cache, key_cache
     if scaling is None:
         scaling = D ** -0.5
     if splits is None:
-        splits = max(1, min((S + 63) // 64, max(1, 1024 // (B * H))))
+        splits = _lib.lib().eetq_decode_attention_splits(B, H, S)
     out = torch.empty((B, H, D), dtype=torch.float16, device=query.device)
     ws = torch.empty((B * H * splits * (D + 4),), dtype=torch.float32, device=query.device)
     strides = (ctypes.c_long * 12)(query.stride(0), key.stride(0), value.stride(0), key_cache.stride(0),

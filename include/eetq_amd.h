@@ -216,6 +216,11 @@ int eetq_decode_attention_f16(const void* q, const void* k_cache, const void* v_
                               int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
                               int64_t* advance, void* stream);
 
+/* The chunk count both decode-attention entry points are tuned for (callers size the workspace with it): about two
+ * workgroups per compute unit over batch * heads * splits, at most 8, at least 64 cache rows per chunk.  Measured at Llama-13B
+ * shapes (tools/attn_bench.py): batch 1 -> 8, batch 2 -> 6, batch 4 -> 3. */
+int eetq_decode_attention_splits(int batch, int heads, int positions);
+
 /* Decode step of a pre-allocated KV cache as ONE launch (extension): eetq_rotary_neox_kvcache_f16 followed by
  * eetq_decode_attention_f16, bit-identical to that pair in the cache rows written and in the output.  The new token's q
  * [batch][heads][head_dim] and k [batch][kv_heads][head_dim] are rotated by cos_sin_cache[positions[b]] (rot_dim =

@@ -77,7 +77,7 @@ if args.stamps:
     import ctypes
     from eetq_amd import _lib
     lib = _lib.lib()
-    splits = max(1, min((S + 63) // 64, max(1, 1024 // (B * H))))
+    splits = lib.eetq_decode_attention_splits(B, H, S)
     if args.splits.split(',')[0].isdigit():
         splits = int(args.splits.split(',')[0])
     nwg = B * H * splits
