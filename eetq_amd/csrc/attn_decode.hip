@@ -107,8 +107,14 @@ __device__ __forceinline__ void attn_chunk(const f16x8& qv, float scaling, KvTri
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = 0.f;
 
+    // Trips are software-pipelined: the next trip's rows are requested (clamped to the chunk: unconditional loads, never
+    // behind a branch) before the current trip is consumed, so a chunk of several trips pays the memory latency once.  The
+    // last iteration's request is wasted (one clamped row).
     constexpr int STEP = (kAttnThreads / 64) * PPW;
+    KvTrip<D>     nxt;
     for (int jb = j0 + wave * PPW;;) {
+        const int jn = jb + U * STEP;
+        load_trip<D>(nxt, kbase, vbase, k_ss, v_ss, jn, j1);
         float sc[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -140,9 +146,9 @@ __device__ __forceinline__ void attn_chunk(const f16x8& qv, float scaling, KvTri
             }
             m = mn;
         }
-        jb += U * STEP;
-        if (jb >= j1) break;  // wave-uniform
-        load_trip<D>(t, kbase, vbase, k_ss, v_ss, jb, j1);
+        if (jn >= j1) break;  // wave-uniform
+        t  = nxt;
+        jb = jn;
     }
     const int set = wave * PPW + grp;
     if (li == 0) {
