@@ -13,9 +13,11 @@ __all__ = ["GraphDecoder"]
 
 
 class GraphDecoder:
-    def __init__(self, model, batch, max_len, capture=True):
+    def __init__(self, model, batch, max_len, capture=True, lean=True):
         """``max_len``: cache rows (prompt + new tokens).  ``capture=False`` keeps the same static-cache stepping but runs
-        every step eagerly (used to check the graph against the launches it was captured from)."""
+        every step eagerly (used to check the graph against the launches it was captured from).  ``lean``: step fully
+        accelerated models layer by layer instead of through the stock model forward (see ``_lean``)."""
+        self.lean = bool(lean)
         from transformers import StaticCache
         self.model = model
         self.batch = int(batch)
@@ -46,8 +48,27 @@ class GraphDecoder:
                     self.s_out = self._step()
         self.cache.reset()
 
+    def _lean(self):
+        """True when every decoder layer is an accelerated one (eet_accelerator with fused_attn / fused_mlp / fused_residual):
+        those read positions and the cache's own token counter and need neither the causal mask nor the cos / sin tensors
+        the stock ``LlamaModel.forward`` builds on every step (~20 small launches per token)."""
+        base = getattr(self.model, "model", None)
+        layers = getattr(base, "layers", None)
+        return (self.lean and layers is not None and len(layers) > 0 and hasattr(base, "embed_tokens") and hasattr(base, "norm")
+                and hasattr(self.model, "lm_head") and all(getattr(l, "fused_layer_step", False) for l in layers))
+
     def _step(self):
-        lg = self.model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True).logits
+        if self._lean():
+            base = self.model.model
+            h = base.embed_tokens(self.s_tok)
+            pos = self.s_pos.view(1, 1).expand(self.batch, 1)
+            for layer in base.layers:
+                h = layer(h, attention_mask=None, position_ids=pos, past_key_values=self.cache, use_cache=True)
+                if isinstance(h, tuple):
+                    h = h[0]
+            lg = self.model.lm_head(base.norm(h))
+        else:
+            lg = self.model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True).logits
         return lg[:, -1].argmax(-1, keepdim=True)
 
     @torch.no_grad()

@@ -206,3 +206,24 @@ def test_compiled_layer_step_equals_python_blocks(ops, width):
                              cache_implementation="static")
     assert out.shape == ref.shape and torch.equal(out[:, :P + 1], ref[:, :P + 1])
     assert (out[:, P:] == ref[:, P:]).float().mean().item() > 0.5
+
+
+def test_graph_decoder_lean_step_equals_model_forward(ops):
+    """The graph decoder steps a fully accelerated model layer by layer (no causal mask, no cos / sin tensors per step);
+    tokens must equal the ones it produces through the stock model forward, captured or not."""
+    from eetq_amd.utils import GraphDecoder, eet_accelerator
+    if ops.BOUNDARY != "ext":
+        pytest.skip("the layer step lives in the compiled module")
+    model = eet_accelerator(_model_13b_width(), quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True,
+                            fused_residual=True)
+    P, NEW = 200, 12
+    with torch.no_grad():
+        for B in (1, 2):
+            g = torch.Generator().manual_seed(7 + B)
+            prompt = torch.randint(0, 32000, (B, P), generator=g).to(DEV)
+            lean = GraphDecoder(model, B, P + NEW + 8)
+            assert lean._lean()
+            a = lean.generate(prompt, NEW)
+            b = GraphDecoder(model, B, P + NEW + 8, lean=False).generate(prompt, NEW)
+            c = GraphDecoder(model, B, P + NEW + 8, capture=False).generate(prompt, NEW)
+            assert torch.equal(a, b) and torch.equal(a, c), B
