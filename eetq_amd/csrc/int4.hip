@@ -190,33 +190,53 @@ __global__ __launch_bounds__(256) void expand_i4_to_i8_kernel(const u32x4* __res
     dst[tile8 * 64 + lane8b] = u32x4{o[4], o[5], o[6], o[7]};
 }
 
-// per-device scratch for the expanded weight (grown on demand; creating or growing it is not capturable)
+// Scratch for the expanded weight: one buffer per (device, stream) -- launches that run concurrently on one device come from
+// different streams and must not share it -- grown on demand (creating or growing one is not capturable).  kStreamsPerDevice
+// streams per device get their own; further streams share the last slot (their calls are then serialised by a device
+// synchronisation whenever the slot changes hands).
 struct Scratch {
-    uint8_t* p     = nullptr;
-    size_t   bytes = 0;
+    uint8_t*    p      = nullptr;
+    size_t      bytes  = 0;
+    hipStream_t stream = nullptr;
+    bool        used   = false;
 };
-std::mutex g_mutex;
-Scratch    g_scratch[64];
+constexpr int kStreamsPerDevice = 8;
+std::mutex    g_mutex;
+Scratch       g_scratch[64][kStreamsPerDevice];
 
 int expanded_scratch(size_t bytes, hipStream_t stream, uint8_t** out)
 {
     int dev = 0;
     EETQ_TRY_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_mutex);
-    Scratch&                    s = g_scratch[dev & 63];
-    if (s.bytes < bytes) {
-        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
+    Scratch* slots = g_scratch[dev & 63];
+    Scratch* s     = nullptr;
+    for (int i = 0; i < kStreamsPerDevice && !s; ++i)
+        if (slots[i].used && slots[i].stream == stream) s = &slots[i];
+    for (int i = 0; i < kStreamsPerDevice && !s; ++i)
+        if (!slots[i].used) s = &slots[i];
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    const bool capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+    if (!s) {  // more streams than slots: the last slot changes hands (whoever used it may still be reading it)
+        if (capturing)
+            return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16 prefill: too many streams on this device for graph capture");
+        s = &slots[kStreamsPerDevice - 1];
+        EETQ_TRY_HIP(hipDeviceSynchronize());
+    }
+    if (s->bytes < bytes) {
+        if (capturing)
             return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] the W4A16 prefill scratch cannot grow during graph capture: run "
                                               "the shape once eagerly first");
         EETQ_TRY_HIP(hipDeviceSynchronize());  // earlier launches may still read the old buffer
-        if (s.p) EETQ_TRY_HIP(hipFree(s.p));
-        s.p     = nullptr;
-        s.bytes = 0;
-        EETQ_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&s.p), bytes));
-        s.bytes = bytes;
+        if (s->p) EETQ_TRY_HIP(hipFree(s->p));
+        s->p     = nullptr;
+        s->bytes = 0;
+        EETQ_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&s->p), bytes));
+        s->bytes = bytes;
     }
-    *out = s.p;
+    s->used   = true;
+    s->stream = stream;
+    *out      = s->p;
     return EETQ_OK;
 }
 

@@ -158,3 +158,27 @@ def test_w4a16_linear_module(ops, oracle):
     qp, s = oracle.quantize_i4(lin.weight.detach().t().contiguous().cpu().numpy())
     want = oracle.w8a16_gemm(x.cpu().numpy(), oracle.i4_values(qp), s).astype(np.float32) + lin.bias.detach().cpu().numpy().astype(np.float32)
     assert np.abs(y.cpu().numpy().astype(np.float32) - want).max() < 3e-3
+
+
+def test_w4a16_expansion_route_on_concurrent_streams(ops, oracle):
+    """M > 16 expands the nibbles into a library-owned buffer: launches on different streams must not share it.  Two streams,
+    two different weights, interleaved many times: every result equals the one computed alone."""
+    rng = np.random.default_rng(9)
+    K, N, M = 2048, 1024, 96
+    ws, ss, refs = [], [], []
+    x = torch.from_numpy((rng.random((M, K)) - 0.5).astype(np.float16)).to(DEV)
+    for i in range(2):
+        qp = rng.integers(-128, 128, (K, N // 2), dtype=np.int8)
+        ws.append(torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV))
+        ss.append(torch.from_numpy((rng.random(N) * 0.02 + 0.001).astype(np.float16)).to(DEV))
+        refs.append(ops.w8_a16_gemm(x, ws[i], ss[i]).clone())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[], []]
+    for it in range(40):
+        for i in range(2):
+            with torch.cuda.stream(streams[i]):
+                outs[i].append(ops.w8_a16_gemm(x, ws[i], ss[i]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert all(torch.equal(o, refs[i]) for o in outs[i]), i
