@@ -62,7 +62,8 @@ enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SIL
  * for an all-zero column.  q_raw (ROW_MAJOR) and q_packed (in `layout`) may each be NULL.
  * All pointers are DEVICE pointers.  `scales` has dtype `w_dtype` and N elements.
  * `workspace` must provide N floats (device); pass NULL to let the library use an internal buffer
- * (allocated once per device and grown on demand). */
+ * (one per device, allocated once and grown on demand: calls that pass NULL must not overlap on one device --
+ * concurrent streams bring their own workspace, as both Python bindings do). */
 int eetq_quantize_i8(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
                      int layout, void* scales, float* workspace, void* stream);
 
