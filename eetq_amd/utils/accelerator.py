@@ -170,61 +170,7 @@ def replace_with_eet_fused_residual(model):
             m._step_weights = None
             m.forward = types.MethodType(forward, m)
             n += 1
-    _install_lean_model_step(model)
     return n
-
-
-def _install_lean_model_step(model):
-    """Single-token steps of a fully accelerated Llama on an initialised static cache skip what the stock
-    ``LlamaModel.forward`` prepares for stock layers on every step and the accelerated layers never read: the 4-D causal
-    mask (they bound the attended rows by the cache's own token counter and take a padding mask as [B, S] rows) and the
-    cos / sin tensors (they index their own fp16 table by position).  ~15 small launches and ~0.25 ms of host time per
-    token.  Anything else (prompts, dynamic caches, hidden-state / attention outputs, inputs_embeds) takes the stock forward."""
-    base = getattr(model, "model", None)
-    layers = getattr(base, "layers", None)
-    if (base is None or type(base).__name__ != "LlamaModel" or not layers or getattr(base, "_eet_lean_step", False)
-            or not all(getattr(l, "fused_layer_step", False) for l in layers)
-            or not all(hasattr(base, a) for a in ("embed_tokens", "norm"))):
-        return False
-    try:
-        from transformers.modeling_outputs import BaseModelOutputWithPast
-    except Exception:  # noqa: BLE001
-        return False
-    stock = base.forward
-
-    def forward(self, input_ids=None, attention_mask=None, position_ids=None, past_key_values=None, inputs_embeds=None,
-                use_cache=None, **kwargs):
-        first = self.layers[0].self_attn
-        if (self.lean_decode_step and input_ids is not None and inputs_embeds is None and input_ids.dim() == 2
-                and input_ids.shape[1] == 1 and position_ids is not None and past_key_values is not None
-                and not kwargs.get("output_attentions") and not kwargs.get("output_hidden_states")
-                and (attention_mask is None or attention_mask.dim() == 2)):
-            cache_layer = first._static_cache_layer(past_key_values)
-            if cache_layer is not None and all(l.fused_layer_step and l.self_attn.fused_decode_step
-                                               and l.self_attn.decode_math_attention is True for l in self.layers):
-                rows = cache_layer.keys.shape[2]
-                mask = attention_mask
-                if mask is not None and mask.shape[-1] < rows:
-                    # [B, L] keep flags of the tokens so far -> additive rows over the whole cache (rows beyond L are never
-                    # attended: the kernels stop at the cache's token counter)
-                    add = torch.zeros(mask.shape[0], rows, dtype=torch.float16, device=mask.device)
-                    add[:, : mask.shape[-1]].masked_fill_(mask == 0, float("-inf"))
-                    mask = add
-                h = self.embed_tokens(input_ids)
-                # the layers accept what the attention block's own conversion accepts; anything else: stock path
-                add = first._decode_mask_rows(mask, h.shape[0], rows, h.dtype, h.device) if h.dtype == torch.float16 else False
-                if add is not False:
-                    for layer in self.layers:
-                        h = layer(h, attention_mask=add, position_ids=position_ids, past_key_values=past_key_values,
-                                  use_cache=use_cache)
-                    return BaseModelOutputWithPast(last_hidden_state=self.norm(h), past_key_values=past_key_values)
-        return stock(input_ids=input_ids, attention_mask=attention_mask, position_ids=position_ids,
-                     past_key_values=past_key_values, inputs_embeds=inputs_embeds, use_cache=use_cache, **kwargs)
-
-    base.lean_decode_step = True
-    base._eet_lean_step = True
-    base.forward = types.MethodType(forward, base)
-    return True
 
 
 def eet_accelerator(model, quantize=False, fused_attn=False, dev="cuda:0", fused_mlp=False, fused_norm=False,

@@ -227,34 +227,3 @@ def test_graph_decoder_lean_step_equals_model_forward(ops):
             b = GraphDecoder(model, B, P + NEW + 8, lean=False).generate(prompt, NEW)
             c = GraphDecoder(model, B, P + NEW + 8, capture=False).generate(prompt, NEW)
             assert torch.equal(a, b) and torch.equal(a, c), B
-
-
-def test_lean_model_step_equals_stock_forward_under_generate(ops):
-    """eet_accelerator installs a model-level step that skips the per-step causal mask and cos / sin tensors for single-token
-    steps on a static cache.  transformers' own generate (static cache, no compile) must produce the same tokens with it
-    switched off, for one prompt and for a left-padded batch of two."""
-    transformers = pytest.importorskip("transformers")
-    from eetq_amd.utils import eet_accelerator
-    if ops.BOUNDARY != "ext":
-        pytest.skip("the layer step lives in the compiled module")
-    cfg = transformers.LlamaConfig(hidden_size=1024, intermediate_size=2816, num_hidden_layers=3, num_attention_heads=16,
-                                   num_key_value_heads=4, vocab_size=1000, max_position_embeddings=512)
-    torch.manual_seed(11)
-    model = transformers.LlamaForCausalLM(cfg).half().to(DEV).eval()
-    model = eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True, fused_residual=True,
-                            static_cache=True)
-    assert model.model.lean_decode_step is True
-    g = torch.Generator().manual_seed(3)
-    one = torch.randint(1, 1000, (1, 40), generator=g).to(DEV)
-    two = torch.randint(1, 1000, (2, 40), generator=g).to(DEV)
-    mask2 = torch.ones_like(two)
-    mask2[1, :13] = 0                       # left padding on the second row
-    two[1, :13] = 0
-    kw = dict(max_new_tokens=12, min_new_tokens=12, do_sample=False, pad_token_id=0)
-    outs = {}
-    with torch.no_grad():
-        for lean in (True, False):
-            model.model.lean_decode_step = lean
-            outs[lean] = (model.generate(one, **kw), model.generate(two, attention_mask=mask2, **kw))
-    assert torch.equal(outs[True][0], outs[False][0])
-    assert torch.equal(outs[True][1], outs[False][1])
