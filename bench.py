@@ -22,6 +22,8 @@ A "step" is one w8_a16_gemm call (one pass of the decode hot path over one batch
              roofline.gemm_m1024: the other half of the metric, fused dequant-GEMM at M=1024 (MFMA roofline).
   cpu_baseline  the oracle's scalar C port of the same GEMV on one host core (bounded sample); beside it
              (cpu_linear_fp16) the north star's CPU torch.nn.Linear fp16 forward, best over a sweep of thread counts.
+  config5    BASELINE configs[4] on the same box (skip with --no-config5): Llama-2-13B shapes, prompt 1024 + 50 new tokens,
+             one replica per GPU, whole-job tokens/s.  Reported beside the headline, never as `value`.
 Multi-GPU: replicas only (model replicated, no data-path collective); rank 0 fans the activations out with one
 broadcast, results are checked to be bit-identical across replicas.  scaling = "weak".
 """
@@ -172,6 +174,50 @@ def load_traffic():
         return {}
 
 
+def config5_leg(grp, prompt_len=1024, new_tokens=50):
+    """BASELINE configs[4] on every replica: random-init Llama-2-13B shapes (no checkpoints offline), eet_accelerator with
+    W8A16 everywhere, identical prompt fanned out from rank 0, greedy decode of 50 tokens through the HIP-graph decoder.
+    Whole-job tokens/s = replicas x 50 / MAX over ranks of the end-to-end time (prefill + decode).  None when transformers
+    is not importable."""
+    try:
+        import transformers
+        from eetq_amd.utils import GraphDecoder, eet_accelerator
+    except Exception as e:  # noqa: BLE001
+        return {"skipped": "transformers / accelerator not importable: %s" % (str(e)[:80],)}
+    dev = grp.device
+    cfg = transformers.LlamaConfig(hidden_size=5120, intermediate_size=13824, num_hidden_layers=40, num_attention_heads=40,
+                                   num_key_value_heads=40, vocab_size=32000, max_position_embeddings=4096)
+    torch.manual_seed(0)
+    old = torch.get_default_dtype()
+    torch.set_default_dtype(torch.float16)
+    try:
+        with torch.device(dev):
+            model = transformers.LlamaForCausalLM(cfg).eval()
+    finally:
+        torch.set_default_dtype(old)
+    eet_accelerator(model, quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True, fused_residual=True)
+    prompt = torch.randint(0, 32000, (1, prompt_len), generator=torch.Generator().manual_seed(1)).to(dev)
+    grp.fan_out(prompt)
+    holder = {}
+    with torch.no_grad():
+        dec = GraphDecoder(model, 1, prompt_len + new_tokens + 8)
+        dec.generate(prompt[:, :64], 4)   # warm-up (allocations, kernel selection)
+        torch.cuda.synchronize()
+
+        def run():
+            holder["out"] = dec.generate(prompt, new_tokens)
+        secs = grp.timed(run)
+        t_prefill = grp.timed(lambda: model(prompt))
+    crcs = grp.gather_checksums(holder["out"][:, prompt_len:].to(torch.int32))
+    res = {"workload": "Llama-2-13B shapes (random init), eet_accelerator W8A16, prompt %d + %d new tokens, batch 1 per replica, "
+                       "HIP-graph greedy decode" % (prompt_len, new_tokens),
+           "tokens_per_s": round(grp.world_size * new_tokens / secs, 2), "end_to_end_s": round(secs, 4),
+           "prefill_s": round(t_prefill, 4), "replicas": grp.world_size, "replicas_identical_tokens": len(set(crcs)) == 1}
+    del dec, model
+    torch.cuda.empty_cache()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -181,6 +227,8 @@ def main():
     ap.add_argument("--min-timed-ms", type=float, default=50.0, help="minimum length of every timed region")
     ap.add_argument("--gemm-steps", type=int, default=200)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-config5", action="store_true",
+                    help="skip the BASELINE configs[4] leg (Llama-2-13B shapes, prompt 1024 + 50 new tokens, one replica per GPU)")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
 
@@ -336,6 +384,13 @@ def main():
                       "sweep_m1_ms": {str(t): round(v * 1e3, 2) for t, v in s1.items()},
                       "sweep_m1024_ms": {str(t): round(v * 1e3, 2) for t, v in s1024.items()}}
 
+    # ---- BASELINE configs[4]: the whole decode path on the same box (reported beside the headline, never as `value`) ----
+    config5 = None
+    if not args.no_config5:
+        del graphs, ggraphs   # the 640 MiB of weight sets stay (captured by the step closures); 13 GB more is no issue
+        torch.cuda.empty_cache()
+        config5 = config5_leg(grp)
+
     if grp.rank == 0:
         line = {
             "metric": "w8a16 GEMV GB/s @ M=1 and dequant-GEMM TFLOPS @ M=1024, N=K=4096",
@@ -349,7 +404,7 @@ def main():
                                  % (len(graphs), steps, replays, timed_steps, seconds * 1e3),
                        "timed_steps": timed_steps, "timed_ms": round(seconds * 1e3, 3)},
             "roofline": roofline, "secondary": gemm, "cpu_baseline": cpu_baseline, "cpu_linear_fp16": cpu_linear,
-            "parity": parity,
+            "parity": parity, "config5": config5,
         }
         print(json.dumps(line))
     grp.close()

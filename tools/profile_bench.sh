@@ -22,7 +22,7 @@ $PY bench.py "$@" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || echo 
 
 echo "== 2. rocprofv3 --kernel-trace --stats of the same command" >&2
 rm -rf /tmp/prof_bench
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- $PY "$ROOT/bench.py" "$@" --no-cpu-baseline \
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- $PY "$ROOT/bench.py" "$@" --no-cpu-baseline --no-config5 \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_rocprof.err" ) || echo "rocprofv3 stats run failed" >&2
 STATS=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1)
 if [ -n "$STATS" ]; then
