@@ -387,9 +387,7 @@ def main():
     # ---- BASELINE configs[4]: the whole decode path on the same box (reported beside the headline, never as `value`) ----
     config5 = None
     if not args.no_config5:
-        del graphs, ggraphs   # the 640 MiB of weight sets stay (captured by the step closures); 13 GB more is no issue
-        torch.cuda.empty_cache()
-        config5 = config5_leg(grp)
+        config5 = config5_leg(grp)   # (the 640 MiB of weight sets stay resident; 13 GB more is no issue on 288 GB)
 
     if grp.rank == 0:
         line = {
