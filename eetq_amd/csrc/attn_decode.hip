@@ -10,14 +10,15 @@
 //            group of D/8 lanes owns one position at a time (16-byte loads of its k and v rows, fully coalesced across the
 //            wave), keeps an online-softmax state (m, l) and 8 output channels per lane; groups and waves are merged
 //            through LDS and the chunk's (m, l, o[D]) goes to an fp32 workspace;
-//   phase 2  grid (heads, batch), D threads: merges the chunks, normalises, writes fp16.
+//   phase 2  grid (heads, batch), 256 threads: merges the chunks (attn_merge), normalises, writes fp16.
 // One-launch form (eetq_rope_decode_attention_f16), the decode step of a static cache: the same phase 1 with the NeoX
 // rotation of the new token's q and k done in registers on the way in (the arithmetic of rotary_neox_kvcache_kernel, fp16
 // with a rounding after every multiply and add), the rotated k and the v written to their cache row by one workgroup per
 // kv head, every workgroup taking the new row from registers rather than from the cache (so nothing in the launch reads
 // what the launch writes), and phase 2 done by whichever workgroup of a head finishes last: partials are published with
 // write-through stores, a ticket per head decides "last" (the in-launch hand-off of gemm_splitk_kernel.hpp), and the last
-// head to finish advances the cache's token counter.  Three launches and ~10 us per layer become one.  Both forms run the
+// head to finish advances the cache's token counter.  Three launches (15.0 us per layer at 13B shapes, 1 k rows) become one
+// (10.9 us).  Both forms run the
 // same chunk code and the same merge arithmetic: their outputs are bit-identical.
 #include <type_traits>
 
