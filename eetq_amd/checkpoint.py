@@ -9,7 +9,12 @@ layout, called ``sm80`` here), tagged only by ``quantization_config = {"quant_me
 * **on disk the weights are kept in the reference's layout** ("wire layout", default ``sm80``): every quantised module
   carries a ``state_dict`` hook that re-encodes its int8 buffer gfx950 -> wire on the way out and a ``load_state_dict``
   pre-hook that re-encodes wire -> gfx950 on the way in.  A checkpoint written here loads in CUDA-EETQ and vice versa,
-  with no extra keys.  In memory (and in ``torch.save(model)`` pickles) the buffers stay gfx950.
+  with no extra keys.  In memory (and in ``torch.save(model)`` pickles, which keep working: the hooks are module-level
+  callables) the buffers stay gfx950.  The layout of the bytes is recorded IN BAND, in the state dict's ``_metadata``
+  entry of the module (next to nn.Module's ``version``; it survives ``torch.save(state_dict)`` and adds no key), and the
+  load hook trusts that tag first: a state dict saved under ``wire_layout("gfx950")`` loads correctly whatever the
+  process-wide setting is at load time.  Untagged dicts (safetensors files, reference-written checkpoints) are read as the
+  module's ``checkpoint_layout`` pin or the process-wide wire layout -- "sm80" unless told otherwise.
 * shapes the reference's layout cannot hold (it needs K % 64 == 0 and N % 64 == 0; the reference cannot quantise such
   layers at all) pass through both hooks unchanged.
 * :func:`set_wire_layout` / :func:`wire_layout` choose the layout for a process or a block (``"gfx950"`` = store native
@@ -26,7 +31,8 @@ import os
 
 import torch
 
-__all__ = ["set_wire_layout", "get_wire_layout", "wire_layout", "install_layout_hooks", "convert_model_layout_",
+__all__ = ["set_wire_layout", "get_wire_layout", "wire_layout", "set_state_dict_device", "install_layout_hooks",
+           "convert_model_layout_",
            "convert_checkpoint", "quantization_config", "checkpoint_layout", "QUANTIZED_WEIGHT_NAMES"]
 
 _LAYOUTS = ("sm80", "gfx950")
@@ -74,28 +80,70 @@ def _reencode(tensor, src, dst):
     return convert_layout(tensor.contiguous(), src, dst)
 
 
+def _offload(t):
+    """state_dict() entries re-encoded to the wire layout are NEW tensors (the live buffer stays gfx950); with
+    ``set_state_dict_device("cpu")`` they are moved to host memory one by one, so taking the state dict of a large model
+    does not hold a second device copy of every int8 weight."""
+    return t.to(_sd_device[0]) if _sd_device[0] is not None else t
+
+
+_sd_device = [None]
+_META_KEY = "eetq_layout"   # in-band layout tag: state_dict()._metadata[<module path>]["eetq_layout"]
+
+
+def set_state_dict_device(device):
+    """Where the re-encoded int8 tensors of ``state_dict()`` live: None (default) = next to the module's buffers,
+    "cpu" = offloaded tensor by tensor (bounds device memory while saving)."""
+    _sd_device[0] = device
+
+
+class _SaveHook:
+    """state_dict hook (a module-level class, so modules that carry it stay picklable: ``torch.save(model)`` works).
+    Re-encodes the int8 buffer gfx950 -> wire and records, in the state dict's ``_metadata`` entry of the module (the
+    dict nn.Module keeps its ``version`` in; it travels with ``torch.save(state_dict)`` and adds no key), which layout
+    the bytes are in -- "gfx950" for shapes the reference's layout cannot hold."""
+
+    def __init__(self, weight_name):
+        self.weight_name = weight_name
+
+    def __call__(self, mod, state_dict, prefix, local_metadata):
+        key = prefix + self.weight_name
+        t = state_dict.get(key)
+        if t is None or t.dtype != torch.int8 or not t.numel():
+            return
+        dst = _wire[0] if _wire_holds(t.shape) else "gfx950"
+        if dst != "gfx950":
+            state_dict[key] = _offload(_reencode(t, "gfx950", dst))
+        if local_metadata is not None:   # the very dict stored at state_dict._metadata[prefix[:-1]]
+            local_metadata[_META_KEY] = dst
+
+
+class _LoadHook:
+    """load_state_dict pre-hook (picklable, see _SaveHook).  Source layout, in this order: the in-band tag written by
+    _SaveHook (present in ``torch.save``d state dicts of this library), the module's ``checkpoint_layout`` pin, the
+    process-wide wire layout (default "sm80" = what the reference writes; safetensors files and reference-written state
+    dicts carry no tag)."""
+
+    def __init__(self, weight_name):
+        self.weight_name = weight_name
+
+    def __call__(self, mod, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        key = prefix + self.weight_name
+        t = state_dict.get(key)
+        if t is None or not isinstance(t, torch.Tensor) or t.dtype != torch.int8 or not t.numel():
+            return
+        src = (local_metadata or {}).get(_META_KEY) or getattr(mod, "checkpoint_layout", None) or _wire[0]
+        state_dict[key] = _reencode(t, _check(src), "gfx950")
+
+
 def install_layout_hooks(module, weight_name):
     """Give ``module`` (whose int8 buffer is called ``weight_name``) the save / load re-encoding hooks described in the
-    module docstring.  Idempotent."""
+    module docstring.  Idempotent; the hooks are picklable."""
     if getattr(module, "_eetq_layout_hooks", False):
         return module
     module._eetq_layout_hooks = True
-
-    def on_save(mod, state_dict, prefix, local_metadata):
-        key = prefix + weight_name
-        t = state_dict.get(key)
-        if t is not None and t.dtype == torch.int8 and t.numel():
-            state_dict[key] = _reencode(t, "gfx950", _wire[0])
-
-    def on_load(mod, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
-        key = prefix + weight_name
-        t = state_dict.get(key)
-        if t is not None and isinstance(t, torch.Tensor) and t.dtype == torch.int8 and t.numel():
-            src = getattr(mod, "checkpoint_layout", None) or _wire[0]
-            state_dict[key] = _reencode(t, _check(src), "gfx950")
-
-    module._register_state_dict_hook(on_save)
-    module._register_load_state_dict_pre_hook(on_load, with_module=True)
+    module._register_state_dict_hook(_SaveHook(weight_name))
+    module._register_load_state_dict_pre_hook(_LoadHook(weight_name), with_module=True)
     return module
 
 

@@ -93,6 +93,42 @@ def test_wire_layout_switch_and_shapes_the_reference_cannot_hold(oracle):
     assert torch.equal(back(x), odd(x))
 
 
+def test_in_band_layout_tag_pickles_and_state_dict_device(tmp_path):
+    """(a) torch.save(state_dict) keeps the layout tag: a dict saved under wire_layout("gfx950") loads correctly under the
+    default setting (the tag, not the setting at load time, says what the bytes are); (b) torch.save(model) of a whole
+    quantised module round-trips; (c) set_state_dict_device("cpu") offloads the re-encoded tensors one by one."""
+    from eetq_amd.checkpoint import set_state_dict_device
+    from eetq_amd.modules.qlinear import W8A16Linear
+    from eetq_amd.utils import wire_layout
+    mod = W8A16Linear.from_torch(_linear(128, 64, True, 7))
+    x = torch.rand(3, 128, dtype=torch.float16, device=DEV)
+    y = mod(x)
+    with wire_layout("gfx950"):
+        torch.save(mod.state_dict(), tmp_path / "native.pt")
+    torch.save(mod.state_dict(), tmp_path / "wire.pt")
+    for name in ("native.pt", "wire.pt"):
+        sd = torch.load(tmp_path / name)
+        assert sd._metadata[""]["eetq_layout"] == ("gfx950" if name == "native.pt" else "sm80")
+        fresh = W8A16Linear(128, 64, bias=True, dev=DEV)
+        fresh.load_state_dict(sd)                       # default process-wide setting (sm80) in both cases
+        assert torch.equal(fresh.qweight, mod.qweight) and torch.equal(fresh(x), y)
+    torch.save(mod, tmp_path / "whole.pt")
+    whole = torch.load(tmp_path / "whole.pt", weights_only=False)
+    assert torch.equal(whole.qweight, mod.qweight) and torch.equal(whole(x), y)
+    again = W8A16Linear(128, 64, bias=True, dev=DEV)
+    again.load_state_dict(whole.state_dict())           # the hooks survived the pickle
+    assert torch.equal(again(x), y)
+    set_state_dict_device("cpu")
+    try:
+        sd = mod.state_dict()
+        assert sd["qweight"].device.type == "cpu" and sd["weight_scales"].device.type == "cuda"
+        fresh = W8A16Linear(128, 64, bias=True, dev=DEV)
+        fresh.load_state_dict(sd)
+        assert torch.equal(fresh(x), y)
+    finally:
+        set_state_dict_device(None)
+
+
 def test_model_round_trip_through_safetensors_and_convert_checkpoint(tmp_path, oracle):
     """eet_quantize -> save (safetensors, sm80 on disk + tagged config) -> init_only model + load -> same logits bit for
     bit; convert_checkpoint rewrites the directory to native bytes and back."""

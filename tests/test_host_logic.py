@@ -253,3 +253,40 @@ def test_glu8_fuse_layout_matches_packing_the_interleaved_matrix():
         assert np.array_equal(fused.reshape(K, 2 * I).numpy(), oracle.gfx950_pack(np.ascontiguousarray(raw)))
     s = _glu8_interleave_columns(torch.arange(32.), 100 + torch.arange(32.))
     assert s[:16].tolist() == list(range(8)) + list(range(100, 108))
+
+
+def test_quantised_modules_pickle_whole():
+    """torch.save(model) / torch.load of whole modules (the reference's examples do this: examples/layers/test_qlinear.py:44,
+    llama_transformers_example.py:49) -- the layout hooks are module-level callables, not closures."""
+    import io
+    from eetq_amd.modules.qlinear import EetqLinear, W8A16Linear
+    for mod in (W8A16Linear(64, 128, bias=True, dev="cpu"), EetqLinear(64, 128, bias=False, device="cpu")):
+        buf = io.BytesIO()
+        torch.save(mod, buf)
+        buf.seek(0)
+        back = torch.load(buf, weights_only=False)
+        assert type(back) is type(mod) and back.in_features == 64 and back.out_features == 128
+        assert len(back._state_dict_hooks) == 1 and len(back._load_state_dict_pre_hooks) == 1   # hooks travel with it
+        name = "qweight" if isinstance(mod, W8A16Linear) else "weight"
+        assert torch.equal(getattr(back, name), getattr(mod, name))
+
+
+def test_state_dict_layout_tag_is_in_band_and_wins_on_load():
+    """The save hook records the layout of the int8 bytes in the state dict's _metadata; the load hook trusts the tag
+    before the module pin and the process-wide setting (host logic only: shapes whose bytes pass through unchanged)."""
+    from eetq_amd.checkpoint import _LoadHook, _SaveHook
+    from eetq_amd.modules.qlinear import W8A16Linear
+    mod = W8A16Linear(48, 16, bias=False, dev="cpu")     # K % 64 != 0: the reference has no layout -> bytes pass through
+    mod.qweight.copy_(torch.arange(48 * 16).reshape(48, 16).to(torch.int8))
+    sd = mod.state_dict()
+    assert sd._metadata[""]["eetq_layout"] == "gfx950" and sd._metadata[""]["version"] == 1
+    other = W8A16Linear(48, 16, bias=False, dev="cpu")
+    other.load_state_dict(sd)
+    assert torch.equal(other.qweight, mod.qweight)
+    # an unknown tag is an error, not a silent pass-through
+    sd._metadata[""]["eetq_layout"] = "sm90"
+    with pytest.raises(ValueError):
+        W8A16Linear(48, 16, bias=False, dev="cpu").load_state_dict(sd)
+    assert isinstance(mod._state_dict_hooks[next(iter(mod._state_dict_hooks))], _SaveHook)
+    assert any(isinstance(getattr(h, "hook", h), _LoadHook) or isinstance(h, _LoadHook)
+               for h in mod._load_state_dict_pre_hooks.values())

@@ -1,0 +1,396 @@
+// Probe (no torch): what does a DEPENDENT chain of M = 1, N = K = 4096 W8A16 GEMVs (y of step e is x of step e + 1) cost
+// per step when the steps' weight streams are allowed to overlap?  Four forms of the same arithmetic, all checked bit for
+// bit against form A:
+//   A  one stream, one launch per step (what eetq_w8a16_gemm does today; the dependent-launch boundary is paid per step)
+//   B  one launch per step on TWO (or three) alternating capture streams: the graph has edges k(e) -> k(e+2) only; step
+//      e + 1 starts while step e runs, has its 64 KiB of weights per CU in flight, and waits for step e's completion
+//      counters (8 shards, one per XCD) before it reads x with L1-bypassing loads.
+//   P  ONE persistent launch for the whole chain (256 workgroups, one per CU): every step prefetches the next step's
+//      weights into a second register buffer, hand-off through the same counters.
+// Every spin is bounded (a stuck wait sets an error word and falls through), so the probe cannot hang the GPU.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16 tools/chain_probe.hip -o tools/chain_probe
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../eetq_amd/csrc/gemv_kernel.hpp"
+
+namespace eetq {
+void set_error(const std::string&) {}
+int  fail(int c, const std::string&) { return c; }
+int  check_hip(hipError_t e, const char*) { return e == hipSuccess ? 0 : -2; }
+ProfEvents next_prof_events() { return {}; }
+}  // namespace eetq
+
+#define CK(x)                                                                                      \
+    do {                                                                                           \
+        hipError_t e_ = (x);                                                                       \
+        if (e_ != hipSuccess) {                                                                    \
+            fprintf(stderr, "HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                               \
+        }                                                                                          \
+    } while (0)
+
+using namespace eetq;
+
+constexpr int      kShards     = 8;       // completion counters, one per XCD (block b runs on XCD b % 8: speed only)
+constexpr int      kShardStep  = 32;      // dwords between counters (128 B: one line each)
+constexpr unsigned kSpinLimit  = 200000;  // bounded wait: ~0.1-0.2 s, then the error word is set and the step falls through
+
+// wave 0 waits until every shard counter has reached `target`; returns false on give-up
+__device__ __forceinline__ bool wait_counters(const unsigned* ctr, unsigned target, int lane, unsigned* err)
+{
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned v = lane < kShards ? __hip_atomic_load(ctr + lane * kShardStep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                          : target;
+        if (__all(v >= target)) return true;
+        if (spins > kSpinLimit) {
+            if (lane == 0) atomicOr(err, 1u);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(1);
+    }
+}
+
+struct StepIO {
+    const f16*     x;
+    const uint8_t* w;
+    const f16*     scales;
+    f16*           y;
+};
+
+// loads of one workgroup's tile row: 16 waves x 4 tiles (K = 4096)
+__device__ __forceinline__ void issue_weights(const uint8_t* w, int ntile, int wave, int lane, u32x4 (&buf)[4])
+{
+    const u32x4* wp = reinterpret_cast<const u32x4*>(w + (size_t)ntile * 64 * kTileBytes) + wave * 64 + lane;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) buf[d] = __builtin_nontemporal_load(wp + d * 16 * 64);
+}
+
+// x with L1-bypassing (sc1) 16-byte loads when it was produced inside the launch window, plain otherwise
+template <bool SC1>
+__device__ __forceinline__ void issue_x(const f16* x, int wave, int g, u32x4 (&xr)[8])
+{
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, 4096 * 2, 0x00020000);
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const int off = ((wave + d * 16) * 64 + 16 * g) * 2;
+        xr[2 * d]     = __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, SC1 ? 16 : 0);
+        xr[2 * d + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs, off + 16, 0, SC1 ? 16 : 0);
+    }
+}
+
+// the GEMV arithmetic of gemv_kernel<1,16,4,EXACT,XREG> (same order of every sum)
+__device__ __forceinline__ float dot_tiles(const u32x4 (&buf)[4], const u32x4 (&xr)[8], f16x2 scale2)
+{
+    float acc = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        f16x2 wq[8];
+        dequant_16(buf[d], scale2, wq);
+        const u32x4 xa = xr[2 * d], xb = xr[2 * d + 1];
+        const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc, false);
+    }
+    return sum_xor32(sum_xor16(acc));
+}
+
+// cross-wave sum (wave 0) and the store of the tile row's 16 outputs; SC1: write-through 8-byte stores + drain + one arrival
+template <bool PUBLISH>
+__device__ __forceinline__ void finish_row(float acc, float* red, int wave, int lane, int g, int c, f16* y, int ntile,
+                                           unsigned* done)
+{
+    if (lane < 16) red[wave * 16 + lane] = acc;
+    __syncthreads();
+    if (wave == 0) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < 4; ++wv) s += red[(g + 4 * wv) * 16 + c];
+        s = sum_xor32(sum_xor16(s));
+        const f16 v = (f16)s;
+        if constexpr (PUBLISH) {
+            const unsigned h  = __builtin_bit_cast(unsigned short, v);
+            const unsigned h1 = __shfl(h, lane + 1, 64), h2 = __shfl(h, lane + 2, 64), h3 = __shfl(h, lane + 3, 64);
+            if (lane < 16 && (lane & 3) == 0) {
+                const unsigned long long pk = (unsigned long long)(h | (h1 << 16)) | ((unsigned long long)(h2 | (h3 << 16)) << 32);
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(y + ntile * 16 + lane), pk, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the storing wave drains its write-through stores
+            if (lane == 0)
+                __hip_atomic_fetch_add(done + (blockIdx.x & (kShards - 1)) * kShardStep, 1u, __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane < 16) y[ntile * 16 + lane] = v;
+        }
+    }
+}
+
+// ---- forms A / B: one launch per step ----
+template <bool CHAIN>
+__global__ __launch_bounds__(1024, 8) void chain_step_kernel(StepIO io, const unsigned* wait, unsigned target, unsigned* done,
+                                                             unsigned* err)
+{
+    __shared__ float red[16 * 16];
+    const int tid = threadIdx.x, ntile = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, c = lane & 15;
+    u32 sraw = reinterpret_cast<const uint16_t*>(io.scales)[ntile * 16 + c];
+    u32x4 buf[4], xr[8];
+    if constexpr (!CHAIN) issue_x<false>(io.x, wave, g, xr);
+    issue_weights(io.w, ntile, wave, lane, buf);
+    if constexpr (CHAIN) {
+        if (wait) {
+            if (wave == 0) wait_counters(wait, target, lane, err);
+            __syncthreads();
+            issue_x<true>(io.x, wave, g, xr);
+        } else {
+            issue_x<false>(io.x, wave, g, xr);
+        }
+    }
+    asm volatile("" : "+v"(sraw));
+    const f16x2 scale2 = as_f16x2(sraw | (sraw << 16));
+    const float acc    = dot_tiles(buf, xr, scale2);
+    finish_row<CHAIN>(acc, red, wave, lane, g, c, io.y, ntile, done);
+}
+
+// ---- form P: the whole chain in one launch ----
+struct ChainArgs {
+    const uint8_t* const* w;       // [S] weight pointers (device array)
+    const f16*            scales;  // shared scales (probe)
+    const f16*            x0;
+    f16*                  ybuf;    // 3 x 4096 halfs, step e writes ybuf[e % 3]
+    unsigned*             flags;   // [S][kShards * kShardStep], zeroed before the launch
+    unsigned*             err;
+    int                   S;
+};
+
+template <bool EARLY_W0>
+__global__ __launch_bounds__(1024, 4) void chain_persistent_kernel(ChainArgs a)
+{
+    __shared__ float red[16 * 16];
+    const int tid = threadIdx.x, ntile = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, c = lane & 15;
+    u32 sraw = reinterpret_cast<const uint16_t*>(a.scales)[ntile * 16 + c];
+    asm volatile("" : "+v"(sraw));
+    const f16x2 scale2 = as_f16x2(sraw | (sraw << 16));
+    const unsigned target = gridDim.x / kShards;
+    u32x4 bufA[4], bufB[4], xr[8];
+    issue_weights(a.w[0], ntile, wave, lane, bufA);
+
+    auto step = [&](int e, u32x4 (&cur)[4], u32x4 (&nxt)[4]) {
+        if (e > 0) {
+            if (wave == 0) wait_counters(a.flags + (size_t)(e - 1) * kShards * kShardStep, target, lane, a.err);
+            __syncthreads();
+            issue_x<true>(a.ybuf + ((e - 1) % 3) * 4096, wave, g, xr);
+        } else {
+            issue_x<false>(a.x0, wave, g, xr);
+        }
+        const uint8_t* wn = a.w[e + 1 < a.S ? e + 1 : a.S - 1];  // unconditional (clamped) prefetch: no load behind a branch
+        // the publishing wave drains with s_waitcnt vmcnt(0), which also waits for whatever it has prefetched: EARLY issues
+        // the next step's weights before the math (the publish then waits for wave 0's tiles), otherwise after the publish
+        if constexpr (EARLY_W0) issue_weights(wn, ntile, wave, lane, nxt);
+        const float acc = dot_tiles(cur, xr, scale2);
+        finish_row<true>(acc, red, wave, lane, g, c, a.ybuf + (e % 3) * 4096, ntile,
+                         a.flags + (size_t)e * kShards * kShardStep);
+        if constexpr (!EARLY_W0) issue_weights(wn, ntile, wave, lane, nxt);
+    };
+    for (int e = 0; e < a.S; e += 2) {
+        step(e, bufA, bufB);
+        step(e + 1, bufB, bufA);
+    }
+}
+
+// --------------------------------------------------------------------------------------------------------------------
+static double time_graph_exec(hipGraphExec_t ge, hipStream_t s, int steps, int reps = 7)
+{
+    CK(hipGraphLaunch(ge, s));
+    CK(hipStreamSynchronize(s));
+    double best = 1e30;
+    for (int r = 0; r < reps; ++r) {
+        auto t0 = std::chrono::high_resolution_clock::now();
+        for (int k = 0; k < 4; ++k) CK(hipGraphLaunch(ge, s));
+        CK(hipStreamSynchronize(s));
+        auto t1 = std::chrono::high_resolution_clock::now();
+        best    = std::min(best, std::chrono::duration<double, std::micro>(t1 - t0).count() / (4.0 * steps));
+    }
+    return best;
+}
+
+int main(int argc, char** argv)
+{
+    const int S = argc > 1 ? atoi(argv[1]) : 64;  // steps per graph (even)
+    const int N = 4096, K = 4096, NBUF = 40;
+    hipDeviceProp_t prop;
+    CK(hipGetDeviceProperties(&prop, 0));
+    printf("device: %s  CUs=%d\n", prop.gcnArchName, prop.multiProcessorCount);
+    int occ = 0;
+    CK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, chain_step_kernel<true>, 1024, 0));
+    printf("chain_step_kernel<true>: %d workgroups of 1024 threads per CU (2 needed for the overlap)\n", occ);
+
+    // weights: uniform bytes (q = b - 128 in [-128, 127]); scale so that |y| ~ |x| along the chain
+    std::vector<uint8_t> host((size_t)N * K);
+    std::vector<uint8_t*> bufs(NBUF);
+    srand(1);
+    for (int b = 0; b < NBUF; ++b) {
+        for (auto& v : host) v = (uint8_t)(rand() >> 7);
+        CK(hipMalloc(&bufs[b], host.size()));
+        CK(hipMemcpy(bufs[b], host.data(), host.size(), hipMemcpyHostToDevice));
+    }
+    const float sc = 1.0f / (73.9f * 64.0f);  // std(q) ~ 73.9, sqrt(K) = 64
+    std::vector<_Float16> hs(N, (_Float16)sc), hx(K);
+    for (auto& v : hx) v = (_Float16)((rand() & 0xffff) / 65536.0f - 0.5f);
+    f16 *scales, *x0, *ybuf, *yref;
+    CK(hipMalloc(&scales, N * 2));
+    CK(hipMalloc(&x0, K * 2));
+    CK(hipMalloc(&ybuf, 3 * N * 2));
+    CK(hipMalloc(&yref, 3 * N * 2));
+    CK(hipMemcpy(scales, hs.data(), N * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(x0, hx.data(), K * 2, hipMemcpyHostToDevice));
+    unsigned *flags, *err;
+    const size_t flag_bytes = (size_t)S * kShards * kShardStep * 4;
+    CK(hipMalloc(&flags, flag_bytes));
+    CK(hipMalloc(&err, 4));
+    CK(hipMemset(err, 0, 4));
+    std::vector<const uint8_t*> wl(S);
+    for (int e = 0; e < S; ++e) wl[e] = bufs[e % NBUF];
+    const uint8_t** wlist;
+    CK(hipMalloc(&wlist, S * sizeof(void*)));
+    CK(hipMemcpy(wlist, wl.data(), S * sizeof(void*), hipMemcpyHostToDevice));
+
+    auto io_of = [&](int e, f16* yb) {
+        return StepIO{e == 0 ? x0 : yb + ((e - 1) % 3) * N, bufs[e % NBUF], scales, yb + (e % 3) * N};
+    };
+    auto flags_of = [&](int e) { return flags + (size_t)e * kShards * kShardStep; };
+    std::vector<uint16_t> ref(N), got(N);
+    auto check = [&](const char* name, f16* yb) {
+        CK(hipMemcpy(got.data(), yb + ((S - 1) % 3) * N, N * 2, hipMemcpyDeviceToHost));
+        unsigned e = 0;
+        CK(hipMemcpy(&e, err, 4, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int i = 0; i < N; ++i) bad += got[i] != ref[i];
+        printf("    %-10s final y vs form A: %d of %d values differ; give-up word %u\n", name, bad, N, e);
+        CK(hipMemset(err, 0, 4));
+    };
+
+    hipStream_t s0, s1, s2;
+    CK(hipStreamCreate(&s0));
+    CK(hipStreamCreate(&s1));
+    CK(hipStreamCreate(&s2));
+    hipEvent_t ev[8];
+    for (auto& e : ev) CK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+
+    // ---- A0: shipping kernel, A: probe kernel without the hand-off ----
+    for (int form = 0; form < 2; ++form) {
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s0, hipStreamCaptureModeGlobal));
+        for (int e = 0; e < S; ++e) {
+            const StepIO io = io_of(e, yref);
+            if (form == 0)
+                hipLaunchKernelGGL((gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>), dim3(N / 16), dim3(1024), 16 * 16 * 4, s0,
+                                   io.x, io.w, io.scales, io.y, N, K, Epilogue{}, Prologue{});
+            else
+                hipLaunchKernelGGL(chain_step_kernel<false>, dim3(N / 16), dim3(1024), 0, s0, io, nullptr, 0u, nullptr, err);
+        }
+        CK(hipStreamEndCapture(s0, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        const double us = time_graph_exec(ge, s0, S);
+        printf("%s  %6.3f us/step  (%.0f GB/s, %.3f of 8 TB/s)\n",
+               form == 0 ? "A0 shipping gemv_kernel, one stream, dependent launches      "
+                         : "A  probe kernel, one stream, dependent launches               ",
+               us, 16801792.0 / us / 1e3, 16801792.0 / us / 8e6);
+        if (form == 0) {
+            CK(hipMemcpy(ref.data(), yref + ((S - 1) % 3) * N, N * 2, hipMemcpyDeviceToHost));
+            float mx = 0;
+            for (int i = 0; i < N; ++i) mx = std::max(mx, std::fabs((float)*reinterpret_cast<_Float16*>(&ref[i])));
+            printf("    max |y| after %d steps: %g\n", S, mx);
+        } else {
+            check("A", yref);
+        }
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(g));
+    }
+
+    // ---- B: alternating capture streams, device-side hand-off ----
+    for (int nstreams = 2; nstreams <= 3; ++nstreams) {
+        hipStream_t ss[3] = {s0, s1, s2};
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s0, hipStreamCaptureModeGlobal));
+        CK(hipMemsetAsync(flags, 0, flag_bytes, s0));
+        CK(hipEventRecord(ev[0], s0));
+        for (int k = 1; k < nstreams; ++k) CK(hipStreamWaitEvent(ss[k], ev[0], 0));
+        for (int e = 0; e < S; ++e) {
+            const StepIO io = io_of(e, ybuf);
+            hipLaunchKernelGGL(chain_step_kernel<true>, dim3(N / 16), dim3(1024), 0, ss[e % nstreams], io,
+                               e ? flags_of(e - 1) : (const unsigned*)nullptr, (unsigned)(N / 16 / kShards), flags_of(e), err);
+        }
+        for (int k = 1; k < nstreams; ++k) {
+            CK(hipEventRecord(ev[k], ss[k]));
+            CK(hipStreamWaitEvent(s0, ev[k], 0));
+        }
+        CK(hipStreamEndCapture(s0, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CK(hipMemset(ybuf, 0, 3 * N * 2));
+        const double us = time_graph_exec(ge, s0, S);
+        printf("B%d one launch per step on %d alternating streams, counter hand-off   %6.3f us/step  (%.0f GB/s, %.3f of 8 TB/s)\n",
+               nstreams, nstreams, us, 16801792.0 / us / 1e3, 16801792.0 / us / 8e6);
+        check(nstreams == 2 ? "B2" : "B3", ybuf);
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(g));
+    }
+
+    // ---- B eager (no graph): the same on two plain streams ----
+    {
+        CK(hipMemset(ybuf, 0, 3 * N * 2));
+        double best = 1e30;
+        for (int r = 0; r < 5; ++r) {
+            CK(hipMemsetAsync(flags, 0, flag_bytes, s0));
+            CK(hipEventRecord(ev[0], s0));
+            CK(hipStreamWaitEvent(s1, ev[0], 0));
+            CK(hipDeviceSynchronize());
+            auto t0 = std::chrono::high_resolution_clock::now();
+            for (int e = 0; e < S; ++e) {
+                const StepIO io = io_of(e, ybuf);
+                hipLaunchKernelGGL(chain_step_kernel<true>, dim3(N / 16), dim3(1024), 0, e & 1 ? s1 : s0, io,
+                                   e ? flags_of(e - 1) : (const unsigned*)nullptr, (unsigned)(N / 16 / kShards), flags_of(e), err);
+            }
+            CK(hipDeviceSynchronize());
+            auto t1 = std::chrono::high_resolution_clock::now();
+            best    = std::min(best, std::chrono::duration<double, std::micro>(t1 - t0).count() / S);
+        }
+        printf("Be eager launches on 2 streams (host-bound?)                           %6.3f us/step\n", best);
+        check("Be", ybuf);
+    }
+
+    // ---- P: persistent ----
+    for (int early = 0; early < 2; ++early) {
+        ChainArgs a{wlist, scales, x0, ybuf, flags, err, S};
+        hipGraph_t g;
+        hipGraphExec_t ge;
+        CK(hipStreamBeginCapture(s0, hipStreamCaptureModeGlobal));
+        CK(hipMemsetAsync(flags, 0, flag_bytes, s0));
+        if (early)
+            hipLaunchKernelGGL(chain_persistent_kernel<true>, dim3(N / 16), dim3(1024), 0, s0, a);
+        else
+            hipLaunchKernelGGL(chain_persistent_kernel<false>, dim3(N / 16), dim3(1024), 0, s0, a);
+        CK(hipStreamEndCapture(s0, &g));
+        CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+        CK(hipMemset(ybuf, 0, 3 * N * 2));
+        const double us = time_graph_exec(ge, s0, S);
+        printf("P%d persistent launch, %d steps, next weights requested %s   %6.3f us/step  (%.0f GB/s, %.3f of 8 TB/s)\n", early, S,
+               early ? "before the math (publish waits)" : "after the publish              ", us, 16801792.0 / us / 1e3,
+               16801792.0 / us / 8e6);
+        check(early ? "P1" : "P0", ybuf);
+        CK(hipGraphExecDestroy(ge));
+        CK(hipGraphDestroy(g));
+    }
+    return 0;
+}

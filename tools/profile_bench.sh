@@ -5,8 +5,11 @@
 #   gpurun_out/<tag>_bench_trace_gemv.txt     percentiles of the GEMV / GEMM / floor / empty dispatches of that trace
 #   gpurun_out/pmc_traffic.json               HBM/fabric bytes per launch from separate --pmc passes (kernel-trace only)
 #   gpurun_out/<tag>_gemv_decomposition.txt   tools/kbench_stamps decompose (un-profiled) + the same under rocprofv3
-# Copy the files you want judged into profiles/ (pmc_traffic.json keeps its name; bench.py reads it from there).
-# usage: tools/profile_bench.sh [tag] [bench args...]      e.g.  tools/profile_bench.sh r02 --steps 2000 --warmup 200
+#   gpurun_out/bench_rocprof.json             average / calls / min of the two headline kernels from that summary, stamped with the
+#                                             commit (EETQ_HEAD, passed in: the GPU box has no .git) and the kernel-source hash
+# Copy the files you want judged into profiles/ (pmc_traffic.json and bench_rocprof.json keep their names; bench.py reads
+# them from there and reports whether the kernel sources still hash to the value they were measured at).
+# usage: EETQ_HEAD=$(git rev-parse --short HEAD) tools/profile_bench.sh [tag] [bench args...]
 set -u
 TAG=${1:-rXX}
 shift || true
@@ -37,6 +40,21 @@ for r in rows[1:]:
         w.writerow([r[0][:120]] + r[1:])
 PYEOF
 fi
+if [ -s "$OUT/${TAG}_bench_kernel_stats.csv" ]; then
+    $PY - "$OUT/${TAG}_bench_kernel_stats.csv" "profiles/${TAG}_bench_kernel_stats.csv" > "$OUT/bench_rocprof.json" <<'PYEOF'
+import csv, json, os, sys, time
+sys.path.insert(0, os.getcwd())
+import bench
+doc = {"file": sys.argv[2], "head": os.environ.get("EETQ_HEAD", "unknown"), "kernel_src_sha16": bench.kernel_source_sha16(),
+       "date": time.strftime("%Y-%m-%d"), "how": "rocprofv3 --kernel-trace --stats -- python bench.py (tools/profile_bench.sh)"}
+for r in csv.DictReader(open(sys.argv[1])):
+    for key, pat in (("gemv", "gemv_kernelILi1ELi16ELi4ELb1ELb1E"), ("gemm_m1024", "gemm_tile_kernelILi0ELi2ELb0E")):
+        if pat in r["Name"] and key not in doc:
+            doc[key] = {"avg_us": round(float(r["AverageNs"]) / 1e3, 3), "calls": int(r["Calls"]),
+                        "min_us": round(float(r["MinNs"]) / 1e3, 3), "max_us": round(float(r["MaxNs"]) / 1e3, 3)}
+print(json.dumps(doc, indent=1))
+PYEOF
+fi
 TRACE=$(find /tmp/prof_bench -name '*kernel_trace.csv' | head -1)
 [ -n "$TRACE" ] && $PY tools/trace_durations.py /tmp/prof_bench | grep -i "eetq\|gemv\|gemm\|stream_read\|empty" > "$OUT/${TAG}_bench_trace_gemv.txt"
 
@@ -49,7 +67,9 @@ if [ -x tools/kbench ]; then
             || echo "pmc pass '$pass' failed" >&2
     done
     $PY - > "$OUT/pmc_traffic.json" <<'PYEOF'
-import csv, glob, json, time
+import csv, glob, json, os, sys, time
+sys.path.insert(0, os.getcwd())
+import bench
 def mean_counter(counter, kern):
     v = []
     for f in glob.glob("/tmp/prof_pmc_*/**/*counter_collection.csv", recursive=True):
@@ -58,7 +78,8 @@ def mean_counter(counter, kern):
                 v.append(float(r["Counter_Value"]))
     return sum(v) / len(v) if v else None
 doc = {"source": "rocprofv3 --pmc on tools/kbench gemm1 via tools/profile_bench.sh (%s, MI355X): separate --pmc passes with "
-                 "--kernel-trace only; 20 dispatches per kernel, mean per dispatch" % time.strftime("%Y-%m-%d")}
+                 "--kernel-trace only; 20 dispatches per kernel, mean per dispatch" % time.strftime("%Y-%m-%d"),
+       "head": os.environ.get("EETQ_HEAD", "unknown"), "kernel_src_sha16": bench.kernel_source_sha16()}
 for key, kern in (("gemv", "gemv_kernel"), ("gemm_m1024", "gemm_tile_kernel")):
     rd, fs = mean_counter("TCC_EA0_RDREQ_sum", kern), mean_counter("FETCH_SIZE", kern)
     wr, ws = mean_counter("TCC_EA0_WRREQ_sum", kern), mean_counter("WRITE_SIZE", kern)
