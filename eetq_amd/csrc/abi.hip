@@ -170,11 +170,39 @@ int eetq_quantize_i8(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_r
                      void* scales, float* workspace, void* stream)
 {
     if (!workspace) {
-        int st = colmax_scratch(N, &workspace);
+        int st = colmax_scratch(quantize_workspace_floats(K, N), &workspace);
         if (st != EETQ_OK) return st;
     }
     return launch_quantize(w, w_dtype, K, N, q_raw, q_packed, layout, scales, workspace,
                            static_cast<hipStream_t>(stream));
+}
+
+size_t eetq_quantize_workspace_floats(size_t K, size_t N) { return quantize_workspace_floats(K, N); }
+
+int eetq_release_workspace(size_t* bytes_freed)
+{
+    size_t freed = 0;
+    int    st    = release_splitk_workspace(&freed);
+    if (st != EETQ_OK) return st;
+    st = release_w4a16_workspace(&freed);
+    if (st != EETQ_OK) return st;
+    {
+        std::lock_guard<std::mutex> lock(g_scratch_mutex);
+        int keep = 0;
+        (void)hipGetDevice(&keep);
+        for (int d = 0; d < 64; ++d) {
+            Scratch& s = g_scratch[d];
+            if (s.ptr && hipSetDevice(d) == hipSuccess) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(s.ptr);
+                freed += s.elems * sizeof(float);
+            }
+            s = Scratch{};
+        }
+        (void)hipSetDevice(keep);
+    }
+    if (bytes_freed) *bytes_freed = freed;
+    return EETQ_OK;
 }
 
 int eetq_pack_i8(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, void* stream)
@@ -197,7 +225,7 @@ int eetq_quantize_i8_host(const void* w, int w_dtype, size_t K, size_t N, int8_t
     const size_t esz = w_dtype == EETQ_DTYPE_F16 ? 2 : 4;
     DevBuf       dw, draw, dpk, dsc, dmax;
     int          st;
-    if ((st = dw.alloc(K * N * esz)) || (st = dsc.alloc(N * esz)) || (st = dmax.alloc(N * sizeof(float)))) return st;
+    if ((st = dw.alloc(K * N * esz)) || (st = dsc.alloc(N * esz)) || (st = dmax.alloc(quantize_workspace_floats(K, N) * sizeof(float)))) return st;
     if (q_raw && (st = draw.alloc(K * N))) return st;
     if (q_packed && (st = dpk.alloc(K * N))) return st;
     EETQ_TRY_HIP(hipMemcpy(dw.p, w, K * N * esz, hipMemcpyHostToDevice));

@@ -204,7 +204,8 @@ inline int opt_in_large_lds(Kern kern, std::atomic<unsigned long long>& done)
 
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------
 int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
-                    int layout, void* scales, float* colmax, hipStream_t stream);
+                    int layout, void* scales, float* workspace, hipStream_t stream);
+size_t quantize_workspace_floats(size_t K, size_t N);  // floats launch_quantize's workspace must hold
 int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
 int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
 int launch_colmax(const void* w, int w_dtype, size_t K, size_t N, float* colmax, hipStream_t stream);
@@ -261,5 +262,8 @@ int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, Epilogue 
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                        hipStream_t stream, int force_nb = 0, int force_s = 0);
 void splitk_plan(int M, int N, int K, int* nb, int* s, int* stages);
+// library-owned scratch (eetq_release_workspace): each frees its buffers on every device and adds the bytes to *freed
+int release_splitk_workspace(size_t* freed);
+int release_w4a16_workspace(size_t* freed);
 
 }  // namespace eetq

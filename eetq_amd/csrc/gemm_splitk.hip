@@ -2,6 +2,7 @@
 // Reference behaviour matched: the small-M preference of the CUTLASS tile heuristic (cutlass_heuristic.cc:123-206) -- the
 // reference never splits K because its wrapper passes no workspace (fpA_intB_gemm_wrapper.cu:169-170); here the workspace
 // is owned by the library so that the operator signature stays workspace-free.
+#include <cstdlib>
 #include <mutex>
 
 #include "gemm_splitk_kernel.hpp"
@@ -11,51 +12,78 @@ namespace eetq {
 namespace {
 
 // ---- scratch: fp32 partial tiles + per-tile tickets --------------------------------------------------------------------
-// One arena per device, cut into kRegions regions; a stream is given a region the first time it launches a split-K GEMM and
-// keeps it (a HIP graph replays with the region of the stream it was captured on).  Launches that run CONCURRENTLY must use
-// different regions: guaranteed for up to kRegions distinct launch streams per device; beyond that, and for graphs captured
-// on one stream but replayed concurrently on several, set EETQ_AMD_SPLITK=0 (the dispatcher then uses the unsplit kernels).
-constexpr int    kRegions       = 16;
+// Up to kMaxRegions regions per device (EETQ_AMD_SPLITK_REGIONS lowers the cap; 0 = never split), each created the first
+// time a stream launches a split-K GEMM and OWNED by that stream from then on (a HIP graph replays with the region of the
+// stream it was captured on).  A region is never shared: a launch that cannot get its own -- every region taken by a live
+// stream, the cap reached, or the region would have to be created during graph capture -- runs unsplit (S = 1), which needs
+// no scratch.  Regions whose owner stream has been destroyed are taken over (after a device synchronisation).  Everything
+// is freed by eetq_release_workspace().  Not covered: one captured graph replayed CONCURRENTLY on several streams (the
+// replays share the capture stream's region) -- capture once per replay stream, or set EETQ_AMD_SPLITK=0.
+constexpr int    kMaxRegions    = 16;
 constexpr size_t kRegionSlabs   = 40ull << 20;  // bytes of fp32 partial tiles per region (largest plan: ~33 MiB)
 constexpr size_t kRegionTickets = 4096;         // tiles per launch (N <= 4096 * 32 columns); one ticket array PER slice count
+// a tile's ticket grows by S per launch and "last" is (old & (S-1)) == S-1: that only works if every launch that touches a
+// ticket uses the same S, so S = 2 and S = 4 launches keep separate ticket arrays
+constexpr size_t kRegionBytes   = kRegionSlabs + 2 * kRegionTickets * sizeof(unsigned);
 
+struct Region {
+    uint8_t*    base  = nullptr;
+    hipStream_t owner = nullptr;
+    bool        used  = false;
+};
 struct Arena {
-    uint8_t*    base = nullptr;
-    hipStream_t owner[kRegions] = {};
-    bool        used[kRegions]  = {};
+    Region r[kMaxRegions];
 };
 std::mutex g_mutex;
 Arena      g_arena[64];
 
+int region_cap()
+{
+    static const int cap = [] {
+        const char* e = getenv("EETQ_AMD_SPLITK_REGIONS");
+        if (!e || !*e) return kMaxRegions;
+        const int v = atoi(e);
+        return v < 0 ? 0 : (v > kMaxRegions ? kMaxRegions : v);
+    }();
+    return cap;
+}
+
+// EETQ_OK with the stream's own region, or EETQ_ERR_UNSUPPORTED (no message) when it cannot have one right now
 int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
 {
     int dev = 0;
     EETQ_TRY_HIP(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lock(g_mutex);
-    Arena&                      a = g_arena[dev & 63];
-    // a tile's ticket grows by S per launch and "last" is (old & (S-1)) == S-1: that only works if every launch that
-    // touches a ticket uses the same S, so S = 2 and S = 4 launches keep separate ticket arrays
-    const size_t region_bytes = kRegionSlabs + 2 * kRegionTickets * sizeof(unsigned);
-    if (!a.base) {
-        // not capturable: the first split-K launch on a device must happen outside graph capture (any eager warm-up does it)
+    Arena&    a   = g_arena[dev & 63];
+    const int cap = region_cap();
+    Region*   reg = nullptr;
+    for (int i = 0; i < cap && !reg; ++i)
+        if (a.r[i].used && a.r[i].owner == stream) reg = &a.r[i];
+    if (!reg) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
         if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-            return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] split-K scratch cannot be created during graph capture");
-        EETQ_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&a.base), region_bytes * kRegions));
-        EETQ_TRY_HIP(hipMemset(a.base, 0, region_bytes * kRegions));  // tickets start at 0 and only ever grow by S per tile
+            return EETQ_ERR_UNSUPPORTED;  // taking or creating a region is not capturable: any eager warm-up does it
+        for (int i = 0; i < cap && !reg; ++i)
+            if (!a.r[i].used) reg = &a.r[i];
+        for (int i = 0; i < cap && !reg; ++i) {  // every region taken: one whose owner no longer exists can be reused
+            const hipError_t q = hipStreamQuery(a.r[i].owner);
+            if (q != hipSuccess && q != hipErrorNotReady) {
+                (void)hipGetLastError();
+                EETQ_TRY_HIP(hipDeviceSynchronize());
+                reg = &a.r[i];
+            }
+        }
+        if (!reg) return EETQ_ERR_UNSUPPORTED;
+        if (!reg->base) {
+            EETQ_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&reg->base), kRegionBytes));
+            // tickets start at 0 and only ever grow by S per tile
+            EETQ_TRY_HIP(hipMemset(reg->base + kRegionSlabs, 0, kRegionBytes - kRegionSlabs));
+        }
+        reg->used  = true;
+        reg->owner = stream;
     }
-    int r = -1;
-    for (int i = 0; i < kRegions; ++i)
-        if (a.used[i] && a.owner[i] == stream) r = i;
-    if (r < 0) {
-        for (int i = 0; i < kRegions && r < 0; ++i)
-            if (!a.used[i]) r = i;
-        if (r < 0) r = (int)(((uintptr_t)stream >> 4) % kRegions);  // more streams than regions: shared (see above)
-        a.used[r]  = true;
-        a.owner[r] = stream;
-    }
-    *slabs   = reinterpret_cast<float*>(a.base + (size_t)r * region_bytes);
-    *tickets = reinterpret_cast<unsigned*>(a.base + (size_t)r * region_bytes + kRegionSlabs);
+    *slabs   = reinterpret_cast<float*>(reg->base);
+    *tickets = reinterpret_cast<unsigned*>(reg->base + kRegionSlabs);
     return EETQ_OK;
 }
 
@@ -77,7 +105,7 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         if ((size_t)tiles > kRegionTickets || (size_t)tiles * S * C::kSlabFloats * 4 > kRegionSlabs) S = 1;
         else {
             int st = region_for(stream, &slabs, &tickets);
-            if (st == EETQ_ERR_UNSUPPORTED) S = 1;  // scratch cannot be created while capturing: run this launch unsplit
+            if (st == EETQ_ERR_UNSUPPORTED) S = 1;  // no region of its own for this stream right now: run this launch unsplit
             else if (st != EETQ_OK) return st;
             else if (S == 4) tickets += kRegionTickets;
         }
@@ -112,6 +140,27 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
 }
 
 }  // namespace
+
+// frees every split-K region of every device (eetq_release_workspace); the caller has synchronised the devices
+int release_splitk_workspace(size_t* freed)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    int keep = 0;
+    (void)hipGetDevice(&keep);
+    for (int d = 0; d < 64; ++d)
+        for (Region& r : g_arena[d].r) {
+            if (r.base) {
+                if (hipSetDevice(d) == hipSuccess) {
+                    (void)hipDeviceSynchronize();
+                    (void)hipFree(r.base);
+                }
+                if (freed) *freed += kRegionBytes;
+            }
+            r = Region{};
+        }
+    (void)hipSetDevice(keep);
+    return EETQ_OK;
+}
 
 // Plan (column blocks per workgroup, K slices, ring depth) for a shape, from the measurements in
 // profiles/r02_kbench_splitk.txt (MI355X, N = K = 4096 unless noted; round-1 unsplit tile in brackets):

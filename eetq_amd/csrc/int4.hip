@@ -242,6 +242,24 @@ int expanded_scratch(size_t bytes, hipStream_t stream, uint8_t** out)
 
 }  // namespace
 
+int release_w4a16_workspace(size_t* freed)
+{
+    std::lock_guard<std::mutex> lock(g_mutex);
+    int keep = 0;
+    (void)hipGetDevice(&keep);
+    for (int d = 0; d < 64; ++d)
+        for (Scratch& s : g_scratch[d]) {
+            if (s.p && hipSetDevice(d) == hipSuccess) {
+                (void)hipDeviceSynchronize();
+                (void)hipFree(s.p);
+                if (freed) *freed += s.bytes;
+            }
+            s = Scratch{};
+        }
+    (void)hipSetDevice(keep);
+    return EETQ_OK;
+}
+
 int launch_quantize_i4(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
                        void* scales, float* colmax, hipStream_t stream)
 {

@@ -4,8 +4,9 @@
 //   quantise  csrc/cutlass_kernels/cutlass_preprocessors.cc:581-678  (ft::symmetric_quantize)
 //   sm80 pack csrc/cutlass_kernels/cutlass_preprocessors.cc:497-534  (preprocess_weights_for_mixed_gemm)
 // The reference runs these single-threaded on the CPU (three strided K x N passes + four re-layout
-// passes); here every pass is one coalesced sweep: a 64(k) x 64(n) tile is read row-wise, transposed
-// through LDS and written in the destination layout with 16-byte stores.
+// passes); here quant_weights is TWO launches -- per-row-block column maxima, then a strip kernel that reduces them,
+// quantises and writes the target layout -- and every pass is one coalesced sweep: 64(k) x 64(n) tiles are read
+// row-wise, transposed through LDS and written in the destination layout with 16-byte stores.
 #include "common.hpp"
 
 namespace eetq {
@@ -24,8 +25,11 @@ __constant__ int kPerm16[16] = {0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14
 // takes rows j, j+4, ...; eight independent 16-byte loads in flight per lane; the four waves' maxima meet in LDS and ONE
 // atomicMax per column and workgroup follows (K / 128 per column in total -- the first version issued one per column per 32
 // rows, 524 k atomics at 4096^2, and ran at 1.2 TB/s).
+// PARTIALS: no atomics and no zero-fill launch before the kernel -- row block y stores its maxima to row y of a
+// [ceil(K / kRowsPerBlock)][N] array and the pack kernel reduces the rows for its 64 columns (the int8 quantiser: two
+// launches per call instead of fill + maxima + pack).
 constexpr int kRowsPerBlock = 128;
-template <typename T, int V>
+template <typename T, int V, bool PARTIALS>
 __global__ __launch_bounds__(256) void colmax_kernel(const T* __restrict__ w, size_t K, size_t N,
                                                      u32* __restrict__ colmax_bits)
 {
@@ -68,7 +72,10 @@ __global__ __launch_bounds__(256) void colmax_kernel(const T* __restrict__ w, si
             float a = part[0][c];
 #pragma unroll
             for (int j = 1; j < 4; ++j) a = (a < part[j][c]) ? part[j][c] : a;
-            atomicMax(colmax_bits + col, __builtin_bit_cast(u32, a));
+            if constexpr (PARTIALS)
+                colmax_bits[(size_t)blockIdx.y * N + col] = __builtin_bit_cast(u32, a);
+            else
+                atomicMax(colmax_bits + col, __builtin_bit_cast(u32, a));
         }
     }
 }
@@ -84,54 +91,11 @@ __device__ __forceinline__ int8_t quantize_elt(float w, float s)
     return (int8_t)(int)lo;
 }
 
-template <typename T>
-struct SrcTraits;
-template <>
-struct SrcTraits<f16> {
-    static constexpr bool kQuantize = true;
-};
-template <>
-struct SrcTraits<float> {
-    static constexpr bool kQuantize = true;
-};
-template <>
-struct SrcTraits<int8_t> {
-    static constexpr bool kQuantize = false;
-};
-
-// Load 16 consecutive columns of one row and produce 16 int8.
-template <typename T>
-__device__ __forceinline__ u32x4 load_quantize_16(const T* __restrict__ src, const float* __restrict__ colmax)
-{
-    union {
-        int8_t b[16];
-        u32x4  v;
-    } out;
-    if constexpr (!SrcTraits<T>::kQuantize) {
-        out.v = *reinterpret_cast<const u32x4*>(src);
-    } else {
-        T v[16];
-        constexpr int kVecs = (int)(sizeof(T) * 16 / 16);
-#pragma unroll
-        for (int i = 0; i < kVecs; ++i)
-            reinterpret_cast<u32x4*>(v)[i] = reinterpret_cast<const u32x4*>(src)[i];
-        float s[16];
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            reinterpret_cast<f32x4*>(s)[i] = reinterpret_cast<const f32x4*>(colmax)[i];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) out.b[i] = quantize_elt((float)v[i], s[i] * (1.f / 128.f));
-    }
-    return out.v;
-}
-
-// ---- pass 2: quantise (or copy) one 64x64 tile and emit it in the requested layouts -----------------------
+// ---- re-layout of a raw int8 tensor: one 64x64 tile per workgroup -----------------------------------------------------
 // grid = (ceil(N/64), K/64), block = 256.  Thread t loads row r = t/4, columns seg*16..+15 (seg = t%4).
-template <typename T, int LAYOUT>
-__global__ __launch_bounds__(256) void tile_pack_kernel(const T* __restrict__ src, size_t K, size_t N,
-                                                        const float* __restrict__ colmax,
-                                                        int8_t* __restrict__ q_raw, uint8_t* __restrict__ q_packed,
-                                                        void* __restrict__ scales, int scales_f32)
+template <int LAYOUT>
+__global__ __launch_bounds__(256) void tile_pack_kernel(const int8_t* __restrict__ src, size_t K, size_t N,
+                                                        uint8_t* __restrict__ q_packed)
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[kQT][kQPitch];
     const int    t   = threadIdx.x;
@@ -142,22 +106,7 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(const T* __restrict__ sr
     const int    seg = t & 3;
     const size_t nc  = n0 + (size_t)seg * 16;
 
-    if (nc < N) {
-        const u32x4 q = load_quantize_16<T>(src + (k0 + r) * N + nc, colmax ? colmax + nc : nullptr);
-        *reinterpret_cast<u32x4*>(&tile[r][seg * 16]) = q;
-        if (q_raw) *reinterpret_cast<u32x4*>(q_raw + (k0 + r) * N + nc) = q;
-    }
-    if constexpr (SrcTraits<T>::kQuantize) {
-        // scales: written once per column by the first row of tiles (:633-634 scale = T(colmax * 2^-7))
-        if (kt == 0 && t < kQT && n0 + t < N && scales) {
-            const float s32 = colmax[n0 + t] * (1.f / 128.f);
-            if (scales_f32)
-                reinterpret_cast<float*>(scales)[n0 + t] = s32;
-            else
-                reinterpret_cast<f16*>(scales)[n0 + t] = (f16)s32;
-        }
-    }
-    if (!q_packed) return;
+    if (nc < N) *reinterpret_cast<u32x4*>(&tile[r][seg * 16]) = *reinterpret_cast<const u32x4*>(src + (k0 + r) * N + nc);
     __syncthreads();
 
     if constexpr (LAYOUT == EETQ_LAYOUT_GFX950) {
@@ -193,6 +142,127 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(const T* __restrict__ sr
         }
         uint8_t* dst = q_packed + ((n0 >> 1) + pair) * (2 * K) + kt * 128 + (size_t)half * 64 + kk;
         *reinterpret_cast<u32x4*>(dst) = u32x4{d[0], d[1], d[2], d[3]};
+    }
+}
+
+// ---- pass 2, int8 quantiser form: a workgroup walks kStripTiles consecutive 64x64 tiles of one 64-column strip --------
+// grid = (ceil(N/64), ceil(K/64 / kStripTiles)), block = 256.  All of the strip's loads are issued first (2 x 16 B per lane
+// and tile at fp16); while they fly the workgroup reduces the P row-block maxima of its 64 columns ONCE (thread t: column
+// t % 64, rows t / 64 + 4 i) -- maxima are order-independent, so the result is the reference's single running maximum
+// (:619-628) bit for bit.  Then every tile is quantised into its own LDS image, one barrier, and written in the target
+// layout with 16-byte stores exactly like tile_pack_kernel.
+constexpr int kStripTiles = 4;
+template <typename T, int LAYOUT>
+__global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ src, size_t K, size_t N,
+                                                          const float* __restrict__ part, int P,
+                                                          int8_t* __restrict__ q_raw, uint8_t* __restrict__ q_packed,
+                                                          void* __restrict__ scales, int scales_f32)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t tile[kStripTiles][kQT][kQPitch];
+    __shared__ float cm[4][kQT];
+    __shared__ __attribute__((aligned(16))) float cmx[kQT];
+    constexpr int kVecs = (int)(sizeof(T) * 16 / 16);  // 16-byte loads per 16 elements
+    const int    t   = threadIdx.x;
+    const size_t n0  = (size_t)blockIdx.x * kQT;
+    const size_t kt0 = (size_t)blockIdx.y * kStripTiles;
+    const size_t KT  = K / kQT;
+    const int    nt  = (int)(KT - kt0 < (size_t)kStripTiles ? KT - kt0 : (size_t)kStripTiles);
+    const int    r   = t >> 2;
+    const int    seg = t & 3;
+    const size_t nc  = n0 + (size_t)seg * 16;
+    const bool   live = nc < N;
+    const size_t ncc  = live ? nc : 0;  // ragged last strip: dead segments read column 0 and are ignored
+
+    u32x4 raw[kStripTiles][kVecs];
+#pragma unroll
+    for (int j = 0; j < kStripTiles; ++j) {
+        const size_t kt = kt0 + (j < nt ? j : nt - 1);  // clamped: no load behind a branch
+        const u32x4* p  = reinterpret_cast<const u32x4*>(src + (kt * kQT + r) * N + ncc);
+#pragma unroll
+        for (int i = 0; i < kVecs; ++i) raw[j][i] = __builtin_nontemporal_load(p + i);
+    }
+    {
+        const int    col = t & 63, p0 = t >> 6;
+        const size_t cg  = n0 + col < N ? n0 + col : 0;
+        float        m   = 0.f;
+        for (int p = p0; p < P; p += 4) {
+            const float a = part[(size_t)p * N + cg];
+            m             = (m < a) ? a : m;
+        }
+        cm[p0][col] = m;
+    }
+    __syncthreads();
+    if (t < kQT) {
+        float a = cm[0][t];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) a = (a < cm[j][t]) ? cm[j][t] : a;
+        cmx[t] = a;
+        if (kt0 == 0 && n0 + t < N && scales) {  // :633-634 scale = T(colmax * 2^-7), written once per column
+            const float s32 = a * (1.f / 128.f);
+            if (scales_f32)
+                reinterpret_cast<float*>(scales)[n0 + t] = s32;
+            else
+                reinterpret_cast<f16*>(scales)[n0 + t] = (f16)s32;
+        }
+    }
+    __syncthreads();
+    float s[16];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) reinterpret_cast<f32x4*>(s)[i] = reinterpret_cast<const f32x4*>(cmx + seg * 16)[i];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] *= (1.f / 128.f);
+#pragma unroll
+    for (int j = 0; j < kStripTiles; ++j) {
+        if (j < nt && live) {
+            union {
+                int8_t b[16];
+                u32x4  v;
+            } out;
+            T v[16];
+#pragma unroll
+            for (int i = 0; i < kVecs; ++i) reinterpret_cast<u32x4*>(v)[i] = raw[j][i];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) out.b[i] = quantize_elt((float)v[i], s[i]);
+            *reinterpret_cast<u32x4*>(&tile[j][r][seg * 16]) = out.v;
+            if (q_raw) *reinterpret_cast<u32x4*>(q_raw + ((kt0 + j) * kQT + r) * N + nc) = out.v;
+        }
+    }
+    if (!q_packed) return;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kStripTiles; ++j) {
+        if (j >= nt) break;
+        const size_t kt = kt0 + j;
+        if constexpr (LAYOUT == EETQ_LAYOUT_GFX950) {
+            const int chunk = t >> 6, lane = t & 63, g = lane >> 4, c = lane & 15;
+            if (n0 + (size_t)chunk * 16 < N) {
+                u32 d[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const u32 b0 = tile[j][16 * g + 4 * i + 0][chunk * 16 + c];
+                    const u32 b1 = tile[j][16 * g + 4 * i + 2][chunk * 16 + c];  // bytes 1<->2 swapped
+                    const u32 b2 = tile[j][16 * g + 4 * i + 1][chunk * 16 + c];
+                    const u32 b3 = tile[j][16 * g + 4 * i + 3][chunk * 16 + c];
+                    d[i]         = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ 0x80808080u;  // +128
+                }
+                const size_t ntile = (n0 >> 4) + chunk;
+                uint8_t*     dst   = q_packed + (ntile * KT + kt) * (size_t)kTileBytes + (size_t)lane * 16;
+                *reinterpret_cast<u32x4*>(dst) = u32x4{d[0], d[1], d[2], d[3]};
+            }
+        } else if constexpr (LAYOUT == EETQ_LAYOUT_SM80) {
+            const int pair = t >> 3, sg = t & 7, half = sg >> 2, kk = (sg & 3) * 16;
+            u32       d[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 b0 = tile[j][kk + kPerm16[4 * i + 0]][2 * pair + half];
+                const u32 b1 = tile[j][kk + kPerm16[4 * i + 2]][2 * pair + half];
+                const u32 b2 = tile[j][kk + kPerm16[4 * i + 1]][2 * pair + half];
+                const u32 b3 = tile[j][kk + kPerm16[4 * i + 3]][2 * pair + half];
+                d[i]         = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ 0x80808080u;
+            }
+            uint8_t* dst = q_packed + ((n0 >> 1) + pair) * (2 * K) + kt * 128 + (size_t)half * 64 + kk;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{d[0], d[1], d[2], d[3]};
+        }
     }
 }
 
@@ -254,17 +324,14 @@ int check_layout_shape(size_t K, size_t N, int layout)
     return EETQ_OK;
 }
 
-template <typename T>
-int launch_tile_pack(const T* src, size_t K, size_t N, const float* colmax, int8_t* q_raw, int8_t* q_packed,
-                     int layout, void* scales, int scales_f32, hipStream_t stream)
+int launch_tile_pack(const int8_t* src, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream)
 {
     dim3     grid((unsigned)((N + kQT - 1) / kQT), (unsigned)(K / kQT));
     uint8_t* p = reinterpret_cast<uint8_t*>(q_packed);
-    if (layout == EETQ_LAYOUT_SM80 && p)
-        tile_pack_kernel<T, EETQ_LAYOUT_SM80><<<grid, 256, 0, stream>>>(src, K, N, colmax, q_raw, p, scales, scales_f32);
+    if (layout == EETQ_LAYOUT_SM80)
+        tile_pack_kernel<EETQ_LAYOUT_SM80><<<grid, 256, 0, stream>>>(src, K, N, p);
     else
-        tile_pack_kernel<T, EETQ_LAYOUT_GFX950><<<grid, 256, 0, stream>>>(src, K, N, colmax, q_raw, p, scales,
-                                                                         scales_f32);
+        tile_pack_kernel<EETQ_LAYOUT_GFX950><<<grid, 256, 0, stream>>>(src, K, N, p);
     return check_hip(hipGetLastError(), "tile_pack_kernel launch");
 }
 
@@ -279,20 +346,45 @@ int launch_colmax(const void* w, int w_dtype, size_t K, size_t N, float* colmax,
     // strips of 64 lanes x V columns, kRowsPerBlock rows per workgroup: (N / 512) x (K / 128) workgroups at fp16 (256 at 4096^2)
     const unsigned yb = (unsigned)((K + kRowsPerBlock - 1) / kRowsPerBlock);
     if (w_dtype == EETQ_DTYPE_F16)
-        colmax_kernel<f16, 8><<<dim3((unsigned)((N + 511) / 512), yb), 256, 0, stream>>>(static_cast<const f16*>(w), K, N,
+        colmax_kernel<f16, 8, false><<<dim3((unsigned)((N + 511) / 512), yb), 256, 0, stream>>>(static_cast<const f16*>(w), K, N,
                                                                                       reinterpret_cast<u32*>(colmax));
     else
-        colmax_kernel<float, 4><<<dim3((unsigned)((N + 255) / 256), yb), 256, 0, stream>>>(static_cast<const float*>(w), K, N,
+        colmax_kernel<float, 4, false><<<dim3((unsigned)((N + 255) / 256), yb), 256, 0, stream>>>(static_cast<const float*>(w), K, N,
                                                                                         reinterpret_cast<u32*>(colmax));
     return check_hip(hipGetLastError(), "colmax_kernel launch");
 }
 
+// floats of workspace the int8 quantiser needs: one row of N maxima per block of kRowsPerBlock weight rows
+size_t quantize_workspace_floats(size_t K, size_t N) { return N * ((K + kRowsPerBlock - 1) / kRowsPerBlock); }
+
+namespace {
+template <typename T, int V>
+int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_t* packed_out, int layout, void* scales,
+                          int scales_f32, float* part, hipStream_t stream)
+{
+    const unsigned P = (unsigned)((K + kRowsPerBlock - 1) / kRowsPerBlock);
+    colmax_kernel<T, V, true><<<dim3((unsigned)((N + 64 * V - 1) / (64 * V)), P), 256, 0, stream>>>(
+        w, K, N, reinterpret_cast<u32*>(part));
+    int st = check_hip(hipGetLastError(), "colmax_kernel launch");
+    if (st != EETQ_OK) return st;
+    const dim3 grid((unsigned)((N + kQT - 1) / kQT), (unsigned)((K / kQT + kStripTiles - 1) / kStripTiles));
+    uint8_t*   p = reinterpret_cast<uint8_t*>(packed_out);
+    if (layout == EETQ_LAYOUT_SM80 && p)
+        strip_quant_kernel<T, EETQ_LAYOUT_SM80><<<grid, 256, 0, stream>>>(w, K, N, part, (int)P, raw_out, p, scales, scales_f32);
+    else
+        strip_quant_kernel<T, EETQ_LAYOUT_GFX950><<<grid, 256, 0, stream>>>(w, K, N, part, (int)P, raw_out, p, scales,
+                                                                           scales_f32);
+    return check_hip(hipGetLastError(), "strip_quant_kernel launch");
+}
+}  // namespace
+
+// `workspace`: quantize_workspace_floats(K, N) floats.  Two launches: row-block maxima, then quantise + pack.
 int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
-                    void* scales, float* colmax, hipStream_t stream)
+                    void* scales, float* workspace, hipStream_t stream)
 {
     int st = check_layout_shape(K, N, q_packed ? layout : EETQ_LAYOUT_ROW_MAJOR);
     if (st != EETQ_OK) return st;
-    EETQ_REQUIRE(w && scales && colmax, "null pointer");
+    EETQ_REQUIRE(w && scales && workspace, "null pointer");
     EETQ_REQUIRE(w_dtype == EETQ_DTYPE_F16 || w_dtype == EETQ_DTYPE_F32,
                  "Invalid datatype. Weight must be FP16 or FP32");
     // ROW_MAJOR "packed" output is just the raw tensor again
@@ -306,14 +398,12 @@ int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_ra
             raw_copy = q_packed;
         packed_out = nullptr;
     }
-    st = launch_colmax(w, w_dtype, K, N, colmax, stream);
-    if (st != EETQ_OK) return st;
     if (w_dtype == EETQ_DTYPE_F16)
-        st = launch_tile_pack<f16>(static_cast<const f16*>(w), K, N, colmax, raw_out, packed_out, layout, scales, 0,
-                                   stream);
+        st = launch_quantize_typed<f16, 8>(static_cast<const f16*>(w), K, N, raw_out, packed_out, layout, scales, 0, workspace,
+                                           stream);
     else
-        st = launch_tile_pack<float>(static_cast<const float*>(w), K, N, colmax, raw_out, packed_out, layout, scales,
-                                     1, stream);
+        st = launch_quantize_typed<float, 4>(static_cast<const float*>(w), K, N, raw_out, packed_out, layout, scales, 1,
+                                             workspace, stream);
     if (st != EETQ_OK) return st;
     if (raw_copy) EETQ_TRY_HIP(hipMemcpyAsync(raw_copy, raw_out, K * N, hipMemcpyDeviceToDevice, stream));
     return EETQ_OK;
@@ -328,7 +418,7 @@ int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int l
         EETQ_TRY_HIP(hipMemcpyAsync(q_packed, q_raw, K * N, hipMemcpyDeviceToDevice, stream));
         return EETQ_OK;
     }
-    return launch_tile_pack<int8_t>(q_raw, K, N, nullptr, nullptr, q_packed, layout, nullptr, 0, stream);
+    return launch_tile_pack(q_raw, K, N, q_packed, layout, stream);
 }
 
 int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream)

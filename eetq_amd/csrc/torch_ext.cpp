@@ -81,7 +81,9 @@ std::vector<Tensor> quant_weights(const Tensor& weight, py::object quant_type, b
     Tensor       w_dev = weight.is_cuda() ? weight : weight.to(dev);
     const auto   i8    = torch::TensorOptions().dtype(at::kChar).device(dev);
     Tensor       raw, processed, scales = torch::empty({(int64_t)N}, weight.options().device(dev));
-    Tensor       colmax = torch::empty({(int64_t)N}, torch::TensorOptions().dtype(at::kFloat).device(dev));
+    // workspace of the quantiser (int8: one row of column maxima per 128 weight rows; int4: N floats)
+    Tensor colmax = torch::empty({(int64_t)(int4 ? N : eetq_quantize_workspace_floats(K, N))},
+                                 torch::TensorOptions().dtype(at::kFloat).device(dev));
     if (!int4) {
         if (return_unprocessed_quantized_tensor) raw = torch::empty({(int64_t)K, (int64_t)N}, i8);
         processed = torch::empty({(int64_t)K, (int64_t)N}, i8);

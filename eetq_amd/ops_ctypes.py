@@ -104,7 +104,7 @@ def quant_weights(origin_weight, quant_type, return_unprocessed_quantized_tensor
         raw = torch.empty((K, N), dtype=torch.int8, device=dev) if return_unprocessed_quantized_tensor else None
         processed = torch.empty((K, N), dtype=torch.int8, device=dev)
         scales = torch.empty((N,), dtype=weight.dtype, device=dev)
-        colmax = torch.empty((N,), dtype=torch.float32, device=dev)
+        colmax = torch.empty((_lib.lib().eetq_quantize_workspace_floats(K, N),), dtype=torch.float32, device=dev)
         check(_lib.lib().eetq_quantize_i8(
             _ptr(w_dev), DTYPE_F16 if weight.dtype == torch.float16 else DTYPE_F32, K, N,
             _ptr(raw) if raw is not None else None, _ptr(processed), lay, _ptr(scales), _ptr(colmax),

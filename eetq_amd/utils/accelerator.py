@@ -177,9 +177,10 @@ def eet_accelerator(model, quantize=False, fused_attn=False, dev="cuda:0", fused
                     fused_residual=False, static_cache=False, glu8=True):
     """Reference semantics (accelerator.py:15-19): ``fused_attn`` first builds fp16 fused-QKV attention blocks, then
     ``quantize`` turns every decoder nn.Linear -- the fused QKV included -- into W8A16.  ``static_cache`` (extension): make
-    ``model.generate`` default to a pre-allocated KV cache without torch.compile (``cache_implementation="static"``,
-    ``disable_compile=True`` in the model's generation config), the form on which the accelerated blocks run a decode
-    step as one launch per attention / one call per layer.  ``glu8``: see ``replace_with_eet_fused_mlp``."""
+    ``model.generate`` default to a pre-allocated KV cache (``cache_implementation="static"`` in the model's generation
+    config), the form on which the accelerated blocks run a decode step as one launch per attention / one call per layer.
+    Any rewrite also sets ``disable_compile=True`` there: the operators break torch.compile's graph, so a compiled static-
+    cache forward would capture nothing.  ``glu8``: see ``replace_with_eet_fused_mlp``."""
     if fused_attn:
         replace_with_eet_fp16_fused_attn(model)
     if quantize:
@@ -190,7 +191,11 @@ def eet_accelerator(model, quantize=False, fused_attn=False, dev="cuda:0", fused
         replace_with_eet_rmsnorm(model)
     if fused_residual:
         replace_with_eet_fused_residual(model)
-    if static_cache and getattr(model, "generation_config", None) is not None:
-        model.generation_config.cache_implementation = "static"
-        model.generation_config.disable_compile = True
+    gen = getattr(model, "generation_config", None)
+    if gen is not None and (quantize or fused_attn or fused_mlp or fused_norm or fused_residual):
+        # the operators are opaque to torch.compile (every one breaks the graph): with a static cache transformers would
+        # compile the forward, capture an EMPTY CUDA graph ("The CUDA Graph is empty" warning) and run eagerly anyway
+        gen.disable_compile = True
+    if static_cache and gen is not None:
+        gen.cache_implementation = "static"
     return model

@@ -61,11 +61,14 @@ enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SIL
  * q = int8(clamp(round_half_away(w / s32), -128, 127)); bit-exact with the reference, including q = 127
  * for an all-zero column.  q_raw (ROW_MAJOR) and q_packed (in `layout`) may each be NULL.
  * All pointers are DEVICE pointers.  `scales` has dtype `w_dtype` and N elements.
- * `workspace` must provide N floats (device); pass NULL to let the library use an internal buffer
- * (one per device, allocated once and grown on demand: calls that pass NULL must not overlap on one device --
- * concurrent streams bring their own workspace, as both Python bindings do). */
+ * Two launches: per-row-block column maxima (no atomics, no fill), then quantise + pack.
+ * `workspace` must provide eetq_quantize_workspace_floats(K, N) floats (device; = N * ceil(K / 128): one row of
+ * partial maxima per 128 weight rows); pass NULL to let the library use an internal buffer (one per device,
+ * allocated once and grown on demand, freed by eetq_release_workspace: calls that pass NULL must not overlap on
+ * one device -- concurrent streams bring their own workspace, as both Python bindings do). */
 int eetq_quantize_i8(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
                      int layout, void* scales, float* workspace, void* stream);
+size_t eetq_quantize_workspace_floats(size_t K, size_t N);
 
 /* Same operation on HOST buffers (what the reference's CPU function receives): uploads w, runs the HIP
  * kernels, downloads the results and synchronises.  Blocking. */
@@ -258,6 +261,16 @@ int eetq_diag_stream_read(const void* p, size_t bytes, void* sink, void* stream)
 /* Diagnostic: a kernel of `grid` x `block` threads that touches no memory (the fixed cost of a dispatch, and the resolution
  * floor of the timing method it is measured with). */
 int eetq_diag_empty(void* sink, int grid, int block, void* stream);
+
+/* ---- library-owned scratch ---------------------------------------------------------------------------
+ * The reference's operators take no workspace argument (fpA_intB_gemm_wrapper.cu:169-170 passes none), so the few
+ * buffers the kernels need are owned by the library: the split-K partial-tile regions (40 MiB per launch stream that
+ * ever ran a 17 <= M <= 128 GEMM, at most EETQ_AMD_SPLITK_REGIONS (default 16) per device; a stream that cannot get a
+ * region of its own runs unsplit -- regions are never shared), the W4A16 prefill expansion buffers and the quantiser's
+ * NULL-workspace buffer.  eetq_release_workspace synchronises the devices that hold any, frees all of it and reports the
+ * bytes freed (bytes_freed may be NULL); later calls re-create what they need.  Do not call it while a HIP graph that
+ * captured a split-K or W4A16 launch is still going to be replayed. */
+int eetq_release_workspace(size_t* bytes_freed);
 
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* eetq_last_error(void);   /* thread-local, never NULL */

@@ -1,0 +1,134 @@
+"""BASELINE.json configs[0]/[1] THROUGH THE MODULE on the GPU: EetqLinear(4096, 4096), M = 1, against the committed CPU
+fp16 nn.Linear fixture (the north star's oracle, atol 1e-2 = the reference's own tolerance, examples/layers/test_qlinear.py:36)
+and against the C oracle (tier A); plus the RCCL branch of the replica fan-out on one GPU."""
+import json
+import os
+import socket
+import subprocess
+import sys
+import textwrap
+import zlib
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _crc(a):
+    return zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("cls_name", ["EetqLinear", "W8A16Linear"])
+def test_config1_module_vs_cpu_linear_fixture_and_oracle(oracle, golden_dir, cls_name):
+    """reference module: python/eetq/modules/qlinear.py:96-124 (EetqLinear) / :27-62 (W8A16Linear)"""
+    from eetq_amd import ops
+    from eetq_amd.modules.qlinear import EetqLinear, W8A16Linear
+    man = json.load(open(os.path.join(golden_dir, "MANIFEST.json")))["linear"][2]
+    assert man["file"] == "linear_config0_m1_k4096_n4096.npz"
+    torch.manual_seed(1)                                   # the fixture's recipe (tests/golden/make_golden.py)
+    lin = torch.nn.Linear(4096, 4096, bias=False, dtype=torch.float16)
+    x = torch.rand(1, 4096, dtype=torch.float16)
+    w = lin.weight.detach().numpy()
+    assert _crc(w) == man["w_crc32"] and _crc(x.numpy()) == man["x_crc32"], "torch RNG drifted: regenerate fixtures"
+    y_gold = np.load(os.path.join(golden_dir, man["file"]))["y"].astype(np.float32)
+    if cls_name == "W8A16Linear":
+        mod = W8A16Linear.from_torch(lin.to(DEV))
+    else:
+        mod = EetqLinear(4096, 4096, bias=False, device=DEV)
+        mod.register_scale(DEV)
+        mod.weight, mod.weight_scales = ops.quant_weights(lin.weight.detach().t().contiguous().to(DEV), torch.int8, False)
+        mod.eval()
+    y = mod(x.to(DEV))
+    torch.cuda.synchronize()
+    got = y.cpu().numpy().astype(np.float32)
+    assert got.shape == (1, 4096)
+    # tier B: against CPU torch.nn.Linear fp16 on the ORIGINAL weights -- the reference's literal check
+    assert torch.allclose(y.cpu(), torch.from_numpy(np.load(os.path.join(golden_dir, man["file"]))["y"]), atol=1e-2)
+    assert np.abs(got - y_gold).max() <= 1e-2
+    # tier A: against the oracle on the same quantised integers
+    q, s = oracle.quantize(np.ascontiguousarray(w.T))
+    ref = oracle.w8a16_gemm(x.numpy(), q, s).astype(np.float32)
+    assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref)), np.abs(got - ref).max()
+    # and the module's buffers are the oracle's bytes
+    wname = "qweight" if cls_name == "W8A16Linear" else "weight"
+    assert np.array_equal(getattr(mod, wname).cpu().numpy(), oracle.gfx950_pack(q))
+    assert mod.weight_scales.cpu().numpy().tobytes() == s.tobytes()
+
+
+def test_replica_group_nccl_single_process():
+    """ReplicaGroup(backend="nccl") with world_size 1 initialises nothing and every collective is a no-op on the GPU."""
+    from eetq_amd.utils.replicas import ReplicaGroup
+    env = {k: os.environ.pop(k) for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK") if k in os.environ}
+    try:
+        g = ReplicaGroup(backend="nccl")
+        assert g.world_size == 1 and g.device.type == "cuda" and g.backend == "nccl"
+        t = torch.arange(8.0, device=g.device)
+        assert g.fan_out(t) is t
+        assert g.timed(lambda: t.mul_(2)) >= 0
+        assert len(g.gather_checksums(t)) == 1
+        g.close()
+    finally:
+        os.environ.update(env)
+
+
+WORKER = textwrap.dedent("""
+    import os, sys, torch
+    sys.path.insert(0, %r)
+    from eetq_amd.utils.replicas import ReplicaGroup
+    from eetq_amd import ops
+    g = ReplicaGroup(backend="nccl", device="cuda:0")        # both ranks on the ONE visible GPU: the RCCL branch runs
+    assert g.world_size == 2 and g.backend == "nccl"
+    torch.manual_seed(g.rank)                                 # different activations per rank until the fan-out
+    x = torch.rand(1, 1024, dtype=torch.float16, device=g.device)
+    g.fan_out(x)
+    torch.manual_seed(5)
+    w = (torch.rand(1024, 512, device=g.device) - 0.5).half()
+    qw, s = ops.quant_weights(w, torch.int8, False)
+    y = ops.w8_a16_gemm(x, qw, s)
+    crcs = g.gather_checksums(y)
+    assert len(crcs) == 2 and crcs[0] == crcs[1], crcs        # replicas bit-identical
+    secs = g.timed(lambda: ops.w8_a16_gemm(x, qw, s))
+    assert secs > 0
+    assert g.gather_checksums(y + g.rank)[0] != g.gather_checksums(y + g.rank)[1]
+    g.close()
+    print("rank", g.rank, "ok")
+""")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_replicas_rccl_on_one_gpu(tmp_path):
+    """The nccl (= RCCL) branch of ReplicaGroup and the checks bench.py --gpus N makes, with two processes sharing the one
+    GPU of this box.  RCCL refuses two ranks on one device in some builds ("duplicate GPU"): that outcome is a skip, any
+    other failure is a failure."""
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % ROOT)
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY="0", NCCL_DEBUG="WARN")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            outs.append(p.communicate(timeout=120)[0])
+        except subprocess.TimeoutExpired:
+            p.kill()
+            outs.append(p.communicate()[0] + "\\nTIMEOUT")
+    text = "\\n".join(outs)
+    if any(p.returncode != 0 for p in procs) and ("uplicate GPU" in text or "invalid usage" in text.lower()):
+        pytest.skip("this RCCL build refuses two ranks on one device: " + text[-200:])
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out[-2000:]
+        assert "rank %d ok" % rank in out

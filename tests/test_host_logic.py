@@ -290,3 +290,34 @@ def test_state_dict_layout_tag_is_in_band_and_wins_on_load():
     assert isinstance(mod._state_dict_hooks[next(iter(mod._state_dict_hooks))], _SaveHook)
     assert any(isinstance(getattr(h, "hook", h), _LoadHook) or isinstance(h, _LoadHook)
                for h in mod._load_state_dict_pre_hooks.values())
+
+
+def test_eetq_py_shim_serves_both_boundaries(monkeypatch):
+    """EETQ.py (executed only when EETQ.cpython-*.so is missing: extension modules win the import) hands out the compiled
+    module when it can be built and the ctypes binding of the same C ABI otherwise."""
+    import importlib.util
+    import os
+    import sys
+    from eetq_amd import _ext
+    names = ["w8_a16_gemm", "w8_a16_gemm_", "preprocess_weights", "quant_weights", "rotary_embedding_neox",
+             "layernorm_forward"]
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "EETQ.py")
+
+    def run_shim(alias):
+        spec = importlib.util.spec_from_file_location(alias, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[alias] = mod
+        try:
+            spec.loader.exec_module(mod)
+            return sys.modules[alias]
+        finally:
+            sys.modules.pop(alias, None)
+
+    def no_compiler(*a, **k):
+        raise RuntimeError("no C++ compiler")
+    monkeypatch.setattr(_ext, "build", no_compiler)
+    fallback = run_shim("EETQ_shim_fallback")
+    assert all(callable(getattr(fallback, n)) for n in names) and not hasattr(fallback, "__eetq_amd_version__")
+    monkeypatch.undo()
+    compiled = run_shim("EETQ_shim_compiled")
+    assert all(callable(getattr(compiled, n)) for n in names) and hasattr(compiled, "__eetq_amd_version__")
