@@ -395,6 +395,13 @@ int eetq_rotary_neox_f16(const int64_t* positions, void* query, void* key, const
                          heads * head_size, heads * head_size, static_cast<hipStream_t>(stream));
 }
 
+int eetq_rotary_neox(const int64_t* positions, void* query, void* key, const void* cos_sin_cache, int dtype, int tokens,
+                     int heads, int head_size, int rot_dim, void* stream)
+{
+    return launch_rotary_any(positions, query, key, cos_sin_cache, dtype, tokens, heads, heads, head_size, rot_dim,
+                             heads * head_size, heads * head_size, static_cast<hipStream_t>(stream));
+}
+
 int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
                                  int tokens, int q_heads, int k_heads, int head_size, int rot_dim, int q_stride,
                                  int k_stride, void* stream)

@@ -228,6 +228,9 @@ int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows
 int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int q_heads, int k_heads,
                   int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream);
 
+int launch_rotary_any(const int64_t* pos, void* q, void* k, const void* cache, int dtype, int tokens, int q_heads,
+                      int k_heads, int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream);
+
 void set_attn_stamps(unsigned long long* buf);
 int launch_rope_attn_decode(const int64_t* positions, const int64_t* slots, int slot_stride, const f16* q, const f16* k,
                             const f16* v, const f16* cos_sin, f16* kc, f16* vc, const f16* mask, f16* out, float* ws,

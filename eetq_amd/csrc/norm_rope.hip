@@ -70,14 +70,18 @@ __global__ __launch_bounds__(THREADS) void rmsnorm_kernel(const f16* __restrict_
 // q: [tokens][q_heads][head_size] with q_stride elements between tokens (the reference's layout is the contiguous case,
 // q_stride = heads * head_size, k_heads = q_heads); a fused QKV projection output is rotated in place with
 // q_stride = k_stride = its row length, and grouped-query models have k_heads < q_heads.
-__global__ void rotary_neox_kernel(const int64_t* __restrict__ positions, f16* __restrict__ query,
-                                   f16* __restrict__ key, const f16* __restrict__ cache, int rot_dim, int q_stride,
+// T = f16 (every product and sum an fp16 operation, like the reference's half operators), float or double (plain IEEE
+// operations of that type, no contraction): the reference dispatches float / double / half / bfloat16
+// (pos_encoding_kernels.cu:73-86); bf16 is outside this library's scope.
+template <typename T>
+__global__ void rotary_neox_kernel(const int64_t* __restrict__ positions, T* __restrict__ query,
+                                   T* __restrict__ key, const T* __restrict__ cache, int rot_dim, int q_stride,
                                    int k_stride, int q_heads, int k_heads, int head_size)
 {
 #pragma clang fp contract(off)
     const int     token = blockIdx.x;
     const int64_t pos   = positions[token];
-    const f16*    cp    = cache + pos * rot_dim;
+    const T*      cp    = cache + pos * rot_dim;
     const int     embed = rot_dim / 2;
     const int     nq = q_heads * embed, n = nq + k_heads * embed;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
@@ -85,11 +89,11 @@ __global__ void rotary_neox_kernel(const int64_t* __restrict__ positions, f16* _
         const int    j    = is_k ? i - nq : i;
         const int    head = j / embed;
         const int    off  = j - head * embed;
-        f16*         p    = (is_k ? key + (size_t)token * k_stride : query + (size_t)token * q_stride) +
-                 (size_t)head * head_size;
-        const f16 c = cp[off], s = cp[embed + off];
-        const f16 vx = p[off], vy = p[embed + off];
-        const f16 xc = vx * c, ys = vy * s, yc = vy * c, xs = vx * s;
+        T*           p    = (is_k ? key + (size_t)token * k_stride : query + (size_t)token * q_stride) +
+               (size_t)head * head_size;
+        const T c = cp[off], s = cp[embed + off];
+        const T vx = p[off], vy = p[embed + off];
+        const T xc = vx * c, ys = vy * s, yc = vy * c, xs = vx * s;
         p[off]         = xc - ys;
         p[embed + off] = yc + xs;
     }
@@ -216,8 +220,9 @@ int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows
     return check_hip(hipGetLastError(), "rmsnorm_kernel launch");
 }
 
-int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int q_heads, int k_heads,
-                  int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream)
+template <typename T>
+static int launch_rotary_t(const int64_t* pos, T* q, T* k, const T* cache, int tokens, int q_heads, int k_heads,
+                           int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream)
 {
     EETQ_REQUIRE(pos && q && k && cache, "null pointer");
     EETQ_REQUIRE(tokens >= 0 && q_heads > 0 && k_heads > 0 && head_size > 0 && rot_dim > 0 && rot_dim % 2 == 0 &&
@@ -228,9 +233,34 @@ int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int toke
     int threads = (q_heads + k_heads) * rot_dim / 2;
     threads     = threads < 512 ? threads : 512;
     threads     = (threads + 63) / 64 * 64;
-    rotary_neox_kernel<<<tokens, threads, 0, stream>>>(pos, q, k, cache, rot_dim, q_stride, k_stride, q_heads, k_heads,
-                                                       head_size);
+    rotary_neox_kernel<T><<<tokens, threads, 0, stream>>>(pos, q, k, cache, rot_dim, q_stride, k_stride, q_heads, k_heads,
+                                                          head_size);
     return check_hip(hipGetLastError(), "rotary_neox_kernel launch");
+}
+
+int launch_rotary(const int64_t* pos, f16* q, f16* k, const f16* cache, int tokens, int q_heads, int k_heads,
+                  int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream)
+{
+    return launch_rotary_t<f16>(pos, q, k, cache, tokens, q_heads, k_heads, head_size, rot_dim, q_stride, k_stride, stream);
+}
+
+// dtype: EETQ_DTYPE_F16 / F32 / F64 (query, key and cache share it)
+int launch_rotary_any(const int64_t* pos, void* q, void* k, const void* cache, int dtype, int tokens, int q_heads,
+                      int k_heads, int head_size, int rot_dim, int q_stride, int k_stride, hipStream_t stream)
+{
+    switch (dtype) {
+        case EETQ_DTYPE_F16:
+            return launch_rotary_t<f16>(pos, static_cast<f16*>(q), static_cast<f16*>(k), static_cast<const f16*>(cache), tokens,
+                                        q_heads, k_heads, head_size, rot_dim, q_stride, k_stride, stream);
+        case EETQ_DTYPE_F32:
+            return launch_rotary_t<float>(pos, static_cast<float*>(q), static_cast<float*>(k), static_cast<const float*>(cache),
+                                          tokens, q_heads, k_heads, head_size, rot_dim, q_stride, k_stride, stream);
+        case EETQ_DTYPE_F64:
+            return launch_rotary_t<double>(pos, static_cast<double*>(q), static_cast<double*>(k),
+                                           static_cast<const double*>(cache), tokens, q_heads, k_heads, head_size, rot_dim,
+                                           q_stride, k_stride, stream);
+        default: return fail(EETQ_ERR_INVALID, "[eetq_amd] rotary_embedding_neox: dtype must be float16, float32 or float64");
+    }
 }
 
 }  // namespace eetq

@@ -397,11 +397,14 @@ void layernorm_forward(const Tensor& input, const Tensor& gamma, Tensor& out, do
                            stream_of(input)));
 }
 
-// reference: rotary_embedding_neox, pos_encoding_kernels.cu:55-87 (fp16 only here)
+// reference: rotary_embedding_neox, pos_encoding_kernels.cu:55-87 (float / double / half; bf16 is out of scope)
 void rotary_embedding_neox(const Tensor& positions, Tensor& query, Tensor& key, int64_t head_size, const Tensor& cos_sin_cache)
 {
-    TORCH_CHECK(query.scalar_type() == at::kHalf && key.scalar_type() == at::kHalf && cos_sin_cache.scalar_type() == at::kHalf,
-                "eetq_amd: rotary_embedding_neox is implemented for float16 only");
+    const auto st = query.scalar_type();
+    TORCH_CHECK(st == at::kHalf || st == at::kFloat || st == at::kDouble,
+                "eetq_amd: rotary_embedding_neox is implemented for float16, float32 and float64");
+    TORCH_CHECK(key.scalar_type() == st && cos_sin_cache.scalar_type() == st,
+                "rotary_embedding_neox: query, key and cos_sin_cache must share one dtype");
     TORCH_CHECK(positions.scalar_type() == at::kLong, "rotary_embedding_neox: positions must be int64");
     TORCH_CHECK(query.is_contiguous() && key.is_contiguous() && cos_sin_cache.is_contiguous() && positions.is_contiguous(),
                 "rotary_embedding_neox: tensors must be contiguous");
@@ -409,8 +412,9 @@ void rotary_embedding_neox(const Tensor& positions, Tensor& query, Tensor& key, 
     const int64_t tokens = positions.numel();
     const int64_t heads  = query.size(-2);
     c10::DeviceGuard guard(query.device());
-    check(eetq_rotary_neox_f16(positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(), cos_sin_cache.data_ptr(),
-                               (int)tokens, (int)heads, (int)head_size, (int)cos_sin_cache.size(1), stream_of(query)));
+    const int dt = st == at::kHalf ? EETQ_DTYPE_F16 : (st == at::kFloat ? EETQ_DTYPE_F32 : EETQ_DTYPE_F64);
+    check(eetq_rotary_neox(positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(), cos_sin_cache.data_ptr(), dt,
+                           (int)tokens, (int)heads, (int)head_size, (int)cos_sin_cache.size(1), stream_of(query)));
 }
 
 // tokens / heads / token stride of a [..., heads, head_size] view whose leading dimensions collapse to one stride

@@ -354,9 +354,12 @@ def layernorm_forward(input, gamma, out, eps):
 
 @_eager_only
 def rotary_embedding_neox(positions, query, key, head_size, cos_sin_cache):
-    """In-place NeoX rotary embedding of query/key (reference: pos_encoding_kernels.cu:55-87). fp16 only."""
-    if query.dtype != torch.float16 or key.dtype != torch.float16 or cos_sin_cache.dtype != torch.float16:
-        raise RuntimeError("eetq_amd: rotary_embedding_neox is implemented for float16 only")
+    """In-place NeoX rotary embedding of query/key (reference: pos_encoding_kernels.cu:55-87): float16, float32, float64."""
+    dts = {torch.float16: 0, torch.float32: 1, torch.float64: 2}
+    if query.dtype not in dts:
+        raise RuntimeError("eetq_amd: rotary_embedding_neox is implemented for float16, float32 and float64")
+    if key.dtype != query.dtype or cos_sin_cache.dtype != query.dtype:
+        raise RuntimeError("rotary_embedding_neox: query, key and cos_sin_cache must share one dtype")
     if positions.dtype != torch.int64:
         raise RuntimeError("rotary_embedding_neox: positions must be int64")
     if not (query.is_contiguous() and key.is_contiguous() and cos_sin_cache.is_contiguous()
@@ -366,8 +369,8 @@ def rotary_embedding_neox(positions, query, key, head_size, cos_sin_cache):
     rot_dim = cos_sin_cache.shape[1]
     heads = query.shape[-2]
     with torch.cuda.device(query.device):
-        check(_lib.lib().eetq_rotary_neox_f16(_ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), tokens,
-                                              heads, int(head_size), rot_dim, _stream_ptr()))
+        check(_lib.lib().eetq_rotary_neox(_ptr(positions), _ptr(query), _ptr(key), _ptr(cos_sin_cache), dts[query.dtype],
+                                          tokens, heads, int(head_size), rot_dim, _stream_ptr()))
     return None
 
 

@@ -31,7 +31,7 @@ enum {
 
 /* Element type of the weight handed to the quantiser and of the scales it returns
  * (reference: symmetric_quantize<half,half> / <float,float>, fpA_intB_gemm_wrapper.cu:78-95). */
-enum { EETQ_DTYPE_F16 = 0, EETQ_DTYPE_F32 = 1 };
+enum { EETQ_DTYPE_F16 = 0, EETQ_DTYPE_F32 = 1, EETQ_DTYPE_F64 = 2 /* rotary only */ };
 
 /* Byte layout of an int8 [K][N]-shaped weight tensor.
  *   ROW_MAJOR : raw two's-complement int8, element (k,n) at k*N+n -- the reference's "unprocessed" tensor.
@@ -151,6 +151,13 @@ int eetq_rmsnorm_f16(const void* x, const void* gamma, void* out, float eps, int
  * ([max_pos][rot_dim], cos half then sin half), every product/sum rounded to fp16 like the reference. */
 int eetq_rotary_neox_f16(const int64_t* positions, void* query, void* key, const void* cos_sin_cache,
                          int tokens, int heads, int head_size, int rot_dim, void* stream);
+
+/* The same entry for every floating type the reference dispatches except bfloat16 (AT_DISPATCH_FLOATING_TYPES_AND2,
+ * pos_encoding_kernels.cu:73-86; bf16 is outside this library's scope): dtype = EETQ_DTYPE_F16 / F32 / F64, shared by
+ * query, key and cache.  F32 / F64 are plain IEEE products and sums of that type WITHOUT contraction (the reference's float
+ * instantiation is whatever nvcc's default FMA contraction makes of `x * cos - y * sin`: agreement within one rounding). */
+int eetq_rotary_neox(const int64_t* positions, void* query, void* key, const void* cos_sin_cache, int dtype,
+                     int tokens, int heads, int head_size, int rot_dim, void* stream);
 
 /* Same rotation on strided operands (no reference counterpart at the pybind boundary; it is what the reference's
  * EETLlamaAttention, python/eetq/modules/llama_modules.py:94-106, needs to rotate the q and k slices of a fused QKV

@@ -873,3 +873,34 @@ void oracle_rotary_neox_f16(const int64_t* positions, uint16_t* q, uint16_t* k, 
         }
     }
 }
+
+/* The same rotation for scalar_t = float / double (pos_encoding_kernels.cu:12-53 instantiated by the dispatch at :73-86):
+ * plain IEEE products and sums of that type, no contraction (this file is built with -ffp-contract=off).  The reference's
+ * own float build is subject to nvcc's default FMA contraction of `x * cos - y * sin`, so a CUDA run may differ from this
+ * by one rounding of one product; the half instantiation above has no such freedom. */
+#define ORACLE_ROTARY(NAME, T)                                                                               \
+    void NAME(const int64_t* positions, T* q, T* k, const T* cache, size_t tokens, size_t heads, size_t head_size, \
+              size_t rot_dim)                                                                                \
+    {                                                                                                        \
+        const size_t embed = rot_dim / 2;                                                                    \
+        for (size_t t = 0; t < tokens; ++t) {                                                                \
+            const T* c = cache + (size_t)positions[t] * rot_dim;                                             \
+            for (size_t h = 0; h < heads; ++h) {                                                             \
+                T* qh = q + (t * heads + h) * head_size;                                                     \
+                T* kh = k + (t * heads + h) * head_size;                                                     \
+                for (size_t i = 0; i < embed; ++i) {                                                         \
+                    const T cs = c[i], sn = c[embed + i];                                                    \
+                    const T qx = qh[i], qy = qh[embed + i];                                                  \
+                    const T a = qx * cs, b = qy * sn, d = qy * cs, e = qx * sn;                              \
+                    qh[i]         = a - b;                                                                   \
+                    qh[embed + i] = d + e;                                                                   \
+                    const T kx = kh[i], ky = kh[embed + i];                                                  \
+                    const T f = kx * cs, g = ky * sn, m = ky * cs, n = kx * sn;                              \
+                    kh[i]         = f - g;                                                                   \
+                    kh[embed + i] = m + n;                                                                   \
+                }                                                                                            \
+            }                                                                                                \
+        }                                                                                                    \
+    }
+ORACLE_ROTARY(oracle_rotary_neox_f32, float)
+ORACLE_ROTARY(oracle_rotary_neox_f64, double)

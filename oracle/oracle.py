@@ -11,7 +11,7 @@ _LIB_PATH = os.path.join(_HERE, "libeetq_oracle.so")
 __all__ = [
     "build", "lib", "quantize", "sm80_pack", "sm80_pack_closed_form", "sm80_unpack", "gfx950_pack",
     "gfx950_unpack", "sm80_reader_unpack", "ref_gemv_sm80", "quantize_i4", "i4_values", "i4_from_values", "sm80_pack_i4",
-    "sm80_unpack_i4", "sm80_reader_unpack_i4", "gfx950_pack_i4", "gfx950_unpack_i4", "w8a16_gemm", "w8a16_gemm_bias_act", "w8a16_gemm_f32acc", "dequant", "rmsnorm_f16", "rotary_neox_f16",
+    "sm80_unpack_i4", "sm80_reader_unpack_i4", "gfx950_pack_i4", "gfx950_unpack_i4", "w8a16_gemm", "w8a16_gemm_bias_act", "w8a16_gemm_f32acc", "dequant", "rmsnorm_f16", "rotary_neox_f16", "rotary_neox",
     "f32_to_f16_bits", "f16_bits_to_f32",
 ]
 
@@ -54,6 +54,8 @@ def lib():
         L.oracle_dequant.argtypes = [vp, vp, vp, sz, sz]
         L.oracle_rmsnorm_f16.argtypes = [vp, vp, vp, ctypes.c_float, sz, sz]
         L.oracle_rotary_neox_f16.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz]
+        L.oracle_rotary_neox_f32.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz]
+        L.oracle_rotary_neox_f64.argtypes = [vp, vp, vp, vp, sz, sz, sz, sz]
         L.oracle_f32_to_f16.argtypes = [ctypes.c_float]
         L.oracle_f32_to_f16.restype = ctypes.c_uint16
         L.oracle_f16_to_f32.argtypes = [ctypes.c_uint16]
@@ -276,4 +278,20 @@ def rotary_neox_f16(positions, q, k, cache, head_size):
     heads = q.size // (tokens * head_size)
     lib().oracle_rotary_neox_f16(_p(positions), _p(q), _p(k), _p(cache), tokens, heads, head_size,
                                  cache.shape[1])
+    return q, k
+
+
+def rotary_neox(positions, q, k, cache, head_size):
+    """The same for float16 / float32 / float64 operands (dtype taken from q): rotated copies (q', k')."""
+    dt = np.dtype(q.dtype)
+    if dt == np.float16:
+        return rotary_neox_f16(positions, q, k, cache, head_size)
+    fn = {np.dtype(np.float32): "oracle_rotary_neox_f32", np.dtype(np.float64): "oracle_rotary_neox_f64"}[dt]
+    positions = _c(positions.reshape(-1), np.int64)
+    q = _c(q, dt).copy()
+    k = _c(k, dt).copy()
+    cache = _c(cache, dt)
+    tokens = positions.shape[0]
+    heads = q.size // (tokens * head_size)
+    getattr(lib(), fn)(_p(positions), _p(q), _p(k), _p(cache), tokens, heads, head_size, cache.shape[1])
     return q, k

@@ -60,7 +60,7 @@ def test_quant_weights_golden(ops, golden_dir, name):
 
 @pytest.mark.parametrize("K,N,dtype", [(64, 16, np.float16), (64, 48, np.float32), (256, 128, np.float16),
                                        (1024, 4096, np.float16), (4096, 4096, np.float16), (4096, 11008, np.float16),
-                                       (512, 1040, np.float32)])
+                                       (512, 1040, np.float32), (320, 80, np.float16), (576, 2000, np.float32)])
 def test_quantize_bit_exact_vs_oracle(ops, oracle, K, N, dtype):
     rng = np.random.default_rng(K * 7 + N)
     w = (rng.standard_normal((K, N)) * 0.02).astype(dtype)
@@ -72,6 +72,33 @@ def test_quantize_bit_exact_vs_oracle(ops, oracle, K, N, dtype):
     assert np.array_equal(raw.cpu().numpy(), q)
     assert scales.cpu().numpy().tobytes() == s.tobytes()
     assert np.array_equal(processed.cpu().numpy(), oracle.gfx950_pack(q))
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+def test_quantize_row_block_partials_edge_values(ops, oracle, dtype):
+    """The two-launch quantiser reduces per-row-block maxima (3 blocks of 128 rows + a 5-tile strip here): NaN is ignored
+    by the running maximum like std::max (cutlass_preprocessors.cc:619-628), inf makes the scale inf, an all-zero column
+    quantises to 127, ties round away from zero -- wherever in K the special value sits; both target layouts."""
+    K, N = 320, 128
+    rng = np.random.default_rng(99)
+    w = (rng.standard_normal((K, N)) * 0.05).astype(dtype)
+    w[:, 5] = 0                                   # zero column -> scale 0 -> 0/0 -> 127
+    w[7, 9] = np.nan                              # NaN in the first row block
+    w[300, 10] = np.nan                           # NaN in the last (partial) row block
+    w[200, 11] = np.inf                           # inf in the middle block
+    w[130, 12] = -np.inf
+    w[:, 13] = 0
+    w[319, 13] = 1.0                              # the column maximum is the very last row
+    w[0, 14] = 2.0                                # ... or the very first
+    w[:, 15] = (np.arange(K) % 5 - 2) * 0.5 / 64  # exact ties: k * amax / 256
+    w[1, 15] = 1.0
+    for layout in ("gfx950", "sm80"):
+        raw, processed, scales = ops.quant_weights(torch.from_numpy(w).to(DEV), torch.int8, True, layout=layout)
+        q, s = oracle.quantize(w)
+        assert np.array_equal(raw.cpu().numpy(), q), layout
+        assert scales.cpu().numpy().tobytes() == s.tobytes(), layout
+        ref = oracle.gfx950_pack(q) if layout == "gfx950" else oracle.sm80_pack(q)
+        assert np.array_equal(processed.cpu().numpy(), ref), layout
 
 
 def test_quantize_default_init_4096(ops, oracle):
@@ -402,6 +429,36 @@ def test_rotary_embedding_neox(ops, oracle, heads, hs, rot):
                                     cache.numpy(), hs)
     assert np.array_equal(qd.cpu().numpy().reshape(b * t, heads, hs), qo)   # fp16 op-for-op: bit-exact
     assert np.array_equal(kd.cpu().numpy().reshape(b * t, heads, hs), ko)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.float64])
+@pytest.mark.parametrize("heads,hs,rot", [(8, 64, 64), (5, 128, 64)])
+def test_rotary_embedding_neox_float_and_double(ops, oracle, dtype, heads, hs, rot):
+    """The reference dispatches float / double / half / bf16 (pos_encoding_kernels.cu:73-86); float and double are plain
+    IEEE operations of that type here and in the oracle (no contraction): bit-exact.  bf16 stays rejected (out of scope)."""
+    torch.manual_seed(heads + rot)
+    b, t = 2, 5
+    q = torch.randn(b, t, 1, heads, hs, dtype=dtype)
+    k = torch.randn(b, t, 1, heads, hs, dtype=dtype)
+    inv = 1.0 / (10000 ** (torch.arange(0, rot, 2).double() / rot))
+    fr = torch.einsum("i,j->ij", torch.arange(64).double(), inv)
+    cache = torch.cat([fr.cos(), fr.sin()], -1).to(dtype)
+    pos = torch.randint(0, 64, (b, t))
+    qd, kd = q.to(DEV), k.to(DEV)
+    assert ops.rotary_embedding_neox(pos.to(DEV), qd, kd, hs, cache.to(DEV)) is None
+    qo, ko = oracle.rotary_neox(pos.numpy(), q.numpy().reshape(b * t, heads, hs), k.numpy().reshape(b * t, heads, hs),
+                                cache.numpy(), hs)
+    assert np.array_equal(qd.cpu().numpy().reshape(b * t, heads, hs), qo)
+    assert np.array_equal(kd.cpu().numpy().reshape(b * t, heads, hs), ko)
+    # against the textbook rotation in float64: only rounding differences
+    x, y = q[..., : rot // 2].double(), q[..., rot // 2: rot].double()
+    c = cache[pos][..., : rot // 2].double()[:, :, None, None, :]
+    sn = cache[pos][..., rot // 2:].double()[:, :, None, None, :]
+    assert torch.allclose(qd.cpu()[..., : rot // 2].double(), x * c - y * sn, atol=1e-5 if dtype == torch.float32 else 1e-12)
+    with pytest.raises(RuntimeError):
+        ops.rotary_embedding_neox(pos.to(DEV), qd.bfloat16(), kd.bfloat16(), hs, cache.to(DEV).bfloat16())
+    with pytest.raises(RuntimeError):   # mixed dtypes
+        ops.rotary_embedding_neox(pos.to(DEV), qd, kd.half(), hs, cache.to(DEV))
 
 
 @pytest.mark.parametrize("hq,hk,hs", [(8, 8, 64), (8, 2, 128), (5, 1, 64)])
