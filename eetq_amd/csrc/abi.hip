@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "common.hpp"
+#include "gemv_kernel.hpp"
 
 namespace eetq {
 
@@ -393,6 +394,59 @@ int eetq_rotary_neox_f16(const int64_t* positions, void* query, void* key, const
     return launch_rotary(positions, static_cast<f16*>(query), static_cast<f16*>(key),
                          static_cast<const f16*>(cos_sin_cache), tokens, heads, heads, head_size, rot_dim,
                          heads * head_size, heads * head_size, static_cast<hipStream_t>(stream));
+}
+
+int eetq_w8a16_gemv_grouped(const eetq_gemv_problem* problems, int count, void* stream)
+{
+    EETQ_REQUIRE(count >= 0 && (problems || count == 0), "grouped GEMV: null problem array");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < count; ++i) {
+        const eetq_gemv_problem& p = problems[i];
+        int st = check_gemm_args(p.x, p.w_packed, p.scales, p.y, 1, p.N, p.K);
+        if (st != EETQ_OK) return st;
+        EETQ_REQUIRE(!p.bias || (uintptr_t)p.bias % 8 == 0, "bias must be 8-byte aligned");
+        EETQ_REQUIRE(!p.residual || (uintptr_t)p.residual % 16 == 0, "residual must be 16-byte aligned");
+    }
+    std::vector<char> done(count, 0);
+    for (int i = 0; i < count; ++i) {
+        if (done[i]) continue;
+        const int K = problems[i].K;
+        if (!gemv_grouped_supports(K)) {  // one by one through the ordinary dispatcher
+            done[i] = 1;
+            int st = gemm_dispatch(problems[i].x, problems[i].w_packed, problems[i].scales, problems[i].bias,
+                                   problems[i].residual, problems[i].y, 1, problems[i].N, K, EETQ_PATH_AUTO, stream);
+            if (st != EETQ_OK) return st;
+            continue;
+        }
+        gemv::GroupedArgs g;
+        g.count  = 0;
+        int rows = 0;
+        for (int j = i; j < count; ++j) {  // every not yet launched problem of this K, kMaxGroup per dispatch
+            if (done[j] || problems[j].K != K) continue;
+            done[j] = 1;
+            gemv::GroupedProblem& q = g.p[g.count++];
+            q.x         = static_cast<const f16*>(problems[j].x);
+            q.w         = reinterpret_cast<const uint8_t*>(problems[j].w_packed);
+            q.scales    = static_cast<const f16*>(problems[j].scales);
+            q.y         = static_cast<f16*>(problems[j].y);
+            q.bias      = static_cast<const f16*>(problems[j].bias);
+            q.residual  = static_cast<const f16*>(problems[j].residual);
+            q.N         = problems[j].N;
+            q.first_row = rows;
+            rows += problems[j].N / kTileN;
+            if (g.count == gemv::kMaxGroup) {
+                int st = launch_gemv_grouped(g, K, rows, s);
+                if (st != EETQ_OK) return st;
+                g.count = 0;
+                rows    = 0;
+            }
+        }
+        if (g.count) {
+            int st = launch_gemv_grouped(g, K, rows, s);
+            if (st != EETQ_OK) return st;
+        }
+    }
+    return EETQ_OK;
 }
 
 int eetq_rotary_neox(const int64_t* positions, void* query, void* key, const void* cos_sin_cache, int dtype, int tokens,

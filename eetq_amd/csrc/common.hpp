@@ -222,6 +222,11 @@ int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
                  hipStream_t stream);
 int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream, Prologue pro = Prologue{});
+namespace gemv {
+struct GroupedArgs;
+}
+bool gemv_grouped_supports(int K);
+int  launch_gemv_grouped(const gemv::GroupedArgs& g, int K, int rows, hipStream_t stream);
 int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                      hipStream_t stream);
 int launch_rmsnorm(const f16* x, const f16* gamma, f16* out, float eps, int rows, int cols, hipStream_t stream);

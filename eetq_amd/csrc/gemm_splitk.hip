@@ -33,9 +33,12 @@ struct Region {
 };
 struct Arena {
     Region r[kMaxRegions];
+    bool   need_spare = true;
 };
 std::mutex g_mutex;
 Arena      g_arena[64];
+
+hipError_t alloc_region(Region& r);
 
 int region_cap()
 {
@@ -46,6 +49,18 @@ int region_cap()
         return v < 0 ? 0 : (v > kMaxRegions ? kMaxRegions : v);
     }();
     return cap;
+}
+
+hipError_t alloc_region(Region& r)
+{
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&r.base), kRegionBytes);
+    if (e != hipSuccess) {
+        r.base = nullptr;
+        return e;
+    }
+    // tickets start at 0 and only ever grow by S per tile
+    e = hipMemset(r.base + kRegionSlabs, 0, kRegionBytes - kRegionSlabs);
+    return e;
 }
 
 // EETQ_OK with the stream's own region, or EETQ_ERR_UNSUPPORTED (no message) when it cannot have one right now
@@ -61,10 +76,13 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
         if (a.r[i].used && a.r[i].owner == stream) reg = &a.r[i];
     if (!reg) {
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-        if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)
-            return EETQ_ERR_UNSUPPORTED;  // taking or creating a region is not capturable: any eager warm-up does it
+        const bool capturing = hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone;
+        // a capturing stream can only TAKE a region that already exists (creating one is not capturable): every eager
+        // launch below leaves one spare region allocated for exactly that (torch captures on a stream of its own, which
+        // has never launched anything eagerly)
         for (int i = 0; i < cap && !reg; ++i)
-            if (!a.r[i].used) reg = &a.r[i];
+            if (!a.r[i].used && (a.r[i].base || !capturing)) reg = &a.r[i];
+        if (!reg && capturing) return EETQ_ERR_UNSUPPORTED;
         for (int i = 0; i < cap && !reg; ++i) {  // every region taken: one whose owner no longer exists can be reused
             const hipError_t q = hipStreamQuery(a.r[i].owner);
             if (q != hipSuccess && q != hipErrorNotReady) {
@@ -74,13 +92,23 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
             }
         }
         if (!reg) return EETQ_ERR_UNSUPPORTED;
-        if (!reg->base) {
-            EETQ_TRY_HIP(hipMalloc(reinterpret_cast<void**>(&reg->base), kRegionBytes));
-            // tickets start at 0 and only ever grow by S per tile
-            EETQ_TRY_HIP(hipMemset(reg->base + kRegionSlabs, 0, kRegionBytes - kRegionSlabs));
+        if (!reg->base) EETQ_TRY_HIP(alloc_region(*reg));
+        reg->used    = true;
+        reg->owner   = stream;
+        a.need_spare = true;  // the spare (if this was it) is gone
+    }
+    if (a.need_spare) {  // keep one free region allocated (never created during capture) so that a graph capture can split too
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (!(hipStreamIsCapturing(stream, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone)) {
+            bool    spare = false;
+            Region* empty = nullptr;
+            for (int i = 0; i < cap; ++i) {
+                if (!a.r[i].used && a.r[i].base) spare = true;
+                if (!a.r[i].used && !a.r[i].base && !empty) empty = &a.r[i];
+            }
+            if (!spare && empty) EETQ_TRY_HIP(alloc_region(*empty));
+            a.need_spare = false;
         }
-        reg->used  = true;
-        reg->owner = stream;
     }
     *slabs   = reinterpret_cast<float*>(reg->base);
     *tickets = reinterpret_cast<unsigned*>(reg->base + kRegionSlabs);
@@ -158,6 +186,7 @@ int release_splitk_workspace(size_t* freed)
             }
             r = Region{};
         }
+    for (int d = 0; d < 64; ++d) g_arena[d].need_spare = true;
     (void)hipSetDevice(keep);
     return EETQ_OK;
 }

@@ -177,6 +177,37 @@ int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     }
 }
 
+// ---- grouped launch (gemv_grouped_kernel): problems of equal K, at most kMaxGroup per dispatch -------------------------------
+namespace {
+template <int WAVES, int D, bool EXACT, bool XREG, int XV, int OCC>
+int launch_grouped_inst(const gemv::GroupedArgs& g, int K, int rows, hipStream_t stream)
+{
+    auto         kern = gemv::gemv_grouped_kernel<WAVES, D, EXACT, XREG, XV, OCC>;
+    const size_t smem = gemv::gemv_smem_bytes(1, K, WAVES, XREG);
+    if (smem > 64 * 1024) {
+        static std::atomic<unsigned long long> opted{0};
+        int st = opt_in_large_lds(kern, opted);
+        if (st != EETQ_OK) return st;
+    }
+    launch_kernel(kern, dim3(rows), dim3(WAVES * 64), smem, stream, g, K);
+    return check_hip(hipGetLastError(), "gemv_grouped_kernel launch");
+}
+}  // namespace
+
+bool gemv_grouped_supports(int K) { return K % kTileK == 0 && K / kTileK >= 32 && K <= 32768; }
+
+// The instantiations are the ones launch_m<1> picks for a single problem of the same K (without the 8-column-unit form),
+// so a grouped result equals the separate launch bit for bit wherever that launch takes the whole-tile-row kernel.
+int launch_gemv_grouped(const gemv::GroupedArgs& g, int K, int rows, hipStream_t stream)
+{
+    if (!gemv_grouped_supports(K)) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] grouped GEMV: K must be a multiple of 64 in [2048, 32768]");
+    if (K == 4096) return launch_grouped_inst<16, 4, true, true, 1, 8>(g, K, rows, stream);
+    const int need = (K / 8 + 1023) / 1024;  // 16-byte activation loads per thread
+    if (need <= 1) return launch_grouped_inst<16, 2, false, false, 1, 8>(g, K, rows, stream);
+    if (need <= 2) return launch_grouped_inst<16, 2, false, false, 2, 8>(g, K, rows, stream);
+    return launch_grouped_inst<16, 2, false, false, 4, 8>(g, K, rows, stream);
+}
+
 }  // namespace eetq
 
 namespace eetq {

@@ -189,10 +189,12 @@ __device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, cons
 //           retire at L2 latency; no LDS, no barrier before the math.
 //   else  : activations are staged once per workgroup in LDS (XV 16-byte loads per thread, clamped).
 // Dynamic LDS: [M*K fp16 activations unless XREG] + WAVES*M*16 floats (cross-wave reduction).
-template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8>
-__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
+// The body is a device function of the tile row `ntile` so that the grouped launch (one dispatch over the tile rows of
+// several problems, gemv_grouped_kernel below) runs exactly the same code as the single-problem kernel.
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int NORM = 0, int BITS = 8>
+__device__ __forceinline__ void gemv_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
+    f16* __restrict__ y, int N, int K, const Epilogue& ep, const Prologue& pro, const int ntile)
 {
     static_assert(!XREG || EXACT, "register-resident activations need the exact-fit shape");
     // NORM: 0 = none, 1 = RMS-norm prologue, 2 = gated-MLP activation prologue
@@ -203,7 +205,6 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     float* red = reinterpret_cast<float*>(smem + (XREG ? 0 : (size_t)M * K * 2));
 
     const int tid   = threadIdx.x;
-    const int ntile = blockIdx.x;
     const int wave  = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane  = tid & 63;
     const int g = lane >> 4, c = lane & 15;
@@ -356,6 +357,49 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
         }
     }
     EETQ_STAMP(2);
+}
+
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8>
+__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
+    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
+{
+    gemv_body<M, WAVES, D, EXACT, XREG, XV, NORM, BITS>(x, w, scales, y, N, K, ep, pro, blockIdx.x);
+}
+
+// ---- grouped launch: ONE dispatch over the tile rows of up to kMaxGroup independent M = 1 problems of equal K ----------
+// A single 16 MiB GEMV dispatch spends ~1.8 us of its ~4.8 on launch ramp, first-byte latency and tail; problems that do not
+// depend on each other (the q / k / v or gate / up projections of an unfused layer, the experts of one token, ...) pay that
+// once when their tile rows share a grid: workgroup b finds its problem from the first_row table (a scalar scan of the
+// kernel arguments) and runs the single-problem body on it.  Same arithmetic, same summation order as gemv_kernel of the
+// same instantiation: results are bit-identical to the separate launches.
+constexpr int kMaxGroup = 32;
+struct GroupedProblem {
+    const f16*     x;
+    const uint8_t* w;
+    const f16*     scales;
+    f16*           y;
+    const f16*     bias;
+    const f16*     residual;
+    int            N;
+    int            first_row;  // tile rows of the problems before this one
+};
+struct GroupedArgs {
+    GroupedProblem p[kMaxGroup];
+    int            count;
+};
+
+template <int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD>
+__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_grouped_kernel(GroupedArgs g, int K)
+{
+    const int b = blockIdx.x;
+    int       i = 0;
+    while (i + 1 < g.count && b >= g.p[i + 1].first_row) ++i;  // wave-uniform
+    const GroupedProblem& pr = g.p[i];
+    Epilogue              ep;
+    ep.bias     = pr.bias;
+    ep.residual = pr.residual;
+    gemv_body<1, WAVES, D, EXACT, XREG, XV>(pr.x, pr.w, pr.scales, pr.y, pr.N, K, ep, Prologue{}, b - pr.first_row);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

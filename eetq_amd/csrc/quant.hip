@@ -7,6 +7,9 @@
 // passes); here quant_weights is TWO launches -- per-row-block column maxima, then a strip kernel that reduces them,
 // quantises and writes the target layout -- and every pass is one coalesced sweep: 64(k) x 64(n) tiles are read
 // row-wise, transposed through LDS and written in the destination layout with 16-byte stores.
+#include <cstdlib>
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace eetq {
@@ -145,14 +148,13 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(const int8_t* __restrict
     }
 }
 
-// ---- pass 2, int8 quantiser form: a workgroup walks kStripTiles consecutive 64x64 tiles of one 64-column strip --------
+// ---- pass 2, int8 quantiser form: a workgroup takes kStripTiles (1, 2 or 4) consecutive 64x64 tiles of one 64-column strip
 // grid = (ceil(N/64), ceil(K/64 / kStripTiles)), block = 256.  All of the strip's loads are issued first (2 x 16 B per lane
 // and tile at fp16); while they fly the workgroup reduces the P row-block maxima of its 64 columns ONCE (thread t: column
 // t % 64, rows t / 64 + 4 i) -- maxima are order-independent, so the result is the reference's single running maximum
 // (:619-628) bit for bit.  Then every tile is quantised into its own LDS image, one barrier, and written in the target
 // layout with 16-byte stores exactly like tile_pack_kernel.
-constexpr int kStripTiles = 4;
-template <typename T, int LAYOUT>
+template <typename T, int LAYOUT, int kStripTiles>
 __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ src, size_t K, size_t N,
                                                           const float* __restrict__ part, int P,
                                                           int8_t* __restrict__ q_raw, uint8_t* __restrict__ q_packed,
@@ -367,13 +369,30 @@ int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_
         w, K, N, reinterpret_cast<u32*>(part));
     int st = check_hip(hipGetLastError(), "colmax_kernel launch");
     if (st != EETQ_OK) return st;
-    const dim3 grid((unsigned)((N + kQT - 1) / kQT), (unsigned)((K / kQT + kStripTiles - 1) / kStripTiles));
-    uint8_t*   p = reinterpret_cast<uint8_t*>(packed_out);
-    if (layout == EETQ_LAYOUT_SM80 && p)
-        strip_quant_kernel<T, EETQ_LAYOUT_SM80><<<grid, 256, 0, stream>>>(w, K, N, part, (int)P, raw_out, p, scales, scales_f32);
+    uint8_t*   p    = reinterpret_cast<uint8_t*>(packed_out);
+    const bool sm80 = layout == EETQ_LAYOUT_SM80 && p;
+    // tiles per workgroup: 1 (most workgroups in flight) unless EETQ_AMD_QUANT_STRIP says 2 or 4 (tuning hook)
+    static const int strip = [] {
+        const char* e = getenv("EETQ_AMD_QUANT_STRIP");
+        const int   v = e ? atoi(e) : 1;
+        return v == 2 || v == 4 ? v : 1;
+    }();
+    auto launch = [&](auto tiles) {
+        constexpr int TT = decltype(tiles)::value;
+        const dim3    grid((unsigned)((N + kQT - 1) / kQT), (unsigned)((K / kQT + TT - 1) / TT));
+        if (sm80)
+            strip_quant_kernel<T, EETQ_LAYOUT_SM80, TT><<<grid, 256, 0, stream>>>(w, K, N, part, (int)P, raw_out, p, scales,
+                                                                                 scales_f32);
+        else
+            strip_quant_kernel<T, EETQ_LAYOUT_GFX950, TT><<<grid, 256, 0, stream>>>(w, K, N, part, (int)P, raw_out, p, scales,
+                                                                                   scales_f32);
+    };
+    if (strip == 4)
+        launch(std::integral_constant<int, 4>{});
+    else if (strip == 2)
+        launch(std::integral_constant<int, 2>{});
     else
-        strip_quant_kernel<T, EETQ_LAYOUT_GFX950><<<grid, 256, 0, stream>>>(w, K, N, part, (int)P, raw_out, p, scales,
-                                                                           scales_f32);
+        launch(std::integral_constant<int, 1>{});
     return check_hip(hipGetLastError(), "strip_quant_kernel launch");
 }
 }  // namespace

@@ -665,6 +665,51 @@ Tensor llama_decode_layer(const Tensor& hidden, const NormArg& input_norm, const
     return w8_a16_gemm(act, down_w, down_s, autop, down_b, h, no_norm, false, none);
 }
 
+// Grouped decode GEMV (extension): independent single-row problems in as few dispatches as possible (eetq_w8a16_gemv_grouped).
+// inputs[i]: fp16 with K_i elements (any shape with one row); weights[i]: processed int8 [K_i, N_i]; scales[i]: fp16 [N_i].
+// Returns fresh outputs shaped like inputs[i] with the last dimension replaced by N_i.
+std::vector<Tensor> w8_a16_gemv_grouped(const std::vector<Tensor>& inputs, const std::vector<Tensor>& weights,
+                                        const std::vector<Tensor>& scales, const std::optional<std::vector<OptTensor>>& biases,
+                                        const std::optional<std::vector<OptTensor>>& residuals)
+{
+    const size_t n = inputs.size();
+    TORCH_CHECK(weights.size() == n && scales.size() == n, "w8_a16_gemv_grouped: inputs, weights and scales must have one entry per problem");
+    TORCH_CHECK(!biases || biases->size() == n, "w8_a16_gemv_grouped: one bias entry (or None) per problem");
+    TORCH_CHECK(!residuals || residuals->size() == n, "w8_a16_gemv_grouped: one residual entry (or None) per problem");
+    std::vector<Tensor>            outs, keep;
+    std::vector<eetq_gemv_problem> probs(n);
+    if (n == 0) return outs;
+    const auto dev = inputs[0].device();
+    for (size_t i = 0; i < n; ++i) {
+        const Tensor& x = inputs[i];
+        const Tensor& w = weights[i];
+        const Tensor& s = scales[i];
+        TORCH_CHECK(x.scalar_type() == at::kHalf, "w8_a16_gemm: input must be float16 (got ", x.scalar_type(), ")");
+        TORCH_CHECK(x.is_cuda(), "input must be a CUDA tensor");
+        TORCH_CHECK(w.scalar_type() == at::kChar && s.scalar_type() == at::kHalf, "w8_a16_gemm: weight must be int8 and scale float16");
+        TORCH_CHECK(w.dim() == 2 && w.is_contiguous() && s.is_contiguous(), "w8_a16_gemm: weight [K, N] and scale must be contiguous");
+        TORCH_CHECK(x.device() == dev && w.device() == dev && s.device() == dev, "w8_a16_gemv_grouped: all tensors must be on one device");
+        const int64_t K = w.size(0), N = w.size(1);
+        TORCH_CHECK(x.numel() == K && x.size(-1) == K, "w8_a16_gemv_grouped: every input must be ONE row of K elements");
+        TORCH_CHECK(s.numel() == N, "w8_a16_gemm: scale must have N elements");
+        Tensor xc = x.is_contiguous() ? x : x.contiguous();
+        keep.push_back(xc);
+        auto shape = x.sizes().vec();
+        shape.back() = N;
+        Tensor y = torch::empty(shape, x.options());
+        outs.push_back(y);
+        probs[i] = eetq_gemv_problem{xc.data_ptr(), w.data_ptr<int8_t>(), s.data_ptr(), y.data_ptr(), nullptr, nullptr, (int)N, (int)K};
+        const OptTensor b = biases ? (*biases)[i] : OptTensor();
+        const OptTensor r = residuals ? (*residuals)[i] : OptTensor();
+        check_epilogue(xc, b, r, 1, N);
+        if (b) probs[i].bias = b->data_ptr();
+        if (r) probs[i].residual = r->data_ptr();
+    }
+    c10::DeviceGuard guard(dev);
+    check(eetq_w8a16_gemv_grouped(probs.data(), (int)n, stream_of(inputs[0])));
+    return outs;
+}
+
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
 {
     m.doc() = "EETQ operator module on libeetq_amd.so (MI355X / gfx950)";
@@ -707,5 +752,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("gate_up_bias"), py::arg("down_weight"), py::arg("down_scale"), py::arg("down_bias"), py::arg("glu8") = false);
     m.def("silu_mul", &silu_mul, "silu(gate) * up on a fused gate|up block (glu8: columns in groups of 8 gate + 8 up)",
           py::arg("gate_up"), py::arg("glu8") = false);
+    m.def("w8_a16_gemv_grouped", &w8_a16_gemv_grouped, "independent single-row W8A16 problems in as few dispatches as possible",
+          py::arg("inputs"), py::arg("weights"), py::arg("scales"), py::arg("biases") = py::none(),
+          py::arg("residuals") = py::none());
     m.attr("__eetq_amd_version__") = eetq_version();
 }

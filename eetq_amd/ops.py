@@ -39,18 +39,19 @@ if _C is not None:
     decode_attention = _C.decode_attention
     rope_decode_attention = _C.rope_decode_attention
     silu_mul = _C.silu_mul
+    w8_a16_gemv_grouped = _C.w8_a16_gemv_grouped
     llama_decode_layer = _C.llama_decode_layer   # compiled boundary only: its point is the interpreter time it saves
 else:
     BOUNDARY = "ctypes"
     from .ops_ctypes import (decode_attention, layernorm_forward, preprocess_weights, quant_weights,  # noqa: F401
                              rope_decode_attention, rotary_embedding_neox, rotary_embedding_neox_kvcache,
                              rotary_embedding_neox_strided, silu_mul,
-                             unprocess_weights, w8_a16_gemm, w8_a16_gemm_)
+                             unprocess_weights, w8_a16_gemm, w8_a16_gemm_, w8_a16_gemv_grouped)
     llama_decode_layer = None
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_", "layernorm_forward",
            "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention",
-           "rope_decode_attention", "silu_mul", "convert_layout", "BOUNDARY"]
+           "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped", "BOUNDARY"]
 
 
 def convert_layout(weight, src_layout, dst_layout, is_int4=False):

@@ -25,7 +25,7 @@ from ._lib import (ACT_GELU, ACT_IDENTITY, ACT_RELU, ACT_SILU, DTYPE_F16, DTYPE_
                    LAYOUT_SM80, PATH_AUTO, PATH_GEMV, PATH_MFMA, check)
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_",
-           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout"]
+           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped"]
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
@@ -353,6 +353,60 @@ def layernorm_forward(input, gamma, out, eps):
 
 
 @_eager_only
+class _GemvProblem(ctypes.Structure):   # eetq_gemv_problem (include/eetq_amd.h)
+    _fields_ = [("x", ctypes.c_void_p), ("w_packed", ctypes.c_void_p), ("scales", ctypes.c_void_p), ("y", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("N", ctypes.c_int), ("K", ctypes.c_int)]
+
+
+@_eager_only
+def w8_a16_gemv_grouped(inputs, weights, scales, biases=None, residuals=None):
+    """Independent single-row W8A16 problems in as few dispatches as possible (extension, eetq_w8a16_gemv_grouped):
+    inputs[i] fp16 with K_i elements, weights[i] processed int8 [K_i, N_i], scales[i] fp16 [N_i]; returns fresh outputs."""
+    n = len(inputs)
+    if len(weights) != n or len(scales) != n:
+        raise RuntimeError("w8_a16_gemv_grouped: inputs, weights and scales must have one entry per problem")
+    if (biases is not None and len(biases) != n) or (residuals is not None and len(residuals) != n):
+        raise RuntimeError("w8_a16_gemv_grouped: one bias / residual entry (or None) per problem")
+    if n == 0:
+        return []
+    dev = inputs[0].device
+    probs = (_GemvProblem * n)()
+    outs, keep = [], []
+    for i, (x, w, s) in enumerate(zip(inputs, weights, scales)):
+        if x.dtype != torch.float16:
+            raise RuntimeError("w8_a16_gemm: input must be float16 (got %s)" % x.dtype)
+        if not x.is_cuda:
+            raise RuntimeError("input must be a CUDA tensor")
+        if w.dtype != torch.int8 or s.dtype != torch.float16:
+            raise RuntimeError("w8_a16_gemm: weight must be int8 and scale float16")
+        if w.dim() != 2 or not w.is_contiguous() or not s.is_contiguous():
+            raise RuntimeError("w8_a16_gemm: weight [K, N] and scale must be contiguous")
+        if x.device != dev or w.device != dev or s.device != dev:
+            raise RuntimeError("w8_a16_gemv_grouped: all tensors must be on one device")
+        K, N = w.shape
+        if x.numel() != K or x.shape[-1] != K:
+            raise RuntimeError("w8_a16_gemv_grouped: every input must be ONE row of K elements")
+        if s.numel() != N:
+            raise RuntimeError("w8_a16_gemm: scale must have N elements")
+        xc = x if x.is_contiguous() else x.contiguous()
+        y = torch.empty(tuple(x.shape[:-1]) + (N,), dtype=torch.float16, device=dev)
+        b = biases[i] if biases is not None else None
+        r = residuals[i] if residuals is not None else None
+        if b is not None and (b.dtype != torch.float16 or b.device != dev or b.numel() != N or not b.is_contiguous()):
+            raise RuntimeError("w8_a16_gemm: bias must be a contiguous float16 [N] tensor on the input's device")
+        if r is not None and (r.dtype != torch.float16 or r.device != dev or r.numel() != N or not r.is_contiguous()
+                              or r.shape[-1] != N):
+            raise RuntimeError("w8_a16_gemm: residual must be a contiguous float16 [..., N] tensor with the output's "
+                               "element count, on the input's device")
+        keep.append(xc)
+        outs.append(y)
+        probs[i] = _GemvProblem(xc.data_ptr(), w.data_ptr(), s.data_ptr(), y.data_ptr(),
+                                b.data_ptr() if b is not None else None, r.data_ptr() if r is not None else None, N, K)
+    with torch.cuda.device(dev):
+        check(_lib.lib().eetq_w8a16_gemv_grouped(probs, n, _stream_ptr()))
+    return outs
+
+
 def rotary_embedding_neox(positions, query, key, head_size, cos_sin_cache):
     """In-place NeoX rotary embedding of query/key (reference: pos_encoding_kernels.cu:55-87): float16, float32, float64."""
     dts = {torch.float16: 0, torch.float32: 1, torch.float64: 2}

@@ -167,6 +167,26 @@ int eetq_rotary_neox_strided_f16(const int64_t* positions, void* query, void* ke
                                  int tokens, int q_heads, int k_heads, int head_size, int rot_dim, int q_stride,
                                  int k_stride, void* stream);
 
+/* Grouped decode GEMV (extension; the reference's launcher takes one problem per call,
+ * csrc/weightOnlyBatchedGemv/kernelLauncher.cu:122-232): `count` INDEPENDENT M = 1 problems -- no problem reads what
+ * another one writes -- in as few dispatches as possible.  Problems of equal K (a multiple of 64 in [2048, 32768]) share
+ * one dispatch per 32 problems: their tile rows form one grid, so the ~1.8 us of launch ramp / first-byte latency / tail
+ * a 16 MiB GEMV pays per dispatch is paid once per group and the weight stream is as long as the group is.  Results are
+ * bit-identical to `count` eetq_w8a16_gemm_fused calls (same kernel body, same summation order) wherever those take the
+ * whole-tile-row GEMV kernel, and within one summation-order difference otherwise.  Problems the grouped kernel cannot
+ * take (other K) are launched one by one.  `problems` is a HOST array, read during the call (the pointers inside are
+ * device pointers, 16-byte aligned; bias / residual may be NULL); capturable in a HIP graph. */
+typedef struct {
+    const void*   x;        /* fp16 [K] */
+    const int8_t* w_packed; /* GFX950 layout of the [K][N] int8 weight */
+    const void*   scales;   /* fp16 [N] */
+    void*         y;        /* fp16 [N] */
+    const void*   bias;     /* fp16 [N] or NULL */
+    const void*   residual; /* fp16 [N] or NULL */
+    int           N, K;
+} eetq_gemv_problem;
+int eetq_w8a16_gemv_grouped(const eetq_gemv_problem* problems, int count, void* stream);
+
 /* RMS-norm -> W8A16 GEMV as one launch, M = 1 (extension): y = fp16(sum_k fp32(xn[k]) * fp32(fp16(q*s))) [+ bias] [+ residual]
  * with xn = eetq_rmsnorm_f16(x, gamma, eps) computed while the activation vector is staged in LDS (same arithmetic; the
  * sum of squares is added in a different order, so xn may differ from the separate op by one fp16 ulp in rare elements). */

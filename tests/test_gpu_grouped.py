@@ -1,0 +1,122 @@
+"""Grouped decode GEMV (eetq_w8a16_gemv_grouped / ops.w8_a16_gemv_grouped): independent M = 1 problems in one dispatch per
+group of equal K.  Same kernel body as the single launch: bit-identical to it wherever the single launch takes the
+whole-tile-row kernel, tier-A against the oracle everywhere (reference numerics: weightOnlyBatchedGemv/kernel.h:294-468,
+argument checks: kernelLauncher.cu:122-232)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import eetq_amd.ops as _ops
+    return _ops
+
+
+def _tier_a(y, ref):
+    y = y.astype(np.float32)
+    ref = ref.astype(np.float32)
+    return np.abs(y - ref) <= 1e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref)
+
+
+def _problem(ops, oracle, K, N, seed, with_oracle=True):
+    rng = np.random.default_rng(seed)
+    w = (rng.standard_normal((K, N)) * 0.02).astype(np.float16)
+    x = rng.random((1, K)).astype(np.float16)
+    qw, s = ops.quant_weights(torch.from_numpy(w).to(DEV), torch.int8, False)
+    ref = None
+    if with_oracle:
+        q, sc = oracle.quantize(w)
+        ref = oracle.w8a16_gemm(x, q, sc)
+    return torch.from_numpy(x).to(DEV), qw, s, ref
+
+
+def test_grouped_equals_separate_launches_7b_shapes(ops, oracle):
+    """q / k / v / o (4096 x 4096) and gate / up (4096 x 11008) of a Llama-2-7B layer: two groups by K -- here all K = 4096,
+    one dispatch.  Bit-identical to six separate calls, with bias and residual on some of them; tier A vs the oracle."""
+    shapes = [(4096, 4096)] * 4 + [(4096, 11008)] * 2
+    probs = [_problem(ops, oracle, K, N, 100 + i) for i, (K, N) in enumerate(shapes)]
+    xs, ws, ss = [p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs]
+    torch.manual_seed(0)
+    biases = [None, torch.randn(4096, dtype=torch.float16, device=DEV), None, None, None,
+              torch.randn(11008, dtype=torch.float16, device=DEV)]
+    residuals = [None, None, torch.randn(1, 4096, dtype=torch.float16, device=DEV), None,
+                 torch.randn(1, 11008, dtype=torch.float16, device=DEV), None]
+    outs = ops.w8_a16_gemv_grouped(xs, ws, ss, biases, residuals)
+    assert len(outs) == 6
+    for i, (x, w, s, ref) in enumerate(probs):
+        single = ops.w8_a16_gemm(x, w, s, bias=biases[i], residual=residuals[i])
+        assert outs[i].shape == single.shape and torch.equal(outs[i], single), i
+        if biases[i] is None and residuals[i] is None:
+            assert _tier_a(outs[i].cpu().numpy(), ref).all(), i
+    # without the optional lists
+    plain = ops.w8_a16_gemv_grouped(xs, ws, ss)
+    for i, (x, w, s, ref) in enumerate(probs):
+        assert torch.equal(plain[i], ops.w8_a16_gemm(x, w, s)) and _tier_a(plain[i].cpu().numpy(), ref).all()
+
+
+def test_grouped_mixed_k_13b_shapes_and_fallback(ops, oracle):
+    """Llama-2-13B shapes (K = 5120 and K = 13824: two groups), plus a K the grouped kernel does not take (1024: launched
+    alone through the ordinary dispatcher), in one call and in scrambled order."""
+    shapes = [(5120, 5120), (13824, 5120), (5120, 13824), (1024, 512), (5120, 5120), (13824, 5120)]
+    probs = [_problem(ops, oracle, K, N, 200 + i) for i, (K, N) in enumerate(shapes)]
+    outs = ops.w8_a16_gemv_grouped([p[0] for p in probs], [p[1] for p in probs], [p[2] for p in probs])
+    for i, (x, w, s, ref) in enumerate(probs):
+        assert _tier_a(outs[i].cpu().numpy(), ref).all(), (i, shapes[i])
+        single = ops.w8_a16_gemm(x, w, s)
+        assert _tier_a(outs[i].cpu().numpy(), single.cpu().numpy()).all()
+        if shapes[i] in ((5120, 13824), (1024, 512)):      # the single launch runs the same whole-tile-row kernel / is the fallback
+            assert torch.equal(outs[i], single), shapes[i]
+
+
+def test_grouped_more_than_one_dispatch_and_graph_replay(ops, oracle):
+    """40 problems of one K (32 per dispatch -> two dispatches), captured in a HIP graph and replayed on new inputs."""
+    K, N = 2048, 4096     # 256 tile rows per problem: the single launch takes the whole-tile-row kernel too
+    base = [_problem(ops, oracle, K, N, 300 + i, with_oracle=(i % 8 == 0)) for i in range(40)]
+    xs, ws, ss = [p[0].clone() for p in base], [p[1] for p in base], [p[2] for p in base]
+    eager = ops.w8_a16_gemv_grouped(xs, ws, ss)
+    for i, p in enumerate(base):
+        assert torch.equal(eager[i], ops.w8_a16_gemm(p[0], p[1], p[2])), i
+        if p[3] is not None:
+            assert _tier_a(eager[i].cpu().numpy(), p[3]).all()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.w8_a16_gemv_grouped(xs, ws, ss)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        captured = ops.w8_a16_gemv_grouped(xs, ws, ss)
+    for x in xs:
+        x.mul_(0.5)                                           # new activations in the same buffers
+    g.replay()
+    torch.cuda.synchronize()
+    for i in range(40):
+        assert torch.equal(captured[i], ops.w8_a16_gemm(xs[i], ws[i], ss[i])), i
+
+
+def test_grouped_argument_checks_and_ctypes_twin(ops):
+    from eetq_amd import ops_ctypes as ct
+    torch.manual_seed(4)
+    w = (torch.rand(2048, 64, device=DEV) - 0.5).half()
+    qw, s = ops.quant_weights(w, torch.int8, False)
+    x = torch.rand(1, 2048, dtype=torch.float16, device=DEV)
+    assert ops.w8_a16_gemv_grouped([], [], []) == []
+    a = ops.w8_a16_gemv_grouped([x, x[0]], [qw, qw], [s, s])
+    b = ct.w8_a16_gemv_grouped([x, x[0]], [qw, qw], [s, s])
+    assert a[0].shape == (1, 64) and a[1].shape == (64,)
+    assert all(torch.equal(p, q) for p, q in zip(a, b))
+    for fn in (ops.w8_a16_gemv_grouped, ct.w8_a16_gemv_grouped):
+        with pytest.raises(RuntimeError):
+            fn([x], [qw, qw], [s])                               # list lengths
+        with pytest.raises(RuntimeError):
+            fn([x.float()], [qw], [s])                            # dtype
+        with pytest.raises(RuntimeError):
+            fn([torch.rand(2, 2048, dtype=torch.float16, device=DEV)], [qw], [s])   # more than one row
+        with pytest.raises(RuntimeError):
+            fn([x], [qw], [s], [torch.zeros(8, dtype=torch.float16, device=DEV)])   # bias length
+        with pytest.raises(RuntimeError):
+            fn([x.cpu()], [qw], [s])                              # host tensor
