@@ -4,8 +4,8 @@
 //   quantise  csrc/cutlass_kernels/cutlass_preprocessors.cc:581-678  (ft::symmetric_quantize)
 //   sm80 pack csrc/cutlass_kernels/cutlass_preprocessors.cc:497-534  (preprocess_weights_for_mixed_gemm)
 // The reference runs these single-threaded on the CPU (three strided K x N passes + four re-layout
-// passes); here quant_weights is TWO launches -- per-row-block column maxima, then a strip kernel that reduces them,
-// quantises and writes the target layout -- and every pass is one coalesced sweep: 64(k) x 64(n) tiles are read
+// passes); here quant_weights is three launches -- per-row-block column maxima (plain stores: no atomics, no zero fill), a
+// small fold of those rows, and a kernel that quantises and writes the target layout -- and every pass is one coalesced sweep: 64(k) x 64(n) tiles are read
 // row-wise, transposed through LDS and written in the destination layout with 16-byte stores.
 #include <cstdlib>
 #include <type_traits>
@@ -148,13 +148,27 @@ __global__ __launch_bounds__(256) void tile_pack_kernel(const int8_t* __restrict
     }
 }
 
+// ---- pass 1b (EETQ_AMD_QUANT_FOLD=1 only): fold the P row-block maxima of every column into row 0 (one thread per
+// column, coalesced rows), so that the pack kernel reads one row.
+__global__ __launch_bounds__(256) void colmax_fold_kernel(float* __restrict__ part, size_t N, int P)
+{
+    const size_t n = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float m = part[n];
+    for (int p = 1; p < P; ++p) {
+        const float a = part[(size_t)p * N + n];
+        m             = (m < a) ? a : m;
+    }
+    part[n] = m;
+}
+
 // ---- pass 2, int8 quantiser form: a workgroup takes kStripTiles (1, 2 or 4) consecutive 64x64 tiles of one 64-column strip
 // grid = (ceil(N/64), ceil(K/64 / kStripTiles)), block = 256.  All of the strip's loads are issued first (2 x 16 B per lane
 // and tile at fp16); while they fly the workgroup reduces the P row-block maxima of its 64 columns ONCE (thread t: column
 // t % 64, rows t / 64 + 4 i) -- maxima are order-independent, so the result is the reference's single running maximum
 // (:619-628) bit for bit.  Then every tile is quantised into its own LDS image, one barrier, and written in the target
 // layout with 16-byte stores exactly like tile_pack_kernel.
-template <typename T, int LAYOUT, int kStripTiles>
+template <typename T, int LAYOUT, int kStripTiles, bool NT = false>
 __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ src, size_t K, size_t N,
                                                           const float* __restrict__ part, int P,
                                                           int8_t* __restrict__ q_raw, uint8_t* __restrict__ q_packed,
@@ -181,7 +195,7 @@ __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ 
         const size_t kt = kt0 + (j < nt ? j : nt - 1);  // clamped: no load behind a branch
         const u32x4* p  = reinterpret_cast<const u32x4*>(src + (kt * kQT + r) * N + ncc);
 #pragma unroll
-        for (int i = 0; i < kVecs; ++i) raw[j][i] = __builtin_nontemporal_load(p + i);
+        for (int i = 0; i < kVecs; ++i) raw[j][i] = NT ? __builtin_nontemporal_load(p + i) : p[i];
     }
     {
         const int    col = t & 63, p0 = t >> 6;
@@ -369,22 +383,45 @@ int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_
         w, K, N, reinterpret_cast<u32*>(part));
     int st = check_hip(hipGetLastError(), "colmax_kernel launch");
     if (st != EETQ_OK) return st;
+    // by default every pack workgroup reduces the P rows of maxima itself (two launches per call); EETQ_AMD_QUANT_FOLD=1
+    // folds them into row 0 with a small launch of their own first (measured slower: one more launch costs more than the
+    // reads it saves, profiles/r03_quant_sweep.txt)
+    static const bool fold = [] {
+        const char* e = getenv("EETQ_AMD_QUANT_FOLD");
+        return e && *e == '1';
+    }();
+    unsigned rows = P;
+    if (fold && P > 1) {
+        colmax_fold_kernel<<<(unsigned)((N + 255) / 256), 256, 0, stream>>>(part, N, (int)P);
+        st = check_hip(hipGetLastError(), "colmax_fold_kernel launch");
+        if (st != EETQ_OK) return st;
+        rows = 1;
+    }
     uint8_t*   p    = reinterpret_cast<uint8_t*>(packed_out);
     const bool sm80 = layout == EETQ_LAYOUT_SM80 && p;
-    // tiles per workgroup: 1 (most workgroups in flight) unless EETQ_AMD_QUANT_STRIP says 2 or 4 (tuning hook)
-    static const int strip = [] {
+    // tiles per workgroup: 1 (most workgroups in flight) for short K, 4 once the P rows of maxima a workgroup reduces
+    // outweigh one tile (K > 8192: 13824 x 5120 94 vs 113 us); EETQ_AMD_QUANT_STRIP = 1 / 2 / 4 overrides (tuning hook)
+    static const int forced = [] {
         const char* e = getenv("EETQ_AMD_QUANT_STRIP");
-        const int   v = e ? atoi(e) : 1;
-        return v == 2 || v == 4 ? v : 1;
+        const int   v = e ? atoi(e) : 0;
+        return v == 1 || v == 2 || v == 4 ? v : 0;
+    }();
+    const int strip = forced ? forced : (K > 8192 ? 4 : 1);
+    static const bool nt = [] {
+        const char* e = getenv("EETQ_AMD_QUANT_NT");
+        return e && *e == '1';
     }();
     auto launch = [&](auto tiles) {
         constexpr int TT = decltype(tiles)::value;
         const dim3    grid((unsigned)((N + kQT - 1) / kQT), (unsigned)((K / kQT + TT - 1) / TT));
         if (sm80)
-            strip_quant_kernel<T, EETQ_LAYOUT_SM80, TT><<<grid, 256, 0, stream>>>(w, K, N, part, (int)P, raw_out, p, scales,
+            strip_quant_kernel<T, EETQ_LAYOUT_SM80, TT><<<grid, 256, 0, stream>>>(w, K, N, part, (int)rows, raw_out, p, scales,
                                                                                  scales_f32);
+        else if (nt)
+            strip_quant_kernel<T, EETQ_LAYOUT_GFX950, TT, true><<<grid, 256, 0, stream>>>(w, K, N, part, (int)rows, raw_out, p,
+                                                                                         scales, scales_f32);
         else
-            strip_quant_kernel<T, EETQ_LAYOUT_GFX950, TT><<<grid, 256, 0, stream>>>(w, K, N, part, (int)P, raw_out, p, scales,
+            strip_quant_kernel<T, EETQ_LAYOUT_GFX950, TT><<<grid, 256, 0, stream>>>(w, K, N, part, (int)rows, raw_out, p, scales,
                                                                                    scales_f32);
     };
     if (strip == 4)
@@ -397,7 +434,8 @@ int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_
 }
 }  // namespace
 
-// `workspace`: quantize_workspace_floats(K, N) floats.  Two launches: row-block maxima, then quantise + pack.
+// `workspace`: quantize_workspace_floats(K, N) floats.  Launches: row-block maxima (no atomics, no zero fill), the fold of
+// those rows, quantise + pack.
 int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
                     void* scales, float* workspace, hipStream_t stream)
 {

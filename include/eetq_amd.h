@@ -61,7 +61,8 @@ enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SIL
  * q = int8(clamp(round_half_away(w / s32), -128, 127)); bit-exact with the reference, including q = 127
  * for an all-zero column.  q_raw (ROW_MAJOR) and q_packed (in `layout`) may each be NULL.
  * All pointers are DEVICE pointers.  `scales` has dtype `w_dtype` and N elements.
- * Two launches: per-row-block column maxima (no atomics, no fill), then quantise + pack.
+ * Two launches: per-row-block column maxima (plain stores: no atomics, no zero fill), then quantise + pack (every pack
+ * workgroup reduces the rows of maxima for its 64 columns).
  * `workspace` must provide eetq_quantize_workspace_floats(K, N) floats (device; = N * ceil(K / 128): one row of
  * partial maxima per 128 weight rows); pass NULL to let the library use an internal buffer (one per device,
  * allocated once and grown on demand, freed by eetq_release_workspace: calls that pass NULL must not overlap on

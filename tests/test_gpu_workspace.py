@@ -10,6 +10,12 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
+@pytest.fixture(scope="module")
+def ops():
+    import eetq_amd.ops as _ops
+    return _ops
+
+
 def _close(a, b):
     a, b = a.float(), b.float()
     return bool(((a - b).abs() <= 1e-3 * b.abs().max() + 2e-3 * b.abs()).all())

@@ -318,6 +318,35 @@ int main(int argc, char** argv)
         CK(hipGraphDestroy(g));
     }
 
+    // ---- allocation / cache experiments on form A0 (shipping kernel): where does the per-dispatch fixed cost come from? ----
+    if (argc > 2 && !strcmp(argv[2], "alloc")) {
+        uint8_t* arena;
+        CK(hipMalloc(&arena, (size_t)NBUF * N * K));
+        for (int b = 0; b < NBUF; ++b) CK(hipMemcpy(arena + (size_t)b * N * K, bufs[b], (size_t)N * K, hipMemcpyDeviceToDevice));
+        auto run = [&](const char* name, auto wsel) {
+            hipGraph_t g;
+            hipGraphExec_t ge;
+            CK(hipStreamBeginCapture(s0, hipStreamCaptureModeGlobal));
+            for (int e = 0; e < S; ++e) {
+                const StepIO io = io_of(e, yref);
+                hipLaunchKernelGGL((gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>), dim3(N / 16), dim3(1024), 16 * 16 * 4, s0,
+                                   io.x, wsel(e), io.scales, io.y, N, K, Epilogue{}, Prologue{});
+            }
+            CK(hipStreamEndCapture(s0, &g));
+            CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+            const double us = time_graph_exec(ge, s0, S);
+            printf("%-72s %6.3f us/step  (%.3f of 8 TB/s)\n", name, us, 16801792.0 / us / 8e6);
+            CK(hipGraphExecDestroy(ge));
+            CK(hipGraphDestroy(g));
+        };
+        run("40 separate 16 MiB allocations, rotated (640 MiB)", [&](int e) { return (const uint8_t*)bufs[e % NBUF]; });
+        run("ONE 640 MiB allocation, 40 slices rotated", [&](int e) { return (const uint8_t*)(arena + (size_t)(e % NBUF) * N * K); });
+        run("ONE allocation, 8 slices rotated (128 MiB: Infinity-Cache resident)", [&](int e) { return (const uint8_t*)(arena + (size_t)(e % 8) * N * K); });
+        run("ONE allocation, 2 slices rotated (32 MiB)", [&](int e) { return (const uint8_t*)(arena + (size_t)(e % 2) * N * K); });
+        run("40 separate allocations again", [&](int e) { return (const uint8_t*)bufs[e % NBUF]; });
+        return 0;
+    }
+
     // ---- B: alternating capture streams, device-side hand-off ----
     for (int nstreams = 2; nstreams <= 3; ++nstreams) {
         hipStream_t ss[3] = {s0, s1, s2};
