@@ -133,6 +133,48 @@ __device__ __forceinline__ void finish_row(float acc, float* red, int wave, int 
     }
 }
 
+// ---- x-delivery variants of form A (same arithmetic, same order of every sum) ----
+//   XMODE 0: x as 16-byte vector loads issued BEFORE the weight loads (the shipping order)
+//   XMODE 1: the same loads issued AFTER the weight loads
+//   XMODE 2: x through the scalar cache: one 128-byte scalar read per tile (wave-uniform address), the lane's k-group picked
+//            with v_cndmask -- no vector-memory traffic for x at all (the vector form moves 2 KiB of lane data per 1 KiB tile)
+template <int XMODE, int OCC = 8>
+__global__ __launch_bounds__(1024, OCC) void xmode_step_kernel(StepIO io)
+{
+    __shared__ float red[16 * 16];
+    const int tid = threadIdx.x, ntile = blockIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, g = lane >> 4, c = lane & 15;
+    u32 sraw = reinterpret_cast<const uint16_t*>(io.scales)[ntile * 16 + c];
+    u32x4 buf[4], xr[8];
+    if constexpr (XMODE == 0) issue_x<false>(io.x, wave, g, xr);
+    issue_weights(io.w, ntile, wave, lane, buf);
+    if constexpr (XMODE == 1) issue_x<false>(io.x, wave, g, xr);
+    if constexpr (XMODE == 2) {
+        const u32x4* __restrict__ xq = reinterpret_cast<const u32x4*>(io.x);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            const int tile = wave + d * 16;  // wave-uniform: 8 x 16 bytes = the tile's 64 activations
+            u32x4 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) t[j] = xq[tile * 8 + j];
+            // lane's k-group g needs vectors 2g, 2g+1
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                u32x4 v;
+                v.x = g == 0 ? t[h].x : g == 1 ? t[2 + h].x : g == 2 ? t[4 + h].x : t[6 + h].x;
+                v.y = g == 0 ? t[h].y : g == 1 ? t[2 + h].y : g == 2 ? t[4 + h].y : t[6 + h].y;
+                v.z = g == 0 ? t[h].z : g == 1 ? t[2 + h].z : g == 2 ? t[4 + h].z : t[6 + h].z;
+                v.w = g == 0 ? t[h].w : g == 1 ? t[2 + h].w : g == 2 ? t[4 + h].w : t[6 + h].w;
+                xr[2 * d + h] = v;
+            }
+        }
+    }
+    asm volatile("" : "+v"(sraw));
+    const f16x2 scale2 = as_f16x2(sraw | (sraw << 16));
+    const float acc    = dot_tiles(buf, xr, scale2);
+    finish_row<false>(acc, red, wave, lane, g, c, io.y, ntile, nullptr);
+}
+
 // ---- forms A / B: one launch per step ----
 template <bool CHAIN>
 __global__ __launch_bounds__(1024, 8) void chain_step_kernel(StepIO io, const unsigned* wait, unsigned target, unsigned* done,
@@ -316,6 +358,34 @@ int main(int argc, char** argv)
         }
         CK(hipGraphExecDestroy(ge));
         CK(hipGraphDestroy(g));
+    }
+
+    if (argc > 2 && !strcmp(argv[2], "xmode")) {
+        for (int rep = 0; rep < 2; ++rep)
+            for (int mode = 0; mode < 5; ++mode) {
+                hipGraph_t g;
+                hipGraphExec_t ge;
+                CK(hipStreamBeginCapture(s0, hipStreamCaptureModeGlobal));
+                for (int e = 0; e < S; ++e) {
+                    const StepIO io = io_of(e, ybuf);
+                    if (mode == 0) hipLaunchKernelGGL(xmode_step_kernel<0>, dim3(N / 16), dim3(1024), 0, s0, io);
+                    if (mode == 1) hipLaunchKernelGGL(xmode_step_kernel<1>, dim3(N / 16), dim3(1024), 0, s0, io);
+                    if (mode == 2) hipLaunchKernelGGL(xmode_step_kernel<2>, dim3(N / 16), dim3(1024), 0, s0, io);
+                    if (mode == 3) hipLaunchKernelGGL((xmode_step_kernel<0, 4>), dim3(N / 16), dim3(1024), 0, s0, io);
+                    if (mode == 4) hipLaunchKernelGGL((xmode_step_kernel<1, 4>), dim3(N / 16), dim3(1024), 0, s0, io);
+                }
+                CK(hipStreamEndCapture(s0, &g));
+                CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+                CK(hipMemset(ybuf, 0, 3 * N * 2));
+                const double us = time_graph_exec(ge, s0, S);
+                printf("x delivery %d (%s)  %6.3f us/step  (%.3f of 8 TB/s)\n", mode,
+                       mode == 0 ? "vector loads before the weights" : mode == 1 ? "vector loads after the weights " : mode == 2 ? "scalar cache + select          " : mode == 3 ? "vector before, <= 128 VGPRs    " : "vector after, <= 128 VGPRs     ",
+                       us, 16801792.0 / us / 8e6);
+                check(mode == 0 ? "x0" : mode == 1 ? "x1" : mode == 2 ? "x2" : mode == 3 ? "x3" : "x4", ybuf);
+                CK(hipGraphExecDestroy(ge));
+                CK(hipGraphDestroy(g));
+            }
+        return 0;
     }
 
     // ---- allocation / cache experiments on form A0 (shipping kernel): where does the per-dispatch fixed cost come from? ----

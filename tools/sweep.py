@@ -1,36 +1,52 @@
 #!/usr/bin/env python
 """BASELINE.json configs[3]: Llama-2-7B shape sweep, (K,N) in {(4096,4096), (4096,11008), (11008,4096)} x M in
-{1, 8, 64, 1024}.  Prints one JSON object per case: kernel-only microseconds (HIP start/stop events on each dispatch),
-algorithmic GB/s and TFLOP/s, and tier-A parity against a torch fp32 matmul over the dequantised weight.
+{1, 8, 64, 1024}.  Prints one JSON object per case: microseconds per call of a HIP-graph-replayed chain of back-to-back
+calls (rotating weight sets; the kernel's begin->end plus the <= 0.1 us inter-dispatch gap -- NOT start/stop event pairs,
+whose own floor of ~4.2 us hid every kernel shorter than that in the round-1/2 sweeps), algorithmic GB/s and TFLOP/s, and
+tier-A parity against a torch fp32 matmul over the dequantised weight.
 Usage: python tools/sweep.py [--out profiles/r01_sweep.json]"""
 import argparse
-import ctypes
 import json
 import os
 import sys
+import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-from eetq_amd import _lib, ops  # noqa: E402
+from eetq_amd import ops  # noqa: E402
 
 
-def kernel_us(run, n):
-    """Per-call kernel time: a call may be more than one launch (the tiled GEMM splits ragged shapes into two), so the
-    recorded per-launch durations are summed per call."""
-    L = _lib.lib()
-    cap = 4 * n
-    _lib.check(L.eetq_prof_begin(cap))
-    run()
-    buf = (ctypes.c_float * cap)()
-    cnt = ctypes.c_int(0)
-    _lib.check(L.eetq_prof_end(buf, cap, ctypes.byref(cnt)))
-    per_call = cnt.value // n
-    assert per_call >= 1 and per_call * n == cnt.value, (cnt.value, n)
-    us = np.array(buf[:cnt.value]).reshape(n, per_call).sum(axis=1)
-    return float(np.median(us)), float(us.mean()), float(us.min())
+def chain_us(step, calls_per_graph, min_seconds=0.03):
+    """Microseconds per call: `calls_per_graph` back-to-back calls captured as ONE HIP graph (step(i) issues call i),
+    replayed until >= min_seconds have been timed; best of 3 timed regions."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(3):
+            step(i)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for i in range(calls_per_graph):
+            step(i)
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    g.replay()
+    torch.cuda.synchronize()
+    reps = max(2, int(min_seconds / max(time.perf_counter() - t0, 1e-6)))
+    best = 1e30
+    for _ in range(3):
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g.replay()
+        torch.cuda.synchronize()
+        best = min(best, (time.perf_counter() - t0) / (reps * calls_per_graph))
+    return best * 1e6
 
 
 def main():
@@ -59,22 +75,18 @@ def main():
         for M in [int(v) for v in args.ms.split(",")]:
             x = (torch.rand(M, K, device=dev, generator=g) - 0.25).half()
             y = torch.empty(M, N, dtype=torch.float16, device=dev)
-            iters = 200 if M <= 64 else 60
+            calls = (4 if M <= 128 else 1) * nbuf     # whole passes over the rotating weight sets
 
-            def run():
-                for i in range(iters):
-                    ops.w8_a16_gemm_(x, sets[i % nbuf][0], sets[i % nbuf][1], y, M, N, K)
-            run()
-            torch.cuda.synchronize()
-            med, mean, mn = kernel_us(run, iters)
+            def step(i):
+                ops.w8_a16_gemm_(x, sets[i % nbuf][0], sets[i % nbuf][1], y, M, N, K)
+            med = chain_us(step, calls)
             ops.w8_a16_gemm_(x, sets[0][0], sets[0][1], y, M, N, K)
             ref = x.float() @ wdq
             err = (y.float() - ref).abs()
             ok = bool((err <= 1e-3 * ref.abs().max() + 2e-3 * ref.abs()).all())
             nbytes = K * N + 2 * M * K + 2 * N + 2 * M * N
             flops = 2.0 * M * N * K
-            results.append({"K": K, "N": N, "M": M, "kernel_us_median": round(med, 2), "kernel_us_mean": round(mean, 2),
-                            "kernel_us_min": round(mn, 2), "GBps": round(nbytes / med / 1e3, 1),
+            results.append({"K": K, "N": N, "M": M, "us_per_call": round(med, 2), "GBps": round(nbytes / med / 1e3, 1),
                             "TFLOPs": round(flops / med / 1e6, 2), "hbm_frac": round(nbytes / med / 1e3 / 8000, 4),
                             "mfma_frac": round(flops / med / 1e6 / 2500, 4), "tier_a_ok": ok,
                             "max_abs_err": float(err.max())})
@@ -83,7 +95,8 @@ def main():
         torch.cuda.empty_cache()
     if args.out:
         with open(args.out, "w") as f:
-            json.dump({"what": "Llama-2 shape sweep, kernel-only time per dispatch, MI355X", "results": results}, f, indent=1)
+            json.dump({"what": "Llama-2 shape sweep, microseconds per call of a graph-replayed chain of back-to-back calls "
+                               "(rotating weight sets), MI355X", "results": results}, f, indent=1)
 
 
 if __name__ == "__main__":
