@@ -286,17 +286,28 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
     switch (path) {
         case EETQ_PATH_AUTO:
             // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
-            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 16 -> MFMA stream kernel (same weight stream,
-            // activations straight from L2 into MFMA operands); 17 <= M <= 128 -> medium-batch LDS tile (32 columns,
-            // 256-deep K steps); larger M -> LDS-tiled MFMA GEMM (128 x 128 tiles, or 128 x 64 when those fill the chip better).
-            // Crossovers measured: profiles/r01_sweep.json.
+            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 8 (<= 16 for weights under 32 Mi) -> MFMA stream kernel
+            // (same weight stream, activations straight from L2 into MFMA operands); up to M = 128 -> split-K medium-batch
+            // tile (M > 64 on wide N: the tiled kernel); larger M -> LDS-tiled MFMA GEMM (128 x 128 tiles, or 128 x 64 when
+            // those fill the chip better).  Crossovers measured as graph-replayed chains: profiles/r03_path_compare_mid.jsonl.
             if (M == 1) return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
-            if (M <= 16) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
+            {
+                static const bool use_splitk = [] {
+                    const char* e = getenv("EETQ_AMD_SPLITK");
+                    return !(e && e[0] == '0');
+                }();
+                const bool fits = (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31);
+                // the register-streaming kernel re-reads the M x K activations per 16-column tile row: beyond 8 rows and 32 Mi
+                // weights the split-K tile (flat in M up to 32) is ahead -- M = 16: 4096 x 11008 12.2 vs 14.1 us, 11008 x 4096
+                // 12.5 vs 14.2, 5120 x 13824 15.5 vs 18.7, 13824 x 5120 19.5 vs 22.3; at 4096^2 (6.6 vs 7.3) and 5120^2 it is not
+                const bool big = (size_t)K * N >= (32ull << 20);
+                if (M <= 8 || (M <= 16 && !(big && use_splitk && fits))) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
+            }
             if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31)) {
-                // wide N: the 128 x 64 tiles of the tiled kernel already give most CUs a workgroup and read the
-                // activations once per 64 columns instead of once per 32 (N = 11008: M = 64 17.5 vs 20.2 us, M = 128
-                // 21.9 vs 40.4 us; N = 4096: 15.9 vs 11.1 us the other way; profiles/r01_kbench_tile_shapes.txt)
-                if (M >= 33 && (N + 63) / 64 >= 160 && K >= 320) return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
+                // wide N, M > 64: the 128 x 64 tiles of the tiled kernel already give most CUs a workgroup and read the
+                // activations once per 64 columns (N = 11008: M = 96 21.0 vs 23.9 us split-K, M = 128 22.4 vs 28.2; up to
+                // M = 64 the split-K tile is ahead: 17.6 vs 18.5, M = 48 16.2 vs 17.8; N = 13824 alike)
+                if (M > 64 && (N + 63) / 64 >= 160 && K >= 320) return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
                 // narrower N: the split-K tile (K slices + in-launch deterministic reduction; N = K = 4096: M = 64 8.8 vs
                 // 11.2 us, M = 128 14.0 vs 20.2, K = 11008 16.3 vs 28.0; profiles/r02_kbench_splitk.txt).  EETQ_AMD_SPLITK=0
                 // keeps the unsplit tile (the split form owns per-stream scratch; see gemm_splitk.hip)
