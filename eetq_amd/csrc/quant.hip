@@ -201,9 +201,15 @@ __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ 
         const int    col = t & 63, p0 = t >> 6;
         const size_t cg  = n0 + col < N ? n0 + col : 0;
         float        m   = 0.f;
-        for (int p = p0; p < P; p += 4) {
-            const float a = part[(size_t)p * N + cg];
-            m             = (m < a) ? a : m;
+        for (int p = p0; p < P; p += 32) {  // 8 independent loads in flight per thread (clamped rows: a repeat is harmless)
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pp = p + 4 * j;
+                a[j]         = part[(size_t)(pp < P ? pp : P - 1) * N + cg];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = (m < a[j]) ? a[j] : m;
         }
         cm[p0][col] = m;
     }

@@ -93,6 +93,17 @@ print(json.dumps(doc, indent=1))
 PYEOF
 fi
 
+echo "== 3b. SQ / GRBM counters of the two headline kernels (their own --pmc passes, kernel-trace only)" >&2
+if [ -x tools/kbench ]; then
+    rm -rf /tmp/prof_sq1 /tmp/prof_sq2
+    ( cd /tmp && rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE \
+        --kernel-trace --output-format csv -d /tmp/prof_sq1 -- "$ROOT/tools/kbench" gemm1 > /dev/null 2>> "$OUT/${TAG}_rocprof.err" ) || echo "sq pass 1 failed" >&2
+    ( cd /tmp && rocprofv3 --pmc GRBM_GUI_ACTIVE GRBM_COUNT SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU_MFMA_MOPS_F16 \
+        --kernel-trace --output-format csv -d /tmp/prof_sq2 -- "$ROOT/tools/kbench" gemm1 > /dev/null 2>> "$OUT/${TAG}_rocprof.err" ) || echo "sq pass 2 failed" >&2
+    { echo "# rocprofv3 --pmc (two passes, kernel-trace only) on tools/kbench gemm1, head ${EETQ_HEAD:-unknown}; mean per dispatch"; \
+      $PY tools/pmc_summary.py /tmp/prof_sq1; $PY tools/pmc_summary.py /tmp/prof_sq2; } > "$OUT/${TAG}_pmc_sq.txt" 2>&1
+fi
+
 echo "== 4. GEMV decomposition (device-clock stamps), un-profiled and under the kernel trace" >&2
 if [ -x tools/kbench_stamps ]; then
     ./tools/kbench_stamps decompose > "$OUT/${TAG}_gemv_decomposition.txt" 2>&1
