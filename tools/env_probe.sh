@@ -1,3 +1,4 @@
+# Round-3 experiment script (run on the GPU box from the repo root); output under profiles/ -- see profiles/README.md
 run() { echo "== $*"; env "$@" ./tools/chain_probe 64 alloc 2>&1 | grep -E "^A0|40 separate 16 MiB allocations, rotated" | head -2; }
 run X=1
 run HIP_FORCE_DEV_KERNARG=1

@@ -1,3 +1,4 @@
+# Round-3 experiment script (run on the GPU box from the repo root); output under profiles/ -- see profiles/README.md
 for nt in 0 1; do for fold in 0 1; do for strip in 1 4; do
 echo "nt=$nt fold=$fold strip=$strip"; EETQ_AMD_QUANT_NT=$nt EETQ_AMD_QUANT_FOLD=$fold EETQ_AMD_QUANT_STRIP=$strip python tools/quant_bench.py 2>&1 | grep -v amdgpu.ids | python -c "
 import sys,json
