@@ -583,6 +583,24 @@ int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slot
                                    strides, kv_len, kv_len_bias, advance, static_cast<hipStream_t>(stream));
 }
 
+namespace eetq {
+int attn_dropped_steps(unsigned* count, bool reset);
+int rope_dropped_steps(unsigned* count, bool reset);
+}  // namespace eetq
+
+int eetq_decode_dropped_steps(unsigned long long* count, int reset)
+{
+    EETQ_REQUIRE(count, "null pointer");
+    EETQ_TRY_HIP(hipDeviceSynchronize());
+    unsigned a = 0, r = 0;
+    int      st = attn_dropped_steps(&a, reset != 0);
+    if (st != EETQ_OK) return st;
+    st = rope_dropped_steps(&r, reset != 0);
+    if (st != EETQ_OK) return st;
+    *count = (unsigned long long)a + r;
+    return EETQ_OK;
+}
+
 int eetq_diag_attn_stamps(unsigned long long* stamps)
 {
     set_attn_stamps(stamps);

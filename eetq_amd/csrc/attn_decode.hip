@@ -25,6 +25,12 @@
 #include "common.hpp"
 
 namespace eetq {
+// decode steps whose new token was NOT written because its cache row was outside the cache (full static cache, negative
+// position): stock StaticLayer.update raises there, these kernels skip the write -- and count it here
+__device__ unsigned g_attn_dropped = 0;
+}  // namespace eetq
+
+namespace eetq {
 
 namespace {
 
@@ -426,6 +432,8 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
     // a slot outside the cache is neither written nor attended, and (like the two-launch form) nothing is rotated then
     const bool have_new = slot64 >= 0 && slot64 < a.S && rpos >= 0;
     const int  slot = have_new ? (int)slot64 : -1;
+    // a full cache (or a bad position) used to be silent: count the dropped steps (eetq_decode_dropped_steps)
+    if (!have_new && split == 0 && h == 0 && threadIdx.x == 0) atomicAdd(&g_attn_dropped, 1u);
     const int  Sv = kv_len ? max(0, (int)min((int64_t)a.S, filled + a.kv_len_bias)) : a.S;
     const int  chunk = (Sv + splits - 1) / splits;
     const int  j0 = split * chunk, j1 = min(Sv, j0 + chunk);
@@ -561,4 +569,16 @@ int launch_rope_attn_decode(const int64_t* positions, const int64_t* slots, int 
     return check_hip(hipGetLastError(), "rope_attn_decode_kernel launch");
 }
 
+}  // namespace eetq
+
+namespace eetq {
+int attn_dropped_steps(unsigned* count, bool reset)
+{
+    EETQ_TRY_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_attn_dropped), sizeof(unsigned)));
+    if (reset) {
+        const unsigned zero = 0;
+        EETQ_TRY_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_attn_dropped), &zero, sizeof(unsigned)));
+    }
+    return EETQ_OK;
+}
 }  // namespace eetq

@@ -8,6 +8,10 @@
 #include "common.hpp"
 
 namespace eetq {
+__device__ unsigned g_rope_dropped = 0;  // decode steps dropped by rotary_neox_kvcache_kernel (cache row outside the cache)
+}  // namespace eetq
+
+namespace eetq {
 
 namespace {
 
@@ -143,7 +147,10 @@ __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions
     const int     b    = blockIdx.x;
     const int64_t rpos = positions[b];                               // index into the cos|sin table
     const int64_t pos  = slots ? slots[(long)b * slot_stride] : rpos;  // cache row the new token is written to
-    if (pos < 0 || pos >= max_pos || rpos < 0) return;  // never write outside the cache
+    if (pos < 0 || pos >= max_pos || rpos < 0) {  // never write outside the cache; counted (eetq_decode_dropped_steps)
+        if (blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&g_rope_dropped, 1u);
+        return;
+    }
     const f16* cp    = cache + rpos * rot_dim;
     const int  embed = rot_dim / 2;
     if (blockIdx.y == 0) {
@@ -263,4 +270,16 @@ int launch_rotary_any(const int64_t* pos, void* q, void* k, const void* cache, i
     }
 }
 
+}  // namespace eetq
+
+namespace eetq {
+int rope_dropped_steps(unsigned* count, bool reset)
+{
+    EETQ_TRY_HIP(hipMemcpyFromSymbol(count, HIP_SYMBOL(g_rope_dropped), sizeof(unsigned)));
+    if (reset) {
+        const unsigned zero = 0;
+        EETQ_TRY_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_rope_dropped), &zero, sizeof(unsigned)));
+    }
+    return EETQ_OK;
+}
 }  // namespace eetq

@@ -51,7 +51,21 @@ else:
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_", "layernorm_forward",
            "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention",
-           "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped", "BOUNDARY"]
+           "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped", "decode_dropped_steps", "BOUNDARY"]
+
+
+def decode_dropped_steps(reset=True, device=None):
+    """Decode steps the KV-cache kernels skipped because the cache row lay outside the cache (a full static cache): 0 unless
+    generation overran ``max_cache_len`` -- then every token after that point is wrong.  Synchronises the device."""
+    import ctypes
+
+    import torch
+
+    from . import _lib
+    n = ctypes.c_ulonglong(0)
+    with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
+        _lib.check(_lib.lib().eetq_decode_dropped_steps(ctypes.byref(n), 1 if reset else 0))
+    return int(n.value)
 
 
 def convert_layout(weight, src_layout, dst_layout, is_int4=False):

@@ -290,6 +290,13 @@ int eetq_diag_stream_read(const void* p, size_t bytes, void* sink, void* stream)
  * floor of the timing method it is measured with). */
 int eetq_diag_empty(void* sink, int grid, int block, void* stream);
 
+/* Decode steps on a pre-allocated KV cache (eetq_rope_decode_attention_f16, eetq_rotary_neox_kvcache_f16) whose new token
+ * was NOT written because its cache row lies outside the cache (slot >= rows: the cache is full; or a negative position).
+ * The kernels skip the write instead of faulting (stock transformers raises an index error there); this entry synchronises
+ * the current device and reports how many such steps its kernels have dropped since the last reset (batch rows count
+ * individually), optionally resetting the count.  A non-zero count means the tokens generated after that point are wrong. */
+int eetq_decode_dropped_steps(unsigned long long* count, int reset);
+
 /* ---- library-owned scratch ---------------------------------------------------------------------------
  * The reference's operators take no workspace argument (fpA_intB_gemm_wrapper.cu:169-170 passes none), so the few
  * buffers the kernels need are owned by the library: the split-K partial-tile regions (40 MiB per launch stream that

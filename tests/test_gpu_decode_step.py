@@ -102,10 +102,13 @@ def test_per_row_slots_full_cache_and_errors(ops):
     kc_a, vc_a, kc_b, vc_b = kc.clone(), vc.clone(), kc.clone(), vc.clone()
     qkv_a = qkv.clone()
     q, k, v = _views(qkv_a, H, Hkv, D)
+    ops.decode_dropped_steps(reset=True)
     ops.rotary_embedding_neox_kvcache(pos, q, k, v, D, table, kc_a, vc_a, slots=slots)
+    assert ops.decode_dropped_steps(reset=True) == 1          # batch row 2's token had no cache row: counted, not silent
     out_a = ops.decode_attention(q, kc_a, vc_a, kv_len=n)
     q2, k2, v2 = _views(qkv, H, Hkv, D)
     out_b = ops.rope_decode_attention(pos, q2, k2, v2, table, kc_b, vc_b, tickets, slots=slots, kv_len=n)
+    assert ops.decode_dropped_steps(reset=True) == 1          # the one-launch form counts the same event once
     assert torch.equal(out_a, out_b) and torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b)
     assert torch.equal(kc_b[2], kc[2]) and not torch.equal(kc_b[0], kc[0])
     assert int(n.item()) == S and torch.count_nonzero(tickets) == 0

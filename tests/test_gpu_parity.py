@@ -809,8 +809,12 @@ def test_rotary_kvcache_write(ops, oracle):
         others = [j for j in range(S) if j != int(pos[b])]
         assert (kc[b][:, others] == 7.0).all() and (vc[b][:, others] == -3.0).all()
     kc2 = torch.zeros(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+    assert ops.decode_dropped_steps(reset=True) == 0          # nothing dropped so far (and reset)
     ops.rotary_embedding_neox_kvcache(torch.tensor([S, S + 3, -1]).to(DEV), q, k, v, D, cache.to(DEV), kc2, kc2.clone())
     assert torch.count_nonzero(kc2) == 0
+    # ... and the skipped writes are counted: a full cache is not silent (stock StaticLayer.update raises there)
+    assert ops.decode_dropped_steps(reset=True) == 3
+    assert ops.decode_dropped_steps() == 0
 
 
 def test_eet_attention_static_cache_decode_matches_stock_path(ops):
