@@ -11,6 +11,10 @@
 
 namespace eetq {
 
+// dropped-step counters of the decode kernels (attn_decode.hip, norm_rope.hip)
+int attn_dropped_steps(unsigned* count, bool reset);
+int rope_dropped_steps(unsigned* count, bool reset);
+
 namespace {
 thread_local std::string g_last_error;
 
@@ -582,11 +586,6 @@ int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slot
                                    workspace, tickets, batch, heads, kv_heads, max_positions, head_dim, splits, scaling,
                                    strides, kv_len, kv_len_bias, advance, static_cast<hipStream_t>(stream));
 }
-
-namespace eetq {
-int attn_dropped_steps(unsigned* count, bool reset);
-int rope_dropped_steps(unsigned* count, bool reset);
-}  // namespace eetq
 
 int eetq_decode_dropped_steps(unsigned long long* count, int reset)
 {
