@@ -23,7 +23,8 @@ class ReplicaGroup:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         use_cuda = torch.cuda.is_available() if device is None else torch.device(device).type == "cuda"
         if device is None:
-            device = torch.device("cuda", self.local_rank) if use_cuda else torch.device("cpu")
+            # one replica per GPU; with fewer visible GPUs than local ranks (a test box) the ranks wrap around and share
+            device = torch.device("cuda", self.local_rank % max(1, torch.cuda.device_count())) if use_cuda else torch.device("cpu")
         self.device = torch.device(device)
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
