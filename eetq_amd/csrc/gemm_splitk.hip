@@ -2,6 +2,7 @@
 // Reference behaviour matched: the small-M preference of the CUTLASS tile heuristic (cutlass_heuristic.cc:123-206) -- the
 // reference never splits K because its wrapper passes no workspace (fpA_intB_gemm_wrapper.cu:169-170); here the workspace
 // is owned by the library so that the operator signature stays workspace-free.
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 
@@ -115,12 +116,12 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
     return EETQ_OK;
 }
 
-template <int MT, int NB, int STAGES, bool KFULL>
+template <int MT, int NB, int SA, int SB, bool KFULL>
 int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    using C   = gemm_splitk::Cfg<MT, NB, STAGES>;
-    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, STAGES, KFULL>;
+    using C   = gemm_splitk::Cfg<MT, NB, SA, SB>;
+    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, SA, SB, KFULL>;
     if (C::kSmem > 64 * 1024) {
         static std::atomic<unsigned long long> opted{0};
         int st = opt_in_large_lds(kern, opted);
@@ -138,33 +139,50 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
             else if (S == 4) tickets += kRegionTickets;
         }
     }
-    launch_kernel(kern, dim3(tiles * S), dim3(gemm_splitk::kThreads), C::kSmem, stream, x, w, scales, y, M, N, K, S, slabs,
+    // ONE workgroup per CU whenever slices hand partial tiles over (S > 1).  Found in round 3 (tools/deepk_check.py): with two
+    // of these workgroups resident on a CU (rings of <= 80 KiB) a split launch returns a few wrong elements per call --
+    // lanes 12..15 mod 16 of single accumulator registers in a handful of tiles, different ones every call -- while the very
+    // same binary is exact with one workgroup per CU, and unsplit launches (S = 1) are exact at two per CU.  The plans AUTO
+    // picked never combined S > 1 with two per CU at the tested shapes, but nothing guaranteed it.  Until the mechanism is
+    // understood the launch asks for more than half of the CU's LDS, which keeps a second workgroup off the CU.
+    size_t lds = C::kSmem;
+    if (S > 1 && lds <= 80 * 1024) {
+        lds = 84 * 1024;
+        static std::atomic<unsigned long long> opted2{0};
+        int st = opt_in_large_lds(kern, opted2);
+        if (st != EETQ_OK) return st;
+    }
+    launch_kernel(kern, dim3(tiles * S), dim3(gemm_splitk::kThreads), lds, stream, x, w, scales, y, M, N, K, S, slabs,
                   tickets, ep);
     return check_hip(hipGetLastError(), "gemm_splitk_kernel launch");
 }
 
-template <int MT, int NB, int STAGES>
+template <int MT, int NB, int SA, int SB>
 int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    return K % gemm_splitk::kBK == 0 ? launch_full<MT, NB, STAGES, true>(x, w, scales, ep, y, M, N, K, S, stream)
-                                     : launch_full<MT, NB, STAGES, false>(x, w, scales, ep, y, M, N, K, S, stream);
+    return K % gemm_splitk::kBK == 0 ? launch_full<MT, NB, SA, SB, true>(x, w, scales, ep, y, M, N, K, S, stream)
+                                     : launch_full<MT, NB, SA, SB, false>(x, w, scales, ep, y, M, N, K, S, stream);
 }
 
+// ring = 10 * SA + SB (activation / weight ring depths, gemm_splitk_kernel.hpp).  The library instantiates the shared rings
+// 22 and 33: deeper weight rings (38, 36, 34, 26, 28, 24: the kernel template and tools/kbench deepk have them) were measured in
+// round 3 and are 0-10 % SLOWER at every shape (profiles/r03_kbench_deepk.txt) -- the weight bytes in flight are not what
+// bounds this kernel.
 template <int MT>
 int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int nb, int S,
-              int stages, hipStream_t stream)
+              int ring, hipStream_t stream)
 {
-    if (nb == 2) {
-        if constexpr (MT <= 2) {
-            if (stages == 3) return launch_inst<MT, 2, 3>(x, w, scales, ep, y, M, N, K, S, stream);
-        }
-        return launch_inst<MT, 2, 2>(x, w, scales, ep, y, M, N, K, S, stream);
-    }
+#define EETQ_RING(NB_, SA_, SB_) \
+    if (nb == NB_ && ring == 10 * SA_ + SB_) return launch_inst<MT, NB_, SA_, SB_>(x, w, scales, ep, y, M, N, K, S, stream);
+    EETQ_RING(1, 2, 2)
+    EETQ_RING(2, 2, 2)
     if constexpr (MT <= 2) {
-        if (stages == 3) return launch_inst<MT, 1, 3>(x, w, scales, ep, y, M, N, K, S, stream);
+        EETQ_RING(1, 3, 3)
+        EETQ_RING(2, 3, 3)
     }
-    return launch_inst<MT, 1, 2>(x, w, scales, ep, y, M, N, K, S, stream);
+#undef EETQ_RING
+    return fail(EETQ_ERR_INVALID, "[eetq_amd] split-K: no instantiation for this (column blocks, ring) plan");
 }
 
 }  // namespace
@@ -212,7 +230,8 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out)
             const int wgs = tiles * s;
             // ring depth 3 (120..144 KiB: one workgroup per CU) when that many workgroups fit anyway, else depth 2 (two per CU at MT <= 2)
             const int stages  = (MT <= 2 && wgs <= ncu) ? 3 : 2;
-            const int per_cu  = (stages == 2 && MT <= 2 && (16 * MT + 8 * nb) * 2 <= 80) ? 2 : 1;
+            // two workgroups per CU only for unsplit plans (launch_full keeps split launches at one per CU)
+            const int per_cu  = (s == 1 && stages == 2 && MT <= 2 && (16 * MT + 8 * nb) * 2 <= 80) ? 2 : 1;
             const int rounds  = (wgs + ncu * per_cu - 1) / (ncu * per_cu);
             const int my_steps = (steps + s - 1) / s;
             // microseconds: per-step ingest at ~70 GB/s per CU (shared by the workgroups on the CU), shallower ring ~15 % slower
@@ -244,12 +263,22 @@ int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilog
     if (force_nb) nb = force_nb;
     if (force_s) s = force_s;
     if (force_nb || force_s) stages = ((M + 31) / 32 <= 2 && ((N + 32 * nb - 1) / (32 * nb)) * s <= device_cu_count()) ? 3 : 2;
+    int ring = 11 * stages;  // shared ring of round 2: SA = SB = stages
+    // EETQ_AMD_SPLITK_PLAN="nb,s,ring" (ring = 10 * SA + SB) overrides the plan: tuning and tests of every instantiation
+    if (const char* e = getenv("EETQ_AMD_SPLITK_PLAN")) {
+        int a = 0, b = 0, c = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
+            nb   = a;
+            s    = b;
+            ring = c;
+        }
+    }
     EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4), "invalid split-K plan");
     switch ((M + 31) / 32) {
-        case 1: return launch_mt<1>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
-        case 2: return launch_mt<2>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
-        case 3: return launch_mt<3>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
-        default: return launch_mt<4>(x, w, scales, ep, y, M, N, K, nb, s, stages, stream);
+        case 1: return launch_mt<1>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
+        case 2: return launch_mt<2>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
+        case 3: return launch_mt<3>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
+        default: return launch_mt<4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
     }
 }
 

@@ -44,31 +44,39 @@ constexpr int kBK      = 256;
 constexpr int kThreads = 256;
 constexpr int kMaxSlices = 4;
 
-template <int MT, int NB, int STAGES>
+// SA / SB: depth of the activation ring and of the weight ring.  They are separate because the two streams are not alike:
+// the weight tiles come from HBM (~2 us under load) and every byte is read once, so what bounds their rate is the bytes a
+// CU has IN FLIGHT -- with one shared 2- or 3-deep ring that was 16-32 KiB per CU, i.e. ~2-3.5 TB/s over the chip, and the
+// K loop ran at the DMA latency per step (round 3: N = K = 4096, M = 64: 9.3 us where stream + launch cost 4.9) -- while the
+// activations are L2-resident (short latency) but four to eight times as many bytes per step.  SB > SA gives the weights a
+// GEMV-like 48-96 KiB in flight per CU in what the activation ring leaves of the 160 KiB.  SA == SB is the round-2 kernel.
+template <int MT, int NB, int SA, int SB = SA>
 struct Cfg {
+    static_assert(SB >= SA && SA >= 2 && SA <= 3, "the wait accounting below covers 2 <= SA <= 3, SB >= SA");
     static constexpr int kRows   = 32 * MT;
     static constexpr int kBN     = 32 * NB;
     static constexpr int kABytes = kRows * kBK * 2;
     static constexpr int kBBytes = kBN * kBK;
-    static constexpr int kStage  = kABytes + kBBytes;
-    static constexpr int kStages = STAGES;
+    static constexpr int kARing  = SA * kABytes;                         // activation stages first, then the weight stages
     static constexpr int kRed    = 4 * MT * NB * 16 * 64 * 4;           // end-of-kernel cross-wave reduction area
-    static constexpr int kSmem   = kStages * kStage;                     // >= kRed + 16 for every MT, NB, STAGES >= 2
-    static_assert(kStages * kStage >= kRed + 16, "the reduction area and the ticket word must fit the ring");
+    static constexpr int kSmem   = SA * kABytes + SB * kBBytes;
+    static_assert(kSmem >= kRed + 16, "the reduction area and the ticket word must fit the rings");
+    static_assert(kSmem <= 160 * 1024, "rings larger than the CU's LDS");
     static constexpr int kAPW    = kABytes / 1024 / 4;                   // A pieces (2 rows of 512 B) per wave and stage
     static constexpr int kBPW    = kBBytes / 1024 / 4;                   // B pieces (native 1 KiB tiles) per wave and stage
     static constexpr int kPieces = kAPW + kBPW;
+    static_assert((SA - 1) * kAPW + (SB - 1) * kBPW <= 63, "vmcnt is a 6-bit counter");
     static constexpr int kSlabFloats = kRows * kBN;                      // fp32 partial tile of one slice
 };
 
 // grid = tiles_n * S workgroups (all of M in one row tile: M <= 32*MT).  slabs: [tiles_n][S][kSlabFloats] floats,
 // counters: [tiles_n] unsigned (both unused when S == 1).
-template <int MT, int NB, int STAGES, bool KFULL>
-__global__ __launch_bounds__(kThreads, (Cfg<MT, NB, STAGES>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
+template <int MT, int NB, int SA, int SB, bool KFULL>
+__global__ __launch_bounds__(kThreads, (Cfg<MT, NB, SA, SB>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
     int N, int K, int S, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
 {
-    using C = Cfg<MT, NB, STAGES>;
+    using C = Cfg<MT, NB, SA, SB>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lds0 = (int)(uint32_t)(uintptr_t)(gemm::lds_void*)smem;
     const int tid  = threadIdx.x;
@@ -118,27 +126,46 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, STAGES>::kSmem <= 80 * 1024 
             dma_voff[i]  = (nt * KT + (b & 3)) * kTileBytes + lane * 16;  // + step*4 tiles
         }
     }
-    auto issue_stage = [&](int buf, int step) {
-        uint8_t* sa = smem + buf * C::kStage;
+    auto issue_a = [&](int buf, int step) {
+        uint8_t* sa = smem + buf * C::kABytes;
 #pragma unroll
-        for (int i = 0; i < C::kPieces; ++i) {
-            if (i < C::kAPW) {
-                // the last step of a K that is not a multiple of 256 reads past the row end into the next row (or is
-                // zero-filled by the descriptor bounds check at the very end): those k tiles are never multiplied
-                gemm::dma16(x_rsrc, dma_voff[i], step * kBK * 2, sa + (wave * C::kAPW + i) * 1024);
-            } else {
-                const int b    = wave * C::kBPW + (i - C::kAPW);
-                const int kt   = step * 4 + (b & 3);
-                const int back = kt < KT ? 0 : (kt - (KT - 1)) * kTileBytes;  // clamp to the last valid k tile
-                gemm::dma16(w_rsrc, dma_voff[i] - back, step * 4 * kTileBytes, sa + C::kABytes + b * 1024);
-            }
+        for (int i = 0; i < C::kAPW; ++i)
+            // the last step of a K that is not a multiple of 256 reads past the row end into the next row (or is
+            // zero-filled by the descriptor bounds check at the very end): those k tiles are never multiplied
+            gemm::dma16(x_rsrc, dma_voff[i], step * kBK * 2, sa + (wave * C::kAPW + i) * 1024);
+    };
+    auto issue_b = [&](int buf, int step) {
+        uint8_t* sb = smem + C::kARing + buf * C::kBBytes;
+#pragma unroll
+        for (int i = C::kAPW; i < C::kPieces; ++i) {
+            const int b    = wave * C::kBPW + (i - C::kAPW);
+            const int kt   = step * 4 + (b & 3);
+            const int back = kt < KT ? 0 : (kt - (KT - 1)) * kTileBytes;  // clamp to the last valid k tile
+            gemm::dma16(w_rsrc, dma_voff[i] - back, step * 4 * kTileBytes, sb + b * 1024);
         }
+    };
+    // s_waitcnt vmcnt(ya * kAPW + yb * kBPW): the immediate must be a constant, the pair is wave-uniform run-time data
+    auto wait_younger = [&](int ya, int yb) {
+#define EETQ_SPLITK_WAIT(A, B)                                                                     \
+    case (A) * 4 + (B):                                                                            \
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((A) * C::kAPW + (B) * C::kBPW) : "memory");      \
+        break;
+        switch (ya * 4 + yb) {
+            EETQ_SPLITK_WAIT(0, 0)
+            EETQ_SPLITK_WAIT(0, 1)
+            EETQ_SPLITK_WAIT(0, 2)
+            EETQ_SPLITK_WAIT(1, 0)
+            EETQ_SPLITK_WAIT(1, 1)
+            EETQ_SPLITK_WAIT(1, 2)
+            default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        }
+#undef EETQ_SPLITK_WAIT
     };
 
     // ---- fragment addressing: lane (fn, fh); this wave owns k tile `wave` of every step ----
     const int fn = lane & 31, fh = lane >> 5;
     // weight fragment of column block nb: 16-column tile (2*nb + (fn >> 4)), k tile `wave`
-    const int b_off = C::kABytes + ((fn >> 4) * 4 + wave) * 1024 + (fn & 15) * 16 + fh * 256;  // + nb*8192 + s*512
+    const int b_off = ((fn >> 4) * 4 + wave) * 1024 + (fn & 15) * 16 + fh * 256;  // in the weight stage; + nb*8192 + s*512
     const int a_key = fn & 15;
     int       a_slot[2][2];
 #pragma unroll
@@ -165,18 +192,35 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, STAGES>::kSmem <= 80 * 1024 
 
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(scale2[nb]));
-    if (s0 < s1) issue_stage(0, s0);
-    if (C::kStages == 3 && s0 + 1 < s1) issue_stage(1, s0 + 1);
-    int buf = 0;
+    // Issue order, kept by the prologue and by every step i (relative to s0): A(i + SA - 1) then B(i + SB - 1).  The prologue
+    // plays the "virtual" steps -(SB-1) .. -1.
+#pragma unroll
+    for (int v = -(SB - 1); v < 0; ++v) {
+        if (v + SA - 1 >= 0 && s0 + v + SA - 1 < s1) issue_a((v + SA - 1) % SA, s0 + v + SA - 1);
+        if (s0 + v + SB - 1 < s1) issue_b((v + SB - 1) % SB, s0 + v + SB - 1);
+    }
+    int bufa = 0, bufb = 0;
     for (int step = s0; step < s1; ++step) {
-        // this wave's pieces of the current stage have landed (a younger stage may stay in flight with a 3-deep ring)
-        if (C::kStages == 3 && step + 1 < s1)
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(C::kPieces) : "memory");
-        else
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // ... everyone's have; everyone is done with the buffer refilled below
+        // this wave's pieces of A(step) and B(step) have landed; everything issued after the later of the two may stay in
+        // flight.  R = steps after this one.  SB > SA: the later one is A(step), issued one virtual step before B(step+SB-SA)
+        // ...: younger = A(step+1 .. step+SA-2) and B(step+SB-SA .. step+SB-2), as far as they exist.  SB == SA: the later one
+        // is B(step); younger = A and B of steps step+1 .. step+SA-2.
+        {
+            const int R  = s1 - 1 - step;
+            const int ya = R < SA - 2 ? R : SA - 2;
+            int       yb;
+            if constexpr (SB > SA) {
+                yb = R - (SB - SA) + 1;
+                yb = yb < 0 ? 0 : (yb > SA - 1 ? SA - 1 : yb);
+            } else {
+                yb = ya;
+            }
+            wait_younger(ya, yb);
+        }
+        __builtin_amdgcn_s_barrier();  // ... everyone's have; everyone is done with the buffers refilled below
         const bool     active = KFULL || step * 4 + wave < KT;  // wave-uniform: k tile beyond K on the last step
-        const int sa = lds0 + buf * C::kStage;  // integer LDS address: see gemm::lds_read16
+        const int sa = lds0 + bufa * C::kABytes;               // integer LDS addresses: see gemm::lds_read16
+        const int sb = lds0 + C::kARing + bufb * C::kBBytes;
         // order inside a step as in gemm_mid_kernel: all fragment reads, then this wave's DMA pieces of the stage
         // kStages-1 steps ahead (they run under the LDS read latency), then dequant + MFMA
         u32x4 wq[NB][2];
@@ -185,7 +229,7 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, STAGES>::kSmem <= 80 * 1024 
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) wq[nb][s] = gemm::lds_read16(sa + b_off + nb * 8192 + s * 512);
+                for (int s = 0; s < 2; ++s) wq[nb][s] = gemm::lds_read16(sb + b_off + nb * 8192 + s * 512);
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
@@ -195,11 +239,8 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, STAGES>::kSmem <= 80 * 1024 
                         xa[s][e][mt] = __builtin_bit_cast(f16x8, gemm::lds_read16(sa + mt * 32 * 512 + a_row_off + a_slot[s][e]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (step + C::kStages - 1 < s1) {
-            int nbuf = buf + C::kStages - 1;
-            nbuf     = nbuf >= C::kStages ? nbuf - C::kStages : nbuf;
-            issue_stage(nbuf, step + C::kStages - 1);
-        }
+        if (step + SA - 1 < s1) issue_a(bufa == 0 ? SA - 1 : bufa - 1, step + SA - 1);  // into the buffer of step - 1
+        if (step + SB - 1 < s1) issue_b(bufb == 0 ? SB - 1 : bufb - 1, step + SB - 1);
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
 #pragma unroll
@@ -220,7 +261,8 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, STAGES>::kSmem <= 80 * 1024 
                 }
             }
         }
-        buf = buf + 1 == C::kStages ? 0 : buf + 1;
+        bufa = bufa + 1 == SA ? 0 : bufa + 1;
+        bufb = bufb + 1 == SB ? 0 : bufb + 1;
     }
 
     // ---- add the four k quarters through LDS; wave q then owns accumulator registers 4q..4q+3 of every block ----

@@ -256,6 +256,42 @@ def test_splitk_is_deterministic_and_back_to_back_safe(ops, oracle):
         assert torch.equal(y, ops.w8_a16_gemm(xd, processed, scales))
 
 
+@pytest.mark.parametrize("K,N,M,plans", [
+    # plans = (column blocks, K slices, ring): every instantiation of the library, including the ones AUTO does not pick.  The
+    # first three rows are the (ring 22, S > 1, more workgroups than CUs) plans that returned wrong elements in round 3 when two
+    # split workgroups shared a CU -- the launcher now keeps split launches at one workgroup per CU (gemm_splitk.hip).
+    (4096, 4096, 64, [(1, 4, 22), (1, 2, 22), (2, 4, 22), (1, 2, 33), (2, 4, 33), (2, 1, 33)]),
+    (4096, 11008, 32, [(2, 2, 22), (2, 4, 22), (1, 2, 22), (1, 1, 22), (2, 1, 33)]),
+    (4096, 11008, 64, [(1, 2, 22), (1, 4, 22), (2, 1, 33), (1, 1, 22)]),
+    (4160, 4112, 50, [(1, 4, 22), (2, 2, 22), (1, 2, 33)]),            # K % 256 != 0, N % 32 != 0, M % 32 != 0
+    (2048, 1024, 128, [(1, 2, 22), (2, 4, 22), (1, 1, 22)]),
+    (2048, 1024, 9, [(1, 2, 33), (2, 4, 22)]),
+])
+def test_splitk_every_plan(ops, oracle, K, N, M, plans):
+    """Every (column blocks, slices, ring) instantiation forced through EETQ_AMD_SPLITK_PLAN: tier A against the oracle on
+    sampled rows, tier A against the tiled kernel on the whole output, and two launches give the same bits."""
+    w, x = _rand_case(K, N, M, seed=K + N + M)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    rows = sorted(set([0, M // 2, M - 1]))
+    ref = oracle.w8a16_gemm(x[rows], q, s)
+    whole = ops.w8_a16_gemm(xd, processed, scales, path="mfma").cpu().numpy()
+    for nb, S, ring in plans:
+        os.environ["EETQ_AMD_SPLITK_PLAN"] = "%d,%d,%d" % (nb, S, ring)
+        try:
+            y1 = ops.w8_a16_gemm(xd, processed, scales, path="splitk")
+            y2 = ops.w8_a16_gemm(xd, processed, scales, path="splitk")
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("EETQ_AMD_SPLITK_PLAN", None)
+        got = y1.cpu().numpy()
+        assert torch.equal(y1, y2), (nb, S, ring)
+        assert _tier_a(got[rows], ref).all(), (nb, S, ring)
+        assert _tier_a(got, whole).all(), (nb, S, ring, np.abs(got.astype(np.float32) - whole.astype(np.float32)).max())
+
+
 @pytest.mark.parametrize("M,K,N", [(5, 64, 16), (8, 256, 128), (17, 128, 144), (64, 1024, 256), (128, 512, 128),
                                    (130, 192, 272), (300, 2048, 384), (8, 4096, 4096), (64, 4096, 1024),
                                    # narrow (128 x 64) and wide tiles with ragged edges: N below / not a multiple of the

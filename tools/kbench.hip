@@ -260,13 +260,13 @@ static void bench_mid(const char* name, int M, int N, int K, const std::vector<u
 }
 
 
-template <int MT, int NB, int STAGES>
+template <int MT, int NB, int STAGES, int SB = STAGES, bool KFULL = true>
 static void bench_splitk(const char* name, int M, int N, int K, int S, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
                               const eetq::f16* scales, eetq::f16* y, float* slabs, unsigned* tickets)
 {
     using namespace eetq::gemm_splitk;
-    using C   = Cfg<MT, NB, STAGES>;
-    auto kern = gemm_splitk_kernel<MT, NB, STAGES, true>;
+    using C   = Cfg<MT, NB, STAGES, SB>;
+    auto kern = gemm_splitk_kernel<MT, NB, STAGES, SB, KFULL>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int    tiles = (N + C::kBN - 1) / C::kBN;
     const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
@@ -282,9 +282,9 @@ static void bench_splitk(const char* name, int M, int N, int K, int S, const std
                                scales, y, M, N, K, S, slabs, tickets, eetq::Epilogue{});
         },
         200);
-    printf("%-26s N=%5d K=%5d M=%3d BN=%2d S=%d st=%d wg=%4d | disp mean %6.2f med %6.2f min %6.2f | graph step %6.2f us -> %6.0f GB/s(med) %6.1f TF\n",
-           name, N, K, M, 32 * NB, S, STAGES, tiles * S, st.mean, st.med, st.mn, g, bytes / st.med / 1e3,
-           2.0 * M * N * K / st.med / 1e6);
+    printf("%-26s N=%5d K=%5d M=%3d BN=%2d S=%d ring %dx%d wg=%4d | disp mean %6.2f med %6.2f min %6.2f | graph step %6.2f us -> %6.0f GB/s %6.1f TF (graph)\n",
+           name, N, K, M, 32 * NB, S, STAGES, SB, tiles * S, st.mean, st.med, st.mn, g, bytes / g / 1e3,
+           2.0 * M * N * K / g / 1e6);
 }
 
 // ---- data-path probe: how many bytes per second can one CU pull from L2 (a) into LDS by LDS-DMA, (b) into registers?
@@ -855,6 +855,74 @@ int main(int argc, char** argv)
         bench_splitk<2, 2, 3>("ring N=11008", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
         bench_splitk<2, 2, 2>("ring N=11008", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
         bench_splitk<4, 2, 2>("ring N=11008 M=128", 128, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+    }
+    if (!strcmp(what, "deepk")) {  // round 3: separate ring depths for activations (SA) and weights (SB)
+        printf("--- split-K kernel: shared ring (SA == SB) vs a deep weight ring (SB > SA); graph step is the figure of merit ---\n");
+        eetq::f16 *xs, *ys;
+        CK(hipMalloc(&xs, 128ull * 13824 * 2));
+        CK(hipMalloc(&ys, 128ull * 13824 * 2));
+        {
+            std::vector<uint16_t> h(128ull * 13824);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
+            CK(hipMemcpy(xs, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        float*    slabs;
+        unsigned* tickets;
+        CK(hipMalloc(&slabs, 64ull << 20));
+        CK(hipMalloc(&tickets, 4096 * 4));
+        CK(hipMemset(tickets, 0, 4096 * 4));
+        std::vector<uint8_t*> bufs13(8);   // 5120 x 13824 (= 13824 x 5120 bytes): Llama-13B gate / up / down
+        for (auto& p : bufs13) {
+            CK(hipMalloc(&p, 5120ull * 13824));
+            CK(hipMemcpy(p, host.data(), 4096ull * 11008, hipMemcpyHostToDevice));
+            CK(hipMemcpy(p + 4096ull * 11008, host.data(), 5120ull * 13824 - 4096ull * 11008, hipMemcpyHostToDevice));
+        }
+        for (int M : {32, 17}) {
+            bench_splitk<1, 1, 3, 3>("M<=32 shared", M, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 1, 3, 8>("M<=32 deep", M, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 1, 3, 8>("M<=32 deep", M, 4096, 4096, 1, bufs, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 2, 3, 6>("M<=32 deep", M, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 2, 3, 6>("M<=32 deep", M, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        }
+        bench_splitk<2, 1, 3, 3>("M=64 shared", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 3, 8>("M=64 deep", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 2, 8>("M=64 deep", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 3, 8>("M=64 deep", 64, 4096, 4096, 1, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3, 4>("M=64 deep", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3, 4>("M=64 deep", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2, 6>("M=64 deep", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2, 6>("M=64 deep", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<3, 1, 2, 2>("M=96 shared", 96, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<3, 1, 2, 8>("M=96 deep", 96, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<3, 2, 2, 4>("M=96 deep", 96, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 2, 2, 2>("M=128 shared", 128, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 1, 2, 4>("M=128 deep", 128, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+        bench_splitk<4, 1, 2, 4>("M=128 deep", 128, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        printf("-- 4096 x 11008 / 11008 x 4096 --\n");
+        bench_splitk<2, 2, 3, 3>("N=11008 shared", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3, 4>("N=11008 deep", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2, 6>("N=11008 deep", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 3, 8>("N=11008 deep", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 2, 3, 6>("N=11008 deep", 32, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 1, 3, 8>("N=11008 deep", 32, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3, 3>("K=11008 shared", 64, 4096, 11008, 4, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3, 4>("K=11008 deep", 64, 4096, 11008, 4, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2, 6>("K=11008 deep", 64, 4096, 11008, 4, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 3, 8>("K=11008 deep", 64, 4096, 11008, 2, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2, 6>("K=11008 deep", 64, 4096, 11008, 2, bufs_big, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 1, 3, 8>("K=11008 deep", 32, 4096, 11008, 2, bufs_big, xs, scales, ys, slabs, tickets);
+        printf("-- Llama-13B: 5120 x 13824 (N = 13824) and 13824 x 5120 --\n");
+        bench_splitk<2, 2, 3, 3>("N=13824 shared", 64, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3, 4>("N=13824 deep", 64, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2, 6>("N=13824 deep", 64, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 2, 3, 6>("N=13824 deep", 32, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3, 3, false>("K=13824 shared", 64, 5120, 13824, 2, bufs13, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2, 6, false>("K=13824 deep", 64, 5120, 13824, 2, bufs13, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 3, 4, false>("K=13824 deep", 64, 5120, 13824, 2, bufs13, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 1, 3, 8, false>("K=13824 deep", 64, 5120, 13824, 1, bufs13, xs, scales, ys, slabs, tickets);
+        bench_splitk<2, 2, 2, 6, false>("K=13824 deep", 64, 5120, 13824, 4, bufs13, xs, scales, ys, slabs, tickets);
+        bench_splitk<1, 2, 3, 6, false>("K=13824 deep", 32, 5120, 13824, 2, bufs13, xs, scales, ys, slabs, tickets);
+        return 0;
     }
     if (!strcmp(what, "all") || !strcmp(what, "mid")) {
         printf("--- medium-batch tile kernel (32-column tiles, 256-deep K steps) ---\n");
