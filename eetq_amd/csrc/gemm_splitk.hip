@@ -143,10 +143,12 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     // of these workgroups resident on a CU (rings of <= 80 KiB, more workgroups than CUs) a split launch returns a few wrong
     // elements per call -- one accumulator register of lanes 12..15 mod 16 in a handful of tiles, different ones every call,
     // off by about one slice's partial sum -- while the very same binary is exact with one workgroup per CU (1058 forced
-    // plans, 0 wrong) and unsplit launches (S = 1) are exact at two per CU.  What was tried at two per CU
-    // (tools/deepk_check.py, 644 plans, 37 wrong as shipped in round 2): an agent acquire fence before the slab read-back 36
-    // wrong; sc0 sc1 slab loads 39; __threadfence() before the ticket 4; all three 4 -- fewer, not none, so it is not (only)
-    // the visibility of the write-through stores.  The plans AUTO picked never combined S > 1 with two per CU at the tested
+    // plans, 0 wrong) and unsplit launches (S = 1) are exact at two per CU, also with more workgroups than the chip holds.
+    // What was tried at two per CU (tools/deepk_check.py, 644 plans, 36-39 wrong as shipped in round 2): an agent acquire
+    // fence before the slab read-back 36 wrong; sc0 sc1 slab loads 39; the read-back as four dword loads 38; a ~10 us sleep
+    // before the read-back 38 (so it is not late visibility: the slab in memory IS wrong); the LDS reduction area read twice
+    // with a sleep between: identical (LDS is not being overwritten after the first read); __threadfence() before the ticket
+    // 4 wrong; with the acquire and sc0 sc1 as well, 4 -- fewer, not none.  The plans AUTO picked never combined S > 1 with two per CU at the tested
     // shapes, but nothing guaranteed it.  Until the mechanism is understood a split launch asks for more than half of the
     // CU's LDS, which keeps a second workgroup off the CU.  EETQ_AMD_SPLITK_TWO_PER_CU=1 re-allows it (to reproduce).
     size_t lds = C::kSmem;

@@ -17,7 +17,9 @@ PLANS = {1: [(1, 22), (2, 22), (1, 33), (2, 33)],
          4: [(1, 22), (2, 22)]}
 bad = 0
 n = 0
-for K, N in ((4096, 4096), (4096, 11008), (11008, 4096), (5120, 13824), (13824, 5120), (4160, 4112), (320, 48), (1024, 80)):
+SHAPES = ((4096, 4096), (4096, 11008), (11008, 4096), (5120, 13824), (13824, 5120), (4160, 4112), (320, 48), (1024, 80),
+          (2048, 22016), (1024, 32768))   # the last two: more unsplit workgroups than the chip holds at two per CU
+for K, N in SHAPES:
     g = torch.Generator(device=dev)
     g.manual_seed(K + N)
     w = ((torch.rand(K, N, device=dev, generator=g) * 2 - 1) / K ** 0.5).half()
