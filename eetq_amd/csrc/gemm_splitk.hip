@@ -116,12 +116,12 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
     return EETQ_OK;
 }
 
-template <int MT, int NB, int SA, int SB, bool KFULL>
+template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4>
 int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    using C   = gemm_splitk::Cfg<MT, NB, SA, SB>;
-    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, SA, SB, KFULL>;
+    using C   = gemm_splitk::Cfg<MT, NB, SA, SB, W>;
+    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, SA, SB, KFULL, W>;
     if (C::kSmem > 64 * 1024) {
         static std::atomic<unsigned long long> opted{0};
         int st = opt_in_large_lds(kern, opted);
@@ -162,23 +162,27 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         int st = opt_in_large_lds(kern, opted2);
         if (st != EETQ_OK) return st;
     }
-    launch_kernel(kern, dim3(tiles * S), dim3(gemm_splitk::kThreads), lds, stream, x, w, scales, y, M, N, K, S, slabs,
+    launch_kernel(kern, dim3(tiles * S), dim3(C::kThreads), lds, stream, x, w, scales, y, M, N, K, S, slabs,
                   tickets, ep);
     return check_hip(hipGetLastError(), "gemm_splitk_kernel launch");
 }
 
-template <int MT, int NB, int SA, int SB>
+template <int MT, int NB, int SA, int SB, int W = 4>
 int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    return K % gemm_splitk::kBK == 0 ? launch_full<MT, NB, SA, SB, true>(x, w, scales, ep, y, M, N, K, S, stream)
-                                     : launch_full<MT, NB, SA, SB, false>(x, w, scales, ep, y, M, N, K, S, stream);
+    return K % gemm_splitk::kBK == 0 ? launch_full<MT, NB, SA, SB, true, W>(x, w, scales, ep, y, M, N, K, S, stream)
+                                     : launch_full<MT, NB, SA, SB, false, W>(x, w, scales, ep, y, M, N, K, S, stream);
 }
 
 // ring = 10 * SA + SB (activation / weight ring depths, gemm_splitk_kernel.hpp).  The library instantiates the shared rings
-// 22 and 33: deeper weight rings (38, 36, 34, 26, 28, 24: the kernel template and tools/kbench deepk have them) were measured in
-// round 3 and are 0-10 % SLOWER at every shape (profiles/r03_kbench_deepk.txt) -- the weight bytes in flight are not what
-// bounds this kernel.
+// 22 and 33 with four waves.  Measured in round 3 and NOT instantiated here (the kernel template and tools/kbench deepk
+// have them): deeper weight rings (38, 36, 34, 26, 28, 24) are 0-10 % slower at every shape
+// (profiles/r03_kbench_deepk.txt); eight waves per workgroup (two per k tile) are within -5 .. +8 %
+// (profiles/r03_kbench_w8.txt; exact in all 1160 forced plans); two or three unsplit workgroups per CU on 2x2 rings lose
+// 12-28 % to the 3x3 ring (profiles/r03_kbench_percu.txt).  What all variants share is the step time (~0.8 us at M = 64):
+// the activation tile of a step is 2/3 of its bytes and has two steps of lookahead whatever else changes, and 160 KiB of
+// LDS cannot hold the ~170 KiB in flight per CU that the weight-stream rate would need at that many activation bytes.
 template <int MT>
 int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int nb, int S,
               int ring, hipStream_t stream)

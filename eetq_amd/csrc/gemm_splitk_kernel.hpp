@@ -50,20 +50,26 @@ constexpr int kMaxSlices = 4;
 // K loop ran at the DMA latency per step (round 3: N = K = 4096, M = 64: 9.3 us where stream + launch cost 4.9) -- while the
 // activations are L2-resident (short latency) but four to eight times as many bytes per step.  SB > SA gives the weights a
 // GEMV-like 48-96 KiB in flight per CU in what the activation ring leaves of the 160 KiB.  SA == SB is the round-2 kernel.
-template <int MT, int NB, int SA, int SB = SA>
+// W = waves per workgroup: 4 (wave j owns k tile j of a step) or 8 (two waves share a k tile, one 32-deep half each).  A step
+// is instruction-issue bound per wave -- 8-12 DMA pieces, 8-12 fragment reads, 96 dequant VALU ops and 8-16 MFMAs in a row,
+// one wave per SIMD -- so eight waves halve each wave's share and put two waves on every SIMD to cover each other.
+template <int MT, int NB, int SA, int SB = SA, int W = 4>
 struct Cfg {
+    static_assert(W == 4 || W == 8, "4 or 8 waves");
     static_assert(SB >= SA && SA >= 2 && SA <= 3, "the wait accounting below covers 2 <= SA <= 3, SB >= SA");
     static constexpr int kRows   = 32 * MT;
     static constexpr int kBN     = 32 * NB;
     static constexpr int kABytes = kRows * kBK * 2;
     static constexpr int kBBytes = kBN * kBK;
     static constexpr int kARing  = SA * kABytes;                         // activation stages first, then the weight stages
-    static constexpr int kRed    = 4 * MT * NB * 16 * 64 * 4;           // end-of-kernel cross-wave reduction area
+    static constexpr int kThreads = W * 64;
+    static constexpr int kRed    = W * MT * NB * 16 * 64 * 4;           // end-of-kernel cross-wave reduction area
     static constexpr int kSmem   = SA * kABytes + SB * kBBytes;
     static_assert(kSmem >= kRed + 16, "the reduction area and the ticket word must fit the rings");
     static_assert(kSmem <= 160 * 1024, "rings larger than the CU's LDS");
-    static constexpr int kAPW    = kABytes / 1024 / 4;                   // A pieces (2 rows of 512 B) per wave and stage
-    static constexpr int kBPW    = kBBytes / 1024 / 4;                   // B pieces (native 1 KiB tiles) per wave and stage
+    static constexpr int kAPW    = kABytes / 1024 / W;                   // A pieces (2 rows of 512 B) per wave and stage
+    static constexpr int kBPW    = kBBytes / 1024 / W;                   // B pieces (native 1 KiB tiles) per wave and stage
+    static_assert(kAPW * 1024 * W == kABytes && kBPW * 1024 * W == kBBytes, "pieces must divide evenly among the waves");
     static constexpr int kPieces = kAPW + kBPW;
     static_assert((SA - 1) * kAPW + (SB - 1) * kBPW <= 63, "vmcnt is a 6-bit counter");
     static constexpr int kSlabFloats = kRows * kBN;                      // fp32 partial tile of one slice
@@ -71,17 +77,19 @@ struct Cfg {
 
 // grid = tiles_n * S workgroups (all of M in one row tile: M <= 32*MT).  slabs: [tiles_n][S][kSlabFloats] floats,
 // counters: [tiles_n] unsigned (both unused when S == 1).
-template <int MT, int NB, int SA, int SB, bool KFULL>
-__global__ __launch_bounds__(kThreads, (Cfg<MT, NB, SA, SB>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
+template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4>
+__global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
     int N, int K, int S, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
 {
-    using C = Cfg<MT, NB, SA, SB>;
+    using C = Cfg<MT, NB, SA, SB, W>;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lds0 = (int)(uint32_t)(uintptr_t)(gemm::lds_void*)smem;
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
+    const int ktw  = wave & 3;   // k tile of a step this wave works on
+    const int half = wave >> 2;  // W == 8: which 32-deep half of that k tile (W == 4: both)
     const int KT   = K >> 6;
     const int steps_total = (KT + 3) >> 2;
 
@@ -165,13 +173,14 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, SA, SB>::kSmem <= 80 * 1024 
     // ---- fragment addressing: lane (fn, fh); this wave owns k tile `wave` of every step ----
     const int fn = lane & 31, fh = lane >> 5;
     // weight fragment of column block nb: 16-column tile (2*nb + (fn >> 4)), k tile `wave`
-    const int b_off = ((fn >> 4) * 4 + wave) * 1024 + (fn & 15) * 16 + fh * 256;  // in the weight stage; + nb*8192 + s*512
+    constexpr int SN = W == 8 ? 1 : 2;  // 32-deep halves of the k tile this wave multiplies
+    const int b_off = ((fn >> 4) * 4 + ktw) * 1024 + (fn & 15) * 16 + fh * 256 + (W == 8 ? half * 512 : 0);  // + nb*8192 + s*512
     const int a_key = fn & 15;
-    int       a_slot[2][2];
+    int       a_slot[SN][2];
 #pragma unroll
-    for (int s = 0; s < 2; ++s)
+    for (int s = 0; s < SN; ++s)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) a_slot[s][e] = ((8 * wave + 4 * s + 2 * fh + e) ^ a_key) << 4;
+        for (int e = 0; e < 2; ++e) a_slot[s][e] = ((8 * ktw + 4 * (W == 8 ? half : s) + 2 * fh + e) ^ a_key) << 4;
     const int a_row_off = fn * 512;
 
     f16x2 scale2[NB];
@@ -218,20 +227,20 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, SA, SB>::kSmem <= 80 * 1024 
             wait_younger(ya, yb);
         }
         __builtin_amdgcn_s_barrier();  // ... everyone's have; everyone is done with the buffers refilled below
-        const bool     active = KFULL || step * 4 + wave < KT;  // wave-uniform: k tile beyond K on the last step
+        const bool     active = KFULL || step * 4 + ktw < KT;  // wave-uniform: k tile beyond K on the last step
         const int sa = lds0 + bufa * C::kABytes;               // integer LDS addresses: see gemm::lds_read16
         const int sb = lds0 + C::kARing + bufb * C::kBBytes;
         // order inside a step as in gemm_mid_kernel: all fragment reads, then this wave's DMA pieces of the stage
         // kStages-1 steps ahead (they run under the LDS read latency), then dequant + MFMA
-        u32x4 wq[NB][2];
-        f16x8 xa[2][2][MT];
+        u32x4 wq[NB][SN];
+        f16x8 xa[SN][2][MT];
         if (active) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int s = 0; s < 2; ++s) wq[nb][s] = gemm::lds_read16(sb + b_off + nb * 8192 + s * 512);
+                for (int s = 0; s < SN; ++s) wq[nb][s] = gemm::lds_read16(sb + b_off + nb * 8192 + s * 512);
 #pragma unroll
-            for (int s = 0; s < 2; ++s)
+            for (int s = 0; s < SN; ++s)
 #pragma unroll
                 for (int e = 0; e < 2; ++e)
 #pragma unroll
@@ -244,9 +253,11 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, SA, SB>::kSmem <= 80 * 1024 
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
 #pragma unroll
-            for (int nb = 0; nb < NB; ++nb) asm volatile("" : "+v"(wq[nb][0]), "+v"(wq[nb][1]));  // reads stay above the dequant
+            for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
+                for (int s = 0; s < SN; ++s) asm volatile("" : "+v"(wq[nb][s]));  // reads stay above the dequant
+#pragma unroll
+            for (int s = 0; s < SN; ++s) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     f16x2 wd[8];
@@ -265,7 +276,7 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, SA, SB>::kSmem <= 80 * 1024 
         bufb = bufb + 1 == SB ? 0 : bufb + 1;
     }
 
-    // ---- add the four k quarters through LDS; wave q then owns accumulator registers 4q..4q+3 of every block ----
+    // ---- add the W partial tiles through LDS; wave q < 4 then owns accumulator registers 4q..4q+3 of every block ----
     __syncthreads();
     float* red = reinterpret_cast<float*>(smem);  // [wave][mt][nb][reg][lane]
 #pragma unroll
@@ -275,6 +286,9 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, SA, SB>::kSmem <= 80 * 1024 
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[(((wave * MT + mt) * NB + nb) * 16 + r) * 64 + lane] = acc[mt][nb][r];
     __syncthreads();
+    if constexpr (W == 8) {
+        if (wave >= 4) return;  // waves 4..7 are done: an ended wave no longer takes part in the workgroup's barriers
+    }
     // s4[mt][nb][i] = partial y[32*mt + fn][n0 + 32*nb + 8*wave + 4*fh + i]
     float s4[MT][NB][4];
 #pragma unroll
@@ -285,7 +299,7 @@ __global__ __launch_bounds__(kThreads, (Cfg<MT, NB, SA, SB>::kSmem <= 80 * 1024 
             for (int i = 0; i < 4; ++i) {
                 float s = 0.f;
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s += red[(((q * MT + mt) * NB + nb) * 16 + 4 * wave + i) * 64 + lane];
+                for (int q = 0; q < W; ++q) s += red[(((q * MT + mt) * NB + nb) * 16 + 4 * wave + i) * 64 + lane];
                 s4[mt][nb][i] = s;
             }
 

@@ -260,30 +260,30 @@ static void bench_mid(const char* name, int M, int N, int K, const std::vector<u
 }
 
 
-template <int MT, int NB, int STAGES, int SB = STAGES, bool KFULL = true>
+template <int MT, int NB, int STAGES, int SB = STAGES, bool KFULL = true, int W = 4>
 static void bench_splitk(const char* name, int M, int N, int K, int S, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
                               const eetq::f16* scales, eetq::f16* y, float* slabs, unsigned* tickets)
 {
     using namespace eetq::gemm_splitk;
-    using C   = Cfg<MT, NB, STAGES, SB>;
-    auto kern = gemm_splitk_kernel<MT, NB, STAGES, SB, KFULL>;
+    using C   = Cfg<MT, NB, STAGES, SB, W>;
+    auto kern = gemm_splitk_kernel<MT, NB, STAGES, SB, KFULL, W>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int    tiles = (N + C::kBN - 1) / C::kBN;
     const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
     auto st = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
-            hipExtLaunchKernelGGL(kern, dim3(tiles * S), dim3(kThreads), C::kSmem, 0, a, b, 0, x,
+            hipExtLaunchKernelGGL(kern, dim3(tiles * S), dim3(C::kThreads), C::kSmem, 0, a, b, 0, x,
                                   (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, S, slabs, tickets, eetq::Epilogue{});
         },
         200);
     const double g = time_graph(
         [&](int i, hipStream_t s) {
-            hipLaunchKernelGGL(kern, dim3(tiles * S), dim3(kThreads), C::kSmem, s, x, (const uint8_t*)bufs[i % bufs.size()],
+            hipLaunchKernelGGL(kern, dim3(tiles * S), dim3(C::kThreads), C::kSmem, s, x, (const uint8_t*)bufs[i % bufs.size()],
                                scales, y, M, N, K, S, slabs, tickets, eetq::Epilogue{});
         },
         200);
-    printf("%-26s N=%5d K=%5d M=%3d BN=%2d S=%d ring %dx%d wg=%4d | disp mean %6.2f med %6.2f min %6.2f | graph step %6.2f us -> %6.0f GB/s %6.1f TF (graph)\n",
-           name, N, K, M, 32 * NB, S, STAGES, SB, tiles * S, st.mean, st.med, st.mn, g, bytes / g / 1e3,
+    printf("%-26s N=%5d K=%5d M=%3d BN=%2d S=%d ring %dx%d w%d wg=%4d | disp mean %6.2f med %6.2f min %6.2f | graph step %6.2f us -> %6.0f GB/s %6.1f TF (graph)\n",
+           name, N, K, M, 32 * NB, S, STAGES, SB, W, tiles * S, st.mean, st.med, st.mn, g, bytes / g / 1e3,
            2.0 * M * N * K / g / 1e6);
 }
 
@@ -898,6 +898,45 @@ int main(int argc, char** argv)
         bench_splitk<4, 2, 2, 2>("M=128 shared", 128, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
         bench_splitk<4, 1, 2, 4>("M=128 deep", 128, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
         bench_splitk<4, 1, 2, 4>("M=128 deep", 128, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
+        if (argc > 2 && !strcmp(argv[2], "w8")) {  // four vs eight waves per workgroup, shared 3x3 ring
+            printf("-- 4 waves (one per k tile) vs 8 waves (two per k tile, one 32-deep half each) --\n");
+#define W48(MT_, NB_, M_, N_, K_, S_, BUFS)                                                                            \
+    bench_splitk<MT_, NB_, 3, 3, true, 4>("4 waves", M_, N_, K_, S_, BUFS, xs, scales, ys, slabs, tickets);            \
+    bench_splitk<MT_, NB_, 3, 3, true, 8>("8 waves", M_, N_, K_, S_, BUFS, xs, scales, ys, slabs, tickets);
+            W48(1, 1, 17, 4096, 4096, 2, bufs)
+            W48(1, 1, 32, 4096, 4096, 2, bufs)
+            W48(1, 2, 32, 4096, 4096, 4, bufs)
+            W48(2, 1, 64, 4096, 4096, 2, bufs)
+            W48(2, 2, 64, 4096, 4096, 4, bufs)
+            W48(2, 2, 64, 11008, 4096, 1, bufs_big)
+            W48(1, 2, 32, 11008, 4096, 1, bufs_big)
+            W48(2, 2, 64, 4096, 11008, 4, bufs_big)
+            W48(1, 1, 32, 4096, 11008, 2, bufs_big)
+            W48(2, 2, 64, 13824, 5120, 1, bufs13)
+            W48(1, 2, 32, 13824, 5120, 1, bufs13)
+            W48(1, 2, 17, 13824, 5120, 1, bufs13)
+            W48(2, 2, 64, 5120, 13824, 2, bufs13)
+            W48(1, 2, 32, 5120, 13824, 2, bufs13)
+#undef W48
+            return 0;
+        }
+        if (argc > 2 && !strcmp(argv[2], "percu")) {  // unsplit plans small enough for two or three workgroups per CU
+            printf("-- unsplit (S = 1) plans: one workgroup per CU (rings > 80 KiB) vs two / three per CU (ring 2x2) --\n");
+            bench_splitk<2, 2, 3, 3>("M=64 BN=64 3x3 1/CU", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 1, 2, 2>("M=64 BN=32 2x2 2/CU", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 1, 3, 3>("M=64 BN=32 3x3 1/CU", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 2, 3, 3>("M=32 BN=64 3x3 1/CU", 32, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 2, 2, 2>("M=32 BN=64 2x2 2/CU", 32, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 1, 2, 2>("M=32 BN=32 2x2 3/CU", 32, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 2, 3, 3>("M=64 BN=64 3x3 1/CU", 64, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 1, 2, 2>("M=64 BN=32 2x2 2/CU", 64, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 2, 3, 3>("M=32 BN=64 3x3 1/CU", 32, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 2, 2, 2>("M=32 BN=64 2x2 2/CU", 32, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 1, 2, 2>("M=32 BN=32 2x2 3/CU", 32, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 1, 2, 2>("M=17 BN=32 2x2 3/CU", 17, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 2, 3, 3>("M=17 BN=64 3x3 1/CU", 17, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            return 0;
+        }
         printf("-- 4096 x 11008 / 11008 x 4096 --\n");
         bench_splitk<2, 2, 3, 3>("N=11008 shared", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
         bench_splitk<2, 2, 3, 4>("N=11008 deep", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
