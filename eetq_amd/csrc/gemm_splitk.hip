@@ -179,10 +179,9 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
 // 22 and 33 with four waves.  Measured in round 3 and NOT instantiated here (the kernel template and tools/kbench deepk
 // have them): deeper weight rings (38, 36, 34, 26, 28, 24) are 0-10 % slower at every shape
 // (profiles/r03_kbench_deepk.txt); eight waves per workgroup (two per k tile) are within -5 .. +8 %
-// (profiles/r03_kbench_w8.txt; exact in all 1160 forced plans); two or three unsplit workgroups per CU on 2x2 rings lose
-// 12-28 % to the 3x3 ring (profiles/r03_kbench_percu.txt).  What all variants share is the step time (~0.8 us at M = 64):
-// the activation tile of a step is 2/3 of its bytes and has two steps of lookahead whatever else changes, and 160 KiB of
-// LDS cannot hold the ~170 KiB in flight per CU that the weight-stream rate would need at that many activation bytes.
+// (profiles/r03_kbench_w8.txt; exact in all 1160 forced plans); DMA pieces interleaved with the MFMA groups, a 4 x 4 ring,
+// 128-column blocks and two or three unsplit workgroups per CU do not help either (r03_kbench_inter / ring4 / bn128 /
+// percu.txt).  DESIGN.md section 4.2b has the table and the reading.
 template <int MT>
 int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int nb, int S,
               int ring, hipStream_t stream)

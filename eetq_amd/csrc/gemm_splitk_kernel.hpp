@@ -56,7 +56,7 @@ constexpr int kMaxSlices = 4;
 template <int MT, int NB, int SA, int SB = SA, int W = 4>
 struct Cfg {
     static_assert(W == 4 || W == 8, "4 or 8 waves");
-    static_assert(SB >= SA && SA >= 2 && SA <= 3, "the wait accounting below covers 2 <= SA <= 3, SB >= SA");
+    static_assert(SB >= SA && SA >= 2 && (SA <= 3 || (SA == 4 && SB == 4)), "the wait accounting covers SA <= 3 (SB >= SA) and 4 x 4");
     static constexpr int kRows   = 32 * MT;
     static constexpr int kBN     = 32 * NB;
     static constexpr int kABytes = kRows * kBK * 2;
@@ -77,7 +77,9 @@ struct Cfg {
 
 // grid = tiles_n * S workgroups (all of M in one row tile: M <= 32*MT).  slabs: [tiles_n][S][kSlabFloats] floats,
 // counters: [tiles_n] unsigned (both unused when S == 1).
-template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4>
+// INTER: the DMA pieces of the stage being refilled are issued BETWEEN the MFMA groups of the step (a few right after the
+// fragment reads, to cover their latency) instead of all of them before the first dequant.
+template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4, bool INTER = false>
 __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
     int N, int K, int S, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
@@ -152,6 +154,18 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
             gemm::dma16(w_rsrc, dma_voff[i] - back, step * 4 * kTileBytes, sb + b * 1024);
         }
     };
+    // one piece (index i of this wave's kPieces) of the stages refilled during `step`: A(step + SA - 1) / B(step + SB - 1)
+    auto issue_piece = [&](int i, int bufa_next, int bufb_next, int step, bool do_a, bool do_b) {
+        if (i < C::kAPW) {
+            if (do_a)
+                gemm::dma16(x_rsrc, dma_voff[i], (step + SA - 1) * kBK * 2, smem + bufa_next * C::kABytes + (wave * C::kAPW + i) * 1024);
+        } else if (do_b) {
+            const int b    = wave * C::kBPW + (i - C::kAPW);
+            const int kt   = (step + SB - 1) * 4 + (b & 3);
+            const int back = kt < KT ? 0 : (kt - (KT - 1)) * kTileBytes;
+            gemm::dma16(w_rsrc, dma_voff[i] - back, (step + SB - 1) * 4 * kTileBytes, smem + C::kARing + bufb_next * C::kBBytes + b * 1024);
+        }
+    };
     // s_waitcnt vmcnt(ya * kAPW + yb * kBPW): the immediate must be a constant, the pair is wave-uniform run-time data
     auto wait_younger = [&](int ya, int yb) {
 #define EETQ_SPLITK_WAIT(A, B)                                                                     \
@@ -165,6 +179,7 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
             EETQ_SPLITK_WAIT(1, 0)
             EETQ_SPLITK_WAIT(1, 1)
             EETQ_SPLITK_WAIT(1, 2)
+            EETQ_SPLITK_WAIT(2, 2)
             default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
         }
 #undef EETQ_SPLITK_WAIT
@@ -248,8 +263,21 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
                         xa[s][e][mt] = __builtin_bit_cast(f16x8, gemm::lds_read16(sa + mt * 32 * 512 + a_row_off + a_slot[s][e]));
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (step + SA - 1 < s1) issue_a(bufa == 0 ? SA - 1 : bufa - 1, step + SA - 1);  // into the buffer of step - 1
-        if (step + SB - 1 < s1) issue_b(bufb == 0 ? SB - 1 : bufb - 1, step + SB - 1);
+        const int  bufa_next = bufa == 0 ? SA - 1 : bufa - 1, bufb_next = bufb == 0 ? SB - 1 : bufb - 1;  // buffers of step - 1
+        const bool do_a = step + SA - 1 < s1, do_b = step + SB - 1 < s1;
+        constexpr int NC  = SN * NB * 2;                          // MFMA groups of a step (MT MFMAs each)
+        constexpr int PPS = (C::kPieces + NC) / (NC + 1);         // DMA pieces per slot: slot 0 before the first group
+        auto dma_slot = [&](int slot) {
+#pragma unroll
+            for (int j = 0; j < PPS; ++j)
+                if (slot * PPS + j < C::kPieces) issue_piece(slot * PPS + j, bufa_next, bufb_next, step, do_a, do_b);
+        };
+        if constexpr (!INTER) {
+            if (do_a) issue_a(bufa_next, step + SA - 1);
+            if (do_b) issue_b(bufb_next, step + SB - 1);
+        } else {
+            dma_slot(0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (active) {
 #pragma unroll
@@ -268,9 +296,17 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt)
                             acc[mt][nb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf, xa[s][e][mt], acc[mt][nb], 0, 0, 0);
+                        if constexpr (INTER) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            dma_slot(1 + (s * NB + nb) * 2 + e);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             }
+        } else if constexpr (INTER) {
+#pragma unroll
+            for (int c = 1; c <= NC; ++c) dma_slot(c);
         }
         bufa = bufa + 1 == SA ? 0 : bufa + 1;
         bufb = bufb + 1 == SB ? 0 : bufb + 1;

@@ -260,13 +260,13 @@ static void bench_mid(const char* name, int M, int N, int K, const std::vector<u
 }
 
 
-template <int MT, int NB, int STAGES, int SB = STAGES, bool KFULL = true, int W = 4>
+template <int MT, int NB, int STAGES, int SB = STAGES, bool KFULL = true, int W = 4, bool INTER = false>
 static void bench_splitk(const char* name, int M, int N, int K, int S, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
                               const eetq::f16* scales, eetq::f16* y, float* slabs, unsigned* tickets)
 {
     using namespace eetq::gemm_splitk;
     using C   = Cfg<MT, NB, STAGES, SB, W>;
-    auto kern = gemm_splitk_kernel<MT, NB, STAGES, SB, KFULL, W>;
+    auto kern = gemm_splitk_kernel<MT, NB, STAGES, SB, KFULL, W, INTER>;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     const int    tiles = (N + C::kBN - 1) / C::kBN;
     const double bytes = (double)K * N + 2.0 * M * K + 2.0 * N + 2.0 * M * N;
@@ -918,6 +918,63 @@ int main(int argc, char** argv)
             W48(2, 2, 64, 5120, 13824, 2, bufs13)
             W48(1, 2, 32, 5120, 13824, 2, bufs13)
 #undef W48
+            return 0;
+        }
+        if (argc > 2 && !strcmp(argv[2], "inter")) {  // DMA pieces issued between the MFMA groups vs all before the first dequant
+            printf("-- DMA issue: block (before the dequant) vs interleaved with the MFMA groups; 4 and 8 waves --\n");
+#define INTERCMP(MT_, NB_, M_, N_, K_, S_, BUFS)                                                                                 \
+    bench_splitk<MT_, NB_, 3, 3, true, 4, false>("w4 block", M_, N_, K_, S_, BUFS, xs, scales, ys, slabs, tickets);               \
+    bench_splitk<MT_, NB_, 3, 3, true, 4, true>("w4 interleaved", M_, N_, K_, S_, BUFS, xs, scales, ys, slabs, tickets);          \
+    bench_splitk<MT_, NB_, 3, 3, true, 8, true>("w8 interleaved", M_, N_, K_, S_, BUFS, xs, scales, ys, slabs, tickets);
+            INTERCMP(1, 1, 32, 4096, 4096, 2, bufs)
+            INTERCMP(2, 1, 64, 4096, 4096, 2, bufs)
+            INTERCMP(2, 2, 64, 4096, 4096, 4, bufs)
+            INTERCMP(2, 2, 64, 11008, 4096, 1, bufs_big)
+            INTERCMP(1, 2, 32, 11008, 4096, 1, bufs_big)
+            INTERCMP(2, 2, 64, 4096, 11008, 4, bufs_big)
+            INTERCMP(2, 2, 64, 13824, 5120, 1, bufs13)
+            INTERCMP(1, 2, 32, 13824, 5120, 1, bufs13)
+            INTERCMP(2, 2, 64, 5120, 13824, 2, bufs13)
+#undef INTERCMP
+            return 0;
+        }
+        if (argc > 2 && !strcmp(argv[2], "ring4")) {  // shared ring of 3 vs 4 stages (activation lookahead 2 vs 3 steps)
+            printf("-- shared ring 3x3 vs 4x4 --\n");
+#define R34(MT_, NB_, M_, N_, K_, S_, BUFS)                                                                        \
+    bench_splitk<MT_, NB_, 3, 3>("ring 3x3", M_, N_, K_, S_, BUFS, xs, scales, ys, slabs, tickets);                 \
+    bench_splitk<MT_, NB_, 4, 4>("ring 4x4", M_, N_, K_, S_, BUFS, xs, scales, ys, slabs, tickets);
+            R34(1, 1, 32, 4096, 4096, 2, bufs)
+            R34(1, 2, 32, 4096, 4096, 4, bufs)
+            R34(2, 1, 64, 4096, 4096, 2, bufs)
+            R34(1, 2, 32, 11008, 4096, 1, bufs_big)
+            R34(1, 1, 32, 4096, 11008, 2, bufs_big)
+            R34(2, 1, 64, 4096, 11008, 2, bufs_big)
+            R34(1, 2, 32, 13824, 5120, 1, bufs13)
+            R34(1, 2, 17, 13824, 5120, 1, bufs13)
+            R34(2, 1, 64, 13824, 5120, 1, bufs13)
+            R34(1, 2, 32, 5120, 13824, 2, bufs13)
+#undef R34
+            return 0;
+        }
+        if (argc > 2 && !strcmp(argv[2], "bn128")) {  // 128-column blocks (NB = 4): the activations re-read half as often
+            printf("-- BN = 64 (shipping plans) vs BN = 128 --\n");
+            bench_splitk<2, 2, 3, 3>("M=64 BN=64", 64, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 4, 2, 3>("M=64 BN=128", 64, 13824, 5120, 2, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 4, 2, 3>("M=64 BN=128", 64, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 4, 2, 3>("M=64 BN=128", 64, 13824, 5120, 4, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 2, 3, 3>("M=32 BN=64", 32, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 4, 3, 3>("M=32 BN=128", 32, 13824, 5120, 2, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 4, 3, 3>("M=32 BN=128", 32, 13824, 5120, 1, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 2, 3, 3>("M=64 BN=64", 64, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 4, 2, 3>("M=64 BN=128", 64, 11008, 4096, 2, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 2, 3, 3>("M=32 BN=64", 32, 11008, 4096, 1, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<1, 4, 3, 3>("M=32 BN=128", 32, 11008, 4096, 2, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 2, 3, 3>("M=64 BN=64", 64, 4096, 11008, 4, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 4, 2, 3>("M=64 BN=128", 64, 4096, 11008, 4, bufs_big, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 2, 3, 3, false>("M=64 BN=64", 64, 5120, 13824, 2, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 4, 2, 3, false>("M=64 BN=128", 64, 5120, 13824, 4, bufs13, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 1, 3, 3>("M=64 BN=32", 64, 4096, 4096, 2, bufs, xs, scales, ys, slabs, tickets);
+            bench_splitk<2, 4, 2, 3>("M=64 BN=128", 64, 4096, 4096, 4, bufs, xs, scales, ys, slabs, tickets);
             return 0;
         }
         if (argc > 2 && !strcmp(argv[2], "percu")) {  // unsplit plans small enough for two or three workgroups per CU
