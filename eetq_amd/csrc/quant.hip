@@ -3,10 +3,12 @@
 // Reference behaviour restated (paths relative to /root/reference):
 //   quantise  csrc/cutlass_kernels/cutlass_preprocessors.cc:581-678  (ft::symmetric_quantize)
 //   sm80 pack csrc/cutlass_kernels/cutlass_preprocessors.cc:497-534  (preprocess_weights_for_mixed_gemm)
-// The reference runs these single-threaded on the CPU (three strided K x N passes + four re-layout
-// passes); here quant_weights is three launches -- per-row-block column maxima (plain stores: no atomics, no zero fill), a
-// small fold of those rows, and a kernel that quantises and writes the target layout -- and every pass is one coalesced sweep: 64(k) x 64(n) tiles are read
-// row-wise, transposed through LDS and written in the destination layout with 16-byte stores.
+// The reference runs these single-threaded on the CPU (three strided K x N passes + four re-layout passes); here
+// quant_weights is two launches: per-row-block column maxima (plain stores: no atomics, no zero fill), then one kernel that
+// reduces those rows for its columns, quantises and writes the target layout.  For the native layout without a row-major
+// copy that kernel is quant_pack_kernel (LDS-DMA ring, column-major in registers, division-free but bit-exact); the sm80
+// wire layout and the calls that also return the row-major int8 tensor use strip_quant_kernel (row-wise reads, byte
+// transpose through LDS, IEEE division).
 #include <cstdlib>
 #include <type_traits>
 
@@ -24,19 +26,21 @@ __constant__ int kPerm16[16] = {0, 1, 8, 9, 2, 3, 10, 11, 4, 5, 12, 13, 6, 7, 14
 // ---- pass 1: per-column max |w| -----------------------------------------------------------------------
 // std::max(a, |w|) with a starting at 0.f ignores NaN (a < NaN is false), see :619-628.  |w| >= 0, so
 // the IEEE bit pattern orders like an unsigned integer and atomicMax on the bits is exact.
-// Workgroup = 4 waves over one strip of 64*V columns (one contiguous 1 KiB per wave-load) x kRowsPerBlock rows: wave j
-// takes rows j, j+4, ...; eight independent 16-byte loads in flight per lane; the four waves' maxima meet in LDS and ONE
-// atomicMax per column and workgroup follows (K / 128 per column in total -- the first version issued one per column per 32
-// rows, 524 k atomics at 4096^2, and ran at 1.2 TB/s).
+// Workgroup = kColmaxWaves waves over one strip of 64*V columns (one contiguous 1 KiB per wave-load) x kRowsPerBlock rows:
+// wave j takes rows j, j+8, ...: all its 16-byte loads are in flight at once; the waves' maxima meet in LDS and ONE
+// store (or atomicMax) per column and workgroup follows (K / 128 per column in total -- the first version issued one atomic
+// per column per 32 rows, 524 k atomics at 4096^2, and ran at 1.2 TB/s).
 // PARTIALS: no atomics and no zero-fill launch before the kernel -- row block y stores its maxima to row y of a
 // [ceil(K / kRowsPerBlock)][N] array and the pack kernel reduces the rows for its 64 columns (the int8 quantiser: two
 // launches per call instead of fill + maxima + pack).
 constexpr int kRowsPerBlock = 128;
+constexpr int kColmaxWaves  = 8;  // 16 rows per wave, all 16 loads of a lane in flight at once: 128 KiB per CU on the wire
+                                  // (4 waves x 8 loads = 32 KiB per CU ran at 3.5 TB/s: latency-bound, profiles/r03_quant_pmc.txt)
 template <typename T, int V, bool PARTIALS>
-__global__ __launch_bounds__(256) void colmax_kernel(const T* __restrict__ w, size_t K, size_t N,
-                                                     u32* __restrict__ colmax_bits)
+__global__ __launch_bounds__(64 * kColmaxWaves) void colmax_kernel(const T* __restrict__ w, size_t K, size_t N,
+                                                                  u32* __restrict__ colmax_bits)
 {
-    __shared__ float part[4][64 * V];
+    __shared__ float part[kColmaxWaves][64 * V];
     const int    wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const size_t col0 = ((size_t)blockIdx.x * 64 + lane) * V;
     const size_t k_begin = (size_t)blockIdx.y * kRowsPerBlock;
@@ -44,37 +48,51 @@ __global__ __launch_bounds__(256) void colmax_kernel(const T* __restrict__ w, si
     if (k_end > K) k_end = K;
     const bool   live = col0 < N;
     const size_t cc   = live ? col0 : 0;  // dead lanes (ragged last strip) read column 0 and are ignored
-    float m[V];
+    constexpr int kBatch = kRowsPerBlock / kColmaxWaves;
+    u32x4 raw[kBatch];
 #pragma unroll
-    for (int i = 0; i < V; ++i) m[i] = 0.f;
-    constexpr int kBatch = 8;
-    for (size_t k = k_begin + wave; k < k_end; k += 4 * kBatch) {
-        u32x4 raw[kBatch];
+    for (int j = 0; j < kBatch; ++j) {
+        const size_t k  = k_begin + wave + (size_t)kColmaxWaves * j;
+        const size_t kk = k < k_end ? k : k_end - 1;  // clamped, never a branch around the load
+        raw[j]          = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w + kk * N + cc));
+    }
+    // max |w| with NaN ignored (std::max(a, |w|) keeps a when |w| is NaN, :619-628): the hardware's maxnum does exactly that,
+    // in the input type (a maximum is exact in any format)
+    float m[V];
+    if constexpr (sizeof(T) == 2) {
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        h2 acc[4] = {h2{0, 0}, h2{0, 0}, h2{0, 0}, h2{0, 0}};
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
-            const size_t kk = k + 4 * j < k_end ? k + 4 * j : k_end - 1;  // clamped, never a branch around the load
-            raw[j]          = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(w + kk * N + cc));
+            const u32 d[4] = {raw[j].x, raw[j].y, raw[j].z, raw[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_elementwise_max(acc[i], __builtin_bit_cast(h2, d[i] & 0x7fff7fffu));
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            m[2 * i]     = (float)acc[i].x;
+            m[2 * i + 1] = (float)acc[i].y;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < V; ++i) m[i] = 0.f;
 #pragma unroll
         for (int j = 0; j < kBatch; ++j) {
             T v[V];
             *reinterpret_cast<u32x4*>(v) = raw[j];
 #pragma unroll
-            for (int i = 0; i < V; ++i) {
-                const float a = __builtin_fabsf((float)v[i]);
-                m[i]          = (m[i] < a) ? a : m[i];
-            }
+            for (int i = 0; i < V; ++i) m[i] = __builtin_fmaxf(m[i], __builtin_fabsf((float)v[i]));
         }
     }
 #pragma unroll
     for (int i = 0; i < V; ++i) part[wave][lane * V + i] = m[i];
     __syncthreads();
-    for (int c = threadIdx.x; c < 64 * V; c += 256) {
+    for (int c = threadIdx.x; c < 64 * V; c += 64 * kColmaxWaves) {
         const size_t col = (size_t)blockIdx.x * 64 * V + c;
         if (col < N) {
             float a = part[0][c];
 #pragma unroll
-            for (int j = 1; j < 4; ++j) a = (a < part[j][c]) ? part[j][c] : a;
+            for (int j = 1; j < kColmaxWaves; ++j) a = __builtin_fmaxf(a, part[j][c]);
             if constexpr (PARTIALS)
                 colmax_bits[(size_t)blockIdx.y * N + col] = __builtin_bit_cast(u32, a);
             else
@@ -288,6 +306,203 @@ __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ 
     }
 }
 
+// ---- quantise + native (gfx950) layout in one pass, column-major in registers -----------------------------------------
+// The native layout gives lane (g, c) of a 16-column x 64-row tile the 16 bytes of ONE column (rows 16g .. 16g+15, rows
+// 1 <-> 2 of every four swapped), i.e. the transpose of how the weight is read.  strip_quant_kernel does that transpose on
+// the quantised BYTES (16 ds_read_u8 + shifts/ors per thread) after an IEEE division per element, and is instruction-bound:
+// 33 VALU ops per element, 15.5 us of issue time at 4096^2 against 20 us measured (profiles/r03_quant_isa.txt).  Here
+//   * the 64 x 64 tile goes HBM -> LDS by LDS-DMA (no registers, no address math per element), rows padded per 1 KiB block
+//     so that the column-wise reads below are bank-conflict free;
+//   * every lane reads the 16 elements of its column as T and quantises them straight into the output byte positions
+//     (v_cvt_pk_u8_f32 of q + 128 does the [-128, 127] clamp, the +128 bias and the byte packing in one instruction);
+//   * no IEEE division: b = fma(w, rcp(s), 128) is w / s + 128 to within 3.1e-5 (t = w / s, |t| <= 128: the 1-ulp
+//     reciprocal moves w * r by <= 1.53e-5, the fma's rounding below 256 by <= 0.77e-5, and the reference's correctly
+//     rounded quotient is within 0.77e-5 of t), which is enough to name the two integers the result can be, f = floor(b)
+//     and f + 1; which one it is follows from the SIGN of m * s - w with m = f - 127.5 the tie between them -- one more
+//     fma, exact in sign -- and a zero there is an exact tie, which C round() resolves away from zero.  Exact ties are
+//     not rare on fp16 grids (1.6 % of the elements of a uniform fp16 matrix, 7.9 % of nn.Linear's default init), so they
+//     are resolved inline; lanes with a NaN weight, a zero / subnormal / huge / NaN scale or (fp32 input) a quotient whose
+//     fp32 rounding could land on a tie redo their 16 elements with quantize_elt (the reference's arithmetic verbatim).
+// grid = (ceil(N/64), ceil(K/64/tiles_per_wg)), block = 256: wave = 16-column chunk, lane = (g, c).
+typedef __attribute__((address_space(3))) void qp_lds_void;
+// 64 lanes x 16 bytes, global (buffer descriptor + per-lane offset) -> LDS at lds_wave_base + lane * 16, no registers
+__device__ __forceinline__ void qp_dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, uint8_t* lds_wave_base)
+{
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (qp_lds_void*)lds_wave_base, 16, voff, 0, 0, 0);
+}
+
+template <typename T>
+struct QpCfg {
+    static constexpr int kRowBytes  = kQT * (int)sizeof(T);     // 128 / 256
+    static constexpr int kRowsPerB  = 1024 / kRowBytes;         // rows per 1 KiB DMA block: 8 / 4
+    static constexpr int kBlocks    = kQT / kRowsPerB;          // DMA blocks per tile: 8 / 16
+    static constexpr int kPad       = sizeof(T) == 2 ? 32 : 16; // 16 rows apart = 16 banks apart for both element sizes
+    static constexpr int kBlockLds  = 1024 + kPad;
+    static constexpr int kTileLds   = kBlocks * kBlockLds;
+};
+
+// A workgroup walks `tiles_per_wg` consecutive 64-row tiles of its 64-column strip with a two-slot LDS ring: tile j+2's DMA
+// is issued as soon as every wave has read tile j out of its slot, so loads stay in flight under the arithmetic and the
+// stores (one tile per workgroup and launch-wide lock-step phases -- everyone loads, then everyone computes, then everyone
+// stores -- measured 18 us at 4096^2 with 45 % fewer instructions than the row-major kernel's 17 us).  The column scales
+// (the reduction of the P row-block maxima) are computed once per workgroup, not once per tile.
+template <typename T>
+__global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ src, unsigned K, unsigned N,
+                                                         const float* __restrict__ part, int P,
+                                                         uint8_t* __restrict__ q_packed, void* __restrict__ scales,
+                                                         int scales_f32, int tiles_per_wg)
+{
+    using C = QpCfg<T>;
+    constexpr int kPer = C::kBlocks / 4;  // DMA instructions per wave and tile
+    // the ring is DYNAMIC LDS (2 * kTileLds bytes): with a static array hipcc puts an s_waitcnt vmcnt(0) in front of the
+    // first LDS read after every LDS-DMA issue (it can name the object both touch), i.e. waits for the prefetched tile too
+    extern __shared__ __attribute__((aligned(16))) uint8_t tiles[];
+    __shared__ float cm[4][kQT];
+    __shared__ float col_s[kQT], col_r[kQT];
+    const int      t    = threadIdx.x;
+    const int      wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int      lane = t & 63;
+    const unsigned n0   = blockIdx.x * kQT;
+    const unsigned KT   = K / kQT;
+    const unsigned kt0  = blockIdx.y * (unsigned)tiles_per_wg;
+    const int      nt   = (int)(KT - kt0 < (unsigned)tiles_per_wg ? KT - kt0 : (unsigned)tiles_per_wg);
+
+    // ---- tiles: HBM -> LDS.  The descriptor starts at this workgroup's first element, so offsets stay 32-bit for any
+    // tensor size; a ragged last strip reads on into the next row (ignored columns) or past the end (zero-filled).
+    const size_t first = ((size_t)kt0 * kQT * N + n0) * sizeof(T);
+    const size_t left  = (size_t)K * N * sizeof(T) - first;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<T*>(src) + ((size_t)kt0 * kQT * N + n0), 0, left > 0xffffffffull ? (int)0xffffffffu : (int)left, 0x00020000);
+    constexpr int  kSegs    = C::kRowBytes / 16;  // 16-byte pieces per row
+    const unsigned lane_off = ((unsigned)(lane / kSegs) + (unsigned)wave * (kPer * C::kRowsPerB)) * N * (unsigned)sizeof(T) +
+                              (unsigned)(lane % kSegs) * 16u;
+    const unsigned tile_pitch = kQT * N * (unsigned)sizeof(T);
+    auto issue = [&](int j, int slot) {
+        uint8_t* base = tiles + slot * C::kTileLds + wave * kPer * C::kBlockLds;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (qp_lds_void*)(base + i * C::kBlockLds), 16,
+                                                     (int)(lane_off + (unsigned)(i * C::kRowsPerB) * N * (unsigned)sizeof(T)),
+                                                     (int)((unsigned)j * tile_pitch), 0, 0);
+    };
+    issue(0, 0);
+    if (nt > 1) issue(1, 1);
+    // ---- this strip's 64 column maxima from the P row-block partials ----
+    {
+        const int      col = t & 63, p0 = t >> 6;
+        const unsigned cg  = n0 + col < N ? n0 + col : 0;
+        float          m   = 0.f;
+        for (int p = p0; p < P; p += 32) {  // 8 independent loads in flight per thread (clamped rows: a repeat is harmless)
+            float a[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int pp = p + 4 * j;
+                a[j]         = part[(size_t)((unsigned)(pp < P ? pp : P - 1) * N + cg)];
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m = (m < a[j]) ? a[j] : m;
+        }
+        cm[p0][col] = m;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (t < kQT) {
+        float a = cm[0][t];
+#pragma unroll
+        for (int j = 1; j < 4; ++j) a = (a < cm[j][t]) ? cm[j][t] : a;
+        const float s32 = a * (1.f / 128.f);  // :633-634 scale = T(colmax * 2^-7), written once per column
+        if (kt0 == 0 && n0 + t < N && scales) {
+            if (scales_f32)
+                reinterpret_cast<float*>(scales)[n0 + t] = s32;
+            else
+                reinterpret_cast<f16*>(scales)[n0 + t] = (f16)s32;
+        }
+        col_s[t] = s32;
+        // outside this range (zero / subnormal / huge / NaN scale) the reciprocal is not trusted: NaN sends every element
+        // of the column down the exact path
+        col_r[t] = (s32 > 1e-30f && s32 < 1e30f) ? __builtin_amdgcn_rcpf(s32) : __builtin_nanf("");
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the scale stores too: from here on vmcnt counts tiles
+    __builtin_amdgcn_s_barrier();
+    const bool  live = n0 + (unsigned)wave * 16 < N;  // false: whole 16-column chunk beyond a ragged N (DMA and barriers only)
+    const int   g = lane >> 4, c = lane & 15;
+    const int   col = wave * 16 + c;
+    const float s = col_s[col], r = col_r[col];
+    // rows 16g .. 16g+15 start at block 16g / kRowsPerB; element (row, col) sits at row % kRowsPerB * kRowBytes + col * sizeof(T)
+    typedef __attribute__((address_space(3))) const T lds_cT;  // integer LDS addresses as in gemm_kernel.hpp::lds_read16
+    const int lbase = (int)(uint32_t)(uintptr_t)(qp_lds_void*)tiles + (16 * g / C::kRowsPerB) * C::kBlockLds + col * (int)sizeof(T);
+    uint8_t* dst = q_packed + ((size_t)((n0 >> 4) + wave) * KT + kt0) * (size_t)kTileBytes + (size_t)lane * 16;
+    for (int j = 0; j < nt; ++j) {
+        // in issue order this wave has outstanding: tile j, [the store of tile j-1], [tile j+1]
+        if (j + 1 < nt) {
+            if (live && j > 0)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer + 1) : "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();  // everyone's pieces of tile j have landed
+        T raw[16];
+        if (live) {
+            const int lt = lbase + (j & 1) * C::kTileLds;
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                raw[i] = *(lds_cT*)(uintptr_t)(uint32_t)(lt + (i / C::kRowsPerB) * C::kBlockLds + (i % C::kRowsPerB) * C::kRowBytes);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // everyone has read the slot: refill it
+        if (j + 2 < nt) issue(j + 2, j & 1);
+        if (!live) continue;
+        u32 d[4] = {0u, 0u, 0u, 0u};
+        unsigned long long gray = 0;    // fp32 input only: lanes where the fp32 ROUNDING of w / s may land on a tie
+        float              nanacc = r;  // NaN as soon as a w (or the column's reciprocal) is
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float wf = (float)raw[i];
+            const float b  = __builtin_fmaf(wf, r, 128.f);  // w / s + 128 to within 3.1e-5 (header)
+            const float f  = __builtin_floorf(b);           // one of the two candidates q + 128 = f, f + 1 -- an f that is off
+                                                            // by one next to an integer picks the same q below
+            const float m  = f - 127.5f;                    // the tie between them, as a quotient
+            const float z  = __builtin_fmaf(m, s, -wf);     // sign of m * s - w, exact (one rounding, never to zero)
+            // q + 128 = f + 1 when w / s > m, or = m and positive (C round(): ties away from zero): "z < 0, or z == 0 and
+            // w > 0".  On the bit patterns as signed integers that is ONE comparison, z <= (w < 0 ? -1 : 0): a negative float
+            // is a negative integer, +0 is 0 (an exact cancellation gives +0), a positive float is >= 1.  For fp16 input any
+            // negative bound >= -32768 does (only NaN patterns lie above it), so the sign-extended fp16 bits themselves serve.
+            int bound;
+            if constexpr (sizeof(T) == 2)
+                bound = (int)(short)__builtin_bit_cast(unsigned short, raw[i]);
+            else
+                bound = __builtin_bit_cast(int, wf) >> 31;
+            bound         = bound < 0 ? bound : 0;
+            const float q = f + ((__builtin_bit_cast(int, z) <= bound) ? 1.f : 0.f);
+            nanacc = __builtin_fmaf(b, 0.f, nanacc);
+            if constexpr (sizeof(T) == 4) {
+                // the reference rounds the QUOTIENT to fp32 first: it becomes the tie m itself when 0 < |w / s - m| <= half an
+                // ulp of m, i.e. |z| <= s * 2^(exponent(m) - 24) (fp16 inputs cannot get that close: two 11-bit significands
+                // put w / s at least 2^-19 |m| away from an m it does not equal).  Too rare to resolve inline.
+                const float hulp = __builtin_bit_cast(float, (__builtin_bit_cast(int, m) & 0x7f800000) - (24 << 23));
+                gray |= __builtin_amdgcn_ballot_w64(z != 0.f && __builtin_fabsf(z) <= s * hulp);
+            }
+            // output byte of row i inside its group of four: rows 1 <-> 2 swapped.  The conversion saturates: 256 -> 255 is the
+            // reference's min(127, .) for w = +max of the column.
+            constexpr int kByte[4] = {0, 2, 1, 3};
+            d[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(q, kByte[i & 3], d[i >> 2]);
+        }
+        if (nanacc != nanacc || ((gray >> lane) & 1)) {  // rare lanes: the reference's arithmetic verbatim
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const u32 b0 = (uint8_t)quantize_elt((float)raw[4 * q + 0], s);
+                const u32 b1 = (uint8_t)quantize_elt((float)raw[4 * q + 2], s);
+                const u32 b2 = (uint8_t)quantize_elt((float)raw[4 * q + 1], s);
+                const u32 b3 = (uint8_t)quantize_elt((float)raw[4 * q + 3], s);
+                d[q]         = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ 0x80808080u;
+            }
+        }
+        *reinterpret_cast<u32x4*>(dst + (size_t)j * kTileBytes) = u32x4{d[0], d[1], d[2], d[3]};
+    }
+}
+
 // ---- inverse: packed layout -> raw row-major ----------------------------------------------------------------
 template <int LAYOUT>
 __global__ __launch_bounds__(256) void tile_unpack_kernel(const uint8_t* __restrict__ q_packed, size_t K, size_t N,
@@ -368,10 +583,10 @@ int launch_colmax(const void* w, int w_dtype, size_t K, size_t N, float* colmax,
     // strips of 64 lanes x V columns, kRowsPerBlock rows per workgroup: (N / 512) x (K / 128) workgroups at fp16 (256 at 4096^2)
     const unsigned yb = (unsigned)((K + kRowsPerBlock - 1) / kRowsPerBlock);
     if (w_dtype == EETQ_DTYPE_F16)
-        colmax_kernel<f16, 8, false><<<dim3((unsigned)((N + 511) / 512), yb), 256, 0, stream>>>(static_cast<const f16*>(w), K, N,
+        colmax_kernel<f16, 8, false><<<dim3((unsigned)((N + 511) / 512), yb), 64 * kColmaxWaves, 0, stream>>>(static_cast<const f16*>(w), K, N,
                                                                                       reinterpret_cast<u32*>(colmax));
     else
-        colmax_kernel<float, 4, false><<<dim3((unsigned)((N + 255) / 256), yb), 256, 0, stream>>>(static_cast<const float*>(w), K, N,
+        colmax_kernel<float, 4, false><<<dim3((unsigned)((N + 255) / 256), yb), 64 * kColmaxWaves, 0, stream>>>(static_cast<const float*>(w), K, N,
                                                                                         reinterpret_cast<u32*>(colmax));
     return check_hip(hipGetLastError(), "colmax_kernel launch");
 }
@@ -385,7 +600,7 @@ int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_
                           int scales_f32, float* part, hipStream_t stream)
 {
     const unsigned P = (unsigned)((K + kRowsPerBlock - 1) / kRowsPerBlock);
-    colmax_kernel<T, V, true><<<dim3((unsigned)((N + 64 * V - 1) / (64 * V)), P), 256, 0, stream>>>(
+    colmax_kernel<T, V, true><<<dim3((unsigned)((N + 64 * V - 1) / (64 * V)), P), 64 * kColmaxWaves, 0, stream>>>(
         w, K, N, reinterpret_cast<u32*>(part));
     int st = check_hip(hipGetLastError(), "colmax_kernel launch");
     if (st != EETQ_OK) return st;
@@ -417,6 +632,33 @@ int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_
         const char* e = getenv("EETQ_AMD_QUANT_NT");
         return e && *e == '1';
     }();
+    // native layout, no row-major copy asked for: the column-major kernel (EETQ_AMD_QUANT_KERNEL=strip keeps the older one
+    // for A/B runs); it indexes with 32-bit row offsets
+    static const bool old_kernel = [] {
+        const char* e = getenv("EETQ_AMD_QUANT_KERNEL");
+        return e && e[0] == 's';
+    }();
+    const bool colmajor = p && !sm80 && !raw_out && !old_kernel && layout == EETQ_LAYOUT_GFX950 && rows * N < 0xffffffffull &&
+                          (size_t)2 * kQT * N * sizeof(T) < 0x7fffffffull && K < 0x7fffffffull && N < 0x7fffffffull;
+    if (colmajor) {
+        // tiles per workgroup: about 512 workgroups (2 per CU: the per-workgroup reduction of the maxima is paid fewer times,
+        // measured 20.1 vs 20.9 us at 4096^2 against 2048 workgroups of 2 tiles), never fewer than two tiles each (one tile =
+        // no overlap of loads and arithmetic), at most 16; EETQ_AMD_QUANT_TILES overrides (tuning hook)
+        static const int forced_tiles = [] {
+            const char* e = getenv("EETQ_AMD_QUANT_TILES");
+            const int   v = e ? atoi(e) : 0;
+            return v >= 1 && v <= 64 ? v : 0;
+        }();
+        const size_t strips = (N + kQT - 1) / kQT, KT = K / kQT;
+        size_t       tpw    = (strips * KT + 511) / 512;
+        tpw                 = tpw < 2 ? 2 : (tpw > 16 ? 16 : tpw);
+        if (forced_tiles) tpw = (size_t)forced_tiles;
+        if (tpw > KT) tpw = KT;
+        while (tpw > 1 && (tpw + 1) * kQT * N * sizeof(T) >= 0x7fffffffull) --tpw;  // 32-bit offsets inside a workgroup's rows
+        const dim3 grid((unsigned)strips, (unsigned)((KT + tpw - 1) / tpw));
+        quant_pack_kernel<T><<<grid, 256, 2 * QpCfg<T>::kTileLds, stream>>>(w, (unsigned)K, (unsigned)N, part, (int)rows, p, scales, scales_f32, (int)tpw);
+        return check_hip(hipGetLastError(), "quant_pack_kernel launch");
+    }
     auto launch = [&](auto tiles) {
         constexpr int TT = decltype(tiles)::value;
         const dim3    grid((unsigned)((N + kQT - 1) / kQT), (unsigned)((K / kQT + TT - 1) / TT));

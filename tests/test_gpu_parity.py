@@ -99,6 +99,55 @@ def test_quantize_row_block_partials_edge_values(ops, oracle, dtype):
         assert scales.cpu().numpy().tobytes() == s.tobytes(), layout
         ref = oracle.gfx950_pack(q) if layout == "gfx950" else oracle.sm80_pack(q)
         assert np.array_equal(processed.cpu().numpy(), ref), layout
+        only, scales2 = ops.quant_weights(torch.from_numpy(w).to(DEV), torch.int8, False, layout=layout)  # no row-major copy
+        assert np.array_equal(only.cpu().numpy(), ref), layout
+        assert scales2.cpu().numpy().tobytes() == s.tobytes(), layout
+
+
+def _near_tie_matrix(dtype, K, N, seed):
+    """Every element sits on, or a few ulps beside, a rounding tie of w / scale: the inputs on which a reciprocal-based
+    quotient and the reference's IEEE division (cutlass_preprocessors.cc:644-648) could round differently."""
+    rng = np.random.default_rng(seed)
+    if dtype == np.float32:
+        amax = (10.0 ** rng.uniform(-3, 1, N)).astype(np.float32)
+        amax[1], amax[2], amax[3] = 1e-36, 3e35, 1e-41          # scale below / above the trusted range, subnormal scale
+    else:
+        amax = (2.0 ** rng.integers(-10, 4, N) * rng.choice([1.0, 1.5, 1.25], N)).astype(np.float16)
+        amax[1], amax[2] = 2.0 ** -20, 6e-8                       # subnormal fp16 columns
+    scale = amax.astype(np.float32) * np.float32(1.0 / 128.0)
+    k = rng.integers(-128, 128, (K, N)).astype(np.float32) + np.float32(0.5)
+    if dtype == np.float32:  # odd columns: just OUTSIDE the band that falls back to the division (3e-5 .. 3e-4 from a tie)
+        off = (rng.choice([-1.0, 1.0], (K, N)) * 10.0 ** rng.uniform(-4.5, -3.5, (K, N))).astype(np.float32)
+        k[:, 1::2] += off[:, 1::2]
+    w = (k * scale[None, :]).astype(dtype)
+    for _ in range(3):                                            # -3 .. +3 ulps of the input type
+        step = rng.integers(-1, 2, (K, N))
+        w = np.where(step > 0, np.nextafter(w, dtype(np.inf)), np.where(step < 0, np.nextafter(w, dtype(-np.inf)), w)).astype(dtype)
+    w = np.clip(w, -amax[None, :], amax[None, :]).astype(dtype)
+    w[rng.integers(0, K, N), np.arange(N)] = amax * rng.choice([-1, 1], N).astype(dtype)  # the maximum is attained
+    return w
+
+
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+@pytest.mark.parametrize("K,N", [(256, 128), (320, 80), (9216, 64)])
+def test_quantize_near_ties_native_layout_only(ops, oracle, dtype, K, N):
+    """quant_weights(..., return_unprocessed=False) in the native layout runs the column-major kernel whose quotient is
+    fma(w, rcp(s), 128) with an exact fallback near ties: bit-identical to the oracle on a matrix made of ties and their
+    neighbours, on special values, on a ragged last strip and on the 4-tile strip (K > 8192)."""
+    w = _near_tie_matrix(dtype, K, N, K + N)
+    w[5, 9] = np.nan
+    w[:, 6] = 0
+    if N > 64:
+        w[17, 70] = np.inf
+    processed, scales = ops.quant_weights(torch.from_numpy(w).to(DEV), torch.int8, False)
+    q, s = oracle.quantize(w)
+    assert scales.cpu().numpy().tobytes() == s.tobytes()
+    got = processed.cpu().numpy()
+    ref = oracle.gfx950_pack(q)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} bytes differ"
+    raw, processed2, _ = ops.quant_weights(torch.from_numpy(w).to(DEV), torch.int8, True)  # the row-major kernel agrees
+    assert np.array_equal(raw.cpu().numpy(), q)
+    assert np.array_equal(processed2.cpu().numpy(), ref)
 
 
 def test_quantize_default_init_4096(ops, oracle):
