@@ -7,8 +7,8 @@
 // quant_weights is two launches: per-row-block column maxima (plain stores: no atomics, no zero fill), then one kernel that
 // reduces those rows for its columns, quantises and writes the target layout.  For the native layout without a row-major
 // copy that kernel is quant_pack_kernel (LDS-DMA ring, column-major in registers, division-free but bit-exact); the sm80
-// wire layout and the calls that also return the row-major int8 tensor use strip_quant_kernel (row-wise reads, byte
-// transpose through LDS, IEEE division).
+// wire layout and the calls that also return the row-major int8 tensor use strip_quant_kernel (row-wise reads, the same
+// arithmetic, byte transpose through LDS).
 #include <cstdlib>
 #include <type_traits>
 
@@ -112,6 +112,49 @@ __device__ __forceinline__ int8_t quantize_elt(float w, float s)
     return (int8_t)(int)lo;
 }
 
+// ---- the same result without a division ------------------------------------------------------------------------
+// Returns q + 128 as an integer-valued float in [0, 256] (256 = the reference's min(127, .) case, saturated by the
+// conversion to a byte).  r = rcp(s), trusted only for 1e-30 < s < 1e30 (the caller passes NaN otherwise).
+// b = fma(w, r, 128) is w / s + 128 to within 3.1e-5 (t = w / s, |t| <= 128: the 1-ulp reciprocal moves w * r by <= 1.53e-5,
+// the fma's rounding below 256 by <= 0.77e-5, and the reference's correctly rounded quotient is within 0.77e-5 of t), which
+// names the two integers the result can be, f = floor(b) and f + 1 -- an f that is off by one next to an integer picks the
+// same q.  Which one: the SIGN of m * s - w, m = f - 127.5 the tie between them as a quotient, one fma, exact in sign (one
+// rounding, never to zero); zero is an exact tie, which C round() sends away from zero.  "z < 0, or z == 0 and w > 0" is ONE
+// comparison of the bit patterns as signed integers, z <= (w < 0 ? -1 : 0): a negative float is a negative integer, +0 is 0
+// (an exact cancellation gives +0), a positive float is >= 1; for fp16 input any negative bound >= -32768 does (only NaN
+// patterns lie above it), so the sign-extended fp16 bits themselves serve.
+// The caller must redo the element with quantize_elt when `nanacc` comes out NaN (a NaN weight or reciprocal) or -- fp32
+// input only -- its lane is set in `gray`: the reference rounds the QUOTIENT to fp32 first, and it becomes the tie m itself
+// when 0 < |w / s - m| <= half an ulp of m, i.e. |z| <= s * 2^(exponent(m) - 24); fp16 inputs cannot get that close (two
+// 11-bit significands put w / s at least 2^-19 |m| away from an m it does not equal).
+template <typename T>
+__device__ __forceinline__ float quantize_biased_nodiv(T raw, float s, float r, float& nanacc, unsigned long long& gray)
+{
+    const float wf = (float)raw;
+    const float b  = __builtin_fmaf(wf, r, 128.f);
+    const float f  = __builtin_floorf(b);
+    const float m  = f - 127.5f;
+    const float z  = __builtin_fmaf(m, s, -wf);
+    int         bound;
+    if constexpr (sizeof(T) == 2)
+        bound = (int)(short)__builtin_bit_cast(unsigned short, raw);
+    else
+        bound = __builtin_bit_cast(int, wf) >> 31;
+    bound  = bound < 0 ? bound : 0;
+    nanacc = __builtin_fmaf(b, 0.f, nanacc);
+    if constexpr (sizeof(T) == 4) {
+        const float hulp = __builtin_bit_cast(float, (__builtin_bit_cast(int, m) & 0x7f800000) - (24 << 23));
+        gray |= __builtin_amdgcn_ballot_w64(z != 0.f && __builtin_fabsf(z) <= s * hulp);
+    }
+    return f + ((__builtin_bit_cast(int, z) <= bound) ? 1.f : 0.f);
+}
+
+// the reciprocal the function above may use for scale s, or NaN (-> every element of the column takes the exact path)
+__device__ __forceinline__ float trusted_rcp(float s)
+{
+    return (s > 1e-30f && s < 1e30f) ? __builtin_amdgcn_rcpf(s) : __builtin_nanf("");
+}
+
 // ---- re-layout of a raw int8 tensor: one 64x64 tile per workgroup -----------------------------------------------------
 // grid = (ceil(N/64), K/64), block = 256.  Thread t loads row r = t/4, columns seg*16..+15 (seg = t%4).
 template <int LAYOUT>
@@ -194,7 +237,7 @@ __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ 
 {
     __shared__ __attribute__((aligned(16))) uint8_t tile[kStripTiles][kQT][kQPitch];
     __shared__ float cm[4][kQT];
-    __shared__ __attribute__((aligned(16))) float cmx[kQT];
+    __shared__ __attribute__((aligned(16))) float cmx[kQT], crx[kQT];
     constexpr int kVecs = (int)(sizeof(T) * 16 / 16);  // 16-byte loads per 16 elements
     const int    t   = threadIdx.x;
     const size_t n0  = (size_t)blockIdx.x * kQT;
@@ -237,6 +280,7 @@ __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ 
 #pragma unroll
         for (int j = 1; j < 4; ++j) a = (a < cm[j][t]) ? cm[j][t] : a;
         cmx[t] = a;
+        crx[t] = trusted_rcp(a * (1.f / 128.f));
         if (kt0 == 0 && n0 + t < N && scales) {  // :633-634 scale = T(colmax * 2^-7), written once per column
             const float s32 = a * (1.f / 128.f);
             if (scales_f32)
@@ -246,9 +290,12 @@ __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ 
         }
     }
     __syncthreads();
-    float s[16];
+    float s[16], rc[16];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) reinterpret_cast<f32x4*>(s)[i] = reinterpret_cast<const f32x4*>(cmx + seg * 16)[i];
+    for (int i = 0; i < 4; ++i) {
+        reinterpret_cast<f32x4*>(s)[i]  = reinterpret_cast<const f32x4*>(cmx + seg * 16)[i];
+        reinterpret_cast<f32x4*>(rc)[i] = reinterpret_cast<const f32x4*>(crx + seg * 16)[i];
+    }
 #pragma unroll
     for (int i = 0; i < 16; ++i) s[i] *= (1.f / 128.f);
 #pragma unroll
@@ -261,8 +308,20 @@ __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ 
             T v[16];
 #pragma unroll
             for (int i = 0; i < kVecs; ++i) reinterpret_cast<u32x4*>(v)[i] = raw[j][i];
+            // division-free, bit-exact (quantize_biased_nodiv); the rare lanes it cannot decide redo their 16 elements
+            u32                d[4]   = {0u, 0u, 0u, 0u};
+            unsigned long long gray   = 0;
+            float              nanacc = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) out.b[i] = quantize_elt((float)v[i], s[i]);
+            for (int i = 0; i < 16; ++i) {
+                nanacc = __builtin_fmaf(rc[i], 0.f, nanacc);
+                d[i >> 2] = __builtin_amdgcn_cvt_pk_u8_f32(quantize_biased_nodiv<T>(v[i], s[i], rc[i], nanacc, gray), i & 3, d[i >> 2]);
+            }
+            out.v = u32x4{d[0] ^ 0x80808080u, d[1] ^ 0x80808080u, d[2] ^ 0x80808080u, d[3] ^ 0x80808080u};  // q + 128 -> int8
+            if (nanacc != nanacc || ((gray >> (t & 63)) & 1)) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) out.b[i] = quantize_elt((float)v[i], s[i]);
+            }
             *reinterpret_cast<u32x4*>(&tile[j][r][seg * 16]) = out.v;
             if (q_raw) *reinterpret_cast<u32x4*>(q_raw + ((kt0 + j) * kQT + r) * N + nc) = out.v;
         }
@@ -315,14 +374,10 @@ __global__ __launch_bounds__(256) void strip_quant_kernel(const T* __restrict__ 
 //     so that the column-wise reads below are bank-conflict free;
 //   * every lane reads the 16 elements of its column as T and quantises them straight into the output byte positions
 //     (v_cvt_pk_u8_f32 of q + 128 does the [-128, 127] clamp, the +128 bias and the byte packing in one instruction);
-//   * no IEEE division: b = fma(w, rcp(s), 128) is w / s + 128 to within 3.1e-5 (t = w / s, |t| <= 128: the 1-ulp
-//     reciprocal moves w * r by <= 1.53e-5, the fma's rounding below 256 by <= 0.77e-5, and the reference's correctly
-//     rounded quotient is within 0.77e-5 of t), which is enough to name the two integers the result can be, f = floor(b)
-//     and f + 1; which one it is follows from the SIGN of m * s - w with m = f - 127.5 the tie between them -- one more
-//     fma, exact in sign -- and a zero there is an exact tie, which C round() resolves away from zero.  Exact ties are
-//     not rare on fp16 grids (1.6 % of the elements of a uniform fp16 matrix, 7.9 % of nn.Linear's default init), so they
-//     are resolved inline; lanes with a NaN weight, a zero / subnormal / huge / NaN scale or (fp32 input) a quotient whose
-//     fp32 rounding could land on a tie redo their 16 elements with quantize_elt (the reference's arithmetic verbatim).
+//   * no IEEE division (quantize_biased_nodiv above).  Exact ties are not rare on fp16 grids (1.6 % of the elements of a
+//     uniform fp16 matrix, 7.9 % of nn.Linear's default init), so they are resolved inline; lanes with a NaN weight, a
+//     zero / subnormal / huge / NaN scale or (fp32 input) a quotient whose fp32 rounding could land on a tie redo their 16
+//     elements with quantize_elt (the reference's arithmetic verbatim).
 // grid = (ceil(N/64), ceil(K/64/tiles_per_wg)), block = 256: wave = 16-column chunk, lane = (g, c).
 typedef __attribute__((address_space(3))) void qp_lds_void;
 // 64 lanes x 16 bytes, global (buffer descriptor + per-lane offset) -> LDS at lds_wave_base + lane * 16, no registers
@@ -418,9 +473,7 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
                 reinterpret_cast<f16*>(scales)[n0 + t] = (f16)s32;
         }
         col_s[t] = s32;
-        // outside this range (zero / subnormal / huge / NaN scale) the reciprocal is not trusted: NaN sends every element
-        // of the column down the exact path
-        col_r[t] = (s32 > 1e-30f && s32 < 1e30f) ? __builtin_amdgcn_rcpf(s32) : __builtin_nanf("");
+        col_r[t] = trusted_rcp(s32);
     }
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // the scale stores too: from here on vmcnt counts tiles
     __builtin_amdgcn_s_barrier();
@@ -459,31 +512,7 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
         float              nanacc = r;  // NaN as soon as a w (or the column's reciprocal) is
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
-            const float wf = (float)raw[i];
-            const float b  = __builtin_fmaf(wf, r, 128.f);  // w / s + 128 to within 3.1e-5 (header)
-            const float f  = __builtin_floorf(b);           // one of the two candidates q + 128 = f, f + 1 -- an f that is off
-                                                            // by one next to an integer picks the same q below
-            const float m  = f - 127.5f;                    // the tie between them, as a quotient
-            const float z  = __builtin_fmaf(m, s, -wf);     // sign of m * s - w, exact (one rounding, never to zero)
-            // q + 128 = f + 1 when w / s > m, or = m and positive (C round(): ties away from zero): "z < 0, or z == 0 and
-            // w > 0".  On the bit patterns as signed integers that is ONE comparison, z <= (w < 0 ? -1 : 0): a negative float
-            // is a negative integer, +0 is 0 (an exact cancellation gives +0), a positive float is >= 1.  For fp16 input any
-            // negative bound >= -32768 does (only NaN patterns lie above it), so the sign-extended fp16 bits themselves serve.
-            int bound;
-            if constexpr (sizeof(T) == 2)
-                bound = (int)(short)__builtin_bit_cast(unsigned short, raw[i]);
-            else
-                bound = __builtin_bit_cast(int, wf) >> 31;
-            bound         = bound < 0 ? bound : 0;
-            const float q = f + ((__builtin_bit_cast(int, z) <= bound) ? 1.f : 0.f);
-            nanacc = __builtin_fmaf(b, 0.f, nanacc);
-            if constexpr (sizeof(T) == 4) {
-                // the reference rounds the QUOTIENT to fp32 first: it becomes the tie m itself when 0 < |w / s - m| <= half an
-                // ulp of m, i.e. |z| <= s * 2^(exponent(m) - 24) (fp16 inputs cannot get that close: two 11-bit significands
-                // put w / s at least 2^-19 |m| away from an m it does not equal).  Too rare to resolve inline.
-                const float hulp = __builtin_bit_cast(float, (__builtin_bit_cast(int, m) & 0x7f800000) - (24 << 23));
-                gray |= __builtin_amdgcn_ballot_w64(z != 0.f && __builtin_fabsf(z) <= s * hulp);
-            }
+            const float q = quantize_biased_nodiv<T>(raw[i], s, r, nanacc, gray);
             // output byte of row i inside its group of four: rows 1 <-> 2 swapped.  The conversion saturates: 256 -> 255 is the
             // reference's min(127, .) for w = +max of the column.
             constexpr int kByte[4] = {0, 2, 1, 3};
