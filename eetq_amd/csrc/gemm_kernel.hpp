@@ -28,10 +28,14 @@ constexpr int STAGES        = 6;
 constexpr int kMinKSteps    = STAGES - 1;   // the statically unrolled drain needs K/64 >= 5
 // J = 32-column blocks per wave: J = 2 -> 128 x 128 tile (the MFMA-bound shape), J = 1 -> 128 x 64 tile (twice the
 // workgroups: fills the chip at 129 <= M <= 512 and trims the last partial round of tiles on other shapes)
-template <int J>
+// CW = waves across the tile's columns (each owns 32*J of them); 2*CW waves per workgroup.  CW = 2: the round-1 geometry,
+// one wave per SIMD.  (J, CW) = (1, 4): the 128 x 128 tile on EIGHT waves, two per SIMD -- half the accumulators and half the
+// DMA pieces per wave, and a second wave on every SIMD to issue MFMAs while the first sits in an LDS-DMA issue or a barrier.
+template <int J, int CW = 2>
 struct TileCfg {
-    static constexpr int BN            = 64 * J;
-    static constexpr int B_STAGE_BYTES = BN * BK;  // 4*J native 1 KiB tiles per K step
+    static constexpr int BN            = 32 * J * CW;
+    static constexpr int WAVES         = 2 * CW;
+    static constexpr int B_STAGE_BYTES = BN * BK;  // BN/16 native 1 KiB tiles per K step
     static constexpr int STAGE_BYTES   = A_STAGE_BYTES + B_STAGE_BYTES;
     static constexpr int SMEM_BYTES    = STAGES * STAGE_BYTES;  // 144 / 120 KiB (also covers the end-of-kernel reduction)
 };
@@ -87,23 +91,25 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // kernel grew from 4.4 k to 21 k instructions (exp / tanh expanded for 128 accumulators) and the SAME main loop ran 11 %
 // slower (M = 1024, N = K = 4096: 40.8 vs 36.7 us, tools/kbench gemm, same box) -- instruction fetch, not registers (both
 // builds use 410).  The identity instantiation keeps the round-1 epilogue.
-template <int ABLATE, int J, bool ACT = false>
-__global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
+template <int ABLATE, int J, bool ACT = false, int CW = 2>
+__global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
 {
     // N = columns of THIS launch (w, scales, y, ep.* already point at its first column); ldc = row stride of y / residual
     EETQ_GEMM_STAMP(0);
-    using Cfg = TileCfg<J>;
-    constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES;
-    constexpr int WN_COLS = 32 * J, PIECES = 4 + J, NMFMA = 8 * J;
+    using Cfg = TileCfg<J, CW>;
+    constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES, NW = Cfg::WAVES;
+    constexpr int APW = 16 / NW;  // activation DMA pieces (8 rows each) per wave and stage: 4 or 2
+    constexpr int WN_COLS = 32 * J, PIECES = APW + J, NMFMA = 8 * J;
     static_assert(J == 1 || J == 2, "slot tables exist for J = 1 and J = 2");
+    static_assert(CW == 2 || (CW == 4 && J == 1), "geometries with slot tables: 4 waves (J = 1, 2) and 8 waves (J = 1)");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int grp  = wave >> 1;  // which 32-deep half of each K step
-    const int wn   = wave & 1;   // which column half (32*J columns) of the tile
+    const int grp  = wave / CW;  // which 32-deep half of each K step
+    const int wn   = wave % CW;  // which 32*J-column part of the tile
     const int KT   = K >> 6;
 
     const int tiles_m = (M + BM - 1) / BM;
@@ -132,13 +138,13 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
         reinterpret_cast<uint8_t*>(const_cast<f16*>(x)) - kShift, 0, (int)((size_t)M * K * 2) + kShift, 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t*>(w) - kShift, 0, (int)((size_t)N * K) + kShift, 0x00020000);
-    // DMA pieces of this wave: i < 4: activation piece 4*wave + i (rows 8p..8p+7, 128 B each); i >= 4: weight tile
-    // J*wave + i - 4 of the stage's 4*J
+    // DMA pieces of this wave: i < APW: activation piece APW*wave + i (rows 8p..8p+7, 128 B each); i >= APW: weight tile
+    // J*wave + i - APW of the stage's BN/16
     int       dma_voff[PIECES];
     const int n_tiles_total = N >> 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int p    = wave * 4 + i;
+    for (int i = 0; i < APW; ++i) {
+        const int p    = wave * APW + i;
         const int row  = p * 8 + (lane >> 3);
         const int slot = (lane & 7) ^ ((row >> 1) & 7);
         int       gm   = m0 + row;
@@ -146,13 +152,13 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
         dma_voff[i]    = (gm * K + slot * 8) * 2 + kShift - i * 1024;
     }
 #pragma unroll
-    for (int i = 4; i < PIECES; ++i) {
-        int nt      = (n0 >> 4) + wave * J + (i - 4);
+    for (int i = APW; i < PIECES; ++i) {
+        int nt      = (n0 >> 4) + wave * J + (i - APW);
         nt          = nt < n_tiles_total ? nt : n_tiles_total - 1;
-        dma_voff[i] = nt * KT * kTileBytes + lane * 16 + kShift - (i - 4) * 1024;
+        dma_voff[i] = nt * KT * kTileBytes + lane * 16 + kShift - (i - APW) * 1024;
     }
-    const int dma_lds_a = wave * 4 * 1024;                    // + i * 1024
-    const int dma_lds_b = A_STAGE_BYTES + wave * J * 1024;    // + (i - 4) * 1024
+    const int dma_lds_a = wave * APW * 1024;                  // + i * 1024
+    const int dma_lds_b = A_STAGE_BYTES + wave * J * 1024;    // + (i - APW) * 1024
 
     const int fn = lane & 31, fh = lane >> 5;
     const int a_key = (fn >> 1) & 7;
@@ -194,10 +200,10 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
 
     auto dma_piece = [&](auto itag) {
         constexpr int i = decltype(itag)::value;
-        if constexpr (i < 4)
+        if constexpr (i < APW)
             dma16_imm<i * 1024>(x_rsrc, dma_voff[i], ka, smem + wr + dma_lds_a);
         else
-            dma16_imm<(i - 4) * 1024>(w_rsrc, dma_voff[i], kb, smem + wr + dma_lds_b);
+            dma16_imm<(i - APW) * 1024>(w_rsrc, dma_voff[i], kb, smem + wr + dma_lds_b);
     };
 
     auto step = [&](const WFrag& wcur, const Frags& fcur, auto read_tag, Frags& fnext, WFrag& wnext, auto dma_tag) {
@@ -270,12 +276,16 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
                     if (i == 5) dma_piece(std::integral_constant<int, 3>{});
                     if (i == 8) dma_piece(std::integral_constant<int, 4>{});
                     if (i == 11) dma_piece(std::integral_constant<int, 5>{});
-                } else {
+                } else if constexpr (CW == 2) {
                     if (i == 0) dma_piece(std::integral_constant<int, 0>{});
                     if (i == 1) dma_piece(std::integral_constant<int, 1>{});
                     if (i == 2) dma_piece(std::integral_constant<int, 2>{});
                     if (i == 3) dma_piece(std::integral_constant<int, 3>{});
                     if (i == 5) dma_piece(std::integral_constant<int, 4>{});
+                } else {  // eight waves: two activation pieces and one weight tile per wave
+                    if (i == 0) dma_piece(std::integral_constant<int, 0>{});
+                    if (i == 2) dma_piece(std::integral_constant<int, 1>{});
+                    if (i == 5) dma_piece(std::integral_constant<int, 2>{});
                 }
             }
             if constexpr (READ) {
@@ -324,10 +334,10 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
         for (int s = 0; s < STAGES - 1; ++s) {  // KT >= STAGES - 1 by launch contract
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {  // plain form: voff carries -IMM, so the LDS address gets it back here
-                if (i < 4)
+                if (i < APW)
                     dma16(x_rsrc, dma_voff[i] + i * 1024, pka, smem + pwr + dma_lds_a + i * 1024);
                 else
-                    dma16(w_rsrc, dma_voff[i] + (i - 4) * 1024, pkb, smem + pwr + dma_lds_b + (i - 4) * 1024);
+                    dma16(w_rsrc, dma_voff[i] + (i - APW) * 1024, pkb, smem + pwr + dma_lds_b + (i - APW) * 1024);
             }
             pwr += STAGE_BYTES;
             pka += BK * 2;
@@ -413,8 +423,8 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     __syncthreads();
     EETQ_GEMM_STAMP(4);
     constexpr int kRowHalfs = BN + 8;                       // row stride of the image: 272 / 144 bytes (bank shift per row)
-    f16* image = reinterpret_cast<f16*>(smem + 2 * (16 * J) * 64 * 16);  // behind both column halves' parked accumulators
-    static_assert(2 * (16 * J) * 64 * 16 + BM * kRowHalfs * 2 <= SMEM_BYTES, "the output image must fit behind the parked halves");
+    f16* image = reinterpret_cast<f16*>(smem + CW * (16 * J) * 64 * 16);  // behind every column part's parked accumulators
+    static_assert(CW * (16 * J) * 64 * 16 + BM * kRowHalfs * 2 <= SMEM_BYTES, "the output image must fit behind the parked halves");
     if (grp == 0) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void gemm_tile_kernel(
     }
     __syncthreads();
     {
-        constexpr int kLanesPerRow = BN / 8, kRowsPerWave = 64 / kLanesPerRow, kRowsPerRound = 4 * kRowsPerWave;
+        constexpr int kLanesPerRow = BN / 8, kRowsPerWave = 64 / kLanesPerRow, kRowsPerRound = NW * kRowsPerWave;
         const int     c            = (lane % kLanesPerRow) * 8;
 #pragma unroll
         for (int r0 = 0; r0 < BM; r0 += kRowsPerRound) {

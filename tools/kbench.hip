@@ -200,19 +200,19 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
            name, N, K, M, st.mean, st.med, st.mn, st.p90, bytes / st.med / 1e3, g, bytes / g / 1e3);
 }
 
-template <int ABLATE, int J = 2>
+template <int ABLATE, int J = 2, int CW = 2>
 static void bench_gemm(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
                         const eetq::f16* scales, eetq::f16* y)
 {
     using namespace eetq::gemm;
-    auto kern = gemm_tile_kernel<ABLATE, J>;
-    constexpr int SMEM_BYTES = TileCfg<J>::SMEM_BYTES, BN = TileCfg<J>::BN;
+    auto kern = gemm_tile_kernel<ABLATE, J, false, CW>;
+    constexpr int SMEM_BYTES = TileCfg<J, CW>::SMEM_BYTES, BN = TileCfg<J, CW>::BN;
     CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
     const int    tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     const double flops = 2.0 * M * N * K;
     auto         st    = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
-            hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(256), SMEM_BYTES, 0, a, b, 0, x,
+            hipExtLaunchKernelGGL(kern, dim3(tiles), dim3(128 * CW), SMEM_BYTES, 0, a, b, 0, x,
                                   (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, N, eetq::Epilogue{});
         },
         60, 10);
@@ -803,6 +803,29 @@ int main(int argc, char** argv)
                16801792.0 / ss.mean / 1e3 / 8000, 16777216.0 / sr.mean / 1e3, sg.mean / sr.mean);
     }
 #endif
+    if (!strcmp(what, "gemm8")) {  // the 128 x 128 tile on 4 waves (J = 2, one per SIMD) vs 8 waves (J = 1, two per SIMD)
+        eetq::f16 *xg, *yg;
+        CK(hipMalloc(&xg, 8192ull * 4096 * 2));
+        CK(hipMalloc(&yg, 8192ull * 11008 * 2));
+        {
+            std::vector<uint16_t> h(8192ull * 4096);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));
+            CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        for (int rep = 0; rep < 3; ++rep) {
+            bench_gemm<0, 2, 2>("gemm 4 waves", 1024, 4096, 4096, bufs, xg, scales, yg);
+            bench_gemm<0, 1, 4>("gemm 8 waves", 1024, 4096, 4096, bufs, xg, scales, yg);
+        }
+        bench_gemm<0, 2, 2>("gemm 4 waves", 4096, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<0, 1, 4>("gemm 8 waves", 4096, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<0, 2, 2>("gemm 4 waves", 1024, 11008, 4096, bufs_big, xg, scales, yg);
+        bench_gemm<0, 1, 4>("gemm 8 waves", 1024, 11008, 4096, bufs_big, xg, scales, yg);
+        bench_gemm<0, 2, 2>("gemm 4 waves", 512, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<0, 1, 4>("gemm 8 waves", 512, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<8, 1, 4>("gemm 8 waves -mfma", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<1, 1, 4>("gemm 8 waves -dma", 1024, 4096, 4096, bufs, xg, scales, yg);
+        bench_gemm<23, 1, 4>("gemm 8 waves mfma only", 1024, 4096, 4096, bufs, xg, scales, yg);
+    }
     if (!strcmp(what, "gemm1")) {  // single configuration for PMC runs
         eetq::f16 *xg, *yg;
         CK(hipMalloc(&xg, 1024ull * 4096 * 2));
