@@ -139,29 +139,13 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
             else if (S == 4) tickets += kRegionTickets;
         }
     }
-    // ONE workgroup per CU whenever slices hand partial tiles over (S > 1).  Found in round 3 (tools/deepk_check.py): with two
-    // of these workgroups resident on a CU (rings of <= 80 KiB, more workgroups than CUs) a split launch returns a few wrong
-    // elements per call -- one accumulator register of lanes 12..15 mod 16 in a handful of tiles, different ones every call,
-    // off by about one slice's partial sum -- while the very same binary is exact with one workgroup per CU (1058 forced
-    // plans, 0 wrong) and unsplit launches (S = 1) are exact at two per CU, also with more workgroups than the chip holds.
-    // What was tried at two per CU (tools/deepk_check.py, 644 plans, 36-39 wrong as shipped in round 2): an agent acquire
-    // fence before the slab read-back 36 wrong; sc0 sc1 slab loads 39; the read-back as four dword loads 38; a ~10 us sleep
-    // before the read-back 38 (so it is not late visibility: the slab in memory IS wrong); the LDS reduction area read twice
-    // with a sleep between: identical (LDS is not being overwritten after the first read); __threadfence() before the ticket
-    // 4 wrong; with the acquire and sc0 sc1 as well, 4 -- fewer, not none.  The plans AUTO picked never combined S > 1 with two per CU at the tested
-    // shapes, but nothing guaranteed it.  Until the mechanism is understood a split launch asks for more than half of the
-    // CU's LDS, which keeps a second workgroup off the CU.  EETQ_AMD_SPLITK_TWO_PER_CU=1 re-allows it (to reproduce).
-    size_t lds = C::kSmem;
-    static const bool two_per_cu = [] {
-        const char* e = getenv("EETQ_AMD_SPLITK_TWO_PER_CU");
-        return e && *e == '1';
-    }();
-    if (S > 1 && lds <= 80 * 1024 && !two_per_cu) {
-        lds = 84 * 1024;
-        static std::atomic<unsigned long long> opted2{0};
-        int st = opt_in_large_lds(kern, opted2);
-        if (st != EETQ_OK) return st;
-    }
+    // Occupancy of split launches.  Round 2 shipped two workgroups per CU for rings of <= 80 KiB and returned a few wrong
+    // elements per call whenever more workgroups than fit were launched that way; round 3 first kept a second workgroup off the
+    // CU (by asking for 84 KiB of LDS) and then found the cause: not the hand-over protocol but a write-after-read on the
+    // slab stores' data registers that hipcc does not guard (gemm_splitk_kernel.hpp, "The stores' DATA registers stay live").
+    // With that fixed both occupancies are exact (tools/deepk_check.py: 812 forced plans, 0 wrong either way;
+    // tools/experiments/sk_debug.py) and equally fast (tools/splitk_occupancy.py), so a split launch asks for what it uses.
+    const size_t lds = C::kSmem;
     launch_kernel(kern, dim3(tiles * S), dim3(C::kThreads), lds, stream, x, w, scales, y, M, N, K, S, slabs,
                   tickets, ep);
     return check_hip(hipGetLastError(), "gemm_splitk_kernel launch");
@@ -243,7 +227,7 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out)
             const int wgs = tiles * s;
             // ring depth 3 (120..144 KiB: one workgroup per CU) when that many workgroups fit anyway, else depth 2 (two per CU at MT <= 2)
             const int stages  = (MT <= 2 && wgs <= ncu) ? 3 : 2;
-            // two workgroups per CU only for unsplit plans (launch_full keeps split launches at one per CU)
+            // the model counts on two workgroups per CU only for unsplit plans (split ones time the same at one and two per CU)
             const int per_cu  = (s == 1 && stages == 2 && MT <= 2 && (16 * MT + 8 * nb) * 2 <= 80) ? 2 : 1;
             const int rounds  = (wgs + ncu * per_cu - 1) / (ncu * per_cu);
             const int my_steps = (steps + s - 1) / s;

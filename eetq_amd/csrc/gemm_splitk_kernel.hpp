@@ -346,16 +346,29 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
             slabs + (size_t)tile * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
         // float4 index inside a slab: ((mt*NB + nb)*4 + wave)*64 + lane
         const int lane_off = (wave * 64 + lane) * 16;
+        u32x4     pub[MT][NB];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const u32x4 v = {__builtin_bit_cast(u32, s4[mt][nb][0]), __builtin_bit_cast(u32, s4[mt][nb][1]),
-                                 __builtin_bit_cast(u32, s4[mt][nb][2]), __builtin_bit_cast(u32, s4[mt][nb][3])};
-                __builtin_amdgcn_raw_buffer_store_b128(v, s_rsrc, (mt * NB + nb) * 4096 + lane_off,
+                pub[mt][nb] = u32x4{__builtin_bit_cast(u32, s4[mt][nb][0]), __builtin_bit_cast(u32, s4[mt][nb][1]),
+                                    __builtin_bit_cast(u32, s4[mt][nb][2]), __builtin_bit_cast(u32, s4[mt][nb][3])};
+                __builtin_amdgcn_raw_buffer_store_b128(pub[mt][nb], s_rsrc, (mt * NB + nb) * 4096 + lane_off,
                                                        slice * C::kSlabFloats * 4, /*sc1*/ 16);
             }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores
+        // The stores' DATA registers stay live until the stores have completed.  hipcc does not guard a 16-byte buffer store
+        // whose soffset is an SGPR against the next instruction overwriting its data registers (GCNHazardRecognizer: "this
+        // hazard only exists if the instruction is not using a register in the soffset field") and reused the first data
+        // register of one store for the address of the next: `buffer_store_dwordx4 v[6:9], v10, ..., s6 offen sc1` /
+        // `v_add_u32 v6, 0x1000, v10`.  On gfx950 the store then sometimes published 0x1000 + lane * 16 instead of the partial
+        // sum in the lanes it reads last (12..15 of every 16) -- whenever the memory pipeline was slow to take the store, i.e.
+        // with two workgroups per CU and more workgroups than fit (found with tools/experiments/sk_debug.py: the published slab
+        // holds the integers 4288, 4304, 4320, 4336).  Nothing may write these registers before the vmcnt(0) above.
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(pub[mt][nb]));
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(smem + C::kSmem - 16);  // inside the one dynamic LDS array
         if (tid == 0)

@@ -315,6 +315,11 @@ def test_splitk_is_deterministic_and_back_to_back_safe(ops, oracle):
     (4160, 4112, 50, [(1, 4, 22), (2, 2, 22), (1, 2, 33)]),            # K % 256 != 0, N % 32 != 0, M % 32 != 0
     (2048, 1024, 128, [(1, 2, 22), (2, 4, 22), (1, 1, 22)]),
     (2048, 1024, 9, [(1, 2, 33), (2, 4, 22)]),
+    # split launches with two workgroups per CU AND more workgroups than the chip holds (1024 / 688 of them, rings of 80 KiB):
+    # the geometry in which the slab stores' data registers were overwritten before round 3's fix -- three launches out of
+    # three returned wrong elements (gemm_splitk_kernel.hpp, tools/experiments/sk_debug.py)
+    (4096, 16384, 64, [(1, 2, 22)]),
+    (2048, 22016, 50, [(1, 2, 22), (1, 4, 22)]),
 ])
 def test_splitk_every_plan(ops, oracle, K, N, M, plans):
     """Every (column blocks, slices, ring) instantiation forced through EETQ_AMD_SPLITK_PLAN: tier A against the oracle on

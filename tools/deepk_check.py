@@ -18,7 +18,8 @@ PLANS = {1: [(1, 22), (2, 22), (1, 33), (2, 33)],
 bad = 0
 n = 0
 SHAPES = ((4096, 4096), (4096, 11008), (11008, 4096), (5120, 13824), (13824, 5120), (4160, 4112), (320, 48), (1024, 80),
-          (2048, 22016), (1024, 32768))   # the last two: more unsplit workgroups than the chip holds at two per CU
+          (2048, 22016), (1024, 32768))   # the last two: more workgroups than the chip holds at two per CU (the geometry of
+                                          # round 2's slab-store data hazard, gemm_splitk_kernel.hpp)
 for K, N in SHAPES:
     g = torch.Generator(device=dev)
     g.manual_seed(K + N)
