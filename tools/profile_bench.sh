@@ -113,4 +113,13 @@ if [ -x tools/kbench_stamps ]; then
       $PY tools/trace_durations.py /tmp/prof_dec; echo "# (kbench's own lines while the tool was attached)"; grep -v "^device" /tmp/dec_under.txt; } \
         >> "$OUT/${TAG}_gemv_decomposition.txt" 2>&1
 fi
+echo "== 5. the un-profiled bench line again, now citing THIS run's sidecars" >&2
+# bench.py reads profiles/bench_rocprof.json and profiles/pmc_traffic.json: on the GPU box's scratch copy they are still the
+# previous run's, so step 1's line cites a stale rocprof average.  Put the fresh sidecars in place and print the line again.
+if [ -s "$OUT/bench_rocprof.json" ]; then
+    cp "$OUT/bench_rocprof.json" profiles/bench_rocprof.json
+    [ -s "$OUT/pmc_traffic.json" ] && cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
+    [ -s "$OUT/${TAG}_bench_kernel_stats.csv" ] && cp "$OUT/${TAG}_bench_kernel_stats.csv" "profiles/${TAG}_bench_kernel_stats.csv"
+    $PY bench.py "$@" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || echo "bench.py (second line) failed" >&2
+fi
 echo "done: $(ls $OUT | tr '\n' ' ')" >&2
