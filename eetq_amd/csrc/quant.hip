@@ -485,17 +485,20 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
     typedef __attribute__((address_space(3))) const T lds_cT;  // integer LDS addresses as in gemm_kernel.hpp::lds_read16
     const int lbase = (int)(uint32_t)(uintptr_t)(qp_lds_void*)tiles + (16 * g / C::kRowsPerB) * C::kBlockLds + col * (int)sizeof(T);
     uint8_t* dst = q_packed + ((size_t)((n0 >> 4) + wave) * KT + kt0) * (size_t)kTileBytes + (size_t)lane * 16;
+    u32x4 done = {0u, 0u, 0u, 0u};  // tile j-1's bytes, stored during step j
     for (int j = 0; j < nt; ++j) {
-        // in issue order this wave has outstanding: tile j, [the store of tile j-1], [tile j+1]
-        if (j + 1 < nt) {
-            if (live && j > 0)
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer + 1) : "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer) : "memory");
-        } else {
+        // In issue order this wave has outstanding: tile j's pieces, [the store of tile j-2], [tile j+1's pieces].  "At most
+        // kPer outstanding" then means tile j has landed WITHOUT assuming that a store retires in order with the loads around
+        // it (LLVM does not assume it either on gfx9: mixed load / store events make its vmcnt "out of order"): loads do retire
+        // in order among themselves, so one missing piece of tile j would leave all kPer of tile j+1 outstanding as well.
+        // The store itself is a whole step old by now -- which is why tile j-1 is stored below, after this wait, and not at
+        // the end of its own step.
+        if (j + 1 < nt)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kPer) : "memory");
+        else
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
         __builtin_amdgcn_s_barrier();  // everyone's pieces of tile j have landed
+        if (live && j > 0) *reinterpret_cast<u32x4*>(dst + (size_t)(j - 1) * kTileBytes) = done;
         T raw[16];
         if (live) {
             const int lt = lbase + (j & 1) * C::kTileLds;
@@ -528,8 +531,9 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
                 d[q]         = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ 0x80808080u;
             }
         }
-        *reinterpret_cast<u32x4*>(dst + (size_t)j * kTileBytes) = u32x4{d[0], d[1], d[2], d[3]};
+        done = u32x4{d[0], d[1], d[2], d[3]};
     }
+    if (live) *reinterpret_cast<u32x4*>(dst + (size_t)(nt - 1) * kTileBytes) = done;
 }
 
 // ---- inverse: packed layout -> raw row-major ----------------------------------------------------------------
