@@ -15,7 +15,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 EETQ_OK = 0
 DTYPE_F16, DTYPE_F32, DTYPE_F64 = 0, 1, 2
 LAYOUT_ROW_MAJOR, LAYOUT_GFX950, LAYOUT_SM80 = 0, 1, 2
-PATH_AUTO, PATH_GEMV, PATH_MFMA, PATH_STREAM, PATH_MID, PATH_SPLITK = 0, 1, 2, 3, 4, 5
+PATH_AUTO, PATH_GEMV, PATH_MFMA, PATH_STREAM, PATH_MID, PATH_SPLITK, PATH_TILESPLIT = 0, 1, 2, 3, 4, 5, 6
 ACT_IDENTITY, ACT_RELU, ACT_GELU, ACT_SILU = 0, 1, 2, 3
 
 _lib = None

@@ -312,6 +312,11 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
                 // activations once per 64 columns (N = 11008: M = 96 21.0 vs 23.9 us split-K, M = 128 22.4 vs 28.2; up to
                 // M = 64 the split-K tile is ahead: 17.6 vs 18.5, M = 48 16.2 vs 17.8; N = 13824 alike)
                 if (M > 64 && (N + 63) / 64 >= 160 && K >= 320) return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
+                // few tiles, deep K, M > 96 (the split-K tile needs four row blocks there and stops being flat in M): K slices of
+                // the tiled kernel's 128 x 64 tile -- M = 128: 11008 x 4096 23.9 vs 27.1 us, 5120^2 20.1 vs 22.6, 13824 x 5120
+                // 40.9 vs 46.8 (tile_splitk_slices has the rule and the cases it leaves alone); at M <= 96 the split-K tile is
+                // ahead (4096^2: 12.5 vs 13.1)
+                if (M > 96 && bp.act == 0 && tile_splitk_slices(M, N, K) > 1) return launch_gemm_tile_splitk(xp, wp, sp, bp, yp, M, N, K, s);
                 // narrower N: the split-K tile (K slices + in-launch deterministic reduction; N = K = 4096: M = 64 8.8 vs
                 // 11.2 us, M = 128 14.0 vs 20.2, K = 11008 16.3 vs 28.0; profiles/r02_kbench_splitk.txt).  EETQ_AMD_SPLITK=0
                 // keeps the unsplit tile (the split form owns per-stream scratch; see gemm_splitk.hip)
@@ -322,12 +327,15 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
                 if (use_splitk) return launch_gemm_splitk(xp, wp, sp, bp, yp, M, N, K, s);
                 return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
             }
-            return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
+            // M > 128: the tiled kernel; with K slices when its tiles would leave most CUs idle (M = 256 at 11008 x 4096: 37.4 vs
+            // 54.7 us) -- launch_gemm_tile_splitk decides and runs the unsplit kernel otherwise
+            return launch_gemm_tile_splitk(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_MID: return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_SPLITK: return launch_gemm_splitk(xp, wp, sp, bp, yp, M, N, K, s);
+        case EETQ_PATH_TILESPLIT: return launch_gemm_tile_splitk(xp, wp, sp, bp, yp, M, N, K, s);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] unknown or unimplemented GEMM path");
     }
 }

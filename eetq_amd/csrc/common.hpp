@@ -270,6 +270,15 @@ int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, Epilogue 
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                        hipStream_t stream, int force_nb = 0, int force_s = 0);
 void splitk_plan(int M, int N, int K, int* nb, int* s, int* stages);
+// the calling stream's own split-K scratch region (gemm_splitk.hip): slabs (*slab_bytes of them), one ticket array per slice
+// count (2 and 4), *max_tiles tickets each.  EETQ_ERR_UNSUPPORTED (no message) when the stream cannot have one right now.
+int splitk_region(hipStream_t stream, float** slabs, size_t* slab_bytes, unsigned** tickets2, unsigned** tickets4, size_t* max_tiles);
+// split-K form of the tiled MFMA GEMM (gemm.hip): K slices of the 128 x 64 tile when whole tiles leave CUs idle; falls back
+// to launch_gemm_mfma when it does not apply.  *used_s (optional) reports the slice count that ran.
+int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
+                            hipStream_t stream, int force_s = 0, int* used_s = nullptr);
+// slices launch_gemm_tile_splitk would use (1 = it would run the unsplit tiled kernel)
+int tile_splitk_slices(int M, int N, int K);
 // library-owned scratch (eetq_release_workspace): each frees its buffers on every device and adds the bytes to *freed
 int release_splitk_workspace(size_t* freed);
 int release_w4a16_workspace(size_t* freed);

@@ -21,6 +21,8 @@
 //     shadow of the current step's MFMAs (sched_barrier-pinned issue order, see gemm_kernel.hpp);
 //   * blockIdx -> tile mapping gives each XCD (own L2) a contiguous run of tiles ordered in groups of 4 row tiles: the
 //     32 workgroups resident on an XCD cover 4 row tiles x 8 column tiles, the smallest fabric footprint per K step.
+#include <cstdlib>
+
 #include "gemm_kernel.hpp"
 
 namespace eetq {
@@ -110,6 +112,59 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         if (st != EETQ_OK) return st;
     }
     return EETQ_OK;
+}
+
+// ---- K slices of the 128 x 64 tile ------------------------------------------------------------------------------------
+// The tiled kernel runs ONE workgroup per tile: M <= 128 at N = 4096 is 64 tiles on 256 CUs (20.6 us at M = 128), M = 256 is
+// 128.  With S workgroups per tile, each on a contiguous S-th of the K steps, the chip fills and the per-workgroup loop
+// shortens S-fold; the price is the hand-over of S partial tiles (32 KiB each) to the workgroup that finishes last.
+int tile_splitk_slices(int M, int N, int K)
+{
+    const int ncu   = device_cu_count();
+    const int tiles = ((M + BM - 1) / BM) * ((N + TileCfg<1>::BN - 1) / TileCfg<1>::BN);
+    const int KT    = K / BK;
+    // Every workgroup must get a CU of its own (a second round costs more than the slices save: M = 256 at 5120^2, 160 tiles,
+    // 35.8 us with two slices vs 27.6 unsplit), and the hand-over (~3.5 us: publish, ticket, read-back of S slabs) must be
+    // small against the loop it shortens -- measured (tools/experiments/tilesplit_check.py, graph-replayed chains, us,
+    // split vs best other path):
+    //   four slices of 43 steps:  M = 128 at 11008 x 4096 23.9 vs 27.1, M = 100 23.3 vs 25.6
+    //   two slices of >= 40:      M = 128 at 5120^2 20.1 vs 22.6, 13824 x 5120 40.9 vs 46.8, M = 256 at 11008 x 4096 37.1 vs 54.4
+    //   four slices of 16:        M = 97..128 at 4096^2 13.5 vs 15.5 on one box, 15.3-15.8 vs 15.0-15.5 on two others: not taken
+    //   two slices of 32:         M = 160 at 4096^2 17.7 vs 16.7, M = 256 19.8 vs 20.9: not taken
+    if (tiles * 4 <= ncu && KT / 4 >= 24) return 4;
+    if (tiles * 2 <= ncu && KT / 2 >= 40) return 2;
+    return 1;
+}
+
+int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
+                            hipStream_t stream, int force_s, int* used_s)
+{
+    if (used_s) *used_s = 1;
+    static const bool allowed = [] {  // EETQ_AMD_SPLITK=0: no library-owned scratch anywhere (gemm_splitk.hip)
+        const char* e = getenv("EETQ_AMD_SPLITK");
+        return !(e && e[0] == '0');
+    }();
+    int S = !allowed ? 1 : (force_s ? force_s : tile_splitk_slices(M, N, K));
+    const int KT = K / BK;
+    const bool fits = (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31);
+    if ((S != 2 && S != 4) || ep.act != 0 || !fits || K % BK != 0 || KT / S < kMinKSteps)
+        return launch_gemm_mfma(x, w, scales, ep, y, M, N, K, stream);
+    constexpr int BN    = TileCfg<1>::BN;
+    const int     tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    float*        slabs = nullptr;
+    unsigned *    t2 = nullptr, *t4 = nullptr;
+    size_t        slab_bytes = 0, max_tiles = 0;
+    int st = splitk_region(stream, &slabs, &slab_bytes, &t2, &t4, &max_tiles);
+    if (st == EETQ_ERR_UNSUPPORTED || (st == EETQ_OK && ((size_t)tiles > max_tiles || (size_t)tiles * S * BM * BN * 4 > slab_bytes)))
+        return launch_gemm_mfma(x, w, scales, ep, y, M, N, K, stream);  // no scratch of its own for this stream: unsplit
+    if (st != EETQ_OK) return st;
+    static std::atomic<unsigned long long> opted{0};
+    st = opt_in_large_lds(gemm_tile_splitk_kernel<1>, opted);
+    if (st != EETQ_OK) return st;
+    launch_kernel(gemm_tile_splitk_kernel<1>, dim3(tiles * S), dim3(256), TileCfg<1>::SMEM_BYTES, stream, x, w, scales, y, M, N, K, N, ep,
+                  S, slabs, S == 2 ? t2 : t4);
+    if (used_s) *used_s = S;
+    return check_hip(hipGetLastError(), "gemm_tile_splitk_kernel launch");
 }
 
 }  // namespace eetq

@@ -91,10 +91,15 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // kernel grew from 4.4 k to 21 k instructions (exp / tanh expanded for 128 accumulators) and the SAME main loop ran 11 %
 // slower (M = 1024, N = K = 4096: 40.8 vs 36.7 us, tools/kbench gemm, same box) -- instruction fetch, not registers (both
 // builds use 410).  The identity instantiation keeps the round-1 epilogue.
-template <int ABLATE, int J, bool ACT = false, int CW = 2>
-__global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
+// SPLIT (gemm_tile_splitk_kernel below): S workgroups share a tile, each runs a contiguous part of the K steps; the partial
+// tiles meet in `slabs` ([tile][slice][BM * BN] floats, accumulator order) and the workgroup that draws the last of the tile's
+// S tickets adds them IN SLICE ORDER (replicas stay bit-identical) and runs the ordinary epilogue.  Same hand-over as
+// gemm_splitk_kernel.hpp: write-through stores, every wave drains them, barrier, one relaxed agent-scope ticket.
+template <int ABLATE, int J, bool ACT, int CW, bool SPLIT>
+__device__ __forceinline__ void gemm_tile_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
+    f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep, int S, float* __restrict__ slabs,
+    unsigned* __restrict__ counters)
 {
     // N = columns of THIS launch (w, scales, y, ep.* already point at its first column); ldc = row stride of y / residual
     EETQ_GEMM_STAMP(0);
@@ -115,10 +120,19 @@ __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
     const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;
     const int T       = tiles_m * tiles_n;
-    int       tile;
+    int       tile, slice = 0, k0 = 0, ksteps = KT;  // this workgroup's K steps: [k0, k0 + ksteps)
     {
-        const int b = blockIdx.x, q = T >> 3, r = T & 7, xcd = b & 7, idx = b >> 3;
+        // SPLIT: T * S virtual tiles in the same XCD-grouped order, a tile's slices next to each other (one XCD, one L2)
+        const int TT = SPLIT ? T * S : T;
+        const int b = blockIdx.x, q = TT >> 3, r = TT & 7, xcd = b & 7, idx = b >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        if constexpr (SPLIT) {
+            const int vt = tile;
+            tile   = vt / S;
+            slice  = vt - tile * S;
+            k0     = (int)(((long)KT * slice) / S);
+            ksteps = (int)(((long)KT * (slice + 1)) / S) - k0;
+        }
     }
     // tile order: row tiles in chunks of kGroupM, inside a chunk column-major.  The 32 workgroups resident on an
     // XCD at a time are consecutive tiles = 4 row tiles x 8 column tiles: the footprint its L2 fetches over the fabric
@@ -195,7 +209,7 @@ __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
 
     // ring state of the step about to run (wave-uniform): rd = LDS offset of the stage whose fragments it reads
     // (stage kt+1), wr = LDS offset its DMA fills (stage kt+5), ka / kb = source offsets of that stage
-    int rd = STAGE_BYTES, wr = (STAGES - 1) * STAGE_BYTES, ka = (STAGES - 1) * BK * 2, kb = (STAGES - 1) * kTileBytes;
+    int rd = STAGE_BYTES, wr = (STAGES - 1) * STAGE_BYTES, ka = (k0 + STAGES - 1) * BK * 2, kb = (k0 + STAGES - 1) * kTileBytes;
     int ra0 = rd + c_a0, ra1 = rd + c_a1, rb0 = rd + c_b0, rb1 = rd + c_b1;
 
     auto dma_piece = [&](auto itag) {
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
     // ---- prologue: STAGES-1 stages in flight; stage 0 -> fragments ----
     asm volatile("" ::"v"(scale2[0]));
     {
-        int pwr = 0, pka = 0, pkb = 0;
+        int pwr = 0, pka = k0 * BK * 2, pkb = k0 * kTileBytes;
 #pragma unroll
         for (int s = 0; s < STAGES - 1; ++s) {  // KT >= STAGES - 1 by launch contract
 #pragma unroll
@@ -380,9 +394,9 @@ __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
         }
     };
     using Steady = std::integral_constant<int, STAGES - 1>;
-    const int tail = (KT & 1) ? 5 : 6;
+    const int tail = (ksteps & 1) ? 5 : 6;
     int       kt   = 0;
-    for (; kt < KT - tail; kt += 2) {
+    for (; kt < ksteps - tail; kt += 2) {
         k_step(Steady{}, w0, f0, w1, f1);
         k_step(Steady{}, w1, f1, w0, f0);
     }
@@ -422,20 +436,108 @@ __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
     }
     __syncthreads();
     EETQ_GEMM_STAMP(4);
+    if constexpr (SPLIT) {
+        // ---- this slice's partial tile -> slab; the last of the tile's S slices adds all of them in slice order ----
+        static_assert(!SPLIT || (CW == 2 && !ACT), "the split form exists for the 4-wave tile with the identity epilogue");
+        constexpr int kSlabFloats = BM * BN;
+        const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            slabs + (size_t)tile * S * kSlabFloats, 0, S * kSlabFloats * 4, 0x00020000);
+        // float4 index inside a slab: (((wn*4 + mt)*J + j)*4 + q)*64 + lane  (only the K-half-0 waves hold sums)
+        const int lane_off = (wn * 16 * J * 64 + lane) * 16;
+        if (grp == 0) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const f32x4 o = red4[((mt * J + j) * 4 + q) * 64 + lane];
+                        acc[mt][j][4 * q + 0] += o.x;
+                        acc[mt][j][4 * q + 1] += o.y;
+                        acc[mt][j][4 * q + 2] += o.z;
+                        acc[mt][j][4 * q + 3] += o.w;
+                    }
+            if (S > 1) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            // (through named floats: __builtin_bit_cast applied directly to an element of the 16-wide
+                            // accumulator vector read element 0 for every index with this hipcc)
+                            const float f0 = acc[mt][j][4 * q + 0], f1 = acc[mt][j][4 * q + 1], f2 = acc[mt][j][4 * q + 2],
+                                        f3 = acc[mt][j][4 * q + 3];
+                            const u32x4 v = {__builtin_bit_cast(u32, f0), __builtin_bit_cast(u32, f1), __builtin_bit_cast(u32, f2),
+                                             __builtin_bit_cast(u32, f3)};
+                            // everything in the per-lane offset, soffset 0: hipcc then guards the store's data registers
+                            // itself (gemm_splitk_kernel.hpp has the story of the form it does not guard)
+                            __builtin_amdgcn_raw_buffer_store_b128(v, s_rsrc, slice * kSlabFloats * 4 + ((mt * J + j) * 4 + q) * 1024 + lane_off,
+                                                                   0, /*sc1*/ 16);
+                        }
+            }
+        }
+        if (S > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // EVERY storing wave drains its write-through stores
+            __syncthreads();
+            unsigned* flag = reinterpret_cast<unsigned*>(smem + SMEM_BYTES - 16);
+            if (tid == 0) *flag = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            const unsigned ticket = *flag;
+            if ((ticket & (unsigned)(S - 1)) != (unsigned)(S - 1)) return;  // not the last slice of this tile
+            // All four waves read back: wave (grp, wn) takes row blocks 2*grp, 2*grp + 1 of its column half, every slice's
+            // float4s requested before the first is used (S * 8 * J loads in flight per lane), summed in slice order -- the
+            // last arriver's own slab like the others, so the result does not depend on who arrived last.
+            u32x4 part[4][2][J][4];
+#pragma unroll
+            for (int sl = 0; sl < 4; ++sl)
+#pragma unroll
+                for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                    for (int j = 0; j < J; ++j)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)  // slices beyond S: clamped address, value unused (no load behind a branch)
+                            part[sl][mm][j][q] = __builtin_amdgcn_raw_buffer_load_b128(
+                                s_rsrc, (sl < S ? sl : S - 1) * kSlabFloats * 4 + (((2 * grp + mm) * J + j) * 4 + q) * 1024 + lane_off, 0, /*sc1*/ 16);
+#pragma unroll
+            for (int mm = 0; mm < 2; ++mm)
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            float t = __builtin_bit_cast(float, (u32)part[0][mm][j][q][i]);
+#pragma unroll
+                            for (int sl = 1; sl < 4; ++sl) {
+                                const float v = __builtin_bit_cast(float, (u32)part[sl][mm][j][q][i]);
+                                t             = sl < S ? t + v : t;
+                            }
+                            // both row blocks of this wave end up in acc[mm] .. the epilogue below maps them back to 2*grp + mm
+                            if (mm == 0) acc[0][j][4 * q + i] = t; else acc[1][j][4 * q + i] = t;
+                        }
+        }
+    }
     constexpr int kRowHalfs = BN + 8;                       // row stride of the image: 272 / 144 bytes (bank shift per row)
     f16* image = reinterpret_cast<f16*>(smem + CW * (16 * J) * 64 * 16);  // behind every column part's parked accumulators
     static_assert(CW * (16 * J) * 64 * 16 + BM * kRowHalfs * 2 <= SMEM_BYTES, "the output image must fit behind the parked halves");
-    if (grp == 0) {
+    // who rounds which row blocks into the image: the K-half-0 waves all four -- or, after a split read-back, every wave the two
+    // it summed (held in acc[0], acc[1])
+    const bool summed = SPLIT && S > 1;
+    if (grp == 0 || summed) {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt_ = 0; mt_ < 4; ++mt_) {
+            if (summed && mt_ >= 2) break;
+            const int mt = summed ? 2 * grp + mt_ : mt_;  // row block of the tile; its sums sit in acc[mt_]
 #pragma unroll
             for (int j = 0; j < J; ++j) {
                 const int ncol = wn * WN_COLS + 32 * j + 4 * fh;  // tile-local column of quad 0
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const f32x4 o  = red4[((mt * J + j) * 4 + q) * 64 + lane];
-                    const float a4[4] = {acc[mt][j][4 * q + 0] + o.x, acc[mt][j][4 * q + 1] + o.y, acc[mt][j][4 * q + 2] + o.z,
-                                         acc[mt][j][4 * q + 3] + o.w};
+                    // (SPLIT: the other K half -- and the other slices -- were added above)
+                    const f32x4 o  = SPLIT ? f32x4{0.f, 0.f, 0.f, 0.f} : red4[((mt * J + j) * 4 + q) * 64 + lane];
+                    const float a4[4] = {acc[mt_][j][4 * q + 0] + o.x, acc[mt_][j][4 * q + 1] + o.y, acc[mt_][j][4 * q + 2] + o.z,
+                                         acc[mt_][j][4 * q + 3] + o.w};
                     f16x2      lo = {}, hi = {};
                     const bool in_n = n0 + ncol + 8 * q < N;  // columns beyond a ragged launch edge: nothing to read or keep
                     if constexpr (ACT) {
@@ -477,6 +579,25 @@ __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     EETQ_GEMM_STAMP(5);
+}
+
+template <int ABLATE, int J, bool ACT = false, int CW = 2>
+__global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
+    f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
+{
+    gemm_tile_body<ABLATE, J, ACT, CW, false>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
+}
+
+// grid = tiles * S workgroups; every slice must own >= kMinKSteps K steps; counters: one per tile, shared only by launches
+// with the same S (they grow by S per launch; "last" is (old & (S-1)) == S-1), S in {2, 4}
+template <int J>
+__global__ __launch_bounds__(256, 1) void gemm_tile_splitk_kernel(
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
+    f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep, int S, float* __restrict__ slabs,
+    unsigned* __restrict__ counters)
+{
+    gemm_tile_body<0, J, false, 2, true>(x, w, scales, y, M, N, K, ldc, ep, S, slabs, counters);
 }
 
 }  // namespace gemm

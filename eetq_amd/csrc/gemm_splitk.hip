@@ -185,6 +185,18 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
 }  // namespace
 
 // frees every split-K region of every device (eetq_release_workspace); the caller has synchronised the devices
+int splitk_region(hipStream_t stream, float** slabs, size_t* slab_bytes, unsigned** tickets2, unsigned** tickets4, size_t* max_tiles)
+{
+    unsigned* t  = nullptr;
+    int       st = region_for(stream, slabs, &t);
+    if (st != EETQ_OK) return st;
+    *slab_bytes = kRegionSlabs;
+    *tickets2   = t;
+    *tickets4   = t + kRegionTickets;
+    *max_tiles  = kRegionTickets;
+    return EETQ_OK;
+}
+
 int release_splitk_workspace(size_t* freed)
 {
     std::lock_guard<std::mutex> lock(g_mutex);

@@ -49,6 +49,7 @@ int path_id(const std::string& name)
     if (name == "stream") return EETQ_PATH_STREAM;
     if (name == "mid") return EETQ_PATH_MID;
     if (name == "splitk") return EETQ_PATH_SPLITK;
+    if (name == "tilesplit") return EETQ_PATH_TILESPLIT;
     throw std::runtime_error("unknown GEMM path '" + name + "'");
 }
 

@@ -30,7 +30,7 @@ __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_g
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
 _PATHS = {"auto": PATH_AUTO, "gemv": PATH_GEMV, "mfma": PATH_MFMA, "stream": _lib.PATH_STREAM, "mid": _lib.PATH_MID,
-          "splitk": _lib.PATH_SPLITK}
+          "splitk": _lib.PATH_SPLITK, "tilesplit": _lib.PATH_TILESPLIT}
 _ACTS = {"": ACT_IDENTITY, "identity": ACT_IDENTITY, "none": ACT_IDENTITY, "relu": ACT_RELU, "gelu": ACT_GELU,
          "silu": ACT_SILU}
 
@@ -191,7 +191,7 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, nor
     """``y = input @ dequant(weight, scale) (+ bias)``: fp16 [..., K] x int8 [K, N] (processed) -> fp16 [..., N].
 
     Reference: w8_a16_gemm_forward_cuda, fpA_intB_gemm_wrapper.cu:130-173 (fresh output tensor, current
-    stream, asynchronous).  ``path`` ("auto" | "gemv" | "stream" | "mfma") is a testing hook.  ``bias`` (extension,
+    stream, asynchronous).  ``path`` ("auto" | "gemv" | "stream" | "mfma" | "mid" | "splitk" | "tilesplit") is a testing hook.  ``bias`` (extension,
     SURVEY 8f row 3) fuses the reference's separate ``output + bias`` into the kernel epilogue, bit-identically;
     ``residual`` (same shape as the output) is added after it, again in fp16 -- the decoder block's ``residual + proj(x)``.
     ``norm=(gamma, eps)`` (extension) RMS-normalises the input first: inside the GEMV launch for a single row, as a

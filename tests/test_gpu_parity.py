@@ -305,10 +305,78 @@ def test_splitk_is_deterministic_and_back_to_back_safe(ops, oracle):
         assert torch.equal(y, ops.w8_a16_gemm(xd, processed, scales))
 
 
+@pytest.mark.parametrize("M,K,N", [(128, 8192, 4096),     # four slices of 32 K steps
+                                   (100, 5120, 5120),     # two slices of 40; ragged last rows of the single row tile
+                                   (256, 11008, 4096),    # two row tiles, two slices of 86
+                                   (128, 11008, 4096),    # four slices of 43 (an odd step count per slice)
+                                   (130, 4160, 4112),     # does not split (130 tiles x 2 > CUs): the unsplit tiled kernel
+                                   (128, 1088, 4096)])    # K too shallow to split
+def test_tile_splitk_vs_oracle_and_unsplit(ops, oracle, M, K, N):
+    """path="tilesplit": K slices of the tiled kernel's 128 x 64 tile, partial tiles handed over through the split-K scratch
+    and added in slice order.  Tier A against the oracle on sampled rows and against the unsplit tiled kernel on the whole
+    output; bias + residual epilogue bit-identical to separate adds; two launches give the same bits; AUTO for M > 96 agrees."""
+    w, x = _rand_case(K, N, M, seed=M + K + N)
+    x[:, ::5] *= -1
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    rows = sorted(set([0, 31, M // 2, M - 1]))
+    ref = oracle.w8a16_gemm(x[rows], q, s)
+    y1 = ops.w8_a16_gemm(xd, processed, scales, path="tilesplit")
+    y2 = ops.w8_a16_gemm(xd, processed, scales, path="tilesplit")
+    whole = ops.w8_a16_gemm(xd, processed, scales, path="mfma")
+    assert torch.equal(y1, y2)
+    got = y1.cpu().numpy()
+    assert _tier_a(got[rows], ref).all(), np.abs(got[rows].astype(np.float32) - ref.astype(np.float32)).max()
+    assert _tier_a(got, whole.cpu().numpy()).all()
+    assert _tier_a(ops.w8_a16_gemm(xd, processed, scales).cpu().numpy(), whole.cpu().numpy()).all()
+    g = torch.Generator(device=DEV); g.manual_seed(1)
+    bias = torch.rand(N, device=DEV, generator=g).half()
+    res = torch.rand(M, N, device=DEV, generator=g).half()
+    fused = ops.w8_a16_gemm(xd, processed, scales, path="tilesplit", bias=bias, residual=res)
+    assert torch.equal(fused, (y1 + bias) + res)
+
+
+def test_tile_splitk_is_deterministic_across_launches_streams_and_graphs(ops, oracle):
+    """The split form of the tiled kernel shares the split-K tickets (one array per slice count, monotonic): interleaved with
+    split-K launches of the same slice counts, on two streams, and replayed from a HIP graph, every result is bit-identical
+    to the first."""
+    w, x = _rand_case(8192, 4096, 128, seed=11)   # four slices (the split-K launches below run with two)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    first = ops.w8_a16_gemm(xd, processed, scales, path="tilesplit")
+    x64 = xd[:64].contiguous()
+    first64 = ops.w8_a16_gemm(x64, processed, scales, path="splitk")
+    for i in range(100):
+        assert torch.equal(ops.w8_a16_gemm(xd, processed, scales, path="tilesplit"), first), i
+        if i % 2 == 0:
+            assert torch.equal(ops.w8_a16_gemm(x64, processed, scales, path="splitk"), first64), i
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        on_side = [ops.w8_a16_gemm(xd, processed, scales, path="tilesplit") for _ in range(20)]
+    on_main = [ops.w8_a16_gemm(xd, processed, scales, path="tilesplit") for _ in range(20)]
+    torch.cuda.synchronize()
+    assert all(torch.equal(t, first) for t in on_side + on_main)
+    y = torch.empty_like(first)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(4):
+            ops.w8_a16_gemm_(xd, processed, scales, y, 128, 4096, 8192)
+    for _ in range(10):
+        y.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(y, first)
+
+
 @pytest.mark.parametrize("K,N,M,plans", [
     # plans = (column blocks, K slices, ring): every instantiation of the library, including the ones AUTO does not pick.  The
-    # first three rows are the (ring 22, S > 1, more workgroups than CUs) plans that returned wrong elements in round 3 when two
-    # split workgroups shared a CU -- the launcher now keeps split launches at one workgroup per CU (gemm_splitk.hip).
+    # first three rows are among the (ring 22, S > 1) plans that returned wrong elements when two split workgroups shared a CU
+    # (the slab stores' data-register hazard, fixed in round 3: gemm_splitk_kernel.hpp).
     (4096, 4096, 64, [(1, 4, 22), (1, 2, 22), (2, 4, 22), (1, 2, 33), (2, 4, 33), (2, 1, 33)]),
     (4096, 11008, 32, [(2, 2, 22), (2, 4, 22), (1, 2, 22), (1, 1, 22), (2, 1, 33)]),
     (4096, 11008, 64, [(1, 2, 22), (1, 4, 22), (2, 1, 33), (1, 1, 22)]),
