@@ -21,13 +21,15 @@ for K, N in shapes[which]:
     L = max(4, int(640e6 // (K * N)))
     ws = [torch.randint(-128, 127, (K, N), dtype=torch.int8, device=dev) for _ in range(L)]
     s = torch.rand(N, dtype=torch.float16, device=dev) * 0.01
-    for M in (8, 16, 17, 24, 32, 48, 64, 96, 128):
+    for M in (8, 16, 17, 24, 32, 48, 64, 96, 112, 128):
         x = torch.randn(M, K, dtype=torch.float16, device=dev)
         row = {"K": K, "N": N, "M": M}
-        for path in ("auto", "stream", "splitk", "mid", "mfma"):
+        for path in ("auto", "stream", "splitk", "mid", "mfma", "tilesplit"):
             if path == "stream" and M > 64:
                 continue
             if path in ("mid", "mfma") and M < 32:
+                continue
+            if path == "tilesplit" and M < 96:
                 continue
 
             def step(i, path=path):
