@@ -38,6 +38,32 @@ for it in range(iters):
         bad += 1
 print("split-K: %d launches, %d mismatches" % (iters, bad))
 
+# ---- K slices of the tiled kernel (shares the split-K tickets): 4 and 2 slices, interleaved with split-K launches ----
+bad_t, n_t = 0, max(1, iters // 4)
+tcases = []
+for M, K, N in ((128, 8192, 4096), (256, 11008, 4096), (100, 5120, 5120)):
+    w = torch.randint(-128, 127, (K, N), dtype=torch.int8, device=dev)
+    s = torch.rand(N, dtype=torch.float16, device=dev) * 0.01
+    x = torch.randn(M, K, dtype=torch.float16, device=dev)
+    tcases.append((x, w, s, ops.w8_a16_gemm(x, w, s, path="tilesplit").clone()))
+for it in range(n_t):
+    x, w, s, ref = tcases[it % len(tcases)]
+    st = streams[it % 3] if it % 4 == 0 else torch.cuda.current_stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        y = ops.w8_a16_gemm(x, w, s, path="tilesplit")
+    torch.cuda.current_stream().wait_stream(st)
+    if it % 3 == 0:
+        xs, ws, ss, rs = cases[it % len(cases)]
+        if not torch.equal(ops.w8_a16_gemm(xs, ws, ss, path="splitk"), rs):
+            bad_t += 1
+    if it % 7 == 0:
+        junk.add_(1)
+    if not torch.equal(y, ref):
+        bad_t += 1
+print("K-sliced tiled kernel: %d launches, %d mismatches" % (n_t, bad_t))
+bad += bad_t
+
 # ---- one-launch decode attention: fixed cache and token, the counter walks and is reset; tickets must stay zero ----
 B, H, Hkv, D, S = 2, 40, 8, 128, 600
 inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
