@@ -136,6 +136,18 @@ int tile_splitk_slices(int M, int N, int K)
     return 1;
 }
 
+// the same question for the 128 x 128 tile (two slices at most: its partial tile is 64 KiB): M = 257..512 on N <= 4096, where
+// whole wide tiles cover half the chip and the narrow tiles that fill it cost 0.70 of a wide pass each.  The 64 KiB hand-over
+// is dearer (~6 us), so only very deep K pays: M = 512 at 11008 x 4096 (86 steps per slice) 51.7 vs 58.3 us; at 4096^2 (32)
+// 27.8 vs 23.2, 8192 x 4096 (64) 40.6 vs 40.0: not taken.
+int wide_tile_splitk_slices(int M, int N, int K)
+{
+    const int ncu   = device_cu_count();
+    const int tiles = ((M + BM - 1) / BM) * ((N + TileCfg<2>::BN - 1) / TileCfg<2>::BN);
+    const int KT    = K / BK;
+    return (tiles * 2 <= ncu && tiles * 4 > ncu && KT / 2 >= 80) ? 2 : 1;
+}
+
 int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                             hipStream_t stream, int force_s, int* used_s)
 {
@@ -145,12 +157,17 @@ int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, E
         return !(e && e[0] == '0');
     }();
     int S = !allowed ? 1 : (force_s ? force_s : tile_splitk_slices(M, N, K));
+    bool wide = false;
+    if (allowed && !force_s && S == 1 && wide_tile_splitk_slices(M, N, K) == 2) {
+        S    = 2;
+        wide = true;
+    }
     const int KT = K / BK;
     const bool fits = (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31);
     if ((S != 2 && S != 4) || ep.act != 0 || !fits || K % BK != 0 || KT / S < kMinKSteps)
         return launch_gemm_mfma(x, w, scales, ep, y, M, N, K, stream);
-    constexpr int BN    = TileCfg<1>::BN;
-    const int     tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int BN    = wide ? TileCfg<2>::BN : TileCfg<1>::BN;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
     float*        slabs = nullptr;
     unsigned *    t2 = nullptr, *t4 = nullptr;
     size_t        slab_bytes = 0, max_tiles = 0;
@@ -158,11 +175,15 @@ int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, E
     if (st == EETQ_ERR_UNSUPPORTED || (st == EETQ_OK && ((size_t)tiles > max_tiles || (size_t)tiles * S * BM * BN * 4 > slab_bytes)))
         return launch_gemm_mfma(x, w, scales, ep, y, M, N, K, stream);  // no scratch of its own for this stream: unsplit
     if (st != EETQ_OK) return st;
-    static std::atomic<unsigned long long> opted{0};
-    st = opt_in_large_lds(gemm_tile_splitk_kernel<1>, opted);
+    static std::atomic<unsigned long long> opted{0}, opted_wide{0};
+    st = wide ? opt_in_large_lds(gemm_tile_splitk_kernel<2>, opted_wide) : opt_in_large_lds(gemm_tile_splitk_kernel<1>, opted);
     if (st != EETQ_OK) return st;
-    launch_kernel(gemm_tile_splitk_kernel<1>, dim3(tiles * S), dim3(256), TileCfg<1>::SMEM_BYTES, stream, x, w, scales, y, M, N, K, N, ep,
-                  S, slabs, S == 2 ? t2 : t4);
+    if (wide)
+        launch_kernel(gemm_tile_splitk_kernel<2>, dim3(tiles * S), dim3(256), TileCfg<2>::SMEM_BYTES, stream, x, w, scales, y, M, N, K, N,
+                      ep, S, slabs, t2);
+    else
+        launch_kernel(gemm_tile_splitk_kernel<1>, dim3(tiles * S), dim3(256), TileCfg<1>::SMEM_BYTES, stream, x, w, scales, y, M, N, K, N,
+                      ep, S, slabs, S == 2 ? t2 : t4);
     if (used_s) *used_s = S;
     return check_hip(hipGetLastError(), "gemm_tile_splitk_kernel launch");
 }

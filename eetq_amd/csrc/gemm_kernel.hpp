@@ -488,9 +488,10 @@ __device__ __forceinline__ void gemm_tile_body(
             // All four waves read back: wave (grp, wn) takes row blocks 2*grp, 2*grp + 1 of its column half, every slice's
             // float4s requested before the first is used (S * 8 * J loads in flight per lane), summed in slice order -- the
             // last arriver's own slab like the others, so the result does not depend on who arrived last.
-            u32x4 part[4][2][J][4];
+            constexpr int kMaxS = J == 1 ? 4 : 2;  // slices a launch may use: the read-back keeps kMaxS * 8 * J float4 per lane
+            u32x4 part[kMaxS][2][J][4];
 #pragma unroll
-            for (int sl = 0; sl < 4; ++sl)
+            for (int sl = 0; sl < kMaxS; ++sl)
 #pragma unroll
                 for (int mm = 0; mm < 2; ++mm)
 #pragma unroll
@@ -509,7 +510,7 @@ __device__ __forceinline__ void gemm_tile_body(
                         for (int i = 0; i < 4; ++i) {
                             float t = __builtin_bit_cast(float, (u32)part[0][mm][j][q][i]);
 #pragma unroll
-                            for (int sl = 1; sl < 4; ++sl) {
+                            for (int sl = 1; sl < kMaxS; ++sl) {
                                 const float v = __builtin_bit_cast(float, (u32)part[sl][mm][j][q][i]);
                                 t             = sl < S ? t + v : t;
                             }
@@ -590,7 +591,7 @@ __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
 }
 
 // grid = tiles * S workgroups; every slice must own >= kMinKSteps K steps; counters: one per tile, shared only by launches
-// with the same S (they grow by S per launch; "last" is (old & (S-1)) == S-1), S in {2, 4}
+// with the same S (they grow by S per launch; "last" is (old & (S-1)) == S-1), S in {2, 4} for J = 1, S = 2 for J = 2
 template <int J>
 __global__ __launch_bounds__(256, 1) void gemm_tile_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,

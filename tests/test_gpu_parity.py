@@ -310,7 +310,8 @@ def test_splitk_is_deterministic_and_back_to_back_safe(ops, oracle):
                                    (256, 11008, 4096),    # two row tiles, two slices of 86
                                    (128, 11008, 4096),    # four slices of 43 (an odd step count per slice)
                                    (130, 4160, 4112),     # does not split (130 tiles x 2 > CUs): the unsplit tiled kernel
-                                   (128, 1088, 4096)])    # K too shallow to split
+                                   (128, 1088, 4096),     # K too shallow to split
+                                   (512, 11008, 4096)])   # the 128 x 128 tile, two slices of 86 (64 KiB partial tiles)
 def test_tile_splitk_vs_oracle_and_unsplit(ops, oracle, M, K, N):
     """path="tilesplit": K slices of the tiled kernel's 128 x 64 tile, partial tiles handed over through the split-K scratch
     and added in slice order.  Tier A against the oracle on sampled rows and against the unsplit tiled kernel on the whole

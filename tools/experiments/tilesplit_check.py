@@ -8,9 +8,8 @@ from eetq_amd import ops
 from sweep import chain_us
 dev = "cuda:0"
 bad = 0
-for (M, K, N) in [(128, 4096, 4096), (112, 4096, 4096), (97, 4096, 4096), (128, 11008, 4096), (100, 11008, 4096), (128, 5120, 5120),
-                  (100, 5120, 5120), (128, 13824, 5120), (256, 4096, 4096), (160, 4096, 4096), (256, 11008, 4096), (256, 5120, 5120),
-                  (192, 13824, 5120), (128, 1088, 4096), (130, 4160, 4112), (512, 1024, 2048), (300, 2048, 1024)]:
+for (M, K, N) in [(512, 4096, 4096), (512, 11008, 4096), (384, 4096, 4096), (300, 4096, 4096), (512, 5120, 5120), (448, 8192, 4096),
+                  (512, 2048, 4096), (1024, 4096, 2048), (128, 11008, 4096), (256, 11008, 4096), (512, 4096, 11008)]:
     nbuf = max(2, (640 << 20) // (K * N))
     g = torch.Generator(device=dev); g.manual_seed(M + K + N)
     sets = []
