@@ -469,6 +469,27 @@ def main():
                       "sweep_m1_rotated_ms": {str(t): round(v * 1e3, 2) for t, v in r1.items()},
                       "sweep_m1024_ms": {str(t): round(v * 1e3, 2) for t, v in s1024.items()}}
 
+    # ---- the quantiser (model-load work, reported beside the headline, never as `value`) ----
+    quantizer = None
+    if grp.rank == 0:
+        g2 = torch.Generator(device=dev)
+        g2.manual_seed(3)
+        srcs = [((torch.rand(K, N, device=dev, generator=g2) * 2 - 1) / K ** 0.5).half() for _ in range(10)]   # 320 MiB rotated
+        for _ in range(3):
+            ops.quant_weights(srcs[0], torch.int8, False)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(50):
+            ops.quant_weights(srcs[i % 10], torch.int8, False)
+        e1.record()
+        torch.cuda.synchronize()
+        q_us = e0.elapsed_time(e1) * 1e3 / 50
+        quantizer = {"what": "quant_weights(fp16 [4096, 4096], int8) -> native layout + scales, per call, eager loop over 10 rotating "
+                             "inputs (two launches: column maxima, quantise + pack); bit-exact vs the oracle in the parity block",
+                     "us_per_call": round(q_us, 1), "moved_GBps": round((K * N * 2 * 2 + K * N) / q_us / 1e3)}
+        del srcs
+
     # ---- BASELINE configs[4]: the whole decode path on the same box (reported beside the headline, never as `value`) ----
     config5 = None
     if not args.no_config5:
@@ -488,7 +509,7 @@ def main():
                                  % (len(graphs), steps, replays, timed_steps, seconds * 1e3),
                        "timed_steps": timed_steps, "timed_ms": round(seconds * 1e3, 3)},
             "roofline": roofline, "secondary": gemm, "cpu_baseline": cpu_baseline, "cpu_linear_fp16": cpu_linear,
-            "parity": parity, "config5": config5,
+            "parity": parity, "quantizer": quantizer, "config5": config5,
         }
         print(json.dumps(line))
     grp.close()
