@@ -28,7 +28,9 @@ class ReplicaGroup:
         self.device = torch.device(device)
         if self.device.type == "cuda":
             torch.cuda.set_device(self.device)
-        self.backend = backend or ("nccl" if self.device.type == "cuda" else "gloo")
+        # EETQ_REPLICA_BACKEND=gloo: a test hook -- two replicas on ONE GPU (RCCL refuses two ranks per device) still run the
+        # whole N > 1 path of bench.py, with gloo carrying the three latency-bound collectives
+        self.backend = backend or os.environ.get("EETQ_REPLICA_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
         self._own_pg = False
         if self.world_size > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

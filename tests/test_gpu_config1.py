@@ -132,3 +132,23 @@ def test_two_replicas_rccl_on_one_gpu(tmp_path):
     for rank, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, out[-2000:]
         assert "rank %d ok" % rank in out
+
+
+def test_bench_two_replicas_on_one_gpu_over_gloo():
+    """bench.py --gpus 2 end to end (the driver's launch line, two ranks) on the one GPU of this box: gloo stands in for RCCL,
+    which refuses two ranks per device; everything else -- device selection by LOCAL_RANK modulo the visible devices, fan-out
+    of the activations, bit-identical replicas, MAX over ranks, whole-job value -- is the code an 8-GPU node runs."""
+    port = str(_free_port())
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "200", "--warmup", "20", "--nbuf", "8",
+           "--no-config5", "--no-cpu-baseline"]
+    env = dict(os.environ, EETQ_REPLICA_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]                      # rank 0 prints ONE line
+    doc = json.loads(lines[0])
+    assert doc["n_gpus"] == 2 and doc["scaling"] == "weak" and doc["steps"] == 200
+    assert doc["parity"]["replicas_bit_identical"] is True
+    # two replicas time-share one GPU here: the whole-job value is two replicas' bytes over the slower rank's time
+    assert doc["value"] > 500 and doc["roofline"]["frac"] > 0
