@@ -29,6 +29,40 @@ namespace eetq {
 
 using namespace gemm;
 
+namespace {
+// S (2 or 4) K slices of the 128 x 64 tile over the columns [c0, c0 + cols) of an M x N problem whose row stride is ldc.
+// EETQ_ERR_UNSUPPORTED (no message): the caller runs those columns unsplit.
+int launch_tile_splitk_cols(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int rows, int c0, int cols,
+                            int K, int ldc, int S, hipStream_t stream)
+{
+    static const bool allowed = [] {  // EETQ_AMD_SPLITK=0: no library-owned scratch anywhere (gemm_splitk.hip)
+        const char* e = getenv("EETQ_AMD_SPLITK");
+        return !(e && e[0] == '0');
+    }();
+    constexpr int BN = TileCfg<1>::BN;
+    const int     KT = K / BK;
+    if (!allowed || (S != 2 && S != 4) || ep.act != 0 || K % BK != 0 || KT / S < kMinKSteps) return EETQ_ERR_UNSUPPORTED;
+    const int tiles = ((rows + BM - 1) / BM) * ((cols + BN - 1) / BN);
+    float*    slabs = nullptr;
+    unsigned *t2 = nullptr, *t4 = nullptr;
+    size_t    slab_bytes = 0, max_tiles = 0;
+    int st = splitk_region(stream, &slabs, &slab_bytes, &t2, &t4, &max_tiles);
+    if (st == EETQ_ERR_UNSUPPORTED || (st == EETQ_OK && ((size_t)tiles > max_tiles || (size_t)tiles * S * BM * BN * 4 > slab_bytes)))
+        return EETQ_ERR_UNSUPPORTED;  // no scratch of its own for this stream right now
+    if (st != EETQ_OK) return st;
+    static std::atomic<unsigned long long> opted{0};
+    st = opt_in_large_lds(gemm_tile_splitk_kernel<1>, opted);
+    if (st != EETQ_OK) return st;
+    Epilogue e = ep;
+    if (e.bias) e.bias += c0;
+    if (e.residual) e.residual += c0;
+    const uint8_t* wc = w + (size_t)(c0 / kTileN) * (K / kTileK) * kTileBytes;
+    launch_kernel(gemm_tile_splitk_kernel<1>, dim3(tiles * S), dim3(256), TileCfg<1>::SMEM_BYTES, stream, x, wc, scales + c0, y + c0, rows,
+                  cols, K, ldc, e, S, slabs, S == 2 ? t2 : t4);
+    return check_hip(hipGetLastError(), "gemm_tile_splitk_kernel launch");
+}
+}  // namespace
+
 int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                      hipStream_t stream)
 {
@@ -103,7 +137,16 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
             if (cols1 > 0 && cols1 < N) {
                 int st = launch_cols(m, rows, 0, cols1, 2);
                 if (st != EETQ_OK) return st;
-                st = launch_cols(m, rows, cols1, N - cols1, 0);
+                // the ragged round: narrow tiles in TWO K slices when those fill the chip once -- half the loop for ~3.5 us of
+                // hand-over (M = 1024, N = 5120: 128 narrow tiles -> 256 workgroups of K / 2; K = 13824 164 -> ~135 us)
+                const int rem_tiles = tiles_m * ((N - cols1 + TileCfg<1>::BN - 1) / TileCfg<1>::BN);
+                st                  = EETQ_ERR_UNSUPPORTED;
+                if (rem_tiles * 2 <= n_cu && (K / BK) / 2 >= 40) {
+                    Epilogue e = ep;
+                    if (e.residual) e.residual += (size_t)m * N;
+                    st = launch_tile_splitk_cols(x + (size_t)m * K, w, scales, e, y + (size_t)m * N, rows, cols1, N - cols1, K, N, 2, stream);
+                }
+                if (st == EETQ_ERR_UNSUPPORTED) st = launch_cols(m, rows, cols1, N - cols1, 0);
                 if (st != EETQ_OK) return st;
                 continue;
             }

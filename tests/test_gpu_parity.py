@@ -339,6 +339,31 @@ def test_tile_splitk_vs_oracle_and_unsplit(ops, oracle, M, K, N):
     assert torch.equal(fused, (y1 + bias) + res)
 
 
+@pytest.mark.parametrize("M,K,N", [(1024, 5120, 5120), (1000, 13824, 5120), (512, 5120, 10240 + 128)])
+def test_mfma_ragged_last_round_runs_in_two_k_slices(ops, oracle, M, K, N):
+    """M = 1024 at N = 5120 is 320 wide tiles on 256 CUs: whole rounds run unsplit, the ragged round's columns as narrow tiles
+    in two K slices (gemm.hip).  Tier A against the oracle on sampled rows and against torch's fp32 matmul over the kernel's
+    fp16 dequantised weights everywhere; fused bias + residual bit-identical to separate adds; repeated launches identical."""
+    w, x = _rand_case(K, N, M, seed=M + K + N)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    rows = sorted(set([0, 127, 128, M // 2, M - 1]))
+    y1 = ops.w8_a16_gemm(xd, processed, scales, path="mfma")
+    y2 = ops.w8_a16_gemm(xd, processed, scales, path="mfma")
+    assert torch.equal(y1, y2)
+    got = y1.cpu().numpy()
+    assert _tier_a(got[rows], oracle.w8a16_gemm(x[rows], q, s)).all()
+    wdq = (torch.from_numpy(q).to(DEV).half() * scales[None, :]).float()
+    ref = xd.float() @ wdq
+    assert bool(((y1.float() - ref).abs() <= 1e-3 * ref.abs().max() + 2e-3 * ref.abs()).all())
+    g = torch.Generator(device=DEV); g.manual_seed(2)
+    bias = torch.rand(N, device=DEV, generator=g).half()
+    res = torch.rand(M, N, device=DEV, generator=g).half()
+    assert torch.equal(ops.w8_a16_gemm(xd, processed, scales, path="mfma", bias=bias, residual=res), (y1 + bias) + res)
+
+
 def test_tile_splitk_is_deterministic_across_launches_streams_and_graphs(ops, oracle):
     """The split form of the tiled kernel shares the split-K tickets (one array per slice count, monotonic): interleaved with
     split-K launches of the same slice counts, on two streams, and replayed from a HIP graph, every result is bit-identical
