@@ -280,6 +280,8 @@ int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, E
 // slices launch_gemm_tile_splitk would use (1 = it would run the unsplit tiled kernel)
 int tile_splitk_slices(int M, int N, int K);
 // library-owned scratch (eetq_release_workspace): each frees its buffers on every device and adds the bytes to *freed
+int launch_quantize_pack_i4_native(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_packed, void* scales,
+                                   const float* colmax, hipStream_t stream);  // quant.hip; UNSUPPORTED -> int4.hip's own route
 int release_splitk_workspace(size_t* freed);
 int release_w4a16_workspace(size_t* freed);
 

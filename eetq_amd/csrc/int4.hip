@@ -14,7 +14,8 @@
 // Native layout (gfx950, int4): 1 KiB tiles of 16 columns x 128 k, tiles ordered [n/16][k/128]; lane = ((k >> 5) & 3) * 16 +
 // (n & 15) holds the 32 k values of its column in 16 bytes; dword d holds k = 8d .. 8d+7 as unsigned nibbles q + 8 at nibble
 // positions [0, 4, 1, 5, 2, 6, 3, 7], so the four mask / shift extractions of the reference's converter yield the fp16 pairs
-// (k0,k1), (k2,k3), (k4,k5), (k6,k7) that v_dot2 wants.  Weight preparation is a one-off: its kernels are plain
+// (k0,k1), (k2,k3), (k4,k5), (k6,k7) that v_dot2 wants.  quant_weights in the native layout is two launches + a fill (column maxima,
+// then quant.hip's fused quantise + pack kernel); the other routes (sm80 layout, row-major copy, pack / unpack alone) are plain
 // one-thread-per-byte gathers, not tuned.
 #include <mutex>
 
@@ -271,6 +272,12 @@ int launch_quantize_i4(const void* w, int w_dtype, size_t K, size_t N, int8_t* q
     EETQ_REQUIRE(q_raw || q_packed, "null pointer");
     st = launch_colmax(w, w_dtype, K, N, colmax, stream);
     if (st != EETQ_OK) return st;
+    // native layout and no row-major copy asked for: one fused quantise + pack launch (quant.hip::quant_pack_kernel<T, 4>:
+    // LDS-DMA ring, column-major in registers, division-free but bit-exact) instead of quantise -> temporary -> gather
+    if (q_packed && !q_raw && layout == EETQ_LAYOUT_GFX950) {
+        st = launch_quantize_pack_i4_native(w, w_dtype, K, N, q_packed, scales, colmax, stream);
+        if (st != EETQ_ERR_UNSUPPORTED) return st;
+    }
     // the raw tensor is the pack kernel's source: the caller's buffer when it wants one, the output itself for ROW_MAJOR,
     // else a stream-ordered temporary
     uint8_t* raw = reinterpret_cast<uint8_t*>(q_raw);

@@ -9,6 +9,7 @@
 // copy that kernel is quant_pack_kernel (LDS-DMA ring, column-major in registers, division-free but bit-exact); the sm80
 // wire layout and the calls that also return the row-major int8 tensor use strip_quant_kernel (row-wise reads, the same
 // arithmetic, byte transpose through LDS).
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -112,6 +113,18 @@ __device__ __forceinline__ int8_t quantize_elt(float w, float s)
     return (int8_t)(int)lo;
 }
 
+// int4 (PACKED_INT4_WEIGHT_ONLY, :581-678): q = clamp(int(round(w / s)), -8, 7) with scale = amax / 8; int(NaN) / out of range is
+// INT_MIN on the reference's x86 hosts, i.e. -8.  Returns the unsigned nibble q + 8.
+__device__ __forceinline__ unsigned quantize_i4_elt(float w, float s)
+{
+    const float scaled = __builtin_roundf(w / s);
+    int         iw;
+    if (scaled != scaled || scaled >= 2147483648.f || scaled < -2147483648.f) iw = (int)0x80000000;
+    else iw = (int)scaled;
+    const int c = iw < -8 ? -8 : (iw > 7 ? 7 : iw);
+    return (unsigned)(c + 8);
+}
+
 // ---- the same result without a division ------------------------------------------------------------------------
 // Returns q + 128 as an integer-valued float in [0, 256] (256 = the reference's min(127, .) case, saturated by the
 // conversion to a byte).  r = rcp(s), trusted only for 1e-30 < s < 1e30 (the caller passes NaN otherwise).
@@ -127,13 +140,14 @@ __device__ __forceinline__ int8_t quantize_elt(float w, float s)
 // input only -- its lane is set in `gray`: the reference rounds the QUOTIENT to fp32 first, and it becomes the tie m itself
 // when 0 < |w / s - m| <= half an ulp of m, i.e. |z| <= s * 2^(exponent(m) - 24); fp16 inputs cannot get that close (two
 // 11-bit significands put w / s at least 2^-19 |m| away from an m it does not equal).
-template <typename T>
+// BIAS = 128 (int8: |w / s| <= 128) or 8 (int4: scale = max / 8, |w / s| <= 8, the error bound only shrinks).
+template <typename T, int BIAS = 128>
 __device__ __forceinline__ float quantize_biased_nodiv(T raw, float s, float r, float& nanacc, unsigned long long& gray)
 {
     const float wf = (float)raw;
-    const float b  = __builtin_fmaf(wf, r, 128.f);
+    const float b  = __builtin_fmaf(wf, r, (float)BIAS);
     const float f  = __builtin_floorf(b);
-    const float m  = f - 127.5f;
+    const float m  = f - ((float)BIAS - 0.5f);
     const float z  = __builtin_fmaf(m, s, -wf);
     int         bound;
     if constexpr (sizeof(T) == 2)
@@ -386,12 +400,18 @@ __device__ __forceinline__ void qp_dma16(__amdgpu_buffer_rsrc_t rsrc, int voff, 
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (qp_lds_void*)lds_wave_base, 16, voff, 0, 0, 0);
 }
 
-template <typename T>
+// BITS = 8: 64-row tiles, a lane reads 16 rows of its column.  BITS = 4: the int4 native tile is 16 columns x 128 k, a lane
+// holds 32 k values of its column (int4.hip): 128-row tiles, 32 rows per lane.
+template <typename T, int BITS = 8>
 struct QpCfg {
+    static constexpr int kRows      = BITS == 8 ? 64 : 128;     // rows of a tile
+    static constexpr int kLaneRows  = kRows / 4;                // rows a lane quantises: 16 / 32
     static constexpr int kRowBytes  = kQT * (int)sizeof(T);     // 128 / 256
     static constexpr int kRowsPerB  = 1024 / kRowBytes;         // rows per 1 KiB DMA block: 8 / 4
-    static constexpr int kBlocks    = kQT / kRowsPerB;          // DMA blocks per tile: 8 / 16
-    static constexpr int kPad       = sizeof(T) == 2 ? 32 : 16; // 16 rows apart = 16 banks apart for both element sizes
+    static constexpr int kBlocks    = kRows / kRowsPerB;        // DMA blocks per tile
+    // lanes g = 0..3 read rows kLaneRows apart: the pad puts them 16 banks apart (int8: both element sizes; int4: fp16 --
+    // fp32 input takes a two-way conflict there, a multiple of 16 bytes cannot avoid it)
+    static constexpr int kPad       = BITS == 8 ? (sizeof(T) == 2 ? 32 : 16) : 16;
     static constexpr int kBlockLds  = 1024 + kPad;
     static constexpr int kTileLds   = kBlocks * kBlockLds;
 };
@@ -401,13 +421,16 @@ struct QpCfg {
 // stores (one tile per workgroup and launch-wide lock-step phases -- everyone loads, then everyone computes, then everyone
 // stores -- measured 18 us at 4096^2 with 45 % fewer instructions than the row-major kernel's 17 us).  The column scales
 // (the reduction of the P row-block maxima) are computed once per workgroup, not once per tile.
-template <typename T>
+// BITS = 4: the same walk over the int4 native layout (`part` then holds the FINAL column maxima, P = 1: the int4 entry's
+// workspace is N floats), 32 rows per lane, nibbles q + 8 at positions [0, 4, 1, 5, 2, 6, 3, 7] of each dword (int4.hip).
+template <typename T, int BITS = 8>
 __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ src, unsigned K, unsigned N,
                                                          const float* __restrict__ part, int P,
                                                          uint8_t* __restrict__ q_packed, void* __restrict__ scales,
                                                          int scales_f32, int tiles_per_wg)
 {
-    using C = QpCfg<T>;
+    using C = QpCfg<T, BITS>;
+    constexpr int kRows = C::kRows, kLR = C::kLaneRows;
     constexpr int kPer = C::kBlocks / 4;  // DMA instructions per wave and tile
     // the ring is DYNAMIC LDS (2 * kTileLds bytes): with a static array hipcc puts an s_waitcnt vmcnt(0) in front of the
     // first LDS read after every LDS-DMA issue (it can name the object both touch), i.e. waits for the prefetched tile too
@@ -418,20 +441,20 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
     const int      wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int      lane = t & 63;
     const unsigned n0   = blockIdx.x * kQT;
-    const unsigned KT   = K / kQT;
+    const unsigned KT   = K / kRows;
     const unsigned kt0  = blockIdx.y * (unsigned)tiles_per_wg;
     const int      nt   = (int)(KT - kt0 < (unsigned)tiles_per_wg ? KT - kt0 : (unsigned)tiles_per_wg);
 
     // ---- tiles: HBM -> LDS.  The descriptor starts at this workgroup's first element, so offsets stay 32-bit for any
     // tensor size; a ragged last strip reads on into the next row (ignored columns) or past the end (zero-filled).
-    const size_t first = ((size_t)kt0 * kQT * N + n0) * sizeof(T);
+    const size_t first = ((size_t)kt0 * kRows * N + n0) * sizeof(T);
     const size_t left  = (size_t)K * N * sizeof(T) - first;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<T*>(src) + ((size_t)kt0 * kQT * N + n0), 0, left > 0xffffffffull ? (int)0xffffffffu : (int)left, 0x00020000);
+        const_cast<T*>(src) + ((size_t)kt0 * kRows * N + n0), 0, left > 0xffffffffull ? (int)0xffffffffu : (int)left, 0x00020000);
     constexpr int  kSegs    = C::kRowBytes / 16;  // 16-byte pieces per row
     const unsigned lane_off = ((unsigned)(lane / kSegs) + (unsigned)wave * (kPer * C::kRowsPerB)) * N * (unsigned)sizeof(T) +
                               (unsigned)(lane % kSegs) * 16u;
-    const unsigned tile_pitch = kQT * N * (unsigned)sizeof(T);
+    const unsigned tile_pitch = kRows * N * (unsigned)sizeof(T);
     auto issue = [&](int j, int slot) {
         uint8_t* base = tiles + slot * C::kTileLds + wave * kPer * C::kBlockLds;
 #pragma unroll
@@ -465,7 +488,7 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
         float a = cm[0][t];
 #pragma unroll
         for (int j = 1; j < 4; ++j) a = (a < cm[j][t]) ? cm[j][t] : a;
-        const float s32 = a * (1.f / 128.f);  // :633-634 scale = T(colmax * 2^-7), written once per column
+        const float s32 = a * (BITS == 8 ? 1.f / 128.f : 1.f / 8.f);  // :633-634 scale = T(colmax * 2^-7 | 2^-3), written once per column
         if (kt0 == 0 && n0 + t < N && scales) {
             if (scales_f32)
                 reinterpret_cast<float*>(scales)[n0 + t] = s32;
@@ -481,9 +504,9 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
     const int   g = lane >> 4, c = lane & 15;
     const int   col = wave * 16 + c;
     const float s = col_s[col], r = col_r[col];
-    // rows 16g .. 16g+15 start at block 16g / kRowsPerB; element (row, col) sits at row % kRowsPerB * kRowBytes + col * sizeof(T)
+    // rows kLR*g .. start at block kLR*g / kRowsPerB; element (row, col) sits at row % kRowsPerB * kRowBytes + col * sizeof(T)
     typedef __attribute__((address_space(3))) const T lds_cT;  // integer LDS addresses as in gemm_kernel.hpp::lds_read16
-    const int lbase = (int)(uint32_t)(uintptr_t)(qp_lds_void*)tiles + (16 * g / C::kRowsPerB) * C::kBlockLds + col * (int)sizeof(T);
+    const int lbase = (int)(uint32_t)(uintptr_t)(qp_lds_void*)tiles + (kLR * g / C::kRowsPerB) * C::kBlockLds + col * (int)sizeof(T);
     uint8_t* dst = q_packed + ((size_t)((n0 >> 4) + wave) * KT + kt0) * (size_t)kTileBytes + (size_t)lane * 16;
     u32x4 done = {0u, 0u, 0u, 0u};  // tile j-1's bytes, stored during step j
     for (int j = 0; j < nt; ++j) {
@@ -499,11 +522,11 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();  // everyone's pieces of tile j have landed
         if (live && j > 0) *reinterpret_cast<u32x4*>(dst + (size_t)(j - 1) * kTileBytes) = done;
-        T raw[16];
+        T raw[kLR];
         if (live) {
             const int lt = lbase + (j & 1) * C::kTileLds;
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
+            for (int i = 0; i < kLR; ++i)
                 raw[i] = *(lds_cT*)(uintptr_t)(uint32_t)(lt + (i / C::kRowsPerB) * C::kBlockLds + (i % C::kRowsPerB) * C::kRowBytes);
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -513,6 +536,25 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
         u32 d[4] = {0u, 0u, 0u, 0u};
         unsigned long long gray = 0;    // fp32 input only: lanes where the fp32 ROUNDING of w / s may land on a tie
         float              nanacc = r;  // NaN as soon as a w (or the column's reciprocal) is
+        if constexpr (BITS == 4) {
+#pragma unroll
+            for (int i = 0; i < kLR; ++i) {
+                // q + 8 in [0, 16]; 16 (w = +max of the column) is the reference's min(7, .): clamp, then the nibble goes to
+                // position (j >> 1) + 4 * (j & 1) of dword i / 8, j = i % 8
+                const float    q = __builtin_fminf(quantize_biased_nodiv<T, 8>(raw[i], s, r, nanacc, gray), 15.f);
+                constexpr int  kNib[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+                d[i >> 3] |= (unsigned)q << (4 * kNib[i & 7]);
+            }
+            if (nanacc != nanacc || ((gray >> lane) & 1)) {  // rare lanes: the reference's arithmetic verbatim
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    d[q] = 0u;
+                    constexpr int kNib[8] = {0, 4, 1, 5, 2, 6, 3, 7};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) d[q] |= quantize_i4_elt((float)raw[8 * q + e], s) << (4 * kNib[e]);
+                }
+            }
+        } else {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const float q = quantize_biased_nodiv<T>(raw[i], s, r, nanacc, gray);
@@ -530,6 +572,7 @@ __global__ __launch_bounds__(256) void quant_pack_kernel(const T* __restrict__ s
                 const u32 b3 = (uint8_t)quantize_elt((float)raw[4 * q + 3], s);
                 d[q]         = (b0 | (b1 << 8) | (b2 << 16) | (b3 << 24)) ^ 0x80808080u;
             }
+        }
         }
         done = u32x4{d[0], d[1], d[2], d[3]};
     }
@@ -745,6 +788,43 @@ int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_ra
     if (st != EETQ_OK) return st;
     if (raw_copy) EETQ_TRY_HIP(hipMemcpyAsync(raw_copy, raw_out, K * N, hipMemcpyDeviceToDevice, stream));
     return EETQ_OK;
+}
+
+// int4, native layout, no row-major copy: quantise + pack in one launch from the FINAL column maxima (launch_colmax).
+// EETQ_ERR_UNSUPPORTED (no message) when the 32-bit offsets of the kernel do not cover the tensor: the caller takes the
+// three-kernel route of int4.hip.
+int launch_quantize_pack_i4_native(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_packed, void* scales,
+                                   const float* colmax, hipStream_t stream)
+{
+    if (K % 128 != 0 || N % 16 != 0 || K >= 0x7fffffffull || N >= 0x7fffffffull) return EETQ_ERR_UNSUPPORTED;
+    const size_t esz    = w_dtype == EETQ_DTYPE_F16 ? 2 : 4;
+    const size_t strips = (N + kQT - 1) / kQT, KT = K / 128;
+    size_t       tpw    = (strips * KT + 511) / 512;  // about 512 workgroups, two to sixteen tiles each (as the int8 kernel)
+    tpw                 = tpw < 2 ? 2 : (tpw > 16 ? 16 : tpw);
+    if (tpw > KT) tpw = KT;
+    while (tpw > 1 && (tpw + 1) * 128 * N * esz >= 0x7fffffffull) --tpw;
+    if ((size_t)2 * 128 * N * esz >= 0x7fffffffull) return EETQ_ERR_UNSUPPORTED;
+    const dim3 grid((unsigned)strips, (unsigned)((KT + tpw - 1) / tpw));
+    uint8_t*   p = reinterpret_cast<uint8_t*>(q_packed);
+    if (w_dtype == EETQ_DTYPE_F16) {
+        quant_pack_kernel<f16, 4><<<grid, 256, 2 * QpCfg<f16, 4>::kTileLds, stream>>>(static_cast<const f16*>(w), (unsigned)K, (unsigned)N,
+                                                                                   colmax, 1, p, scales, 0, (int)tpw);
+    } else {
+        // 66.5 KiB of dynamic LDS: the per-kernel opt-in, for exactly that much (the kernel also has 1.5 KiB of static LDS, so
+        // common.hpp's "whole CU" request is refused for it)
+        static std::atomic<unsigned long long> opted{0};
+        int dev = 0;
+        EETQ_TRY_HIP(hipGetDevice(&dev));
+        const unsigned long long bit = 1ull << (dev & 63);
+        if (!(opted.load(std::memory_order_relaxed) & bit)) {
+            EETQ_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(quant_pack_kernel<float, 4>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * QpCfg<float, 4>::kTileLds));
+            opted.fetch_or(bit, std::memory_order_relaxed);
+        }
+        quant_pack_kernel<float, 4><<<grid, 256, 2 * QpCfg<float, 4>::kTileLds, stream>>>(static_cast<const float*>(w), (unsigned)K,
+                                                                                       (unsigned)N, colmax, 1, p, scales, 1, (int)tpw);
+    }
+    return check_hip(hipGetLastError(), "quant_pack_kernel (int4) launch");
 }
 
 int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream)

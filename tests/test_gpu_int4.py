@@ -42,6 +42,43 @@ def test_quant_weights_int4_bit_exact(ops, oracle, K, N, dtype):
         assert np.array_equal(sm.numpy(), oracle.sm80_pack_i4(q))     # the bytes the reference would have produced
 
 
+@pytest.mark.parametrize("dtype", [np.float16, np.float32])
+@pytest.mark.parametrize("K,N", [(256, 128), (384, 80), (4224, 64)])
+def test_quant_weights_int4_near_ties_native_layout_only(ops, oracle, dtype, K, N):
+    """quant_weights(..., quint4x2, return_unprocessed=False) in the native layout is ONE fused quantise + pack launch whose
+    quotient is fma(w, rcp(s), 8) with an exact sign test (quant.hip::quant_pack_kernel<T, 4>): bit-identical to the oracle on a
+    matrix made of rounding ties (k + 0.5) * amax / 8 and their neighbours, on NaN / inf / zero columns, a ragged last strip and
+    a 16-tile walk."""
+    rng = np.random.default_rng(K * 3 + N)
+    if dtype == np.float32:
+        amax = (10.0 ** rng.uniform(-3, 1, N)).astype(np.float32)
+        amax[1], amax[2] = 1e-36, 3e37
+    else:
+        amax = (2.0 ** rng.integers(-10, 4, N) * rng.choice([1.0, 1.5, 1.25], N)).astype(np.float16)
+        amax[1] = 2.0 ** -20
+    scale = amax.astype(np.float32) * np.float32(1.0 / 8.0)
+    k = rng.integers(-8, 8, (K, N)).astype(np.float32) + np.float32(0.5)
+    if dtype == np.float32:
+        off = (rng.choice([-1.0, 1.0], (K, N)) * 10.0 ** rng.uniform(-5.5, -3.5, (K, N))).astype(np.float32)
+        k[:, 1::2] += off[:, 1::2]
+    w = (k * scale[None, :]).astype(dtype)
+    step = rng.integers(-2, 3, (K, N))
+    for _ in range(2):
+        w = np.where(step > 0, np.nextafter(w, dtype(np.inf)), np.where(step < 0, np.nextafter(w, dtype(-np.inf)), w)).astype(dtype)
+    w = np.clip(w, -amax[None, :], amax[None, :]).astype(dtype)
+    w[rng.integers(0, K, N), np.arange(N)] = amax * rng.choice([-1, 1], N).astype(dtype)
+    w[5, 9] = np.nan
+    w[:, 6] = 0
+    w[17, 40] = np.inf
+    q, s = oracle.quantize_i4(w)
+    processed, scales = ops.quant_weights(torch.from_numpy(w).to(DEV), torch.quint4x2, False)
+    assert scales.cpu().numpy().tobytes() == s.tobytes()
+    got, ref = processed.cpu().numpy(), oracle.gfx950_pack_i4(q)
+    assert np.array_equal(got, ref), f"{int((got != ref).sum())} bytes differ"
+    raw = ops.quant_weights(torch.from_numpy(w).to(DEV), torch.quint4x2, True)[0]      # the three-kernel route agrees
+    assert np.array_equal(raw.cpu().numpy(), q)
+
+
 @pytest.mark.parametrize("layout", ["gfx950", "sm80"])
 @pytest.mark.parametrize("K,N", [(128, 64), (384, 256), (4096, 4096)])
 def test_preprocess_unprocess_int4(ops, oracle, layout, K, N):

@@ -15,19 +15,19 @@ def _fma(a, b, c):  # fp32 fma: the product of two fp32 is exact in fp64
     return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
 
 
-def _model(w, s, fp32_input, ulp):
+def _model(w, s, fp32_input, ulp, bias=128):
     w = w.astype(np.float32)
     s = np.broadcast_to(s.astype(np.float32), w.shape)
     with np.errstate(all="ignore"):
         r = (np.float32(1) / s).astype(np.float32)
     r = np.where(ulp > 0, np.nextafter(r, np.float32(np.inf)), np.where(ulp < 0, np.nextafter(r, np.float32(-np.inf)), r))
     r = r.astype(np.float32)
-    b = _fma(w, r, np.full_like(w, 128))
+    b = _fma(w, r, np.full_like(w, bias))
     f = np.floor(b)
-    m = (f - np.float32(127.5)).astype(np.float32)
+    m = (f - np.float32(bias - 0.5)).astype(np.float32)
     z = _fma(m, s, -w)
     up = z.view(np.int32) <= np.where(w < 0, -1, 0)
-    q = np.clip(f + up, 0, 255) - 128
+    q = np.clip(f + up, 0, 2 * bias - 1) - bias
     fallback = ~((s > 1e-30) & (s < 1e30)) | np.isnan(b)
     if fp32_input:
         hulp = ((m.view(np.int32) & 0x7F800000) - (24 << 23)).astype(np.int32).view(np.float32)
@@ -67,3 +67,24 @@ def test_division_free_rounding_equals_the_oracle(name, w):
     assert np.array_equal(q[keep], q_ref[keep]), f"{name}: {int((q[keep] != q_ref[keep]).sum())} elements differ"
     if w.dtype == np.float16:
         assert keep.all() or not np.isfinite(s).all() or (s <= 1e-30).any()
+
+
+@pytest.mark.parametrize("name,w", [m for m in _matrices() if "tiny" not in m[0]], ids=lambda v: v if isinstance(v, str) else "")
+def test_division_free_rounding_equals_the_oracle_int4(name, w):
+    """The int4 instantiation (quant_pack_kernel<T, 4>): scale = amax / 8, bias 8, nibble = q + 8 in [0, 15]."""
+    w = (w.astype(np.float32) * np.float32(1.0 / 16.0)).astype(w.dtype) if "ties" in name else w   # ties of amax / 8 as well
+    if w.shape[1] % 2:
+        w = w[:, :-1]
+    packed, _ = oracle.quantize_i4(w)                       # [K, N/2], even column in the low nibble, two's complement
+    lo = (packed.astype(np.uint8) & 0xF).astype(np.int8)
+    hi = (packed.astype(np.uint8) >> 4).astype(np.int8)
+    q_ref = np.empty(w.shape, np.int8)
+    q_ref[:, 0::2] = np.where(lo > 7, lo - 16, lo)
+    q_ref[:, 1::2] = np.where(hi > 7, hi - 16, hi)
+    amax = np.abs(w.astype(np.float32)).max(axis=0)
+    s = amax * np.float32(1 / 8)
+    rng = np.random.default_rng(len(name) + 4)
+    q, fallback = _model(w, s[None, :], w.dtype == np.float32, rng.integers(-1, 2, w.shape), bias=8)
+    keep = ~fallback
+    assert keep.mean() > 0.5
+    assert np.array_equal(q[keep], q_ref[keep]), f"{name}: {int((q[keep] != q_ref[keep]).sum())} elements differ"
