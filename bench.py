@@ -7,12 +7,13 @@ A "step" is one w8_a16_gemm call (one pass of the decode hot path over one batch
 (weight, scale) sets -- NBUF*16 MiB >= 512 MiB, so the weights come from HBM, not the 256 MB Infinity Cache.
 
   value      whole-job GB/s: algorithmic bytes (K*N + 2*M*K + 2*N + 2*M*N = 16 801 792 B/step) x steps x replicas / wall
-             time of the timed region.  K steps are captured as HIP graphs of dependent launches -- as many graphs as it
-             takes for their concatenation to visit every weight set equally (K = 20, NBUF = 40: two graphs) -- and the
-             timed region replays them round-robin until it is at least --min-timed-ms long (default 50 ms) whatever K is,
-             with barrier + synchronize on both sides and the MAX over ranks.  ms_per_step = region / (replays x K); the
-             line carries `timed_steps` (= replays x K) and `timed_ms` at top level, so ms_per_step x timed_steps = timed_ms
-             describes the timed region whatever --steps was.
+             time of the timed region.  The K-step sequence is captured, repeated, as ONE HIP graph of dependent
+             launches whose length does not depend on K: the smallest common multiple of K and NBUF that is >= 1000
+             launches (K = 20 and K = 2000, NBUF = 40: 1000 and 2000 launches), so the ~7 us between two graph replays is
+             spread over >= 1000 steps whatever the driver passes as --steps.  The timed region replays that graph until
+             it is at least --min-timed-ms long (default 50 ms), with barrier + synchronize on both sides and the MAX over
+             ranks.  ms_per_step = region / (replays x graph launches); the line carries `timed_steps` and `timed_ms` at
+             top level, so ms_per_step x timed_steps = timed_ms describes the timed region whatever --steps was.
              Includes the ~1.5-1.9 us dependent-kernel boundary of every step.
   roofline   dominant kernel (gemv_kernel): algorithmic bytes / kernel duration, where the duration is the timed region's
              own quantity -- K back-to-back dependent launches replayed as HIP graphs, divided by K (the rocprofv3 trace of
@@ -76,23 +77,36 @@ def make_weight_sets(ops, nbuf, K, N, dev):
     return sets, w0, lin
 
 
-def capture_graphs(fn, nsteps, nbuf):
-    """Graphs of `nsteps` dependent launches each; graph g runs steps [g*nsteps, (g+1)*nsteps).  Enough graphs that their
-    concatenation is a whole number of passes over the nbuf weight sets."""
-    count = nbuf // math.gcd(nsteps, nbuf)
+GRAPH_MIN_LAUNCHES = 1000   # a captured graph holds at least this many launches whatever --steps is
+
+
+def graph_length(nsteps, nbuf, min_launches=GRAPH_MIN_LAUNCHES):
+    """Launches per captured graph: the smallest common multiple of `nsteps` (so the timed region is a whole number of
+    K-step sequences) and `nbuf` (so every weight set is visited equally often) that is >= min_launches.  The length does
+    NOT shrink with --steps: a 20-launch graph spreads the ~7 us between two graph replays over 20 steps (+0.34 us per
+    4.6 us step, the round-3 driver line), a 1000-launch graph over 1000."""
+    unit = nsteps * nbuf // math.gcd(nsteps, nbuf)
+    if unit > 20000:   # odd --steps: keep whole K-step sequences, let the last pass over the sets be partial
+        unit = nsteps
+    return unit * max(1, -(-min_launches // unit))
+
+
+def capture_graphs(fn, nsteps, nbuf, min_launches=GRAPH_MIN_LAUNCHES):
+    """ONE graph of graph_length(nsteps, nbuf) dependent launches = the K-step sequence repeated, continuing the rotation
+    over the weight sets (step i uses set i % nbuf), so the graph is a whole number of K-step sequences and of passes over
+    the sets.  Returned as a list for timed_replays()."""
+    length = graph_length(nsteps, nbuf, min_launches)
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
         fn(0, 3)  # warm the capture stream / lazy init outside capture
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
-    graphs = []
-    for gi in range(count):
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            fn(gi * nsteps, nsteps)
-        graphs.append(g)
-    return graphs
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for first in range(0, length, nsteps):
+            fn(first, nsteps)
+    return [g], length
 
 
 def timed_replays(grp, graphs, nsteps, min_seconds):
@@ -120,6 +134,37 @@ def timed_replays(grp, graphs, nsteps, min_seconds):
             rounds = int(grp.max_over_ranks(float(rounds)))
         seconds = grp.timed(run)
     return seconds, rounds * len(graphs)
+
+
+def stamped_chain(grp, fn, nlaunches, min_seconds):
+    """Times `nlaunches` dependent launches issued by fn(first, count), captured as ONE graph between two clock-stamp
+    launches (eetq_diag_clock_stamp: 512 one-wave workgroups record XCC_ID, s_memtime = shader cycles, s_memrealtime =
+    100 MHz), replayed for >= min_seconds.  Returns (us per launch, effective shader clock in MHz = median over the XCDs of
+    d(memtime) / d(memrealtime) x 100 over the last replay, number of XCDs seen)."""
+    from eetq_amd import _lib
+    L = _lib.lib()
+    dev = grp.device
+    nwg = 512
+    a = torch.zeros(nwg * 4, dtype=torch.int64, device=dev)
+    b = torch.zeros(nwg * 4, dtype=torch.int64, device=dev)
+
+    def body(first, count):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(L.eetq_diag_clock_stamp(ctypes.c_void_p(a.data_ptr()), nwg, st))
+        fn(first, count)
+        _lib.check(L.eetq_diag_clock_stamp(ctypes.c_void_p(b.data_ptr()), nwg, st))
+    graphs, _ = capture_graphs(body, nlaunches, 1, nlaunches)
+    seconds, replays = timed_replays(grp, graphs, nlaunches, min_seconds)
+    sa = a.cpu().numpy().reshape(nwg, 4)
+    sb = b.cpu().numpy().reshape(nwg, 4)
+    mhz = []
+    for xcc in sorted(set(sa[:, 0].tolist()) & set(sb[:, 0].tolist())):
+        ra = sa[sa[:, 0] == xcc][0]
+        rb = sb[sb[:, 0] == xcc][0]
+        dt = float(rb[3] - ra[3])
+        if dt > 0:
+            mhz.append(float(rb[2] - ra[2]) / dt * 100.0)
+    return seconds * 1e6 / (replays * nlaunches), (float(np.median(mhz)) if mhz else None), len(mhz)
 
 
 def dispatch_kernel_time(run, nlaunches):
@@ -320,9 +365,9 @@ def main():
     # ---- timed region: W warm-up steps, then K-step graphs replayed for >= min_timed_ms ----
     gemv_steps(0, warmup)
     torch.cuda.synchronize()
-    graphs = capture_graphs(gemv_steps, steps, nbuf)
+    graphs, graph_len = capture_graphs(gemv_steps, steps, nbuf)
     seconds, replays = timed_replays(grp, graphs, steps, min_s)
-    timed_steps = replays * steps
+    timed_steps = replays * graph_len
     step_bytes = gemv_bytes(M, N, K)
     value = grp.world_size * timed_steps * step_bytes / seconds / 1e9
 
@@ -391,9 +436,9 @@ def main():
             same = all(torch.equal(chk[i], ops.w8_a16_gemm(x, sets[i][0], sets[i][1])) for i in range(G))
             grouped_steps(0, per_pass)
             torch.cuda.synchronize()
-            gg = capture_graphs(grouped_steps, 5 * per_pass, per_pass)
+            gg, gg_len = capture_graphs(grouped_steps, 5 * per_pass, per_pass, 200)
             gs, gr = timed_replays(grp, gg, 5 * per_pass, min_s)
-            n_prob = gr * 5 * per_pass * G
+            n_prob = gr * gg_len * G
             us = gs * 1e6 / n_prob
             grouped = {"what": "eetq_w8a16_gemv_grouped: %d independent M=1, N=K=4096 problems per dispatch (graph-replayed, rotating "
                                "over the same %d weight sets); NOT the headline configuration" % (G, nbuf),
@@ -416,9 +461,9 @@ def main():
 
     gemm_steps(0, 60)  # warm-up: lets the clocks settle under MFMA load
     torch.cuda.synchronize()
-    ggraphs = capture_graphs(gemm_steps, args.gemm_steps, nbuf)
+    ggraphs, ggraph_len = capture_graphs(gemm_steps, args.gemm_steps, nbuf, 400)
     gsec, greplays = timed_replays(grp, ggraphs, args.gemm_steps, min_s)
-    gtimed = greplays * args.gemm_steps
+    gtimed = greplays * ggraph_len
     flops = 2.0 * Mg * N * K
     g_step = gsec / gtimed
     gemm_roofline = {"kernel": "gemm_tile_kernel", "bound": "mfma", "achieved": round(flops / g_step / 1e12, 2),
@@ -430,6 +475,43 @@ def main():
                      "algorithmic_flops_per_launch": flops, "launches_timed": gtimed,
                      "whole_job_tflops": round(grp.world_size * gtimed * flops / gsec / 1e12, 2),
                      "ms_per_step": round(gsec * 1e3 / gtimed, 5), "timed_steps": gtimed}
+    # Evidence for "power-bound" in the driver-run line (rank 0; labelled extras, never `value`): the same kernel and launch
+    # sequence (a) as above, (b) on all-zero operands (q = 0, x = 0: nothing toggles), (c) on N(0, 0.02) weights (the shape of
+    # trained weights; the BASELINE recipe's U(+-1/sqrt(K)) quantises to UNIFORM int8, the worst case for switching energy),
+    # each between two device clock stamps: us per launch and the shader clock the chip held.  Every rank runs it (the timed
+    # regions hold barriers); rank 0's figures are reported.
+    if True:
+        nl = max(100, min(args.gemm_steps, 400))
+        zeros_w = torch.full((K, N), -128, dtype=torch.int8, device=dev)     # processed byte 0x80 = q 0
+        zeros_s = torch.ones(N, dtype=torch.float16, device=dev)
+        zeros_x = torch.zeros(Mg, K, dtype=torch.float16, device=dev)
+        gg3 = torch.Generator(device=dev)
+        gg3.manual_seed(5)
+        gsets = [ops.quant_weights((torch.randn(K, N, device=dev, generator=gg3) * 0.02).half(), torch.int8, False)
+                 for _ in range(8)]
+
+        def zero_steps(first, count):
+            for i in range(first, first + count):
+                ops.w8_a16_gemm_(zeros_x, zeros_w, zeros_s, yg[i % 2], Mg, N, K)
+
+        def gauss_steps(first, count):
+            for i in range(first, first + count):
+                w, s = gsets[i % len(gsets)]
+                ops.w8_a16_gemm_(xg, w, s, yg[i % 2], Mg, N, K)
+        diag = {}
+        for name, fn in (("uniform_int8_weights", gemm_steps), ("zero_operands", zero_steps),
+                         ("gaussian_weights_0p02", gauss_steps)):
+            fn(0, 40)
+            torch.cuda.synchronize()
+            us, mhz, nx = stamped_chain(grp, fn, nl, min_s)
+            diag[name] = {"us": round(us, 2), "frac": round(flops / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                          "effective_clock_mhz": round(mhz) if mhz else None, "xcds": nx}
+        diag["what"] = ("gemm_tile_kernel M=1024, N=K=4096, %d dependent launches per graph between two clock-stamp launches "
+                        "(s_memtime / s_memrealtime per XCD): `uniform_int8_weights` is the BASELINE recipe as timed above, "
+                        "`zero_operands` the same instruction stream with nothing toggling, `gaussian_weights_0p02` weights "
+                        "~ N(0, 0.02) (bell-shaped int8)" % nl)
+        gemm_roofline["power_check"] = diag
+        del gsets, zeros_w, zeros_x
     roofline["gemm_m1024"] = gemm_roofline
     gemm = {"metric": "dequant-GEMM TFLOPS @ M=1024, N=K=4096", "value": gemm_roofline["whole_job_tflops"],
             "unit": "TFLOP/s", "steps": args.gemm_steps, "timed_steps": gtimed,
@@ -505,8 +587,10 @@ def main():
             "config": {"workload": "w8a16 GEMV M=1, N=K=4096 (BASELINE configs[1]); %d distinct weight sets rotated (%d MiB)"
                                    % (nbuf, nbuf * K * N // (1 << 20)), "M": M, "N": N, "K": K,
                        "parallelism": "replicas x%d (no data-path collective)" % grp.world_size,
-                       "launch": "%d HIP graph(s) of %d dependent launches, replayed %d times (%d timed steps, %.1f ms)"
-                                 % (len(graphs), steps, replays, timed_steps, seconds * 1e3),
+                       "launch": "one HIP graph of %d dependent launches (= %d x the %d-step sequence, whole passes over the "
+                                 "weight sets; its length does not depend on --steps), replayed %d times (%d timed steps, "
+                                 "%.1f ms)" % (graph_len, graph_len // steps, steps, replays, timed_steps, seconds * 1e3),
+                       "graph_launches": graph_len,
                        "timed_steps": timed_steps, "timed_ms": round(seconds * 1e3, 3)},
             "roofline": roofline, "secondary": gemm, "cpu_baseline": cpu_baseline, "cpu_linear_fp16": cpu_linear,
             "parity": parity, "quantizer": quantizer, "config5": config5,

@@ -162,6 +162,11 @@ int eetq_diag_empty(void* sink, int grid, int block, void* stream)
     return launch_empty(static_cast<unsigned*>(sink), grid, block, static_cast<hipStream_t>(stream));
 }
 
+int eetq_diag_clock_stamp(unsigned long long* out, int grid, void* stream)
+{
+    return launch_clock_stamp(out, grid, static_cast<hipStream_t>(stream));
+}
+
 int eetq_device_supported(void)
 {
     int dev = 0;

@@ -22,7 +22,31 @@ __global__ __launch_bounds__(1024) void empty_kernel(unsigned* sink, int never)
 {
     if (never == 12345) sink[0] = threadIdx.x;
 }
+// one wave per workgroup; lane 0 records where it ran and both device clocks, read back to back:
+//   out[4b + 0] = XCC_ID (the XCD the workgroup landed on), [1] = HW_ID, [2] = s_memtime (one tick = one SHADER cycle,
+//   MI355X_MICROARCH.md), [3] = s_memrealtime (constant 100 MHz).  Two such launches around a chain of kernels give, per XCD,
+//   d(memtime) / d(memrealtime) x 100 MHz = the average shader clock the chip held over the chain.
+__global__ __launch_bounds__(64) void clock_stamp_kernel(unsigned long long* __restrict__ out)
+{
+    if (threadIdx.x != 0) return;
+    unsigned long long tm, tr;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm), "=s"(tr)::"memory");
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);    // hwreg(HW_REG_XCC_ID, 0, 4)
+    const unsigned hw  = __builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4);    // hwreg(HW_REG_HW_ID)
+    unsigned long long* o = out + (size_t)blockIdx.x * 4;
+    o[0] = xcc;
+    o[1] = hw;
+    o[2] = tm;
+    o[3] = tr;
+}
 }  // namespace
+
+int launch_clock_stamp(unsigned long long* out, int grid, hipStream_t stream)
+{
+    EETQ_REQUIRE(out && grid > 0 && grid <= 65536, "clock stamp: invalid arguments");
+    launch_kernel(clock_stamp_kernel, dim3((unsigned)grid), dim3(64), 0, stream, out);
+    return check_hip(hipGetLastError(), "clock_stamp_kernel launch");
+}
 
 int launch_empty(unsigned* sink, int grid, int block, hipStream_t stream)
 {

@@ -290,6 +290,11 @@ int eetq_diag_stream_read(const void* p, size_t bytes, void* sink, void* stream)
 /* Diagnostic: a kernel of `grid` x `block` threads that touches no memory (the fixed cost of a dispatch, and the resolution
  * floor of the timing method it is measured with). */
 int eetq_diag_empty(void* sink, int grid, int block, void* stream);
+/* Diagnostic: `grid` one-wave workgroups each record {XCC_ID, HW_ID, s_memtime (shader cycles), s_memrealtime (100 MHz)} into
+ * out[4 * workgroup .. +3] (DEVICE, grid * 4 uint64).  Two launches around a chain of kernels give the average shader clock
+ * the chip held over the chain, per XCD: d(memtime) / d(memrealtime) x 100 MHz (bench.py `effective_clock_mhz`: the
+ * evidence for "power-bound").  Graph-capturable. */
+int eetq_diag_clock_stamp(unsigned long long* out, int grid, void* stream);
 
 /* Decode steps on a pre-allocated KV cache (eetq_rope_decode_attention_f16, eetq_rotary_neox_kvcache_f16) whose new token
  * was NOT written because its cache row lies outside the cache (slot >= rows: the cache is full; or a negative position).

@@ -152,3 +152,32 @@ def test_bench_two_replicas_on_one_gpu_over_gloo():
     assert doc["parity"]["replicas_bit_identical"] is True
     # two replicas time-share one GPU here: the whole-job value is two replicas' bytes over the slower rank's time
     assert doc["value"] > 500 and doc["roofline"]["frac"] > 0
+
+
+def _bench_line(*args):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", *args, "--no-config5", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_step_time_does_not_depend_on_steps():
+    """The driver runs `bench.py --gpus 1 --steps 20 --warmup 5`; the builder's default is --steps 2000.  Both capture one graph
+    of >= 1000 dependent launches, so the per-step time of the headline (and of the M = 1024 leg) must not depend on --steps
+    (round 3: 4.97 vs 4.63 us, a 20-launch graph paying the inter-replay gap every 20 steps).  Back to back on one box; the
+    better of two tries each absorbs clock drift between the four processes."""
+    def best(*args):
+        docs = [_bench_line(*args) for _ in range(2)]
+        return min(docs, key=lambda d: d["ms_per_step"])
+    short = best("--steps", "20", "--warmup", "5")
+    long_ = best("--steps", "2000", "--warmup", "200")
+    assert short["steps"] == 20 and long_["steps"] == 2000
+    assert short["config"]["graph_launches"] >= 1000 and short["config"]["graph_launches"] % 20 == 0
+    assert short["timed_steps"] % short["config"]["graph_launches"] == 0
+    assert abs(short["ms_per_step"] * short["timed_steps"] - short["timed_ms"]) <= 1e-3 * short["timed_ms"] + 1e-3
+    a, b = short["ms_per_step"], long_["ms_per_step"]
+    assert abs(a - b) <= 0.03 * b, (a, b)
+    ga, gb = short["secondary"]["ms_per_step"], long_["secondary"]["ms_per_step"]
+    assert abs(ga - gb) <= 0.05 * gb, (ga, gb)      # the GEMM leg is clock / power sensitive: 5 %
