@@ -176,18 +176,31 @@ int eetq_device_supported(void)
     return std::string(prop.gcnArchName).rfind("gfx950", 0) == 0 ? 1 : 0;
 }
 
-int eetq_quantize_i8(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
-                     void* scales, float* workspace, void* stream)
+int eetq_quantize_i8_ws(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
+                        void* scales, float* workspace, size_t workspace_floats, void* stream)
 {
     if (!workspace) {
-        int st = colmax_scratch(quantize_workspace_floats(K, N), &workspace);
+        workspace_floats = quantize_workspace_floats(K, N);
+        int st           = colmax_scratch(workspace_floats, &workspace);
         if (st != EETQ_OK) return st;
     }
-    return launch_quantize(w, w_dtype, K, N, q_raw, q_packed, layout, scales, workspace,
+    return launch_quantize(w, w_dtype, K, N, q_raw, q_packed, layout, scales, workspace, workspace_floats,
                            static_cast<hipStream_t>(stream));
 }
 
+// The size-less entry of ABI revision 1: a caller-provided workspace is only known to hold the N floats that revision asked
+// for, so it takes the N-float route (zero fill + atomicMax maxima); NULL uses the library's buffer and the fast route.
+int eetq_quantize_i8(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
+                     void* scales, float* workspace, void* stream)
+{
+    return eetq_quantize_i8_ws(w, w_dtype, K, N, q_raw, q_packed, layout, scales, workspace, workspace ? N : 0, stream);
+}
+
+int eetq_abi_version(void) { return EETQ_AMD_ABI_VERSION; }
+
 size_t eetq_quantize_workspace_floats(size_t K, size_t N) { return quantize_workspace_floats(K, N); }
+
+int eetq_release_stream_workspace(void* stream) { return release_splitk_region(static_cast<hipStream_t>(stream)); }
 
 int eetq_release_workspace(size_t* bytes_freed)
 {
@@ -240,7 +253,7 @@ int eetq_quantize_i8_host(const void* w, int w_dtype, size_t K, size_t N, int8_t
     if (q_packed && (st = dpk.alloc(K * N))) return st;
     EETQ_TRY_HIP(hipMemcpy(dw.p, w, K * N * esz, hipMemcpyHostToDevice));
     st = launch_quantize(dw.p, w_dtype, K, N, static_cast<int8_t*>(draw.p), static_cast<int8_t*>(dpk.p), layout,
-                         dsc.p, static_cast<float*>(dmax.p), nullptr);
+                         dsc.p, static_cast<float*>(dmax.p), quantize_workspace_floats(K, N), nullptr);
     if (st != EETQ_OK) return st;
     EETQ_TRY_HIP(hipStreamSynchronize(nullptr));
     if (q_raw) EETQ_TRY_HIP(hipMemcpy(q_raw, draw.p, K * N, hipMemcpyDeviceToHost));
@@ -339,7 +352,7 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
         case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_MID: return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
-        case EETQ_PATH_SPLITK: return launch_gemm_splitk(xp, wp, sp, bp, yp, M, N, K, s);
+        case EETQ_PATH_SPLITK: return launch_gemm_splitk(xp, wp, sp, bp, yp, M, N, K, s, 0, 0, /*env_plan=*/true);
         case EETQ_PATH_TILESPLIT: return launch_gemm_tile_splitk(xp, wp, sp, bp, yp, M, N, K, s);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] unknown or unimplemented GEMM path");
     }

@@ -204,7 +204,7 @@ inline int opt_in_large_lds(Kern kern, std::atomic<unsigned long long>& done)
 
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------
 int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
-                    int layout, void* scales, float* workspace, hipStream_t stream);
+                    int layout, void* scales, float* workspace, size_t workspace_floats, hipStream_t stream);
 size_t quantize_workspace_floats(size_t K, size_t N);  // floats launch_quantize's workspace must hold
 int launch_pack(const int8_t* q_raw, size_t K, size_t N, int8_t* q_packed, int layout, hipStream_t stream);
 int launch_unpack(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, int layout, hipStream_t stream);
@@ -267,9 +267,11 @@ constexpr int kStreamMaxM = 64;
 constexpr int kMidMaxM    = 128;
 int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                     hipStream_t stream);
-// split-K form of the medium-batch tile (gemm_splitk.hip); force_nb / force_s (0 = planned) are tuning hooks
+// split-K form of the medium-batch tile (gemm_splitk.hip); force_nb / force_s (0 = planned) are tuning hooks; `env_plan`:
+// honour EETQ_AMD_SPLITK_PLAN (only the explicitly forced path EETQ_PATH_SPLITK does: tests and tuning -- AUTO launches
+// never read the environment)
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
-                       hipStream_t stream, int force_nb = 0, int force_s = 0);
+                       hipStream_t stream, int force_nb = 0, int force_s = 0, bool env_plan = false);
 void splitk_plan(int M, int N, int K, int* nb, int* s, int* stages);
 // the calling stream's own split-K scratch region (gemm_splitk.hip): slabs (*slab_bytes of them), one ticket array per slice
 // count (2 and 4), *max_tiles tickets each.  EETQ_ERR_UNSUPPORTED (no message) when the stream cannot have one right now.
@@ -284,6 +286,7 @@ int tile_splitk_slices(int M, int N, int K);
 int launch_quantize_pack_i4_native(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_packed, void* scales,
                                    const float* colmax, hipStream_t stream);  // quant.hip; UNSUPPORTED -> int4.hip's own route
 int release_splitk_workspace(size_t* freed);
+int  release_splitk_region(hipStream_t stream);
 int release_w4a16_workspace(size_t* freed);
 
 }  // namespace eetq

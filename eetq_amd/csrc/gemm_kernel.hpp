@@ -471,7 +471,9 @@ __device__ __forceinline__ void gemm_tile_body(
                             const u32x4 v = {__builtin_bit_cast(u32, f0), __builtin_bit_cast(u32, f1), __builtin_bit_cast(u32, f2),
                                              __builtin_bit_cast(u32, f3)};
                             // everything in the per-lane offset, soffset 0: hipcc then guards the store's data registers
-                            // itself (gemm_splitk_kernel.hpp has the story of the form it does not guard)
+                            // itself (gemm_splitk_kernel.hpp has the story of the form it does not guard); the build
+                            // disassembles this object and fails if a store's data register is rewritten too early or
+                            // the uniform part ever moves into an SGPR soffset (tools/check_store_hazard.py, Makefile)
                             __builtin_amdgcn_raw_buffer_store_b128(v, s_rsrc, slice * kSlabFloats * 4 + ((mt * J + j) * 4 + q) * 1024 + lane_off,
                                                                    0, /*sc1*/ 16);
                         }

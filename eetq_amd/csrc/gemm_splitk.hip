@@ -84,14 +84,9 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
         for (int i = 0; i < cap && !reg; ++i)
             if (!a.r[i].used && (a.r[i].base || !capturing)) reg = &a.r[i];
         if (!reg && capturing) return EETQ_ERR_UNSUPPORTED;
-        for (int i = 0; i < cap && !reg; ++i) {  // every region taken: one whose owner no longer exists can be reused
-            const hipError_t q = hipStreamQuery(a.r[i].owner);
-            if (q != hipSuccess && q != hipErrorNotReady) {
-                (void)hipGetLastError();
-                EETQ_TRY_HIP(hipDeviceSynchronize());
-                reg = &a.r[i];
-            }
-        }
+        // every region taken: this stream runs unsplit.  Nothing is inferred about the owners (a stream that is capturing
+        // on another thread, or a destroyed one whose captured graphs are still replayed, must keep its region):
+        // regions come back only through eetq_release_stream_workspace / eetq_release_workspace.
         if (!reg) return EETQ_ERR_UNSUPPORTED;
         if (!reg->base) EETQ_TRY_HIP(alloc_region(*reg));
         reg->used    = true;
@@ -197,6 +192,28 @@ int splitk_region(hipStream_t stream, float** slabs, size_t* slab_bytes, unsigne
     return EETQ_OK;
 }
 
+// gives the region `stream` owns back to the pool (it stays allocated and becomes the spare a graph capture can take);
+// the stream is synchronised first.  EETQ_OK whether or not the stream owned one.
+int release_splitk_region(hipStream_t stream)
+{
+    int dev = 0;
+    EETQ_TRY_HIP(hipGetDevice(&dev));
+    {
+        std::lock_guard<std::mutex> lock(g_mutex);
+        bool owns = false;
+        for (Region& r : g_arena[dev & 63].r) owns |= r.used && r.owner == stream;
+        if (!owns) return EETQ_OK;
+    }
+    EETQ_TRY_HIP(hipStreamSynchronize(stream));
+    std::lock_guard<std::mutex> lock(g_mutex);
+    for (Region& r : g_arena[dev & 63].r)
+        if (r.used && r.owner == stream) {
+            r.used  = false;
+            r.owner = nullptr;
+        }
+    return EETQ_OK;
+}
+
 int release_splitk_workspace(size_t* freed)
 {
     std::lock_guard<std::mutex> lock(g_mutex);
@@ -262,7 +279,7 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out)
 }
 
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
-                       hipStream_t stream, int force_nb, int force_s)
+                       hipStream_t stream, int force_nb, int force_s, bool env_plan)
 {
     if (M < 1 || M > kMidMaxM) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] split-K tile path supports 1 <= M <= 128");
     EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31),
@@ -273,8 +290,9 @@ int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilog
     if (force_s) s = force_s;
     if (force_nb || force_s) stages = ((M + 31) / 32 <= 2 && ((N + 32 * nb - 1) / (32 * nb)) * s <= device_cu_count()) ? 3 : 2;
     int ring = 11 * stages;  // shared ring of round 2: SA = SB = stages
-    // EETQ_AMD_SPLITK_PLAN="nb,s,ring" (ring = 10 * SA + SB) overrides the plan: tuning and tests of every instantiation
-    if (const char* e = getenv("EETQ_AMD_SPLITK_PLAN")) {
+    // EETQ_AMD_SPLITK_PLAN="nb,s,ring" (ring = 10 * SA + SB) overrides the plan of the FORCED path only (EETQ_PATH_SPLITK:
+    // tuning and tests of every instantiation); production (AUTO) launches never read the environment
+    if (const char* e = env_plan ? getenv("EETQ_AMD_SPLITK_PLAN") : nullptr) {
         int a = 0, b = 0, c = 0;
         if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
             nb   = a;

@@ -673,12 +673,20 @@ size_t quantize_workspace_floats(size_t K, size_t N) { return N * ((K + kRowsPer
 namespace {
 template <typename T, int V>
 int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_t* packed_out, int layout, void* scales,
-                          int scales_f32, float* part, hipStream_t stream)
+                          int scales_f32, float* part, bool final_maxima, hipStream_t stream)
 {
-    const unsigned P = (unsigned)((K + kRowsPerBlock - 1) / kRowsPerBlock);
-    colmax_kernel<T, V, true><<<dim3((unsigned)((N + 64 * V - 1) / (64 * V)), P), 64 * kColmaxWaves, 0, stream>>>(
-        w, K, N, reinterpret_cast<u32*>(part));
-    int st = check_hip(hipGetLastError(), "colmax_kernel launch");
+    unsigned P = (unsigned)((K + kRowsPerBlock - 1) / kRowsPerBlock);
+    int      st;
+    if (final_maxima) {
+        // the caller's workspace holds N floats only (the contract of the first ABI revision): zero fill + atomicMax on the
+        // bit patterns leave the FINAL maxima in row 0 -- same values, one memset node more, a few us slower
+        st = launch_colmax(w, std::is_same<T, float>::value ? EETQ_DTYPE_F32 : EETQ_DTYPE_F16, K, N, part, stream);
+        P  = 1;
+    } else {
+        colmax_kernel<T, V, true><<<dim3((unsigned)((N + 64 * V - 1) / (64 * V)), P), 64 * kColmaxWaves, 0, stream>>>(
+            w, K, N, reinterpret_cast<u32*>(part));
+        st = check_hip(hipGetLastError(), "colmax_kernel launch");
+    }
     if (st != EETQ_OK) return st;
     // by default every pack workgroup reduces the P rows of maxima itself (two launches per call); EETQ_AMD_QUANT_FOLD=1
     // folds them into row 0 with a small launch of their own first (measured slower: one more launch costs more than the
@@ -758,16 +766,19 @@ int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_
 }
 }  // namespace
 
-// `workspace`: quantize_workspace_floats(K, N) floats.  Launches: row-block maxima (no atomics, no zero fill), the fold of
-// those rows, quantise + pack.
+// `workspace`: `workspace_floats` floats.  >= quantize_workspace_floats(K, N): row-block maxima (no atomics, no zero fill),
+// then quantise + pack (each pack workgroup folds the rows of maxima of its columns).  >= N only (what the first revision
+// of the ABI asked for): zero fill + atomicMax maxima, then quantise + pack.  Fewer: EETQ_ERR_INVALID, nothing launched.
 int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed, int layout,
-                    void* scales, float* workspace, hipStream_t stream)
+                    void* scales, float* workspace, size_t workspace_floats, hipStream_t stream)
 {
     int st = check_layout_shape(K, N, q_packed ? layout : EETQ_LAYOUT_ROW_MAJOR);
     if (st != EETQ_OK) return st;
     EETQ_REQUIRE(w && scales && workspace, "null pointer");
     EETQ_REQUIRE(w_dtype == EETQ_DTYPE_F16 || w_dtype == EETQ_DTYPE_F32,
                  "Invalid datatype. Weight must be FP16 or FP32");
+    EETQ_REQUIRE(workspace_floats >= N, "quantise: the workspace holds fewer than N floats");
+    const bool final_maxima = workspace_floats < quantize_workspace_floats(K, N);
     // ROW_MAJOR "packed" output is just the raw tensor again
     int8_t* raw_out    = q_raw;
     int8_t* packed_out = q_packed;
@@ -781,10 +792,10 @@ int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_ra
     }
     if (w_dtype == EETQ_DTYPE_F16)
         st = launch_quantize_typed<f16, 8>(static_cast<const f16*>(w), K, N, raw_out, packed_out, layout, scales, 0, workspace,
-                                           stream);
+                                           final_maxima, stream);
     else
         st = launch_quantize_typed<float, 4>(static_cast<const float*>(w), K, N, raw_out, packed_out, layout, scales, 1,
-                                             workspace, stream);
+                                             workspace, final_maxima, stream);
     if (st != EETQ_OK) return st;
     if (raw_copy) EETQ_TRY_HIP(hipMemcpyAsync(raw_copy, raw_out, K * N, hipMemcpyDeviceToDevice, stream));
     return EETQ_OK;

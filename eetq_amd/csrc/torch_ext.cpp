@@ -88,9 +88,9 @@ std::vector<Tensor> quant_weights(const Tensor& weight, py::object quant_type, b
     if (!int4) {
         if (return_unprocessed_quantized_tensor) raw = torch::empty({(int64_t)K, (int64_t)N}, i8);
         processed = torch::empty({(int64_t)K, (int64_t)N}, i8);
-        check(eetq_quantize_i8(w_dev.data_ptr(), st == at::kHalf ? EETQ_DTYPE_F16 : EETQ_DTYPE_F32, K, N,
-                               raw.defined() ? raw.data_ptr<int8_t>() : nullptr, processed.data_ptr<int8_t>(), lay,
-                               scales.data_ptr(), colmax.data_ptr<float>(), stream_of(w_dev)));
+        check(eetq_quantize_i8_ws(w_dev.data_ptr(), st == at::kHalf ? EETQ_DTYPE_F16 : EETQ_DTYPE_F32, K, N,
+                                  raw.defined() ? raw.data_ptr<int8_t>() : nullptr, processed.data_ptr<int8_t>(), lay,
+                                  scales.data_ptr(), colmax.data_ptr<float>(), (size_t)colmax.numel(), stream_of(w_dev)));
     } else {
         // packed int4: two values per byte along N (reference output shape [K, N/2], fpA_intB_gemm_wrapper.cu:60-66)
         TORCH_CHECK(N % 2 == 0, "int4 quantization needs an even number of columns");

@@ -105,9 +105,9 @@ def quant_weights(origin_weight, quant_type, return_unprocessed_quantized_tensor
         processed = torch.empty((K, N), dtype=torch.int8, device=dev)
         scales = torch.empty((N,), dtype=weight.dtype, device=dev)
         colmax = torch.empty((_lib.lib().eetq_quantize_workspace_floats(K, N),), dtype=torch.float32, device=dev)
-        check(_lib.lib().eetq_quantize_i8(
+        check(_lib.lib().eetq_quantize_i8_ws(
             _ptr(w_dev), DTYPE_F16 if weight.dtype == torch.float16 else DTYPE_F32, K, N,
-            _ptr(raw) if raw is not None else None, _ptr(processed), lay, _ptr(scales), _ptr(colmax),
+            _ptr(raw) if raw is not None else None, _ptr(processed), lay, _ptr(scales), _ptr(colmax), colmax.numel(),
             _stream_ptr()))
         if not weight.is_cuda:
             processed, scales = processed.cpu(), scales.cpu()
@@ -352,7 +352,6 @@ def layernorm_forward(input, gamma, out, eps):
     return None
 
 
-@_eager_only
 class _GemvProblem(ctypes.Structure):   # eetq_gemv_problem (include/eetq_amd.h)
     _fields_ = [("x", ctypes.c_void_p), ("w_packed", ctypes.c_void_p), ("scales", ctypes.c_void_p), ("y", ctypes.c_void_p),
                 ("bias", ctypes.c_void_p), ("residual", ctypes.c_void_p), ("N", ctypes.c_int), ("K", ctypes.c_int)]
@@ -407,6 +406,7 @@ def w8_a16_gemv_grouped(inputs, weights, scales, biases=None, residuals=None):
     return outs
 
 
+@_eager_only
 def rotary_embedding_neox(positions, query, key, head_size, cos_sin_cache):
     """In-place NeoX rotary embedding of query/key (reference: pos_encoding_kernels.cu:55-87): float16, float32, float64."""
     dts = {torch.float16: 0, torch.float32: 1, torch.float64: 2}

@@ -7,3 +7,4 @@ from .accelerator import (eet_accelerator, replace_with_eet_fp16_fused_attn, rep
 from .graph_decoder import GraphDecoder  # noqa: F401,E402
 from ..checkpoint import (checkpoint_layout, convert_checkpoint, convert_model_layout_, get_wire_layout,  # noqa: F401,E402
                          quantization_config, set_wire_layout, wire_layout)
+from .hf import use_with_transformers  # noqa: F401,E402

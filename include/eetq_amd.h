@@ -64,10 +64,21 @@ enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SIL
  * All pointers are DEVICE pointers.  `scales` has dtype `w_dtype` and N elements.
  * Two launches: per-row-block column maxima (plain stores: no atomics, no zero fill), then quantise + pack (every pack
  * workgroup reduces the rows of maxima for its 64 columns).
- * `workspace` must provide eetq_quantize_workspace_floats(K, N) floats (device; = N * ceil(K / 128): one row of
- * partial maxima per 128 weight rows); pass NULL to let the library use an internal buffer (one per device,
- * allocated once and grown on demand, freed by eetq_release_workspace: calls that pass NULL must not overlap on
- * one device -- concurrent streams bring their own workspace, as both Python bindings do). */
+ * eetq_quantize_i8_ws (ABI revision 2): `workspace` holds `workspace_floats` floats (device).
+ *   >= eetq_quantize_workspace_floats(K, N) (= N * ceil(K / 128): one row of partial maxima per 128 weight rows): the
+ *      two-launch route above;
+ *   >= N: a zero fill + atomicMax maxima launch instead of the partial rows (same bytes out, a few us slower);
+ *   <  N: EETQ_ERR_INVALID, nothing is launched.
+ *   workspace = NULL: the library uses an internal buffer (one per device, allocated once and grown on demand, freed by
+ *   eetq_release_workspace: calls that pass NULL must not overlap on one device -- concurrent streams bring their own
+ *   workspace, as both Python bindings do); workspace_floats is ignored then.
+ * eetq_quantize_i8 (ABI revision 1, kept): no size argument, and revision 1 documented the workspace as N floats -- a
+ *   caller-provided workspace is therefore treated as exactly N floats (the atomicMax route); NULL as above.  Callers that
+ *   allocate eetq_quantize_workspace_floats() floats should move to eetq_quantize_i8_ws to get the faster route. */
+#define EETQ_AMD_ABI_VERSION 2
+int eetq_abi_version(void);   /* EETQ_AMD_ABI_VERSION of the loaded library */
+int eetq_quantize_i8_ws(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
+                        int layout, void* scales, float* workspace, size_t workspace_floats, void* stream);
 int eetq_quantize_i8(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
                      int layout, void* scales, float* workspace, void* stream);
 size_t eetq_quantize_workspace_floats(size_t K, size_t N);
@@ -312,6 +323,11 @@ int eetq_decode_dropped_steps(unsigned long long* count, int reset);
  * bytes freed (bytes_freed may be NULL); later calls re-create what they need.  Do not call it while a HIP graph that
  * captured a split-K or W4A16 launch is still going to be replayed. */
 int eetq_release_workspace(size_t* bytes_freed);
+/* Gives the split-K region owned by `stream` (current device) back to the pool after synchronising the stream; call it
+ * before destroying a stream that ran 17 <= M <= 128 GEMMs, unless HIP graphs captured on it are still going to be
+ * replayed.  The library never reclaims a region on its own: once all regions are owned, further streams run the unsplit
+ * kernels.  EETQ_OK also when the stream owns nothing. */
+int eetq_release_stream_workspace(void* stream);
 
 /* ---- misc ------------------------------------------------------------------------------------------ */
 const char* eetq_last_error(void);   /* thread-local, never NULL */

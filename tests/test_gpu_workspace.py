@@ -83,3 +83,84 @@ def test_quantize_null_workspace_and_release():
     freed = ctypes.c_size_t(0)
     _lib.check(L.eetq_release_workspace(ctypes.byref(freed)))
     assert freed.value >= 65536 * 4
+
+
+@pytest.mark.parametrize("K,N", [(1024, 512), (4096, 4096)])
+def test_quantize_workspace_contract_of_both_abi_revisions(oracle, K, N):
+    """ABI revision 1 documented the quantiser's workspace as N floats and had no size argument; revision 2 wants
+    N * ceil(K / 128) for the fast route.  A caller built against revision 1 must not get out-of-bounds writes: the size-less
+    entry treats a caller workspace as N floats (atomicMax route), eetq_quantize_i8_ws validates the size it is told.
+    Every route gives the oracle's bytes; a guard band behind the N floats stays untouched."""
+    from eetq_amd import _lib
+    L = _lib.lib()
+    assert L.eetq_abi_version() >= 2
+    torch.manual_seed(K)
+    w = ((torch.rand(K, N) - 0.5) * 0.2).half()
+    q_ref, s_ref = oracle.quantize(w.numpy())
+    want = oracle.gfx950_pack(q_ref)
+    wd = w.to(DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    full = L.eetq_quantize_workspace_floats(K, N)
+    assert full == N * ((K + 127) // 128) and full > N
+    guard = 7.25
+
+    def run(entry, ws_floats):
+        ws = torch.full((full + 64,), guard, dtype=torch.float32, device=DEV)
+        q = torch.zeros(K, N, dtype=torch.int8, device=DEV)
+        s = torch.zeros(N, dtype=torch.float16, device=DEV)
+        if entry == "v1":
+            st = L.eetq_quantize_i8(p(wd), _lib.DTYPE_F16, K, N, None, p(q), _lib.LAYOUT_GFX950, p(s), p(ws), stream)
+        else:
+            st = L.eetq_quantize_i8_ws(p(wd), _lib.DTYPE_F16, K, N, None, p(q), _lib.LAYOUT_GFX950, p(s), p(ws), ws_floats,
+                                       stream)
+        torch.cuda.synchronize()
+        return st, q, s, ws
+
+    for entry, floats in (("v1", N), ("v2", N), ("v2", full - 1), ("v2", full)):
+        st, q, s, ws = run(entry, floats)
+        assert st == 0, (entry, floats, L.eetq_last_error())
+        assert np.array_equal(q.cpu().numpy(), want), (entry, floats)
+        assert s.cpu().numpy().tobytes() == s_ref.tobytes()
+        used = N if floats < full else full
+        assert bool((ws[used:] == guard).all()), (entry, floats)          # nothing written behind what the caller owns
+    st, q, s, ws = run("v2", N - 1)
+    assert st != 0 and b"workspace" in L.eetq_last_error()
+    assert bool((ws == guard).all()) and not q.any()                      # rejected before any launch
+
+
+def test_release_stream_workspace_returns_a_region_to_the_pool(ops):
+    """Regions are never reclaimed by guessing (a stream that is capturing elsewhere, or a destroyed stream whose graphs are
+    still replayed, keeps its region): a stream that found none runs unsplit until some owner hands its region back with
+    eetq_release_stream_workspace."""
+    from eetq_amd import _lib
+    L = _lib.lib()
+    _lib.check(L.eetq_release_workspace(None))
+    torch.manual_seed(4)
+    K, N, M = 4096, 4096, 64
+    w = (torch.rand(K, N, device=DEV) - 0.5).half() * 0.05
+    qw, s = ops.quant_weights(w, torch.int8, False)
+    x = torch.rand(M, K, dtype=torch.float16, device=DEV)
+    ref = ops.w8_a16_gemm(x, qw, s)                           # default stream: owns region 0, split plan
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(17)]
+    outs = []
+    for st in streams:
+        st.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(st):
+            outs.append(ops.w8_a16_gemm(x, qw, s))
+    torch.cuda.synchronize()
+    for o in outs[:15]:
+        assert torch.equal(o, ref)                            # own region, same plan: same bits
+    for o in outs[15:]:
+        assert _close(o, ref)                                 # no region left: unsplit kernel
+    sp = lambda st: ctypes.c_void_p(st.cuda_stream)
+    _lib.check(L.eetq_release_stream_workspace(sp(streams[16])))      # owns nothing: fine
+    _lib.check(L.eetq_release_stream_workspace(sp(streams[0])))
+    with torch.cuda.stream(streams[16]):
+        late = ops.w8_a16_gemm(x, qw, s)
+    with torch.cuda.stream(streams[1]):
+        keep = ops.w8_a16_gemm(x, qw, s)
+    torch.cuda.synchronize()
+    assert torch.equal(late, ref) and torch.equal(keep, ref)
+    _lib.check(L.eetq_release_workspace(None))

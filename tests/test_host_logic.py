@@ -321,3 +321,34 @@ def test_eetq_py_shim_serves_both_boundaries(monkeypatch):
     monkeypatch.undo()
     compiled = run_shim("EETQ_shim_compiled")
     assert all(callable(getattr(compiled, n)) for n in names) and hasattr(compiled, "__eetq_amd_version__")
+
+
+def test_transformers_hook_redirects_the_kernel_lookup():
+    """eetq_amd.utils.hf.use_with_transformers(): transformers' replace_with_eetq_linear fetches its kernel module with
+    get_kernel("kernels-community/quantization-eetq") (needs the `kernels` package and a network); after the hook that
+    lookup, the module-level handle and the quantizer's environment check resolve to this repo's EETQ module, other kernels
+    are still looked up the stock way, and every EetqLinear carries the wire-format save hook.  No GPU needed: the modules
+    are created on the meta device, as transformers does."""
+    transformers = pytest.importorskip("transformers")
+    import torch
+    from eetq_amd.utils.hf import HUB_KERNEL_NAME, use_with_transformers
+    mod = use_with_transformers()
+    assert use_with_transformers() is mod                       # idempotent
+    import transformers.integrations.eetq as hf_eetq
+    import transformers.integrations.hub_kernels as hub
+    import transformers.quantizers.quantizer_eetq as hf_q
+    assert hub.get_kernel(HUB_KERNEL_NAME, version=1) is mod
+    assert hf_q.is_kernels_available() is True
+    for name in ("quant_weights", "w8_a16_gemm"):               # the two functions transformers calls
+        assert callable(getattr(mod, name))
+    with pytest.raises(Exception):
+        hub.get_kernel("kernels-community/some-other-kernel")   # still the stock path (no `kernels` package here)
+    cfg = transformers.LlamaConfig(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
+                                   num_key_value_heads=2, vocab_size=100)
+    with torch.device("meta"):
+        model = transformers.LlamaForCausalLM(cfg)
+    model = hf_eetq.replace_with_eetq_linear(model, modules_to_not_convert=["lm_head"])
+    assert hf_eetq.eetq_kernels_hub is mod
+    lins = [m for m in model.modules() if isinstance(m, hf_eetq.EetqLinear)]
+    assert len(lins) == 7 and all(getattr(m, "_eetq_layout_hooks", False) for m in lins)
+    assert isinstance(model.lm_head, torch.nn.Linear)
