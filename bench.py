@@ -113,11 +113,11 @@ def timed_replays(grp, graphs, nsteps, min_seconds):
     """Replays the graphs round-robin for >= min_seconds (a whole number of rounds); returns (seconds, replays)."""
     for g in graphs:  # one untimed replay each: graph upload
         g.replay()
-    torch.cuda.synchronize()
+    grp.synchronize()
     t0 = time.perf_counter()
     for g in graphs:
         g.replay()
-    torch.cuda.synchronize()
+    grp.synchronize()
     est = max((time.perf_counter() - t0) / len(graphs), 1e-6)      # seconds per replay (incl. launch latency: an upper bound)
     rounds = max(1, int(math.ceil(min_seconds / est / len(graphs))))
     if grp.world_size > 1:  # every rank must time the same amount of work

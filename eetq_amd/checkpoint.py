@@ -109,7 +109,7 @@ class _SaveHook:
     def __call__(self, mod, state_dict, prefix, local_metadata):
         key = prefix + self.weight_name
         t = state_dict.get(key)
-        if t is None or t.dtype != torch.int8 or not t.numel():
+        if t is None or t.dtype != torch.int8 or not t.numel() or t.is_meta:   # meta: a skeleton being loaded, no bytes yet
             return
         dst = _wire[0] if _wire_holds(t.shape) else "gfx950"
         if dst != "gfx950":
@@ -130,7 +130,7 @@ class _LoadHook:
     def __call__(self, mod, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
         key = prefix + self.weight_name
         t = state_dict.get(key)
-        if t is None or not isinstance(t, torch.Tensor) or t.dtype != torch.int8 or not t.numel():
+        if t is None or not isinstance(t, torch.Tensor) or t.dtype != torch.int8 or not t.numel() or t.is_meta:
             return
         src = (local_metadata or {}).get(_META_KEY) or getattr(mod, "checkpoint_layout", None) or _wire[0]
         state_dict[key] = _reencode(t, _check(src), "gfx950")

@@ -41,6 +41,16 @@ class ReplicaGroup:
             dist.init_process_group(self.backend, rank=self.rank, world_size=self.world_size, **kw)
             self._own_pg = True
 
+    @property
+    def collective_device(self):
+        """Where the tensors handed to the collectives live: RCCL ("nccl") only moves device memory, so they sit on this
+        replica's GPU; gloo moves host memory."""
+        return self.device if self.backend == "nccl" else torch.device("cpu")
+
+    def synchronize(self):
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+
     # ---- collectives (no-ops for a single replica) ----
     def fan_out(self, tensor, src=0):
         """Every replica receives rank ``src``'s tensor (identical prompts / activations)."""
@@ -51,13 +61,12 @@ class ReplicaGroup:
     def barrier(self):
         if self.world_size > 1:
             dist.barrier()
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
+        self.synchronize()
 
     def max_over_ranks(self, seconds):
         if self.world_size == 1:
             return float(seconds)
-        t = torch.tensor([seconds], dtype=torch.float64, device=self.device if self.backend == "nccl" else "cpu")
+        t = torch.tensor([seconds], dtype=torch.float64, device=self.collective_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -66,8 +75,7 @@ class ReplicaGroup:
         self.barrier()
         t0 = time.perf_counter()
         fn()
-        if self.device.type == "cuda":
-            torch.cuda.synchronize(self.device)
+        self.synchronize()
         t1 = time.perf_counter()
         local = t1 - t0
         self.barrier()
@@ -78,7 +86,7 @@ class ReplicaGroup:
         crc = zlib.crc32(tensor.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes()) & 0xFFFFFFFF
         if self.world_size == 1:
             return [crc]
-        t = torch.tensor([crc], dtype=torch.int64, device=self.device if self.backend == "nccl" else "cpu")
+        t = torch.tensor([crc], dtype=torch.int64, device=self.collective_device)
         out = [torch.zeros_like(t) for _ in range(self.world_size)]
         dist.all_gather(out, t)
         return [int(o.item()) for o in out]
