@@ -411,6 +411,12 @@ int eetq_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, in
 int eetq_w4a16_gemm(const void* x, const int8_t* w_packed, const void* scales, const void* bias, const void* residual,
                     void* y, int M, int N, int K, void* stream)
 {
+    return eetq_w4a16_gemm_ex(x, w_packed, scales, bias, residual, y, M, N, K, EETQ_PATH_AUTO, stream);
+}
+
+int eetq_w4a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales, const void* bias, const void* residual,
+                       void* y, int M, int N, int K, int path, void* stream)
+{
     EETQ_REQUIRE(x && w_packed && scales && y, "null pointer");
     EETQ_REQUIRE(M >= 1 && N >= 1 && K >= 1, "invalid GEMM shape");
     EETQ_REQUIRE(K % 128 == 0, "int4: k must be a multiple of 128");
@@ -420,7 +426,8 @@ int eetq_w4a16_gemm(const void* x, const int8_t* w_packed, const void* scales, c
     ep.bias     = static_cast<const f16*>(bias);
     ep.residual = static_cast<const f16*>(residual);
     return launch_w4a16(static_cast<const f16*>(x), reinterpret_cast<const uint8_t*>(w_packed),
-                        static_cast<const f16*>(scales), ep, static_cast<f16*>(y), M, N, K, static_cast<hipStream_t>(stream));
+                        static_cast<const f16*>(scales), ep, static_cast<f16*>(y), M, N, K, static_cast<hipStream_t>(stream),
+                        path);
 }
 
 int eetq_rmsnorm_f16(const void* x, const void* gamma, void* out, float eps, int rows, int cols, void* stream)

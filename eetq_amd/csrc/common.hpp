@@ -219,7 +219,7 @@ int launch_streamk_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogu
 int launch_gemv_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                    hipStream_t stream);
 int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
-                 hipStream_t stream);
+                 hipStream_t stream, int path = EETQ_PATH_AUTO);
 int launch_gemv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream, Prologue pro = Prologue{});
 namespace gemv {
@@ -272,6 +272,8 @@ int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, Epilogue 
 // never read the environment)
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                        hipStream_t stream, int force_nb = 0, int force_s = 0, bool env_plan = false);
+int launch_gemm_splitk_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
+                          hipStream_t stream, bool env_plan = false);
 void splitk_plan(int M, int N, int K, int* nb, int* s, int* stages);
 // the calling stream's own split-K scratch region (gemm_splitk.hip): slabs (*slab_bytes of them), one ticket array per slice
 // count (2 and 4), *max_tiles tickets each.  EETQ_ERR_UNSUPPORTED (no message) when the stream cannot have one right now.

@@ -111,12 +111,12 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
     return EETQ_OK;
 }
 
-template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4>
+template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4, int BITS = 8>
 int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    using C   = gemm_splitk::Cfg<MT, NB, SA, SB, W>;
-    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, SA, SB, KFULL, W>;
+    using C   = gemm_splitk::Cfg<MT, NB, SA, SB, W, BITS>;
+    auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, SA, SB, KFULL, W, false, BITS>;
     if (C::kSmem > 64 * 1024) {
         static std::atomic<unsigned long long> opted{0};
         int st = opt_in_large_lds(kern, opted);
@@ -146,12 +146,12 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     return check_hip(hipGetLastError(), "gemm_splitk_kernel launch");
 }
 
-template <int MT, int NB, int SA, int SB, int W = 4>
+template <int MT, int NB, int SA, int SB, int W = 4, int BITS = 8>
 int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
-    return K % gemm_splitk::kBK == 0 ? launch_full<MT, NB, SA, SB, true, W>(x, w, scales, ep, y, M, N, K, S, stream)
-                                     : launch_full<MT, NB, SA, SB, false, W>(x, w, scales, ep, y, M, N, K, S, stream);
+    return K % gemm_splitk::kBK == 0 ? launch_full<MT, NB, SA, SB, true, W, BITS>(x, w, scales, ep, y, M, N, K, S, stream)
+                                     : launch_full<MT, NB, SA, SB, false, W, BITS>(x, w, scales, ep, y, M, N, K, S, stream);
 }
 
 // ring = 10 * SA + SB (activation / weight ring depths, gemm_splitk_kernel.hpp).  The library instantiates the shared rings
@@ -161,12 +161,12 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
 // (profiles/r03_kbench_w8.txt; exact in all 1160 forced plans); DMA pieces interleaved with the MFMA groups, a 4 x 4 ring,
 // 128-column blocks and two or three unsplit workgroups per CU do not help either (r03_kbench_inter / ring4 / bn128 /
 // percu.txt).  DESIGN.md section 4.2b has the table and the reading.
-template <int MT>
+template <int MT, int BITS = 8>
 int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int nb, int S,
               int ring, hipStream_t stream)
 {
 #define EETQ_RING(NB_, SA_, SB_) \
-    if (nb == NB_ && ring == 10 * SA_ + SB_) return launch_inst<MT, NB_, SA_, SB_>(x, w, scales, ep, y, M, N, K, S, stream);
+    if (nb == NB_ && ring == 10 * SA_ + SB_) return launch_inst<MT, NB_, SA_, SB_, 4, BITS>(x, w, scales, ep, y, M, N, K, S, stream);
     EETQ_RING(1, 2, 2)
     EETQ_RING(2, 2, 2)
     if constexpr (MT <= 2) {
@@ -306,6 +306,37 @@ int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilog
         case 2: return launch_mt<2>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
         case 3: return launch_mt<3>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
         default: return launch_mt<4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
+    }
+}
+
+
+// W4A16, 17 <= M <= 128 (round 4): the same tile on int4 weight tiles (gemm_splitk_kernel<..., BITS = 4>) instead of expanding
+// the nibbles to int8 tiles first (one more pass over the weights and a scratch buffer that cannot be created while a graph
+// is being captured; M = 64 was 2x the W8A16 time).  The plan is the int8 one: x traffic, not the weight stream, shapes it.
+int launch_gemm_splitk_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
+                          hipStream_t stream, bool env_plan)
+{
+    if (M < 1 || M > kMidMaxM) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] split-K tile path supports 1 <= M <= 128");
+    EETQ_REQUIRE(K % 128 == 0 && N % 16 == 0, "W4A16 needs K % 128 == 0 and N % 16 == 0");
+    EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K / 2 < (1ull << 31),
+                 "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
+    int nb, s, stages;
+    splitk_plan(M, N, K, &nb, &s, &stages);
+    int ring = 11 * stages;
+    if (const char* e = env_plan ? getenv("EETQ_AMD_SPLITK_PLAN") : nullptr) {
+        int a = 0, b = 0, c = 0;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
+            nb   = a;
+            s    = b;
+            ring = c;
+        }
+    }
+    EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4), "invalid split-K plan");
+    switch ((M + 31) / 32) {
+        case 1: return launch_mt<1, 4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
+        case 2: return launch_mt<2, 4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
+        case 3: return launch_mt<3, 4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
+        default: return launch_mt<4, 4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
     }
 }
 

@@ -36,6 +36,7 @@
 #pragma once
 #include "common.hpp"
 #include "gemm_kernel.hpp"
+#include "gemv_kernel.hpp"  // gemv::dequant_dword_i4
 
 namespace eetq {
 namespace gemm_splitk {
@@ -53,14 +54,21 @@ constexpr int kMaxSlices = 4;
 // W = waves per workgroup: 4 (wave j owns k tile j of a step) or 8 (two waves share a k tile, one 32-deep half each).  A step
 // is instruction-issue bound per wave -- 8-12 DMA pieces, 8-12 fragment reads, 96 dequant VALU ops and 8-16 MFMAs in a row,
 // one wave per SIMD -- so eight waves halve each wave's share and put two waves on every SIMD to cover each other.
-template <int MT, int NB, int SA, int SB = SA, int W = 4>
+// BITS = 4 (W4A16, round 4): the weight stage holds int4 tiles -- 1 KiB = 16 columns x 128 k, a lane's 16 bytes = 32 consecutive k
+// of one column (DESIGN.md "int4 layout") -- so a 256-deep step is TWO k tiles per 16 columns and half the weight bytes; wave
+// j still multiplies k 64j..64j+63 of the step: lane (fn, fh) reads k group 2*(j&1) + fh of tile j>>1 (ONE 16-byte read per
+// column block instead of two) and dword d of it is the weight operand of MFMA k chunk d, against x at k = 64j + 32fh + 8d.
+// Everything after the MFMAs (cross-wave reduction, slabs, tickets, epilogue) is the int8 kernel's.
+template <int MT, int NB, int SA, int SB = SA, int W = 4, int BITS = 8>
 struct Cfg {
     static_assert(W == 4 || W == 8, "4 or 8 waves");
+    static_assert(BITS == 8 || (BITS == 4 && W == 4), "int4 tiles: the 4-wave form");
     static_assert(SB >= SA && SA >= 2 && (SA <= 3 || (SA == 4 && SB == 4)), "the wait accounting covers SA <= 3 (SB >= SA) and 4 x 4");
     static constexpr int kRows   = 32 * MT;
     static constexpr int kBN     = 32 * NB;
     static constexpr int kABytes = kRows * kBK * 2;
-    static constexpr int kBBytes = kBN * kBK;
+    static constexpr int kBBytes = kBN * kBK * BITS / 8;
+    static constexpr int kTilesPerStep = BITS == 8 ? 4 : 2;              // 1 KiB weight tiles per 16 columns and K step
     static constexpr int kARing  = SA * kABytes;                         // activation stages first, then the weight stages
     static constexpr int kThreads = W * 64;
     static constexpr int kRed    = W * MT * NB * 16 * 64 * 4;           // end-of-kernel cross-wave reduction area
@@ -79,12 +87,13 @@ struct Cfg {
 // counters: [tiles_n] unsigned (both unused when S == 1).
 // INTER: the DMA pieces of the stage being refilled are issued BETWEEN the MFMA groups of the step (a few right after the
 // fragment reads, to cover their latency) instead of all of them before the first dequant.
-template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4, bool INTER = false>
-__global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
+template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4, bool INTER = false, int BITS = 8>
+__global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
     int N, int K, int S, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
 {
-    using C = Cfg<MT, NB, SA, SB, W>;
+    using C = Cfg<MT, NB, SA, SB, W, BITS>;
+    constexpr int TPS = C::kTilesPerStep;  // weight tiles per 16 columns and step
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int lds0 = (int)(uint32_t)(uintptr_t)(gemm::lds_void*)smem;
     const int tid  = threadIdx.x;
@@ -92,7 +101,8 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
     const int lane = tid & 63;
     const int ktw  = wave & 3;   // k tile of a step this wave works on
     const int half = wave >> 2;  // W == 8: which 32-deep half of that k tile (W == 4: both)
-    const int KT   = K >> 6;
+    const int KT   = K >> 6;                      // 64-deep k tiles (what a wave multiplies per step)
+    const int KTW  = BITS == 8 ? KT : (K >> 7);  // 1 KiB weight tiles per 16 columns along K
     const int steps_total = (KT + 3) >> 2;
 
     // ---- block id -> (column tile, K slice): a tile's slices are consecutive ids on one XCD when tiles_n % 8 == 0 ----
@@ -114,11 +124,11 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
     const __amdgpu_buffer_rsrc_t x_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, (int)((size_t)M * K * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t w_rsrc =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(w), 0, (int)((size_t)N * K), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(w), 0, (int)((size_t)N * K * BITS / 8), 0x00020000);
 
     // ---- DMA pieces of this wave (roles fixed per index: no run-time branch per piece) ----
     //   i < kAPW : A piece p = wave*kAPW + i  -> rows 2p, 2p+1 (512 B each)
-    //   else     : B piece b = wave*kBPW + (i - kAPW) -> 16-column tile b>>2, k tile b&3 of the step
+    //   else     : B piece b = wave*kBPW + (i - kAPW) -> 16-column tile b / TPS, weight tile b % TPS of the step
     int dma_voff[C::kPieces];
 #pragma unroll
     for (int i = 0; i < C::kPieces; ++i) {
@@ -131,9 +141,9 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
             dma_voff[i]    = (gm * K + slot * 8) * 2;
         } else {
             const int b  = wave * C::kBPW + (i - C::kAPW);
-            int       nt = (n0 >> 4) + (b >> 2);
+            int       nt = (n0 >> 4) + b / TPS;
             nt           = nt < n_tiles_total ? nt : n_tiles_total - 1;
-            dma_voff[i]  = (nt * KT + (b & 3)) * kTileBytes + lane * 16;  // + step*4 tiles
+            dma_voff[i]  = (nt * KTW + b % TPS) * kTileBytes + lane * 16;  // + step*TPS tiles
         }
     }
     auto issue_a = [&](int buf, int step) {
@@ -149,9 +159,9 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
 #pragma unroll
         for (int i = C::kAPW; i < C::kPieces; ++i) {
             const int b    = wave * C::kBPW + (i - C::kAPW);
-            const int kt   = step * 4 + (b & 3);
-            const int back = kt < KT ? 0 : (kt - (KT - 1)) * kTileBytes;  // clamp to the last valid k tile
-            gemm::dma16(w_rsrc, dma_voff[i] - back, step * 4 * kTileBytes, sb + b * 1024);
+            const int kt   = step * TPS + b % TPS;
+            const int back = kt < KTW ? 0 : (kt - (KTW - 1)) * kTileBytes;  // clamp to the last valid weight tile
+            gemm::dma16(w_rsrc, dma_voff[i] - back, step * TPS * kTileBytes, sb + b * 1024);
         }
     };
     // one piece (index i of this wave's kPieces) of the stages refilled during `step`: A(step + SA - 1) / B(step + SB - 1)
@@ -161,9 +171,9 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
                 gemm::dma16(x_rsrc, dma_voff[i], (step + SA - 1) * kBK * 2, smem + bufa_next * C::kABytes + (wave * C::kAPW + i) * 1024);
         } else if (do_b) {
             const int b    = wave * C::kBPW + (i - C::kAPW);
-            const int kt   = (step + SB - 1) * 4 + (b & 3);
-            const int back = kt < KT ? 0 : (kt - (KT - 1)) * kTileBytes;
-            gemm::dma16(w_rsrc, dma_voff[i] - back, (step + SB - 1) * 4 * kTileBytes, smem + C::kARing + bufb_next * C::kBBytes + b * 1024);
+            const int kt   = (step + SB - 1) * TPS + b % TPS;
+            const int back = kt < KTW ? 0 : (kt - (KTW - 1)) * kTileBytes;
+            gemm::dma16(w_rsrc, dma_voff[i] - back, (step + SB - 1) * TPS * kTileBytes, smem + C::kARing + bufb_next * C::kBBytes + b * 1024);
         }
     };
     // s_waitcnt vmcnt(ya * kAPW + yb * kBPW): the immediate must be a constant, the pair is wave-uniform run-time data
@@ -189,13 +199,16 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
     const int fn = lane & 31, fh = lane >> 5;
     // weight fragment of column block nb: 16-column tile (2*nb + (fn >> 4)), k tile `wave`
     constexpr int SN = W == 8 ? 1 : 2;  // 32-deep halves of the k tile this wave multiplies
-    const int b_off = ((fn >> 4) * 4 + ktw) * 1024 + (fn & 15) * 16 + fh * 256 + (W == 8 ? half * 512 : 0);  // + nb*8192 + s*512
+    // int8: tile (fn >> 4) of the block's two, k tile ktw, k group fh + 2s.  int4: k tile ktw >> 1, k group 2*(ktw & 1) + fh
+    const int b_off = BITS == 8 ? ((fn >> 4) * 4 + ktw) * 1024 + (fn & 15) * 16 + fh * 256 + (W == 8 ? half * 512 : 0)  // + nb*8192 + s*512
+                                : ((fn >> 4) * 2 + (ktw >> 1)) * 1024 + (fn & 15) * 16 + (2 * (ktw & 1) + fh) * 256;    // + nb*4096
     const int a_key = fn & 15;
     int       a_slot[SN][2];
 #pragma unroll
     for (int s = 0; s < SN; ++s)
 #pragma unroll
-        for (int e = 0; e < 2; ++e) a_slot[s][e] = ((8 * ktw + 4 * (W == 8 ? half : s) + 2 * fh + e) ^ a_key) << 4;
+        for (int e = 0; e < 2; ++e)  // int8: k = 64 ktw + 32 s + 16 fh + 8 e; int4 (chunk d = 2s + e): k = 64 ktw + 32 fh + 8 d
+            a_slot[s][e] = ((BITS == 8 ? 8 * ktw + 4 * (W == 8 ? half : s) + 2 * fh + e : 8 * ktw + 4 * fh + 2 * s + e) ^ a_key) << 4;
     const int a_row_off = fn * 512;
 
     f16x2 scale2[NB];
@@ -247,13 +260,14 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
         const int sb = lds0 + C::kARing + bufb * C::kBBytes;
         // order inside a step as in gemm_mid_kernel: all fragment reads, then this wave's DMA pieces of the stage
         // kStages-1 steps ahead (they run under the LDS read latency), then dequant + MFMA
-        u32x4 wq[NB][SN];
+        constexpr int WR = BITS == 8 ? SN : 1;  // 16-byte weight reads per column block
+        u32x4 wq[NB][WR];
         f16x8 xa[SN][2][MT];
         if (active) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int s = 0; s < SN; ++s) wq[nb][s] = gemm::lds_read16(sb + b_off + nb * 8192 + s * 512);
+                for (int s = 0; s < WR; ++s) wq[nb][s] = gemm::lds_read16(sb + b_off + nb * (BITS == 8 ? 8192 : 4096) + s * 512);
 #pragma unroll
             for (int s = 0; s < SN; ++s)
 #pragma unroll
@@ -283,13 +297,24 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W>::kSmem <=
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
-                for (int s = 0; s < SN; ++s) asm volatile("" : "+v"(wq[nb][s]));  // reads stay above the dequant
+                for (int s = 0; s < WR; ++s) asm volatile("" : "+v"(wq[nb][s]));  // reads stay above the dequant
 #pragma unroll
             for (int s = 0; s < SN; ++s) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
                     f16x2 wd[8];
-                    dequant_16(wq[nb][s], scale2[nb], wd);
+                    if constexpr (BITS == 8) {
+                        dequant_16(wq[nb][s], scale2[nb], wd);
+                    } else {  // dwords 2s, 2s + 1 of the lane's 32 k: MFMA k chunks d = 2s + e
+                        f16x2 lo[4], hi[4];
+                        gemv::dequant_dword_i4(s == 0 ? wq[nb][0].x : wq[nb][0].z, scale2[nb], lo);
+                        gemv::dequant_dword_i4(s == 0 ? wq[nb][0].y : wq[nb][0].w, scale2[nb], hi);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            wd[i]     = lo[i];
+                            wd[4 + i] = hi[i];
+                        }
+                    }
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const f16x8 wf = gemm::make_frag(wd[4 * e], wd[4 * e + 1], wd[4 * e + 2], wd[4 * e + 3]);

@@ -333,14 +333,30 @@ int launch_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, 
     return check_hip(hipGetLastError(), "unpack_i4_kernel launch");
 }
 
-int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, hipStream_t stream)
+int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, hipStream_t stream,
+                 int path)
 {
+    // explicit kernel paths (tests, tuning): GEMV (M <= 4), STREAM (M <= 16), SPLITK (M <= 128, honours EETQ_AMD_SPLITK_PLAN),
+    // MFMA (the expansion route); anything else but AUTO is refused
+    if (path == EETQ_PATH_GEMV) return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
+    if (path == EETQ_PATH_STREAM) {
+        if (M > 16) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16 stream kernel supports M <= 16");
+        return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
+    }
+    if (path == EETQ_PATH_SPLITK) return launch_gemm_splitk_i4(x, w, scales, ep, y, M, N, K, stream, /*env_plan=*/true);
+    if (path != EETQ_PATH_AUTO && path != EETQ_PATH_MFMA)
+        return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16: unknown or unimplemented GEMM path");
+    const bool expand = path == EETQ_PATH_MFMA;
     // decode: the wave-reduction GEMV on int4 tiles (gemv_kernel<..., BITS = 4>)
-    if (M == 1) return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
+    if (M == 1 && !expand) return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
     // batched decode, 2 <= M <= 16: the register-streaming MFMA kernel on int4 tiles (streamk_kernel<..., BITS = 4>) -- the
     // weight stream bounds these M, and it is half as long as the int8 one (M = 8, N = K = 4096: 4.5 vs 5.1 us; the dot2
     // GEMV at M = 4 needs 6.9).  Larger M are bound by the activation traffic / the matrix cores, where int4 buys nothing.
-    if (M <= 16) return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
+    if (M <= 16 && !expand) return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
+    // 17 <= M <= 128: the split-K MFMA tile on int4 weight tiles (gemm_splitk_kernel<..., BITS = 4>; round 4) -- no expansion
+    // pass, no per-stream weight scratch, capturable into a HIP graph
+    if (!expand && M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K / 2 < (1ull << 31))
+        return launch_gemm_splitk_i4(x, w, scales, ep, y, M, N, K, stream);
     // larger batches: expand the nibbles to the int8 tile layout once per call (K*N/2 bytes read, K*N written; the GEMM that
     // follows is MFMA- or x-bound at these M) and run the W8A16 kernels on it -- same integers, same scales, same contract
     uint8_t* w8 = nullptr;

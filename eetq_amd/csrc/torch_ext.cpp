@@ -243,12 +243,11 @@ Tensor& gemm_launch(const Tensor& input, const Tensor& weight, const Tensor& sca
     Tensor           x = input.contiguous();
     c10::DeviceGuard guard(input.device());
     const bool       int4 = weight.size(-1) * 2 == n && weight.size(-1) != n;  // packed int4: [K, N/2] bytes
-    TORCH_CHECK(!int4 || (act == EETQ_ACT_IDENTITY && path == EETQ_PATH_AUTO),
-                "w8_a16_gemm: int4 weights take neither an explicit kernel path nor an activation epilogue");
+    TORCH_CHECK(!int4 || act == EETQ_ACT_IDENTITY, "w8_a16_gemm: int4 weights take no activation epilogue");
     if (int4)
-        check(eetq_w4a16_gemm(x.data_ptr(), weight.data_ptr<int8_t>(), scale.data_ptr(), bias ? bias->data_ptr() : nullptr,
-                              residual ? residual->data_ptr() : nullptr, output.data_ptr(), (int)m, (int)n, (int)k,
-                              stream_of(input)));
+        check(eetq_w4a16_gemm_ex(x.data_ptr(), weight.data_ptr<int8_t>(), scale.data_ptr(), bias ? bias->data_ptr() : nullptr,
+                                 residual ? residual->data_ptr() : nullptr, output.data_ptr(), (int)m, (int)n, (int)k, path,
+                                 stream_of(input)));
     else
         check(eetq_w8a16_gemm_act(x.data_ptr(), weight.data_ptr<int8_t>(), scale.data_ptr(),
                                   bias ? bias->data_ptr() : nullptr, residual ? residual->data_ptr() : nullptr,

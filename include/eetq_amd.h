@@ -152,6 +152,12 @@ int eetq_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, in
 /* y = fp16( sum_k fp32(x) * fp32( fp16( q4[k][n] * scales[n] ) ) ) [+ bias] [+ residual]; w_packed in the GFX950 int4 layout. */
 int eetq_w4a16_gemm(const void* x, const int8_t* w_packed, const void* scales, const void* bias, const void* residual,
                     void* y, int M, int N, int K, void* stream);
+/* As above with an explicit kernel path: EETQ_PATH_AUTO (M = 1: dot2 GEMV on int4 tiles; 2..16: register-streaming MFMA
+ * kernel; 17..128: split-K MFMA tile on int4 tiles; above: nibbles expanded to int8 tiles + the W8A16 kernels),
+ * EETQ_PATH_GEMV (M <= 4), EETQ_PATH_STREAM (M <= 16), EETQ_PATH_SPLITK (M <= 128; honours EETQ_AMD_SPLITK_PLAN),
+ * EETQ_PATH_MFMA (the expansion route at any M).  Other paths: EETQ_ERR_UNSUPPORTED. */
+int eetq_w4a16_gemm_ex(const void* x, const int8_t* w_packed, const void* scales, const void* bias, const void* residual,
+                       void* y, int M, int N, int K, int path, void* stream);
 
 /* ---- side ops --------------------------------------------------------------------------------------
  * Replaces EETQ.layernorm_forward -> layernorm_forward_cuda (csrc/layernorm_kernels/layernorm.cu:98-113):

@@ -1,6 +1,8 @@
 """W4A16 (int4 weight-only): the quint4x2 branch of quant_weights / preprocess_weights bit-exact against the oracle's
 restatement of cutlass_preprocessors.cc (writer) pinned by the reference GEMV's Int4b reader, and the W4A16 GEMM
 (extension) against the same numerics contract as W8A16: y = fp16(sum_k fp32(x) * fp32(fp16(q4 * s)))."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -105,7 +107,9 @@ def test_int4_shape_errors(ops):
 
 
 @pytest.mark.parametrize("M", [1, 2, 3, 4])
-@pytest.mark.parametrize("K,N", [(128, 16), (256, 48), (1024, 256), (4096, 512), (11008, 64), (2176, 32)])
+@pytest.mark.parametrize("K,N", [(128, 16), (256, 48), (1024, 256), (4096, 512), (11008, 64), (2176, 32),
+                                 # the Llama-2-13B widths: straight-line instantiations at M = 1 (8 waves x 5 tiles, 12 x 9)
+                                 (5120, 272), (13824, 80), (8192, 48)])
 def test_w4a16_gemv_vs_oracle(ops, oracle, M, K, N):
     rng = np.random.default_rng(M + K + N)
     w = (rng.standard_normal((K, N)) * 0.05).astype(np.float16)
@@ -136,10 +140,11 @@ def test_w4a16_identity_is_exact_dequant(ops, oracle):
         assert np.array_equal(one[0], want[r]), r
 
 
-@pytest.mark.parametrize("M", [5, 8, 16, 17, 33, 64, 65, 200, 1024])
+@pytest.mark.parametrize("M", [5, 8, 16, 17, 33, 64, 65, 128, 129, 200, 1024])
 def test_w4a16_larger_batches(ops, oracle, M):
-    """2 <= M <= 16: the register-streaming MFMA kernel on int4 tiles; above: nibbles expanded to int8 tiles + the W8A16
-    kernels.  Both against the oracle on the exact integers; the expansion route is bit-identical to W8A16 on them."""
+    """2 <= M <= 16: the register-streaming MFMA kernel on int4 tiles; 17 <= M <= 128: the split-K MFMA tile on int4 tiles
+    (round 4; it was the expansion route); above: nibbles expanded to int8 tiles + the W8A16 kernels.  All against the oracle
+    on the exact integers; the expansion route (M > 128, or forced with path="mfma") is bit-identical to W8A16 on them."""
     K, N = 1024, 384
     rng = np.random.default_rng(M)
     w = (rng.standard_normal((K, N)) * 0.05).astype(np.float16)
@@ -155,11 +160,99 @@ def test_w4a16_larger_batches(ops, oracle, M):
     assert _tier_a(y.cpu().numpy()[rows], ref).all()
     p8 = torch.from_numpy(oracle.gfx950_pack(oracle.i4_values(qp))).to(DEV)
     y8 = ops.w8_a16_gemm(xd, p8, sd)
-    if M > 16:   # the expanded weight is exactly the int8 tile image of the same integers: bit-identical to W8A16 on them
+    if M > 128:  # the expanded weight is exactly the int8 tile image of the same integers: bit-identical to W8A16 on them
         assert torch.equal(y, y8)
     else:        # same dequantised values, another summation order
         assert _tier_a(y.cpu().numpy(), y8.float().cpu().numpy()).all()
+        if M > 16:
+            assert torch.equal(ops.w8_a16_gemm(xd, processed, sd, path="mfma"), y8)    # the expansion route is still there
     assert torch.equal(ops.w8_a16_gemm(xd, processed, sd, bias=bias, residual=res), y + bias + res)
+    assert torch.equal(ops.w8_a16_gemm(xd, processed, sd), y)                            # launch to launch: same bits
+
+
+# 7B and 13B layer shapes, K with a 128-deep last step (384, 11008 + 128), one k tile in all (128), ragged N (not a multiple of
+# the 32- / 64-column blocks), every row-tile count
+@pytest.mark.parametrize("K,N", [(4096, 4096), (4096, 11008), (11008, 4096), (5120, 5120), (5120, 13824), (13824, 5120),
+                                 (128, 16), (384, 80), (11136, 48), (1024, 1040)])
+@pytest.mark.parametrize("M", [17, 32, 40, 64, 96, 128])
+def test_w4a16_splitk_tile_vs_oracle(ops, oracle, M, K, N):
+    """gemm_splitk_kernel<..., BITS = 4>, AUTO's plan: oracle on sampled rows and columns (big shapes) / everything (small)."""
+    rng = np.random.default_rng(K + N + M)
+    qp = rng.integers(-128, 128, (K, N // 2), dtype=np.int8)
+    s = (rng.random(N) * 0.02 + 0.001).astype(np.float16)
+    x = (rng.random((M, K)) - 0.5).astype(np.float16)
+    pk = torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV)
+    xd, sd = torch.from_numpy(x).to(DEV), torch.from_numpy(s).to(DEV)
+    y1 = ops.w8_a16_gemm(xd, pk, sd)
+    y2 = ops.w8_a16_gemm(xd, pk, sd, path="splitk")
+    assert torch.equal(y1, y2)                                   # AUTO takes this kernel at these M
+    y = y1.cpu().numpy()
+    rows = sorted(set([0, 1, M // 3, M - 1]))
+    c0 = 0 if N <= 512 else int(rng.integers(0, N // 16 - 16)) * 16
+    cols = slice(c0, min(N, c0 + 256))
+    for cs in (cols, slice(max(0, N - 64), N)):
+        ref = oracle.w8a16_gemm(x[rows], np.ascontiguousarray(oracle.i4_values(qp)[:, cs]), s[cs])
+        assert _tier_a(y[rows][:, cs], ref).all(), (cs, np.abs(y[rows][:, cs].astype(np.float32) - ref.astype(np.float32)).max())
+
+
+@pytest.mark.parametrize("K,N,M,plans", [
+    (4096, 4096, 64, [(1, 1, 22), (1, 2, 22), (1, 4, 22), (2, 1, 22), (2, 2, 22), (2, 4, 22), (1, 2, 33), (2, 4, 33)]),
+    (2048, 1024, 100, [(1, 1, 22), (2, 2, 22), (1, 4, 22)]),
+    (1024, 2048, 20, [(1, 2, 33), (2, 1, 33), (2, 4, 22)]),
+    (5120, 13824, 48, [(2, 2, 33), (1, 4, 22)]),
+    # the geometry that exposed the store-data hazard in the int8 kernel: split launches, two workgroups per CU, more
+    # workgroups than the chip holds
+    (4096, 16384, 64, [(1, 2, 22)]),
+])
+def test_w4a16_splitk_every_plan(ops, oracle, K, N, M, plans):
+    """Every (column blocks, slices, ring) instantiation of the int4 tile forced through EETQ_AMD_SPLITK_PLAN: tier A against
+    the oracle on sampled rows, against the expansion route on the whole output, and launch-to-launch bit identity."""
+    rng = np.random.default_rng(K + N + M)
+    qp = rng.integers(-128, 128, (K, N // 2), dtype=np.int8)
+    s = (rng.random(N) * 0.02 + 0.001).astype(np.float16)
+    x = (rng.random((M, K)) - 0.5).astype(np.float16)
+    pk = torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV)
+    xd, sd = torch.from_numpy(x).to(DEV), torch.from_numpy(s).to(DEV)
+    whole = ops.w8_a16_gemm(xd, pk, sd, path="mfma").cpu().numpy()
+    rows = sorted(set([0, M // 2, M - 1]))
+    cols = slice(0, 256)
+    ref = oracle.w8a16_gemm(x[rows], np.ascontiguousarray(oracle.i4_values(qp)[:, cols]), s[cols])
+    for nb, S, ring in plans:
+        os.environ["EETQ_AMD_SPLITK_PLAN"] = "%d,%d,%d" % (nb, S, ring)
+        try:
+            y1 = ops.w8_a16_gemm(xd, pk, sd, path="splitk")
+            y2 = ops.w8_a16_gemm(xd, pk, sd, path="splitk")
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("EETQ_AMD_SPLITK_PLAN", None)
+        got = y1.cpu().numpy()
+        assert torch.equal(y1, y2), (nb, S, ring)
+        assert _tier_a(got[rows][:, cols], ref).all(), (nb, S, ring)
+        assert _tier_a(got, whole).all(), (nb, S, ring, np.abs(got.astype(np.float32) - whole.astype(np.float32)).max())
+
+
+def test_w4a16_medium_batch_is_graph_capturable(ops, oracle):
+    """The expansion route needed a per-stream scratch that cannot be created during capture; the int4 tile does not."""
+    K, N, M = 2048, 1024, 64
+    rng = np.random.default_rng(3)
+    qp = rng.integers(-128, 128, (K, N // 2), dtype=np.int8)
+    s = (rng.random(N) * 0.02 + 0.001).astype(np.float16)
+    pk = torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV)
+    xd = torch.rand(M, K, dtype=torch.float16, device=DEV)
+    sd = torch.from_numpy(s).to(DEV)
+    eager = ops.w8_a16_gemm(xd, pk, sd)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.w8_a16_gemm(xd, pk, sd)
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = ops.w8_a16_gemm(xd, pk, sd)
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager)
 
 
 @pytest.mark.parametrize("K,N", [(4096, 4096), (5120, 15360), (5120, 27648), (13824, 5120), (512, 64), (128, 16), (2048, 1024)])

@@ -10,7 +10,7 @@ from eetq_amd import ops
 from sweep import chain_us
 
 dev = "cuda:0"
-for K, N in [(4096, 4096), (4096, 11008), (11008, 4096), (5120, 13824)]:
+for K, N in [(4096, 4096), (4096, 11008), (11008, 4096), (5120, 5120), (5120, 13824), (13824, 5120)]:
     nbuf = max(2, (640 << 20) // (K * N))
     g = torch.Generator(device=dev); g.manual_seed(1)
     s8, s4 = [], []
@@ -19,7 +19,7 @@ for K, N in [(4096, 4096), (4096, 11008), (11008, 4096), (5120, 13824)]:
         s8.append(tuple(ops.quant_weights(w, torch.int8, False)))
         s4.append(tuple(ops.quant_weights(w, torch.quint4x2, False)))
         del w
-    for M in (1, 4, 8, 64):
+    for M in (tuple(int(a) for a in sys.argv[1].split(',')) if len(sys.argv) > 1 else (1, 4, 8, 64)):
         x = torch.rand(M, K, device=dev, generator=g).half()
         out = {}
         for name, sets in (("w8", s8), ("w4", s4)):

@@ -155,6 +155,95 @@ static void bench_overhead(const std::vector<uint8_t*>& bufs, unsigned* out)
     }
 }
 
+
+// ---- same FLOPs on fewer CUs (round 4): does the chip pay idle CUs back as clock? -----------------------------------------
+// one wave per workgroup records {XCC_ID, s_memtime (shader cycles), s_memrealtime (100 MHz)}; two launches around a chain give
+// the average shader clock per XCD over the chain (eetq_amd/csrc/diag.hip has the library's copy)
+__global__ __launch_bounds__(64) void kb_clock_stamp(unsigned long long* out)
+{
+    if (threadIdx.x != 0) return;
+    unsigned long long tm, tr;
+    asm volatile("s_memtime %0\n\ts_memrealtime %1\n\ts_waitcnt lgkmcnt(0)" : "=s"(tm), "=s"(tr)::"memory");
+    const unsigned xcc = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
+    out[blockIdx.x * 3 + 0] = xcc;
+    out[blockIdx.x * 3 + 1] = tm;
+    out[blockIdx.x * 3 + 2] = tr;
+}
+
+struct ChainResult {
+    double us, mhz;
+};
+// `iters` back-to-back launches between two stamp launches, captured as one graph, best of `reps` replays
+static ChainResult time_chain_clock(const std::function<void(int, hipStream_t)>& plain, int iters, int reps = 4)
+{
+    const int           nwg = 512;
+    unsigned long long *sa, *sb;
+    CK(hipMalloc(&sa, nwg * 24));
+    CK(hipMalloc(&sb, nwg * 24));
+    hipStream_t s;
+    CK(hipStreamCreate(&s));
+    hipGraph_t     g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(s, hipStreamCaptureModeGlobal));
+    hipLaunchKernelGGL(kb_clock_stamp, dim3(nwg), dim3(64), 0, s, sa);
+    for (int i = 0; i < iters; ++i) plain(i, s);
+    hipLaunchKernelGGL(kb_clock_stamp, dim3(nwg), dim3(64), 0, s, sb);
+    CK(hipStreamEndCapture(s, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, s));
+    CK(hipStreamSynchronize(s));
+    ChainResult best{1e30, 0};
+    std::vector<unsigned long long> ha(nwg * 3), hb(nwg * 3);
+    for (int r = 0; r < reps; ++r) {
+        auto t0 = std::chrono::high_resolution_clock::now();
+        CK(hipGraphLaunch(ge, s));
+        CK(hipStreamSynchronize(s));
+        auto         t1 = std::chrono::high_resolution_clock::now();
+        const double us = std::chrono::duration<double, std::micro>(t1 - t0).count() / iters;
+        CK(hipMemcpy(ha.data(), sa, nwg * 24, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(hb.data(), sb, nwg * 24, hipMemcpyDeviceToHost));
+        std::vector<double> mhz;
+        for (unsigned x = 0; x < 8; ++x) {
+            int ia = -1, ib = -1;
+            for (int i = 0; i < nwg && (ia < 0 || ib < 0); ++i) {
+                if (ia < 0 && ha[i * 3] == x) ia = i;
+                if (ib < 0 && hb[i * 3] == x) ib = i;
+            }
+            if (ia >= 0 && ib >= 0 && hb[ib * 3 + 2] > ha[ia * 3 + 2])
+                mhz.push_back((double)(hb[ib * 3 + 1] - ha[ia * 3 + 1]) / (double)(hb[ib * 3 + 2] - ha[ia * 3 + 2]) * 100.0);
+        }
+        std::sort(mhz.begin(), mhz.end());
+        if (us < best.us) best = ChainResult{us, mhz.empty() ? 0.0 : mhz[mhz.size() / 2]};
+    }
+    CK(hipGraphExecDestroy(ge));
+    CK(hipGraphDestroy(g));
+    CK(hipStreamDestroy(s));
+    CK(hipFree(sa));
+    CK(hipFree(sb));
+    return best;
+}
+
+template <int ABLATE, int J = 2>
+static void bench_gemm_cu(const char* name, int M, int N, int K, const std::vector<uint8_t*>& bufs, const eetq::f16* x,
+                          const eetq::f16* scales, eetq::f16* y)
+{
+    using namespace eetq::gemm;
+    auto kern = gemm_tile_kernel<ABLATE, J, false, 2>;
+    constexpr int SMEM_BYTES = TileCfg<J, 2>::SMEM_BYTES, BN = TileCfg<J, 2>::BN;
+    CK(hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, SMEM_BYTES));
+    const int    tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const double flops = 2.0 * M * N * K;
+    auto r = time_chain_clock(
+        [&](int i, hipStream_t s) {
+            hipLaunchKernelGGL(kern, dim3(tiles), dim3(256), SMEM_BYTES, s, x, (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N,
+                               K, N, eetq::Epilogue{});
+        },
+        100);
+    const double mfma_cycles = (double)(K / 64) * 8 * J * 36.0;  // per wave: MFMAs x ~36 cycles each (32 passes + issue)
+    printf("%-34s M=%5d N=%5d K=%5d wgs=%4d | %7.2f us/launch %6.0f MHz -> %6.1f k cycles (MFMA floor %5.1f k) %7.1f TF\n", name, M, N, K,
+           tiles, r.us, r.mhz, r.us * r.mhz / 1e3, mfma_cycles / 1e3, flops / r.us / 1e6);
+}
+
 template <int LOADS, bool NT>
 static void bench_stream(const char* name, int threads, const std::vector<uint8_t*>& bufs, size_t bytes, unsigned* out)
 {
@@ -641,6 +730,39 @@ int main(int argc, char** argv)
                                (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{}, eetq::Prologue{});
         CK(hipDeviceSynchronize());
     }
+    if (!strcmp(what, "gemmcu")) {
+        // 34.36 GFLOP every time; 256 / 128 / 64 workgroups of the 128 x 128 tile (one per CU), the K loop 1x / 2x / 4x as long.
+        // If idle CUs came back as clock, the full kernel on 128 CUs would approach its 256-CU time.
+        printf("--- same FLOPs on fewer CUs: 128 x 128 tile, full kernel and MFMA stream alone, random vs zero operands ---\n");
+        const size_t WB = 4096ull * 8192;
+        setvbuf(stdout, nullptr, _IOLBF, 0);
+        eetq::f16 *xg, *yg, *xz;
+        CK(hipMalloc(&xg, 1024ull * 16384 * 2));
+        CK(hipMalloc(&xz, 1024ull * 16384 * 2));
+        CK(hipMalloc(&yg, 1024ull * 4096 * 2));
+        CK(hipMemset(xz, 0, 1024ull * 16384 * 2));
+        {
+            std::vector<uint16_t> h(1024ull * 16384);
+            for (auto& v : h) v = (uint16_t)(0x3000 + (rand() & 0xfff) + ((rand() & 1) << 15));  // +-[0.125, 0.5)
+            CK(hipMemcpy(xg, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+        }
+        std::vector<uint8_t*> zb(4);
+        for (auto& p : zb) {
+            CK(hipMalloc(&p, WB));
+            CK(hipMemset(p, 0x80, WB));  // q = 0
+        }
+        struct Shape { int M, N, K; };
+        for (Shape sh : {Shape{1024, 4096, 4096}, Shape{1024, 2048, 8192}, Shape{512, 4096, 8192}, Shape{1024, 1024, 16384}}) {
+            for (int rep = 0; rep < 2; ++rep) {
+                bench_gemm_cu<0>("full kernel, random operands", sh.M, sh.N, sh.K, bufs_big, xg, scales, yg);
+                bench_gemm_cu<0>("full kernel, zero operands", sh.M, sh.N, sh.K, zb, xz, scales, yg);
+                bench_gemm_cu<23>("MFMA stream only, random regs", sh.M, sh.N, sh.K, bufs_big, xg, scales, yg);
+            }
+        }
+        bench_gemm_cu<0, 1>("128 x 64 tile, random operands", 1024, 4096, 4096, bufs_big, xg, scales, yg);
+        bench_gemm_cu<0, 1>("128 x 64 tile, random operands", 1024, 2048, 8192, bufs_big, xg, scales, yg);
+        return 0;
+    }
 #ifdef EETQ_KBENCH_STAMPS
     if (!strcmp(what, "geometry")) {
         unsigned long long* st;
@@ -662,6 +784,7 @@ int main(int argc, char** argv)
     }
 #endif
 #ifdef EETQ_KBENCH_STAMPS
+
     if (!strcmp(what, "gemmstamps")) {
         // Where do the tile GEMM's microseconds go at M = 1024, N = K = 4096 (one tile per workgroup, 256 workgroups)?
         // Device-clock stamps of wave 0 of every workgroup: 0 entry, 1 first stage landed, 2 steady loop done, 3 drain steps
