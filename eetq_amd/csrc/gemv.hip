@@ -156,13 +156,9 @@ int launch_m_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         if (KT == 32) return launch_inst_i4<M, 16, 2, true, true, 1, 4>(x, w, scales, ep, y, N, K, stream);
         if (KT == 64) return launch_inst_i4<M, 16, 4, true, true, 1, 2>(x, w, scales, ep, y, N, K, stream);
     }
-    if constexpr (M == 1) {
-        // the Llama-2-13B widths: K = 5120 is 40 tiles = 8 waves x 5, K = 13824 is 108 = 12 waves x 9 -- straight-line code with
-        // the whole tile row in flight instead of the generic loop's 2.5 / 6.75 tiles per wave (round 3: 5120 x 13824 11.4 us
-        // for 35 MB, 0.39 of the roofline)
-        if (KT == 40) return launch_inst_i4<M, 8, 5, true, true, 1, 2>(x, w, scales, ep, y, N, K, stream);
-        if (KT == 108) return launch_inst_i4<M, 12, 9, true, false, 4, 1>(x, w, scales, ep, y, N, K, stream);
-    }
+    // (round 4: straight-line instantiations for the 13B widths -- K = 5120 as 8 waves x 5 tiles, K = 13824 as 12 x 9 -- were
+    // measured and dropped: 5120 x 13824 11.9 vs 11.4 us with the generic loop.  The int4 GEMV is not bound by the shape of its
+    // load stream but by ~2.1 VALU operations per weight that overlap poorly with it: profiles/r04_int4_m1.jsonl)
     if (KT >= 64) return launch_lds_i4<M, 16, 4, 4>(x, w, scales, ep, y, N, K, stream);  // every wave owns >= 4 tiles
     if (KT >= 32) return launch_lds_i4<M, 16, 2, 4>(x, w, scales, ep, y, N, K, stream);
     if (KT >= 16) return launch_lds_i4<M, 8, 2, 2>(x, w, scales, ep, y, N, K, stream);
