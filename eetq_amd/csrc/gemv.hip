@@ -68,6 +68,42 @@ int launch_half_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue e
     return check_hip(hipGetLastError(), "gemv_half_kernel launch");
 }
 
+// 8 + 8 + 4 (gemv_mixed_kernel): N splits into exactly N / CUs = 8a + 4 columns per CU -- N = 5120 on 256 CUs: two 8-column
+// units and one 4-column unit each, 768 workgroups resident at once, instead of 640 eight-column units of which a quarter of
+// the CUs get three.  EETQ_AMD_GEMV_MIXED=0 keeps the 8-column units (A/B runs).
+bool mixed_units_pay(int N, int K)
+{
+    static const bool allowed = [] {
+        const char* e = getenv("EETQ_AMD_GEMV_MIXED");
+        return !(e && e[0] == '0');
+    }();
+    const int KT = K / kTileK, ncu = device_cu_count();
+    if (!allowed || KT % 4 || KT / 4 < 16 || K > 32768 || N % (4 * ncu)) return false;  // groups of 4 k tiles, >= 2 per wave
+    const int per = N / ncu;
+    return per % 8 == 4 && per >= 12 && per <= 28;
+}
+
+template <int XV, int NORM = 0>
+int launch_mixed_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream,
+                    Prologue pro)
+{
+    if constexpr (!NORM) {
+        if (pro.gamma) return launch_mixed_xv<XV, 1>(x, w, scales, ep, y, N, K, stream, pro);
+        if (pro.up) return launch_mixed_xv<XV, 2>(x, w, scales, ep, y, N, K, stream, pro);
+    }
+    auto         kern = gemv::gemv_mixed_kernel<8, 2, XV, 8, NORM>;
+    const size_t smem = gemv::gemv_half_smem_bytes(K, 8);
+    if (smem > 64 * 1024) {
+        static std::atomic<unsigned long long> opted{0};
+        int st = opt_in_large_lds(kern, opted);
+        if (st != EETQ_OK) return st;
+    }
+    const int ncu = device_cu_count(), per = N / ncu;
+    const int n8 = ncu * (per / 8), n4 = (N - 8 * n8) / 4;
+    launch_kernel(kern, dim3(n8 + n4), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep, pro, n8);
+    return check_hip(hipGetLastError(), "gemv_mixed_kernel launch");
+}
+
 bool half_units_pay(int N, int K)
 {
     const int KT = K / kTileK;
@@ -83,6 +119,11 @@ int launch_half(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
                 Prologue pro)
 {
     const int need = (K / 8 + 511) / 512;  // 16-byte activation loads per thread
+    if (mixed_units_pay(N, K)) {
+        if (need <= 2) return launch_mixed_xv<2>(x, w, scales, ep, y, N, K, stream, pro);
+        if (need <= 4) return launch_mixed_xv<4>(x, w, scales, ep, y, N, K, stream, pro);
+        return launch_mixed_xv<8>(x, w, scales, ep, y, N, K, stream, pro);
+    }
     if (need <= 2) return launch_half_xv<2>(x, w, scales, ep, y, N, K, stream, pro);
     if (need <= 4) return launch_half_xv<4>(x, w, scales, ep, y, N, K, stream, pro);
     return launch_half_xv<8>(x, w, scales, ep, y, N, K, stream, pro);

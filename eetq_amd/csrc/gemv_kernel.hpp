@@ -403,29 +403,33 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_grouped_k
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Half-tile-row form, M = 1: one workgroup per 8 output columns (N/8 workgroups).  For N/16 a little above a multiple of
-// the CU count (N = 5120: 320 tile rows on 256 CUs) whole tile rows leave a quarter of the CUs with twice the bytes of the
-// others; in 8-column units the busiest CU gets 3 units of 8 instead of 2 units of 16.
-// A wave instruction covers the 8-column halves of TWO k tiles: lane = sub*32 + kg*8 + c reads the 16 bytes of column
-// half*8 + c, k-group kg of k tile 2p + sub -- eight full 128-byte lines.  Wave w owns pairs w, w+WAVES, ...; D pairs in
-// flight; K/64 must be even (launcher contract).  Activations are staged in LDS like the generic form.
-template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0>
-__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kernel(
+// Column-unit forms, M = 1: one workgroup per COLS output columns, COLS = 8 (gemv_half_kernel, N/8 workgroups) or a mix of 8-
+// and 4-column units (gemv_mixed_kernel).  For N/16 a little above a multiple of the CU count (N = 5120: 320 tile rows on 256
+// CUs) whole tile rows leave a quarter of the CUs with twice the bytes of the others; in 8-column units the busiest CU gets 3
+// units of 8 (24 columns) instead of 2 units of 16, and with 8 + 8 + 4 every CU gets its exact share of 20 (round 4).
+// A wave instruction covers the COLS-column slices of 64 / (4 * COLS) k tiles: COLS = 8: lane = sub*32 + kg*8 + c reads the 16
+// bytes of column col0 + c, k-group kg of k tile 2p + sub -- eight full 128-byte lines; COLS = 4: lane = sub*16 + kg*4 + c, k
+// tile 4p + sub -- sixteen 64-byte half lines (the other half belongs to the neighbouring 4-column unit, which the launcher
+// places on the same XCD so that the line is fetched into one L2 only).  Wave w owns groups w, w+WAVES, ...; D groups in
+// flight; K/64 must be a multiple of the group size (launcher contract).  Activations are staged in LDS like the generic form.
+template <int COLS, int WAVES, int D, int XV, int NORM>
+__device__ __forceinline__ void gemv_unit_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
+    f16* __restrict__ y, int N, int K, const Epilogue& ep, const Prologue& pro, const int col0)
 {
+    static_assert(COLS == 8 || COLS == 4, "8- or 4-column units");
+    constexpr int G = 64 / (4 * COLS);  // k tiles per wave instruction: 2 or 4
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     f16*   xs  = reinterpret_cast<f16*>(smem);
     float* red = reinterpret_cast<float*>(smem + (size_t)K * 2);
 
     const int tid  = threadIdx.x;
-    const int unit = blockIdx.x;  // 8-column unit: tile row unit >> 1, half unit & 1
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int sub = lane >> 5, kg = (lane >> 3) & 3, c = lane & 7;
-    const int KT = K >> 6, NP = KT >> 1;  // pairs of k tiles
+    const int sub = lane / (4 * COLS), kg = (lane / COLS) & 3, c = lane & (COLS - 1);
+    const int KT = K >> 6, NP = KT / G;  // groups of G k tiles
 
-    u32 sraw = reinterpret_cast<const uint16_t*>(scales)[unit * 8 + c];
+    u32 sraw = reinterpret_cast<const uint16_t*>(scales)[col0 + c];
 
     u32x4        xv[XV];
     const int    xvecs = K >> 3;
@@ -445,10 +449,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
         }
     }
 
-    // byte offset of this lane inside its k tile: lane index kg*16 + (half*8 + c) of the native tile
-    const uint8_t* wbase = w + (size_t)(unit >> 1) * KT * kTileBytes + (size_t)sub * kTileBytes +
-                           (kg * 16 + (unit & 1) * 8 + c) * 16;
-    auto wptr = [&](int pair) { return reinterpret_cast<const u32x4*>(wbase + (size_t)pair * 2 * kTileBytes); };
+    // byte offset of this lane inside its k tile: lane index kg*16 + (col0 % 16 + c) of the native tile
+    const uint8_t* wbase = w + (size_t)(col0 >> 4) * KT * kTileBytes + (size_t)sub * kTileBytes +
+                           (kg * 16 + (col0 & 15) + c) * 16;
+    auto wptr = [&](int grp) { return reinterpret_cast<const u32x4*>(wbase + (size_t)grp * G * kTileBytes); };
     u32x4 buf[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[d] = load_w<true>(wptr(wave + d * WAVES));
@@ -465,13 +469,13 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
     __syncthreads();
 
     float      acc[1] = {0.f};
-    const f16* xl     = xs + sub * 64 + 16 * kg;  // + 128 halfs per pair
-    const int  n      = (NP - wave + WAVES - 1) / WAVES;  // pairs of this wave (>= D by launch contract)
+    const f16* xl     = xs + sub * 64 + 16 * kg;  // + 64 * G halfs per group
+    const int  n      = (NP - wave + WAVES - 1) / WAVES;  // groups of this wave (>= D by launch contract)
     int        i      = 0;
     for (; i + 2 * D <= n; i += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            consume_tile<1>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * 128, K, acc);
+            consume_tile<1>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * (64 * G), K, acc);
             buf[d] = load_w<true>(wptr(wave + (i + d + D) * WAVES));
         }
     }
@@ -483,24 +487,53 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
         tail[d]     = load_w<true>(wptr(wave + (t < n ? t : n - 1) * WAVES));
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d) consume_tile<1>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * 128, K, acc);
+    for (int d = 0; d < D; ++d) consume_tile<1>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * (64 * G), K, acc);
 #pragma unroll
     for (int d = 0; d < D - 1; ++d)
-        if (d < r) consume_tile<1>(tail[d], scale2, xl + (size_t)(wave + (i + D + d) * WAVES) * 128, K, acc);
+        if (d < r) consume_tile<1>(tail[d], scale2, xl + (size_t)(wave + (i + D + d) * WAVES) * (64 * G), K, acc);
 
-    // lanes with the same c: 4 k-groups (xor 8, 16) x 2 tiles of the pair (xor 32), then across waves via LDS
+    // lanes with the same c: 4 k-groups and G k tiles of the group, then across waves via LDS
     float a = acc[0];
+    if constexpr (COLS == 4) a += __shfl_xor(a, 4, 64);
     a += __shfl_xor(a, 8, 64);
     a = sum_xor32(sum_xor16(a));
-    if (lane < 8) red[wave * 8 + lane] = a;
+    if (lane < COLS) red[wave * COLS + lane] = a;
     __syncthreads();
-    if (tid < 8) {
+    if (tid < COLS) {
         float s = 0.f;
 #pragma unroll
-        for (int wv = 0; wv < WAVES; ++wv) s += red[wv * 8 + tid];
-        f16 v = finish_element(s, ep, unit * 8 + tid);
-        if (ep.residual) v = v + ep.residual[unit * 8 + tid];
-        y[unit * 8 + tid] = v;
+        for (int wv = 0; wv < WAVES; ++wv) s += red[wv * COLS + tid];
+        f16 v = finish_element(s, ep, col0 + tid);
+        if (ep.residual) v = v + ep.residual[col0 + tid];
+        y[col0 + tid] = v;
+    }
+}
+
+template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0>
+__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kernel(
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
+    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
+{
+    gemv_unit_body<8, WAVES, D, XV, NORM>(x, w, scales, y, N, K, ep, pro, blockIdx.x * 8);
+}
+
+// Workgroups [0, n8) take the 8-column units of columns [0, 8 * n8); the rest take 4-column units of the remaining columns,
+// ordered so that the two units sharing 128-byte lines (2p, 2p + 1) are 8 block ids apart -- the same XCD when the dispatcher
+// places block b on XCD b % 8 (a speed matter only).  With n8 = 2 * CUs and n4 = CUs all workgroups are resident at once and
+// every CU streams 20 columns.
+template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0>
+__global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_mixed_kernel(
+    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
+    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro, int n8)
+{
+    const int b = blockIdx.x;
+    if (b < n8) {
+        gemv_unit_body<8, WAVES, D, XV, NORM>(x, w, scales, y, N, K, ep, pro, b * 8);
+    } else {
+        const int q  = b - n8, n4 = (int)gridDim.x - n8;
+        int       u4 = q;
+        if ((n4 & 15) == 0) u4 = 2 * ((q >> 4) * 8 + (q & 7)) + ((q >> 3) & 1);
+        gemv_unit_body<4, WAVES, D, XV, NORM>(x, w, scales, y, N, K, ep, pro, n8 * 8 + u4 * 4);
     }
 }
 

@@ -1230,11 +1230,13 @@ def test_tiled_gemm_column_split_launches(ops, oracle, M, K, N):
     assert torch.equal(ops.w8_a16_gemm(xd, processed, scales, path="mfma", bias=bias, residual=res), res + (y + bias))
 
 
-@pytest.mark.parametrize("K,N", [(2048, 5120), (2176, 6144), (4096, 5120), (2048, 13824), (2048, 24), (4224, 40)])
+@pytest.mark.parametrize("K,N", [(2048, 5120), (2176, 6144), (4096, 5120), (2048, 13824), (2048, 24), (4224, 40),
+                                 # 8 + 8 + 4 columns per CU (gemv_mixed_kernel, round 4): N / 256 = 20, 12, 28 and K / 256 >= 16
+                                 (5120, 5120), (13824, 5120), (4096, 3072), (8192, 7168)])
 def test_gemv_half_tile_row_units_vs_oracle(ops, oracle, K, N):
-    """M = 1 shapes for which the launcher picks 8-column units (gemv_half_kernel): N/16 a little above a multiple of the
-    CU count, and small N; N = 24 / 40 end in half a tile row... which the native layout does not allow (N % 16), so those
-    must be rejected, not mis-computed."""
+    """M = 1 shapes for which the launcher picks 8-column units (gemv_half_kernel) or the 8 + 8 + 4 mix (gemv_mixed_kernel):
+    N/16 a little above a multiple of the CU count, and small N; N = 24 / 40 end in half a tile row... which the native layout
+    does not allow (N % 16), so those must be rejected, not mis-computed."""
     if N % 16:
         w = np.zeros((K, 32), np.float16)
         q, s = oracle.quantize(w)
