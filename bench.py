@@ -329,6 +329,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the BASELINE configs[4] leg (Llama-2-13B shapes, prompt 1024 + 50 new tokens, one replica per GPU)")
+    ap.add_argument("--no-power-check", action="store_true",
+                    help="skip the zero-operand / Gaussian-weight GEMM chains (tools/profile_bench.sh: the rocprofv3 average of "
+                         "gemm_tile_kernel must cover the BASELINE operands only)")
     ap.add_argument("--cpu-budget", type=float, default=10.0)
     args = ap.parse_args()
 
@@ -496,7 +499,7 @@ def main():
     # trained weights; the BASELINE recipe's U(+-1/sqrt(K)) quantises to UNIFORM int8, the worst case for switching energy),
     # each between two device clock stamps: us per launch and the shader clock the chip held.  Every rank runs it (the timed
     # regions hold barriers); rank 0's figures are reported.
-    if True:
+    if not args.no_power_check:
         nl = max(100, min(args.gemm_steps, 400))
         zeros_w = torch.full((K, N), -128, dtype=torch.int8, device=dev)     # processed byte 0x80 = q 0
         zeros_s = torch.ones(N, dtype=torch.float16, device=dev)

@@ -25,7 +25,7 @@ $PY bench.py "$@" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || echo 
 
 echo "== 2. rocprofv3 --kernel-trace --stats of the same command" >&2
 rm -rf /tmp/prof_bench
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- $PY "$ROOT/bench.py" "$@" --no-cpu-baseline --no-config5 \
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- $PY "$ROOT/bench.py" "$@" --no-cpu-baseline --no-config5 --no-power-check \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_rocprof.err" ) || echo "rocprofv3 stats run failed" >&2
 STATS=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1)
 if [ -n "$STATS" ]; then
@@ -60,7 +60,7 @@ TRACE=$(find /tmp/prof_bench -name '*kernel_trace.csv' | head -1)
 
 echo "== 3. PMC passes (separate runs, --kernel-trace only) on tools/kbench gemm1" >&2
 if [ -x tools/kbench ]; then
-    for pass in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE" "TCC_EA0_WRREQ_sum"; do
+    for pass in "FETCH_SIZE" "TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum" "WRITE_SIZE" "TCC_EA0_WRREQ_sum" "TCP_TCC_READ_REQ_sum" "TCC_REQ_sum TCC_READ_sum"; do
         d=/tmp/prof_pmc_$(echo $pass | tr ' ' '_')
         rm -rf $d
         ( cd /tmp && rocprofv3 --pmc $pass --kernel-trace --output-format csv -d $d -- "$ROOT/tools/kbench" gemm1 > /dev/null 2>> "$OUT/${TAG}_rocprof.err" ) \
@@ -87,8 +87,13 @@ for key, kern in (("gemv", "gemv_kernel"), ("gemm_m1024", "gemm_tile_kernel")):
     # gfx950: a 16 B/lane stream's requests are 128 B each; FETCH_SIZE (KiB) reports half the bytes of such a stream
     # (MI355X_MICROARCH.md, HBM section) -> doubled.  The two must agree; the request count is the one reported.
     doc[key + "_hbm_bytes_per_launch"] = int(rd * 128) if rd else (int(fs * 1024 * 2) if fs else None)
+    # CU <- L2 read requests (the LDS-DMA and vector loads of all CUs): x 128 B = what the kernel pulls out of the L2s
+    l1 = mean_counter("TCP_TCC_READ_REQ_sum", kern)
+    l2rd = mean_counter("TCC_READ_sum", kern)
+    doc[key + "_l2_to_cu_bytes_per_launch"] = int(l1 * 128) if l1 else (int(l2rd * 128) if l2rd else None)
     doc[key + "_raw"] = {"TCC_EA0_RDREQ_sum": rd, "FETCH_SIZE_KiB": fs, "FETCH_SIZE_x2_bytes": fs * 2048 if fs else None,
-                         "TCC_EA0_WRREQ_sum": wr, "WRITE_SIZE_KiB": ws, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss}
+                         "TCC_EA0_WRREQ_sum": wr, "WRITE_SIZE_KiB": ws, "TCC_HIT_sum": hit, "TCC_MISS_sum": miss,
+                         "TCP_TCC_READ_REQ_sum": l1, "TCC_READ_sum": l2rd, "TCC_REQ_sum": mean_counter("TCC_REQ_sum", kern)}
 print(json.dumps(doc, indent=1))
 PYEOF
 fi

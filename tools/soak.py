@@ -23,6 +23,12 @@ for M, K, N in ((64, 4096, 4096), (32, 4096, 4096), (128, 4096, 4096), (64, 1100
     s = torch.rand(N, dtype=torch.float16, device=dev) * 0.01
     x = torch.randn(M, K, dtype=torch.float16, device=dev)
     cases.append((x, w, s, ops.w8_a16_gemm(x, w, s, path="splitk").clone()))
+# the same tile on int4 weight tiles (W4A16, gemm_splitk_kernel<BITS = 4>): same slabs, same ticket arrays, interleaved
+for M, K, N in ((64, 4096, 4096), (40, 5120, 5120), (128, 2048, 2048)):
+    w4 = torch.randint(-128, 127, (K, N // 2), dtype=torch.int8, device=dev)      # packed nibbles: any byte is a valid pair
+    s = torch.rand(N, dtype=torch.float16, device=dev) * 0.01
+    x = torch.randn(M, K, dtype=torch.float16, device=dev)
+    cases.append((x, w4, s, ops.w8_a16_gemm(x, w4, s, path="splitk").clone()))
 junk = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
 streams = [torch.cuda.Stream() for _ in range(3)]
 for it in range(iters):
