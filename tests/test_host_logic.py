@@ -352,3 +352,21 @@ def test_transformers_hook_redirects_the_kernel_lookup():
     lins = [m for m in model.modules() if isinstance(m, hf_eetq.EetqLinear)]
     assert len(lins) == 7 and all(getattr(m, "_eetq_layout_hooks", False) for m in lins)
     assert isinstance(model.lm_head, torch.nn.Linear)
+
+
+def test_eetq_package_exports_the_reference_surface():
+    """`from eetq import AutoEETQForCausalLM` (python/eetq/__init__.py:1-2) resolves lazily; `import eetq` itself does not pull
+    transformers in.  The class refuses direct construction like the reference's (auto.py:20-23)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import eetq; assert 'transformers' not in sys.modules; "
+            "from eetq import AutoEETQForCausalLM, eet_quantize, eet_accelerator, W8A16Linear; "
+            "from eetq.models import AutoEETQForCausalLM as A2, BaseEETQForCausalLM; assert A2 is AutoEETQForCausalLM; print('ok')")
+    from conftest import ROOT
+    out = subprocess.run([sys.executable, "-c", code % ROOT], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+    from eetq import AutoEETQForCausalLM
+    with pytest.raises(EnvironmentError):
+        AutoEETQForCausalLM()
+    for name in ("from_pretrained", "from_quantized"):
+        assert callable(getattr(AutoEETQForCausalLM, name))
