@@ -150,3 +150,41 @@ def test_save_pretrained_writes_reference_bytes_and_reloads(oracle, eetq_model, 
     ids = torch.randint(0, 1000, (1, 16), generator=torch.Generator().manual_seed(6)).to(DEV)
     with torch.no_grad():
         assert torch.equal(eetq_model(ids).logits, again(ids).logits)
+
+
+def test_tgi_layer_call_pattern(oracle):
+    """text-generation-inference's EETQ layer (server/text_generation_server/layers/eetq.py, `from EETQ import quant_weights,
+    w8_a16_gemm`): fp16 weight -> `torch.t(w).contiguous().cpu()` -> `quant_weights(w, torch.int8, False)` -> `.cuda(device)`;
+    forward = `w8_a16_gemm(input, weight, scale)` (+ bias).  The same lines on this repo's EETQ module, against the oracle."""
+    from EETQ import quant_weights, w8_a16_gemm
+
+    class EETQLinear(torch.nn.Module):          # the call sequence of TGI's layer, nothing else
+        def __init__(self, weight, bias):
+            super().__init__()
+            device = weight.device
+            if weight.dtype != torch.float16:
+                weight = weight.to(dtype=torch.float16)
+            weight = torch.t(weight).contiguous().cpu()
+            weight, scale = quant_weights(weight, torch.int8, False)
+            self.weight = weight.cuda(device)
+            self.scale = scale.cuda(device)
+            self.bias = bias.cuda(device) if bias is not None else None
+
+        def forward(self, input):
+            output = w8_a16_gemm(input, self.weight, self.scale)
+            return output + self.bias if self.bias is not None else output
+
+    torch.manual_seed(8)
+    lin = torch.nn.Linear(512, 1024, bias=True, dtype=torch.float16)
+    layer = EETQLinear(lin.weight.detach().to(DEV), lin.bias.detach().to(DEV))
+    q, s = oracle.quantize(lin.weight.detach().t().contiguous().numpy())
+    assert np.array_equal(layer.weight.cpu().numpy(), oracle.gfx950_pack(q)) and layer.scale.cpu().numpy().tobytes() == s.tobytes()
+    for shape in ((1, 512), (3, 7, 512), (130, 512)):       # decode row, [batch, tokens, hidden], a prefill block
+        x = torch.rand(*shape, dtype=torch.float16)
+        y = layer(x.to(DEV))
+        assert y.shape == shape[:-1] + (1024,)
+        want = oracle.w8a16_gemm(x.reshape(-1, 512).numpy(), q, s).astype(np.float32) + lin.bias.detach().float().numpy()
+        got = y.float().cpu().numpy().reshape(-1, 1024)
+        assert np.all(np.abs(got - want) <= 1e-3 * np.abs(want).max() + 2e-3 * np.abs(want) + 1e-3)
+        with torch.no_grad():
+            assert np.abs(got - lin(x).float().numpy().reshape(-1, 1024)).max() <= 1e-2
