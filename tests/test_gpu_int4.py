@@ -121,6 +121,33 @@ def test_w4a16_gemv_vs_oracle(ops, oracle, M, K, N):
     assert y.shape == (M, N) and _tier_a(y, ref).all(), np.abs(y.astype(np.float32) - ref.astype(np.float32)).max()
 
 
+@pytest.mark.parametrize("K,N", [(2048, 8208), (2176, 16400), (4096, 24592), (5120, 13824), (5120, 27648), (2048, 8192)])
+def test_w4a16_gemv_many_tile_rows_vs_oracle(ops, oracle, K, N):
+    """M = 1 with more tile rows than fit the chip at once (N / 16 > 2 * CUs: 513, 1025, 1537 rows and the 13B fused shapes).
+    Oracle on sampled columns from both ends, the expansion route on all of them; bias + residual epilogue; launch-to-launch bit
+    identity.  (Written for the several-rows-per-workgroup kernel of round 4, which passed it and was shelved on its timings --
+    tools/experiments/i4_rows_kernel.patch, profiles/r04_i4_rows.txt; kept as coverage of large-N decode shapes.)"""
+    rng = np.random.default_rng(K + N)
+    qp = rng.integers(-128, 128, (K, N // 2), dtype=np.int8)
+    s = (rng.random(N) * 0.02 + 0.001).astype(np.float16)
+    x = (rng.random((1, K)) - 0.5).astype(np.float16)
+    pk = torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV)
+    xd, sd = torch.from_numpy(x).to(DEV), torch.from_numpy(s).to(DEV)
+    y = ops.w8_a16_gemm(xd, pk, sd)
+    assert torch.equal(y, ops.w8_a16_gemm(xd, pk, sd))
+    got = y.cpu().numpy()
+    vals = oracle.i4_values(qp)
+    for c0 in (0, 16, 32, 48, (N // 32) * 16, N - 64):
+        cs = slice(c0, c0 + 64)
+        ref = oracle.w8a16_gemm(x, np.ascontiguousarray(vals[:, cs]), s[cs])
+        assert _tier_a(got[:, cs], ref).all(), (c0, np.abs(got[:, cs].astype(np.float32) - ref.astype(np.float32)).max())
+    whole = ops.w8_a16_gemm(xd, pk, sd, path="mfma")            # the expansion route over all columns
+    assert _tier_a(got, whole.cpu().numpy()).all()
+    bias = torch.randn(N, dtype=torch.float16, device=DEV)
+    res = torch.randn(1, N, dtype=torch.float16, device=DEV)
+    assert torch.equal(ops.w8_a16_gemm(xd, pk, sd, bias=bias, residual=res), y + bias + res)
+
+
 def test_w4a16_identity_is_exact_dequant(ops, oracle):
     """x = I selects single products: the GEMM must return fp16(q4 * s) exactly, for every nibble value and k position
     (GEMV path for the first rows, the expanded-int8 route for the whole identity)."""
