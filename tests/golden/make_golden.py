@@ -79,7 +79,14 @@ def main():
     rng = np.random.default_rng(7)
     manifest["quant"].append(quant_case("quant_rand_f16_k192_n256", (rng.standard_normal((192, 256)) * 0.02).astype(np.float16)))
     manifest["quant"].append(quant_case("quant_rand_f32_k64_n64", (rng.standard_normal((64, 64)) * 3.0).astype(np.float32)))
-    with open(os.path.join(HERE, "MANIFEST.json"), "w") as f:
+    # sections other scripts / hands own (reference_python_layer: make_reference_python_golden.py; machine_code: the hazard
+    # fixture of tools/check_store_hazard.py) are carried over
+    path = os.path.join(HERE, "MANIFEST.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            for key, value in json.load(f).items():
+                manifest.setdefault(key, value)
+    with open(path, "w") as f:
         json.dump(manifest, f, indent=1)
     print(json.dumps(manifest, indent=1))
 
