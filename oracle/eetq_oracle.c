@@ -36,7 +36,8 @@
  *   - one known answer of the compiled reference that survives in SURVEY.md (section 7, Appendix A): 208 of 32768
  *     values differ from half-to-even rounding on a seed-1 fp16 Linear(256->128); the oracle reproduces it.
  * The quantiser's rounding / clamp / NaN behaviour beyond that count is restated from the source lines cited
- * above: for the raw int8 values parity remains "restated, unpinned by a reference build".
+ * above: for the raw int8 values the status is **parity unpinned** (restated, not pinned by a reference build or by
+ * reference-held vectors).
  */
 #include <math.h>
 #include <stddef.h>
