@@ -148,6 +148,30 @@ def test_w4a16_gemv_many_tile_rows_vs_oracle(ops, oracle, K, N):
     assert torch.equal(ops.w8_a16_gemm(xd, pk, sd, bias=bias, residual=res), y + bias + res)
 
 
+def test_w4a16_explicit_paths_and_their_limits(ops, oracle):
+    """eetq_w4a16_gemm_ex: the explicit kernel paths agree with AUTO where both apply (tier A; bit-identical where AUTO takes
+    that very kernel) and refuse what they cannot run instead of mis-computing."""
+    K, N = 1024, 256
+    rng = np.random.default_rng(5)
+    qp = rng.integers(-128, 128, (K, N // 2), dtype=np.int8)
+    s = (rng.random(N) * 0.02 + 0.001).astype(np.float16)
+    pk = torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV)
+    sd = torch.from_numpy(s).to(DEV)
+    for M, same, others in ((1, "gemv", ("stream", "splitk", "mfma")), (4, "stream", ("gemv", "splitk", "mfma")),
+                            (16, "stream", ("splitk", "mfma")), (40, "splitk", ("mfma",)), (200, "mfma", ())):
+        x = torch.rand(M, K, dtype=torch.float16, device=DEV) - 0.5
+        auto = ops.w8_a16_gemm(x, pk, sd)
+        assert torch.equal(ops.w8_a16_gemm(x, pk, sd, path=same), auto), (M, same)
+        for p in others:
+            assert _tier_a(ops.w8_a16_gemm(x, pk, sd, path=p).cpu().numpy(), auto.float().cpu().numpy()).all(), (M, p)
+    x = torch.rand(20, K, dtype=torch.float16, device=DEV)
+    for bad in ("gemv", "stream", "mid", "tilesplit"):
+        with pytest.raises(RuntimeError):
+            ops.w8_a16_gemm(x, pk, sd, path=bad)
+    with pytest.raises(RuntimeError):
+        ops.w8_a16_gemm(torch.rand(200, K, dtype=torch.float16, device=DEV), pk, sd, path="splitk")   # M > 128
+
+
 def test_w4a16_identity_is_exact_dequant(ops, oracle):
     """x = I selects single products: the GEMM must return fp16(q4 * s) exactly, for every nibble value and k position
     (GEMV path for the first rows, the expanded-int8 route for the whole identity)."""
