@@ -188,10 +188,52 @@ int launch_lds_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep
     return launch_inst_i4<M, WAVES, D, false, false, 8, OCC>(x, w, scales, ep, y, N, K, stream);
 }
 
+// 8-column units on int4 tiles (gemv_half_kernel<..., BITS = 4>): the same rule as for int8 tiles -- whole tile rows would leave CUs
+// idle or put a second workgroup on only a few (N = 5120 on 256 CUs) -- with pairs of 128-deep k tiles
+template <int XV>
+int launch_half_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
+{
+    auto         kern = gemv::gemv_half_kernel<8, 2, XV, 4, 0, 4>;
+    const size_t smem = gemv::gemv_half_smem_bytes(K, 8);
+    if (smem > 64 * 1024) {
+        static std::atomic<unsigned long long> opted{0};
+        int st = opt_in_large_lds(kern, opted);
+        if (st != EETQ_OK) return st;
+    }
+    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep, Prologue{});
+    return check_hip(hipGetLastError(), "gemv_half_kernel (int4) launch");
+}
+
+bool half_units_pay_i4(int N, int K)
+{
+    const int KT = K / 128;
+    if (KT % 2 || KT < 32 || K > 32768) return false;  // pairs of k tiles, >= 2 pairs per wave in flight (8 waves), x fits in LDS
+    static const int forced = [] {  // EETQ_AMD_I4_UNITS=1: 8-column units wherever they can run, =0: never (A/B runs)
+        const char* e = getenv("EETQ_AMD_I4_UNITS");
+        return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1;
+    }();
+    if (forced >= 0) return forced == 1;
+    // Measured (profiles/r04_int4_units_ab.txt, us with / without): deep K wins everywhere -- 11008 x 4096 7.45 / 8.40, 5120 x 13824
+    // 10.14 / 11.36, 13824 x 5120 10.82 / 13.3, 5120^2 5.66 / 6.10 -- the int4 GEMV is issue- and latency-bound and
+    // 8-wave workgroups of 8 columns overlap better than 16-wave workgroups of 16; K = 4096 loses (4.53 / 4.06: the
+    // straight-line register-resident form exists there, as at K = 8192)
+    if (KT != 64 && KT >= 40) return true;
+    const int ncu = device_cu_count(), rows = N / kTileN;
+    return KT != 32 && KT != 64 && (2 * rows <= ncu || (rows > ncu && 10 * rows <= 13 * ncu));
+}
+
 template <int M>
 int launch_m_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int N, int K, hipStream_t stream)
 {
     const int KT = K / 128;
+    if constexpr (M == 1) {
+        if (ep.act == 0 && half_units_pay_i4(N, K)) {
+            const int need = (K / 8 + 511) / 512;  // 16-byte activation loads per thread
+            if (need <= 2) return launch_half_i4<2>(x, w, scales, ep, y, N, K, stream);
+            if (need <= 4) return launch_half_i4<4>(x, w, scales, ep, y, N, K, stream);
+            return launch_half_i4<8>(x, w, scales, ep, y, N, K, stream);
+        }
+    }
     if constexpr (M <= 2) {
         // whole tile row in flight, activations straight to registers (the K = 4096 / 8192 decode shapes)
         if (KT == 32) return launch_inst_i4<M, 16, 2, true, true, 1, 4>(x, w, scales, ep, y, N, K, stream);

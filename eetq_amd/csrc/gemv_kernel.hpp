@@ -412,7 +412,8 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_grouped_k
 // tile 4p + sub -- sixteen 64-byte half lines (the other half belongs to the neighbouring 4-column unit, which the launcher
 // places on the same XCD so that the line is fetched into one L2 only).  Wave w owns groups w, w+WAVES, ...; D groups in
 // flight; K/64 must be a multiple of the group size (launcher contract).  Activations are staged in LDS like the generic form.
-template <int COLS, int WAVES, int D, int XV, int NORM>
+// BITS = 4: the same units on int4 tiles (16 columns x 128 k, a lane's 16 bytes = 32 k of its column).
+template <int COLS, int WAVES, int D, int XV, int NORM, int BITS = 8>
 __device__ __forceinline__ void gemv_unit_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int N, int K, const Epilogue& ep, const Prologue& pro, const int col0)
@@ -427,7 +428,8 @@ __device__ __forceinline__ void gemv_unit_body(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
     const int sub = lane / (4 * COLS), kg = (lane / COLS) & 3, c = lane & (COLS - 1);
-    const int KT = K >> 6, NP = KT / G;  // groups of G k tiles
+    constexpr int TK = Codec<BITS>::kTileK, LK = Codec<BITS>::kLaneK;  // k per tile / per lane: 64 / 16 (int8), 128 / 32 (int4)
+    const int KT = K / TK, NP = KT / G;  // groups of G k tiles
 
     u32 sraw = reinterpret_cast<const uint16_t*>(scales)[col0 + c];
 
@@ -469,13 +471,13 @@ __device__ __forceinline__ void gemv_unit_body(
     __syncthreads();
 
     float      acc[1] = {0.f};
-    const f16* xl     = xs + sub * 64 + 16 * kg;  // + 64 * G halfs per group
+    const f16* xl     = xs + sub * TK + LK * kg;  // + TK * G halfs per group
     const int  n      = (NP - wave + WAVES - 1) / WAVES;  // groups of this wave (>= D by launch contract)
     int        i      = 0;
     for (; i + 2 * D <= n; i += D) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            consume_tile<1>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * (64 * G), K, acc);
+            consume_tile<1, BITS>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * (TK * G), K, acc);
             buf[d] = load_w<true>(wptr(wave + (i + d + D) * WAVES));
         }
     }
@@ -487,10 +489,10 @@ __device__ __forceinline__ void gemv_unit_body(
         tail[d]     = load_w<true>(wptr(wave + (t < n ? t : n - 1) * WAVES));
     }
 #pragma unroll
-    for (int d = 0; d < D; ++d) consume_tile<1>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * (64 * G), K, acc);
+    for (int d = 0; d < D; ++d) consume_tile<1, BITS>(buf[d], scale2, xl + (size_t)(wave + (i + d) * WAVES) * (TK * G), K, acc);
 #pragma unroll
     for (int d = 0; d < D - 1; ++d)
-        if (d < r) consume_tile<1>(tail[d], scale2, xl + (size_t)(wave + (i + D + d) * WAVES) * (64 * G), K, acc);
+        if (d < r) consume_tile<1, BITS>(tail[d], scale2, xl + (size_t)(wave + (i + D + d) * WAVES) * (TK * G), K, acc);
 
     // lanes with the same c: 4 k-groups and G k tiles of the group, then across waves via LDS
     float a = acc[0];
@@ -509,12 +511,12 @@ __device__ __forceinline__ void gemv_unit_body(
     }
 }
 
-template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0>
+template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
 {
-    gemv_unit_body<8, WAVES, D, XV, NORM>(x, w, scales, y, N, K, ep, pro, blockIdx.x * 8);
+    gemv_unit_body<8, WAVES, D, XV, NORM, BITS>(x, w, scales, y, N, K, ep, pro, blockIdx.x * 8);
 }
 
 // Workgroups [0, n8) take the 8-column units of columns [0, 8 * n8); the rest take 4-column units of the remaining columns,

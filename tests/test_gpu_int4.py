@@ -121,7 +121,9 @@ def test_w4a16_gemv_vs_oracle(ops, oracle, M, K, N):
     assert y.shape == (M, N) and _tier_a(y, ref).all(), np.abs(y.astype(np.float32) - ref.astype(np.float32)).max()
 
 
-@pytest.mark.parametrize("K,N", [(2048, 8208), (2176, 16400), (4096, 24592), (5120, 13824), (5120, 27648), (2048, 8192)])
+@pytest.mark.parametrize("K,N", [(2048, 8208), (2176, 16400), (4096, 24592), (5120, 13824), (5120, 27648), (2048, 8192),
+                                 # N = 5120 on 256 CUs: 8-column units on int4 tiles (gemv_half_kernel<..., BITS = 4>)
+                                 (5120, 5120), (13824, 5120), (4096, 1024)])
 def test_w4a16_gemv_many_tile_rows_vs_oracle(ops, oracle, K, N):
     """M = 1 with more tile rows than fit the chip at once (N / 16 > 2 * CUs: 513, 1025, 1537 rows and the 13B fused shapes).
     Oracle on sampled columns from both ends, the expansion route on all of them; bias + residual epilogue; launch-to-launch bit
