@@ -108,6 +108,11 @@ bool half_units_pay(int N, int K)
 {
     const int KT = K / kTileK;
     if (KT % 2 || KT < 32 || K > 32768) return false;  // pairs of k tiles, >= 2 pairs per wave in flight, x fits in LDS
+    static const int forced = [] {  // EETQ_AMD_I8_UNITS=1: column units wherever they can run, =0: never (A/B runs)
+        const char* e = getenv("EETQ_AMD_I8_UNITS");
+        return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1;
+    }();
+    if (forced >= 0) return forced == 1;
     // Measured (profiles/r01_kbench_gemv.txt): worth it when whole tile rows leave CUs idle (rows <= CUs / 2) or put a
     // second workgroup on only a few CUs (N = 5120: 320 rows on 256 CUs, K = 13824 14.5 -> 13.2 us, K = 5120 6.24 -> 6.04);
     // a wash or a small loss elsewhere (N = 6144, 13824, 4096).
