@@ -1,6 +1,8 @@
 // Medium-batch (2 <= M <= 64) W8A16 stream GEMM launcher; kernel in streamk_kernel.hpp.
 // Covers the reference's batched-GEMV range (m <= 4, weightOnlyBatchedGemv/kernelLauncher.cu:165-192) and the
 // small-M end of its CUTLASS range, where the weight stream -- not the matrix cores -- bounds the time.
+#include <cstdlib>
+
 #include "streamk_kernel.hpp"
 
 namespace eetq {
@@ -33,13 +35,29 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
         // + 2 activation loads, times the workgroups the busiest CU gets.  N = 5120 (320 tile rows on 256 CUs): M = 8
         // 10.0 -> 7.5 us, K = 13824 23.6 -> 17.2 us; N = 22016: 24.5 -> 17.0 us; N = 4096 stays at NT = 1 (5.0 vs 5.8 us)
         // -- profiles/r01_kbench_streamk_nt.txt
+        static const int forced_waves = [] {  // EETQ_AMD_I8_STREAM_WAVES=8 / 16: force the workgroup size (A/B runs)
+            const char* e = getenv("EETQ_AMD_I8_STREAM_WAVES");
+            return e ? atoi(e) : 0;
+        }();
         if constexpr (MT == 1) {
+            const int ncu = device_cu_count();
+            int       nt  = 1;
             if (N % (2 * kTileN) == 0) {
-                const int  ncu   = device_cu_count();
                 const long cost1 = (long)((N / kTileN + ncu - 1) / ncu) * 3;
                 const long cost2 = (long)((N / (2 * kTileN) + ncu - 1) / ncu) * 4;
-                if (cost2 < cost1) return launch_inst<MT, 2, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+                if (cost2 < cost1) nt = 2;
             }
+            // Workgroup size (round 4, profiles/r04_int8_stream_waves_ab.txt, us with 16 / 8 waves): 8-wave workgroups win
+            // wherever there are two tile rows per workgroup or more workgroups than CUs, and at M > 4 -- 5120^2 M = 4 7.59 /
+            // 7.08, 13824 x 5120 M = 4 17.03 / 15.26, 5120 x 13824 M = 8 15.69 / 14.67, 4096^2 M = 8 5.66 / 5.32; one tile row
+            // per workgroup on <= one workgroup per CU at M <= 4 keeps 16 waves (11008 x 4096 M = 2 9.66 / 10.27).  Four tiles
+            // in flight per wave instead of two lose (r04_int8_stream_waves_ab2.txt).
+            const int  wgs   = N / (kTileN * nt);
+            const bool eight = forced_waves ? forced_waves == 8 : (M > 4 || nt == 2 || wgs > ncu);
+            if (nt == 2)
+                return eight ? launch_inst<MT, 2, 8, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
+                             : launch_inst<MT, 2, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+            if (eight) return launch_inst<MT, 1, 8, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
         }
         return launch_inst<MT, 1, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     }
@@ -53,14 +71,28 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
 int launch_mt_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, hipStream_t stream)
 {
     const int KT = K / 128;
+    static const int forced_waves = [] {  // EETQ_AMD_I4_STREAM_WAVES=8 / 16: force the workgroup size (A/B runs)
+        const char* e = getenv("EETQ_AMD_I4_STREAM_WAVES");
+        return e ? atoi(e) : 0;
+    }();
     if (KT >= 32) {
+        const int ncu = device_cu_count();
+        int       nt  = 1;
         if (N % (2 * kTileN) == 0) {
-            const int  ncu   = device_cu_count();
             const long cost1 = (long)((N / kTileN + ncu - 1) / ncu) * 5;
             const long cost2 = (long)((N / (2 * kTileN) + ncu - 1) / ncu) * 6;
-            if (cost2 < cost1) return launch_inst<1, 2, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+            if (cost2 < cost1) nt = 2;
         }
-        return launch_inst<1, 1, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+        // 8-wave workgroups when there are enough of them to give every CU one (round 4, profiles/r04_int4_stream_waves_ab.txt:
+        // 4096 x 11008 M = 4 8.99 -> 8.34 us, 5120 x 13824 10.93 -> 10.44, 11008 x 4096 8.46 -> 8.10; the int4 kernels are issue-
+        // and latency-bound and smaller workgroups overlap better); 16 waves when two tile rows per workgroup leave fewer
+        // workgroups than CUs (N = 5120: 160 workgroups, 5.84 vs 6.29 us with 8 waves)
+        const int  wgs   = N / (kTileN * nt);
+        const bool eight = forced_waves ? forced_waves == 8 : wgs >= ncu;
+        if (nt == 2) return eight ? launch_inst<1, 2, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
+                                  : launch_inst<1, 2, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+        return eight ? launch_inst<1, 1, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
+                     : launch_inst<1, 1, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     }
     if (KT >= 16) return launch_inst<1, 1, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     if (KT >= 4) return launch_inst<1, 1, 4, 1, 1, 4>(x, w, scales, ep, y, M, N, K, stream);
