@@ -159,6 +159,19 @@ int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16
         }
     }
     // generic K: every wave must own >= D tiles; D = 2 in flight per wave won at K = 11008
+    if constexpr (M == 1) {
+        // Workgroup size (round 4, profiles/r04_i8_gemv_waves_ab.txt, us with 16 / 8 waves): with more than two tile rows per CU
+        // 8-wave workgroups overlap one another better -- 5120 x 13824 13.91 / 13.37, 5120 x 15360 14.64 / 13.89, 5120 x 27648
+        // 23.16 / 22.50 -- with one tile row per CU they starve it (11008 x 4096 9.37 / 10.28); 8192^2 is a wash.
+        // EETQ_AMD_I8_GEMV_WAVES = 16 / 82 / 84 forces 16 waves / 8 waves with 2 / 4 tiles in flight (A/B runs)
+        static const int forced = [] {
+            const char* e = getenv("EETQ_AMD_I8_GEMV_WAVES");
+            return e ? atoi(e) : 0;
+        }();
+        if (KT >= 32 && forced == 84) return launch_lds<M, 8, 4, false, 8>(x, w, scales, ep, y, N, K, stream, pro);
+        if (KT >= 32 && (forced == 82 || (forced == 0 && N / kTileN > 2 * device_cu_count())))
+            return launch_lds<M, 8, 2, false, 8>(x, w, scales, ep, y, N, K, stream, pro);
+    }
     if (KT >= 32) return launch_lds<M, 16, 2, false, (M == 1 ? 8 : 4)>(x, w, scales, ep, y, N, K, stream, pro);
     if (KT >= 16) return launch_lds<M, 8, 2, false, 2>(x, w, scales, ep, y, N, K, stream, pro);
     if (KT >= 4) return launch_lds<M, 4, 1, false, 1>(x, w, scales, ep, y, N, K, stream, pro);
@@ -287,8 +300,9 @@ int launch_grouped_inst(const gemv::GroupedArgs& g, int K, int rows, hipStream_t
 
 bool gemv_grouped_supports(int K) { return K % kTileK == 0 && K / kTileK >= 32 && K <= 32768; }
 
-// The instantiations are the ones launch_m<1> picks for a single problem of the same K (without the 8-column-unit form),
-// so a grouped result equals the separate launch bit for bit wherever that launch takes the whole-tile-row kernel.
+// The instantiations are the 16-wave whole-tile-row ones launch_m<1> picks for a single problem of the same K, so a grouped
+// result equals the separate launch bit for bit wherever that launch takes the same kernel (K = 4096 always; other K unless the
+// single launch takes a column-unit form or -- more than two tile rows per CU -- the 8-wave form: tier A there).
 int launch_gemv_grouped(const gemv::GroupedArgs& g, int K, int rows, hipStream_t stream)
 {
     if (!gemv_grouped_supports(K)) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] grouped GEMV: K must be a multiple of 64 in [2048, 32768]");
