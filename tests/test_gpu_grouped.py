@@ -68,8 +68,10 @@ def test_grouped_mixed_k_13b_shapes_and_fallback(ops, oracle):
         assert _tier_a(outs[i].cpu().numpy(), ref).all(), (i, shapes[i])
         single = ops.w8_a16_gemm(x, w, s)
         assert _tier_a(outs[i].cpu().numpy(), single.cpu().numpy()).all()
-        if shapes[i] in ((5120, 13824), (1024, 512)):      # the single launch runs the same whole-tile-row kernel / is the fallback
+        if shapes[i] == (1024, 512):      # the fallback inside the grouped call IS the single launch
             assert torch.equal(outs[i], single), shapes[i]
+        # (5120 x 13824: since round 4 a single launch with more than two tile rows per CU runs 8-wave workgroups, the grouped
+        # kernel 16-wave ones -- same products, another summation order: tier A above, no bit identity)
 
 
 def test_grouped_more_than_one_dispatch_and_graph_replay(ops, oracle):
