@@ -148,6 +148,19 @@ int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16
         if (ep.act != kActGlu8 && half_units_pay(N, K)) return launch_half(x, w, scales, ep, y, N, K, stream, pro);
     }
     // Tuned on MI355X with tools/kbench (profiles/r01_kbench_gemv.txt):
+    if constexpr (M == 1) {
+        // K = 4096 with more than two tile rows per CU (the 7B up / gate projections and their fused forms): the 8-wave generic form
+        // beats the straight-line 16-wave one -- 4096 x 11008 9.57 -> 8.87 us, 4096 x 22016 16.79 -> 15.52, 4096 x 12288 9.98 -> 9.48
+        // (profiles/r04_i8_gemv_k4096_ab.txt); at one tile row per CU (4096^2) it loses (5.10 vs 4.69).
+        // EETQ_AMD_I8_GEMV_K4096 = 16 / 82 / 88: force the straight-line form / 8 waves generic / 8 waves x 8 tiles (A/B runs)
+        static const int forced64 = [] {
+            const char* e = getenv("EETQ_AMD_I8_GEMV_K4096");
+            return e ? atoi(e) : 0;
+        }();
+        if (KT == 64 && forced64 == 88) return launch_lds<M, 8, 8, true, 4>(x, w, scales, ep, y, N, K, stream, pro);
+        if (KT == 64 && (forced64 == 82 || (forced64 == 0 && N / kTileN > 2 * device_cu_count())))
+            return launch_lds<M, 8, 2, false, 8>(x, w, scales, ep, y, N, K, stream, pro);
+    }
     if (KT == 64) {  // K = 4096: 16 waves x 4 tiles, straight-line; <= 64 VGPRs so two workgroups fit a CU
         // (register-resident activations only for one row: at M = 2 they cost 32 more VGPRs and the second workgroup per CU --
         // 14.5 instead of 5.9 us at N = 4096, tools/path_compare.py)
