@@ -19,7 +19,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "--one":
     print(json.dumps(out))
     sys.exit(0)
 for rep in range(2):
-    for u in ("0", "82", "84"):
+    for u in (sys.argv[1:] or ["0", "82", "84"]):
         env = dict(os.environ, EETQ_AMD_I8_GEMV_WAVES=u)
         r = subprocess.run([sys.executable, __file__, "--one"], env=env, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")]
