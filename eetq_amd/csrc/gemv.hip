@@ -265,6 +265,18 @@ int launch_m_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
             return launch_half_i4<8>(x, w, scales, ep, y, N, K, stream);
         }
     }
+    if constexpr (M == 1) {
+        // K = 4096 with more than two tile rows per CU: the 8-wave generic form, as for int8 tiles -- 4096 x 11008 8.0 -> 7.05 us,
+        // 4096 x 22016 13.6 -> 11.8, 4096 x 12288 8.2 -> 7.2; 4096^2 keeps the straight-line form (4.04 vs 4.12)
+        // (profiles/r04_i4_gemv_k4096_ab.txt).  EETQ_AMD_I4_GEMV_K4096 = 16 / 82 / 84 forces a form (A/B runs)
+        static const int forced32 = [] {
+            const char* e = getenv("EETQ_AMD_I4_GEMV_K4096");
+            return e ? atoi(e) : 0;
+        }();
+        if (KT == 32 && forced32 == 84) return launch_lds_i4<M, 8, 4, 2>(x, w, scales, ep, y, N, K, stream);
+        if (KT == 32 && (forced32 == 82 || (forced32 == 0 && N / kTileN > 2 * device_cu_count())))
+            return launch_lds_i4<M, 8, 2, 2>(x, w, scales, ep, y, N, K, stream);
+    }
     if constexpr (M <= 2) {
         // whole tile row in flight, activations straight to registers (the K = 4096 / 8192 decode shapes)
         if (KT == 32) return launch_inst_i4<M, 16, 2, true, true, 1, 4>(x, w, scales, ep, y, N, K, stream);
