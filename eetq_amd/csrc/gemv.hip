@@ -331,6 +331,11 @@ bool gemv_grouped_supports(int K) { return K % kTileK == 0 && K / kTileK >= 32 &
 int launch_gemv_grouped(const gemv::GroupedArgs& g, int K, int rows, hipStream_t stream)
 {
     if (!gemv_grouped_supports(K)) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] grouped GEMV: K must be a multiple of 64 in [2048, 32768]");
+    static const int forced = [] {  // EETQ_AMD_GROUPED_WAVES = 16 / 8: force the K = 4096 form (A/B runs)
+        const char* e = getenv("EETQ_AMD_GROUPED_WAVES");
+        return e ? atoi(e) : 0;
+    }();
+    if (K == 4096 && forced == 8) return launch_grouped_inst<8, 2, false, false, 1, 8>(g, K, rows, stream);
     if (K == 4096) return launch_grouped_inst<16, 4, true, true, 1, 8>(g, K, rows, stream);
     const int need = (K / 8 + 1023) / 1024;  // 16-byte activation loads per thread
     if (need <= 1) return launch_grouped_inst<16, 2, false, false, 1, 8>(g, K, rows, stream);
