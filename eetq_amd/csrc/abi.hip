@@ -308,7 +308,7 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
     switch (path) {
         case EETQ_PATH_AUTO:
             // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
-            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 8 (<= 16 for weights under 32 Mi) -> MFMA stream kernel
+            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 10 (<= 12 / 16 for narrower / smaller weights) -> MFMA stream kernel
             // (same weight stream, activations straight from L2 into MFMA operands); up to M = 128 -> split-K medium-batch
             // tile (M > 64 on wide N: the tiled kernel); larger M -> LDS-tiled MFMA GEMM (128 x 128 tiles, or 128 x 64 when
             // those fill the chip better).  Crossovers measured as graph-replayed chains: profiles/r03_path_compare_mid.jsonl.
@@ -322,8 +322,13 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
                 // the register-streaming kernel re-reads the M x K activations per 16-column tile row: beyond 8 rows and 32 Mi
                 // weights the split-K tile (flat in M up to 32) is ahead -- M = 16: 4096 x 11008 12.2 vs 14.1 us, 11008 x 4096
                 // 12.5 vs 14.2, 5120 x 13824 15.5 vs 18.7, 13824 x 5120 19.5 vs 22.3; at 4096^2 (6.6 vs 7.3) and 5120^2 it is not
-                const bool big = (size_t)K * N >= (32ull << 20);
-                if (M <= 8 || (M <= 16 && !(big && use_splitk && fits))) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
+                // round 4 (8-wave workgroups in the stream kernel, profiles/r04_stream_splitk_seam.jsonl): on those big weights the
+                // stream kernel now holds up to M = 10 (M = 9: 4096 x 11008 11.6 vs 12.6 us, 11008 x 4096 10.8 vs 12.5, 13824 x 5120
+                // 17.4 vs 20.4, 5120 x 13824 15.4 vs 15.6) and to M = 12 where N < 8192 (11008 x 4096 12.1 vs 12.6, 13824 x 5120 19.1 vs
+                // 20.4; 5120 x 13824 16.5 vs 15.6 the other way)
+                const bool big  = (size_t)K * N >= (32ull << 20);
+                const int  mmax = !(big && use_splitk && fits) ? 16 : (N < 8192 ? 12 : 10);
+                if (M <= mmax) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
             }
             if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31)) {
                 // wide N, M > 64: the 128 x 64 tiles of the tiled kernel already give most CUs a workgroup and read the
