@@ -325,17 +325,28 @@ int launch_grouped_inst(const gemv::GroupedArgs& g, int K, int rows, hipStream_t
 
 bool gemv_grouped_supports(int K) { return K % kTileK == 0 && K / kTileK >= 32 && K <= 32768; }
 
-// The instantiations are the 16-wave whole-tile-row ones launch_m<1> picks for a single problem of the same K, so a grouped
-// result equals the separate launch bit for bit wherever that launch takes the same kernel (K = 4096 always; other K unless the
-// single launch takes a column-unit form or -- more than two tile rows per CU -- the 8-wave form: tier A there).
+// (body choice and what it means for bit identity with separate launches: see inside)
 int launch_gemv_grouped(const gemv::GroupedArgs& g, int K, int rows, hipStream_t stream)
 {
     if (!gemv_grouped_supports(K)) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] grouped GEMV: K must be a multiple of 64 in [2048, 32768]");
-    static const int forced = [] {  // EETQ_AMD_GROUPED_WAVES = 16 / 8: force the K = 4096 form (A/B runs)
+    // Body: with more than two tile rows per CU in the dispatch the 8-wave generic form (two tiles in flight per wave, x staged in
+    // LDS), as for single launches with many tile rows -- 8 x (4096 x 4096): 2.83 -> 2.64 us per problem (0.80 of 8 TB/s), 16
+    // problems 2.50 (0.84) (profiles/r04_grouped_waves_ab.txt); smaller dispatches keep the 16-wave forms (K = 4096: the
+    // straight-line register-resident one, bit-identical to a separate 4096 x 4096 launch).  A grouped result is always the
+    // same bits from call to call; against separate launches it is tier A (another summation order) unless both take the same
+    // body.  EETQ_AMD_GROUPED_WAVES = 16 / 8 forces a body (A/B runs).
+    static const int forced = [] {
         const char* e = getenv("EETQ_AMD_GROUPED_WAVES");
         return e ? atoi(e) : 0;
     }();
-    if (K == 4096 && forced == 8) return launch_grouped_inst<8, 2, false, false, 1, 8>(g, K, rows, stream);
+    const bool eight = forced ? forced == 8 : rows > 2 * device_cu_count();
+    const int  need8 = (K / 8 + 511) / 512;  // 16-byte activation loads per thread, 8 waves
+    if (eight) {
+        if (need8 <= 1) return launch_grouped_inst<8, 2, false, false, 1, 8>(g, K, rows, stream);
+        if (need8 <= 2) return launch_grouped_inst<8, 2, false, false, 2, 8>(g, K, rows, stream);
+        if (need8 <= 4) return launch_grouped_inst<8, 2, false, false, 4, 8>(g, K, rows, stream);
+        return launch_grouped_inst<8, 2, false, false, 8, 8>(g, K, rows, stream);
+    }
     if (K == 4096) return launch_grouped_inst<16, 4, true, true, 1, 8>(g, K, rows, stream);
     const int need = (K / 8 + 1023) / 1024;  // 16-byte activation loads per thread
     if (need <= 1) return launch_grouped_inst<16, 2, false, false, 1, 8>(g, K, rows, stream);
