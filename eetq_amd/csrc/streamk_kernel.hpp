@@ -13,17 +13,27 @@
 namespace eetq {
 namespace streamk {
 
+typedef __attribute__((address_space(3))) void       lds_void;
+typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
+
 // grid.x = N / (16*NT); block = WAVES*64; wave w takes k tiles w, w+WAVES, ... (each >= D tiles by launch contract).
 // Dynamic LDS: WAVES * MT*NT*256 floats (cross-wave reduction only).
+// XLDS (MT = 1, K % 128 == 0, M*K*2 bytes fit): the M activation rows are copied ONCE per workgroup into LDS (LDS-DMA,
+// 16 B/lane, no VGPR round trip; the 16-byte chunk index within a row is xor-ed with the row number so that the 16 lanes of an MFMA
+// A fragment -- 16 rows, same k -- hit 16 different bank groups) and the A fragments are LDS reads: the vector-memory path then
+// carries the weight stream only, instead of 16 (clamped) rows x 128 B of activations from L2 per 1 KiB weight tile.
+// Dynamic LDS then: [roundup(M*K*2, 1024) activations] + the reduction floats.
 // BITS = 4 (W4A16): the 1 KiB tile holds 16 columns x 128 k, a lane's 16 bytes are 32 k values of its column (the int4
 // layout of int4.hip / gemv_kernel.hpp): four MFMAs and four activation vectors per tile instead of two.
-template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD, int BITS = 8>
+template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD, int BITS = 8, bool XLDS = false>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, Epilogue ep)
 {
+    static_assert(!XLDS || MT == 1, "LDS-staged activations: one row tile");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    float* red = reinterpret_cast<float*>(smem);
+    const int xs_bytes = XLDS ? ((M * K * 2 + 1023) & ~1023) : 0;
+    float*    red      = reinterpret_cast<float*>(smem + xs_bytes);
 
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -35,8 +45,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     const int ntile0 = blockIdx.x * NT;
 
     u32 sraw[NT];
+    if constexpr (!XLDS) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) sraw[t] = reinterpret_cast<const uint16_t*>(scales)[(ntile0 + t) * 16 + c];
+        for (int t = 0; t < NT; ++t) sraw[t] = reinterpret_cast<const uint16_t*>(scales)[(ntile0 + t) * 16 + c];
+    }
 
     // per-lane activation row pointers: row 16*mt + c (clamped: rows >= M compute garbage that is never stored)
     const u32x4* xrow[MT];
@@ -51,17 +63,49 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     for (int t = 0; t < NT; ++t)
         wp[t] = reinterpret_cast<const u32x4*>(w + (size_t)(ntile0 + t) * KT * kTileBytes) + lane;  // + 64 per k tile
 
+    // XLDS: the copy goes first in the memory queue (returns are in order), the first D weight stages right behind it
+    // a row's 16-byte chunks are xor-ed with the row number inside 256-byte windows: one int4 k tile, two int8 k tiles (bit 3 of
+    // the row number then flips the parity of the k tile)
+    int xl_base[XQ], xl_hi = 0;
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) xl_base[q] = 0;
+    if constexpr (XLDS) {
+        const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, M * K * 2, 0x00020000);
+        const int row_bytes = K * 2;
+        for (int p = wave; p < (xs_bytes >> 10); p += WAVES) {
+            const int flat = p * 1024 + lane * 16;  // LDS byte this lane fills: (row r, chunk) -> source chunk ^ (r & 15)
+            const int r    = flat / row_bytes;      // rows are multiples of 256 B: uniform per 16 lanes; r >= M reads 0 (bounds)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_void*)(smem + p * 1024), 16,
+                                                     r * row_bytes + ((flat - r * row_bytes) ^ ((r & 15) << 4)), 0, 0, 0);
+        }
+        const int rc   = c < M ? c : M - 1;         // rows >= M: garbage in, never stored
+        const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem;
+#pragma unroll
+        for (int q = 0; q < XQ; ++q)
+            xl_base[q] = lds0 + rc * row_bytes + (((XQ * g + q) ^ (BITS == 8 ? (rc & 7) : rc)) << 4);
+        xl_hi = BITS == 8 ? rc >> 3 : 0;
+        // the scales come after the copy: a load pending at the head of the copy loop would be waited for there
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sraw[t] = reinterpret_cast<const uint16_t*>(scales)[(ntile0 + t) * 16 + c];
+    }
+
     struct Stage {
         u32x4 wq[NT];
-        u32x4 xa[MT][XQ];
+        u32x4 xa[XLDS ? 1 : MT][XLDS ? 1 : XQ];
+        int   kt;
     };
     auto load_stage = [&](int kt, Stage& s) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) s.wq[t] = gemv::load_w<true>(wp[t] + (size_t)kt * 64);
+        if constexpr (XLDS) {
+            s.kt = kt;
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+            for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int q = 0; q < XQ; ++q) s.xa[mt][q] = xrow[mt][(size_t)kt * (CD::kTileK / 8) + q];
+                for (int q = 0; q < XQ; ++q) s.xa[mt][q] = xrow[mt][(size_t)kt * (CD::kTileK / 8) + q];
+        }
     };
 
     f32x4 acc[MT][NT];
@@ -72,9 +116,22 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
 
     f16x2 scale2[NT];
     auto  consume = [&](const Stage& s) {
+        u32x4 xa[XQ];
+        if constexpr (XLDS) {
+            const int ko = BITS == 8 ? (s.kt ^ xl_hi) << 7 : s.kt << 8;
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) xa[q] = *(lds_cu32x4*)(uintptr_t)(uint32_t)(xl_base[q] + ko);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if constexpr (BITS == 8) {
+            if constexpr (BITS == 8 && XLDS) {
+                f16x2 wq[8];
+                dequant_16(s.wq[t], scale2[t], wq);
+                const f16x8 b0 = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
+                const f16x8 b1 = {wq[4].x, wq[4].y, wq[5].x, wq[5].y, wq[6].x, wq[6].y, wq[7].x, wq[7].y};
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xa[0]), b0, acc[0][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xa[1]), b1, acc[0][t], 0, 0, 0);
+            } else if constexpr (BITS == 8) {
                 f16x2 wq[8];
                 dequant_16(s.wq[t], scale2[t], wq);
                 const f16x8 b0 = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
@@ -93,10 +150,14 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
                     f16x2 wq[4];
                     gemv::dequant_dword_i4(wd[d], scale2[t], wq);
                     const f16x8 b = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
+                    if constexpr (XLDS) {
+                        acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xa[d]), b, acc[0][t], 0, 0, 0);
+                    } else {
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s.xa[mt][d]), b,
-                                                                            acc[mt][t], 0, 0, 0);
+                        for (int mt = 0; mt < MT; ++mt)
+                            acc[mt][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, s.xa[mt][d]), b,
+                                                                                acc[mt][t], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -111,6 +172,12 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     for (int t = 0; t < NT; ++t) {
         asm volatile("" : "+v"(sraw[t]));
         scale2[t] = as_f16x2(sraw[t] | (sraw[t] << 16));
+    }
+    if constexpr (XLDS) {
+        // this wave's pieces of the copy have landed once only the D * NT weight loads issued after them are outstanding
+        constexpr int kOut = D * NT;  // (the scale loads sit between the copy and these: already waited for above)
+        __builtin_amdgcn_s_waitcnt(((kOut >> 4) << 14) | 0x0F70 | (kOut & 15));
+        __syncthreads();
     }
     int i = 0;
     for (; i + 2 * D <= n; i += D) {
