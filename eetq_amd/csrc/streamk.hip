@@ -1,7 +1,9 @@
 // Medium-batch (2 <= M <= 64) W8A16 stream GEMM launcher; kernel in streamk_kernel.hpp.
 // Covers the reference's batched-GEMV range (m <= 4, weightOnlyBatchedGemv/kernelLauncher.cu:165-192) and the
 // small-M end of its CUTLASS range, where the weight stream -- not the matrix cores -- bounds the time.
+#include <cstdio>
 #include <cstdlib>
+#include <cstring>
 
 #include "streamk_kernel.hpp"
 
@@ -9,12 +11,14 @@ namespace eetq {
 
 namespace {
 
-template <int MT, int NT, int WAVES, int D, int OCC, int BITS = 8, bool XLDS = false>
+template <int MT, int NT, int WAVES, int D, int OCC, int BITS = 8, int XM = 0>
 int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream)
 {
-    auto         kern = streamk::streamk_kernel<MT, NT, WAVES, D, OCC, BITS, XLDS>;
-    const size_t smem = streamk::streamk_smem_bytes(MT, NT, WAVES) + (XLDS ? (((size_t)M * K * 2 + 1023) & ~(size_t)1023) : 0);
+    auto         kern = streamk::streamk_kernel<MT, NT, WAVES, D, OCC, BITS, XM>;
+    const size_t smem = streamk::streamk_smem_bytes(MT, NT, WAVES) +
+                        (XM == 1 ? (((size_t)M * K * 2 + 1023) & ~(size_t)1023)
+                                 : XM >= 2 ? (size_t)WAVES * (2 * D - 1) * (BITS == 4 && XM == 2 ? 2048 : 1024) : 0);
     if (smem > 64 * 1024) {
         static std::atomic<unsigned long long> opted{0};
         int st = opt_in_large_lds(kern, opted);
@@ -22,6 +26,91 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     }
     launch_kernel(kern, dim3(N / (kTileN * NT)), dim3(WAVES * 64), smem, stream, x, w, scales, y, M, N, K, ep);
     return check_hip(hipGetLastError(), "streamk_kernel launch");
+}
+
+// How a small-batch launch gets its activation fragments: form 0 = registers, 1 = block copy in LDS, 2 = per-wave ring in LDS
+struct StreamPlan {
+    int form, nt, waves;
+};
+
+inline StreamPlan plan_from_env(const char* name)
+{
+    StreamPlan  p{-1, 0, 0};
+    const char* e = getenv(name);
+    if (!e) return p;
+    char form[16] = {0};
+    int  nt = 0, waves = 0;
+    if (sscanf(e, "%15[^,],%d,%d", form, &nt, &waves) >= 1) {
+        p.form  = !strcmp(form, "regs") ? 0 : !strcmp(form, "block") ? 1 : !strcmp(form, "ring") ? 2 : -1;
+        p.nt    = nt == 1 || nt == 2 ? nt : 0;
+        p.waves = waves == 8 || waves == 16 ? waves : 0;
+    }
+    return p;
+}
+
+// The rule (int8, one row tile, K / 64 >= 32), read off profiles/r04_stream_plan_sweep.txt (21 shapes x M = 2..8 x 7 plans; "rpc" =
+// 16-column tile rows per CU) and checked against the register form of rounds 1-3 in the same run
+// (profiles/r04_stream_plan_rule_check.txt, us per launch, registers -> rule; geometric mean over the grid 0.943, worst +1.1 %).
+// nt0 / eight0: the register form's tile rows per workgroup and workgroup size.
+//   rpc <= 1          ring, 1 row, 16 waves   4096^2 M = 4 5.21 -> 4.71, M = 8 5.33 -> 5.02; 11008 x 4096 M = 4 10.07 -> 8.97;
+//                                             8192 x 1024 M = 4 7.04 -> 5.79, M = 8 7.51 -> 6.71; 4096 x 1024 M = 8 4.82 -> 4.21
+//   1 < rpc <= 2      registers               (5120^2, 13824 x 5120, 6144^2, 7168^2, 28672 x 8192: nothing beats them by > 2 %)
+//                     except N = 32 * CUs (rpc = 2) with K <= 8192 at M <= 5: ring, 1 row, 8 waves (8192^2 M = 4 12.73 -> 11.96)
+//   2 < rpc <= 3      block copy, 1 row, while M*K*2 <= 24 KiB (4096 x 11008 M = 2 10.91 -> 8.94; 3072 x 9216 M = 2 8.43 -> 6.77),
+//                     then ring, 1 row, 16 waves (4096 x 11008 M = 4 11.10 -> 9.28, M = 6 11.19 -> 9.65, M = 8 11.41 -> 10.22; 4096 x
+//                     12288 M = 4 11.31 -> 9.84; the block copy falls off a cliff once its LDS leaves two workgroups per CU: M = 6 11.64)
+//   3 < rpc <= 4      ring, 2 rows, 8 waves   5120 x 13824 M = 4 14.16 -> 13.36, M = 8 14.97 -> 14.21; 4096 x 14336 M = 8 11.96 -> 11.60
+//   rpc > 4           ring, 1 row, 16 waves while M <= K / 1024 - 1, else 2 rows, 8 waves
+//                                             8192 x 28672 M = 2 40.5 -> 35.0, M = 4 40.7 -> 35.9; 5120 x 27648 M = 4 24.8 -> 23.7,
+//                                             M = 8 27.6 -> 25.7; 4096 x 22016 M = 8 16.77 -> 16.27
+// M > 8: registers.  All forms are bit-identical at equal wave count, so a wrong pick costs time only.
+inline StreamPlan pick_plan(int M, int N, int K, int ncu, int nt0, bool eight0)
+{
+    static const bool lds_off = [] {
+        const char* e = getenv("EETQ_AMD_I8_STREAM_XLDS");
+        return e && atoi(e) == 0;
+    }();
+    StreamPlan p{0, nt0, eight0 ? 8 : 16};
+    if (lds_off || M > 8) return p;
+    const int  rows   = N / kTileN;
+    const long xbytes = (long)M * K * 2;
+    if (rows <= ncu) return StreamPlan{2, 1, 16};
+    if (rows <= 2 * ncu) return (rows == 2 * ncu && K <= 8192 && M <= 5) ? StreamPlan{2, 1, 8} : p;
+    if (rows <= 3 * ncu) return (K % 128 == 0 && xbytes <= 24 * 1024) ? StreamPlan{1, 1, 8} : StreamPlan{2, 1, 16};
+    if (rows <= 4 * ncu) return N % (2 * kTileN) == 0 ? StreamPlan{2, 2, 8} : StreamPlan{2, 1, 16};
+    return (M <= K / 1024 - 1 || N % (2 * kTileN) != 0) ? StreamPlan{2, 1, 16} : StreamPlan{2, 2, 8};
+}
+
+// W4A16 (K / 128 >= 32, i.e. K >= 4096), read off profiles/r04_stream_plan_sweep_i4.txt and checked against the register form in
+// the same run (profiles/r04_stream_plan_rule_check_i4.txt, us per launch, registers -> rule; geometric mean 0.963 at M <= 8, worst
+// +1.6 %).  The register form issues FOUR activation loads per weight load; the ring one DMA per tile at M <= 4, two at M <= 8.
+//   rpc <= 1, M <= 8     ring, 1 row, 16 waves   11008 x 4096 M = 4 7.98 -> 6.92; 8192 x 1024 M = 4 6.07 -> 5.02; 4096^2 M = 8 4.73 -> 4.46
+//   rpc <= 1, M >= 9     block copy while M*K*2 <= 144 KiB at K = 4096 (4096^2 M = 16 6.09 -> 5.32)
+//   1 < rpc <= 2         ring, 2 rows, 16 waves above K = 8192 (13824 x 5120 M = 8 13.68 -> 12.32; 28672 x 8192 M = 4 25.5 -> 23.5)
+//   2 < rpc <= 3, K 4096 block copy, 1 row, at M <= 5 (4096 x 11008 M = 2 8.36 -> 6.87, M = 5 8.48 -> 7.64; 4096 x 12288 M = 4 8.45 ->
+//                        7.62), ring, 1 row, 8 waves above (M = 8 9.00 -> 8.68)
+//   rpc > 4              ring, 1 row, 8 waves at M <= 4 from K = 5120 (5120 x 27648 M = 4 18.28 -> 16.57; 8192 x 28672 25.9 -> 24.5);
+//                        ring, 2 rows, 8 waves at M >= 5 from K = 8192 (8192 x 28672 M = 8 27.9 -> 26.9)
+// and registers everywhere else (5120^2, 5120 x 13824 / 15360, 4096 x 14336 / 22016, 6144^2 ...: nothing beats them by more than 2-3 %).
+inline StreamPlan pick_plan_i4(int M, int N, int K, int ncu, int nt0, bool eight0)
+{
+    static const bool lds_off = [] {
+        const char* e = getenv("EETQ_AMD_I4_STREAM_XLDS");
+        return e && atoi(e) == 0;
+    }();
+    StreamPlan p{0, nt0, eight0 ? 8 : 16};
+    if (lds_off) return p;
+    const int  rows   = N / kTileN;
+    const long xbytes = (long)M * K * 2;
+    const bool even   = N % (2 * kTileN) == 0;
+    if (M > 8) return (K <= 4096 && rows <= ncu && xbytes <= 144 * 1024) ? StreamPlan{1, 1, rows >= ncu ? 8 : 16} : p;
+    if (rows <= ncu) return StreamPlan{2, 1, 16};
+    if (rows <= 2 * ncu) return K > 8192 ? StreamPlan{2, even ? 2 : 1, 16} : p;
+    if (rows <= 3 * ncu) return K > 4096 ? p : M <= 5 ? StreamPlan{1, 1, 8} : StreamPlan{2, 1, 8};
+    if (rows <= 4 * ncu) return p;
+    if (M <= 4 && K >= 5120) return StreamPlan{2, 1, 8};
+    if (M >= 5 && K >= 8192 && even) return StreamPlan{2, 2, 8};
+    return p;
 }
 
 template <int MT>
@@ -54,51 +143,45 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
             // in flight per wave instead of two lose (r04_int8_stream_waves_ab2.txt).
             const int  wgs   = N / (kTileN * nt);
             const bool eight = forced_waves ? forced_waves == 8 : (M > 4 || nt == 2 || wgs > ncu);
-            // Activations staged ONCE per workgroup in LDS instead of 16 clamped rows from L2 per weight tile (round 4,
-            // profiles/r04_stream_xlds_ab.txt; same fragments into the same MFMAs: bit-identical to the register form).  The
-            // per-tile cost is then the weight load alone, the copy (M*K*2 bytes) is per workgroup -- one tile row per
-            // workgroup becomes affordable again where two leave the CUs unevenly loaded.  Adopted where it measured faster:
-            //   2..4 tile rows per CU (7B / 13B up, gate, fused q|k|v): 4096 x 11008 M = 2 10.99 -> 9.05 us, M = 4 11.17 -> 9.47,
-            //     M = 8 11.48 -> 10.97; 4096 x 12288 M = 4 11.40 -> 10.12; 5120 x 13824 M = 4 14.18 -> 13.29
-            //   <= one tile row per CU, M <= 4: 4096^2 M = 4 5.23 -> 5.06, 11008 x 4096 M = 2 9.68 -> 9.18
-            // and left alone elsewhere (4096 x 22016, 8192^2, 5120^2: within +-4 % either way; M*K*2 > 64 KiB: one workgroup per CU).
-            // EETQ_AMD_I8_STREAM_XLDS = 0: never; = 1 (default): the rule; >= 1024: everywhere up to that many bytes (A/B runs),
-            // EETQ_AMD_I8_STREAM_XLDS_NT = 1 / 2 then forces the tile rows per workgroup.
-            static const long xlds_mode = [] {
-                const char* e = getenv("EETQ_AMD_I8_STREAM_XLDS");
-                return e ? atol(e) : 1L;
-            }();
-            static const int xlds_nt = [] {
-                const char* e = getenv("EETQ_AMD_I8_STREAM_XLDS_NT");
-                return e ? atoi(e) : 0;
-            }();
-            const long xbytes = (long)M * K * 2;
-            const int  rows   = N / kTileN;
-            int        xnt    = 0;  // 0: register form
-            if (xlds_mode >= 1024) {
-                if (K % 128 == 0 && xbytes <= xlds_mode) xnt = xlds_nt ? xlds_nt : nt;
-            } else if (xlds_mode == 1 && K % 128 == 0 && xbytes <= 64 * 1024) {
-                if (rows > 2 * ncu && rows <= 4 * ncu && M <= (K <= 4096 ? 8 : 5)) {
-                    const long c1 = (long)((rows + ncu - 1) / ncu) * (8 + M);
-                    const long c2 = (long)((rows / 2 + ncu - 1) / ncu) * (16 + M);
-                    xnt           = (N % (2 * kTileN) == 0 && c2 <= c1) ? 2 : 1;
-                } else if (rows <= ncu && M <= 4) {
-                    xnt = 1;
-                }
+            // Where the activation fragments come from (round 4; all three forms feed the same fragments to the same MFMAs in the
+            // same order -- bit-identical results, tests/test_gpu_stream_xlds.py):
+            //   regs  : straight from L2 into registers, 16 (clamped) rows x 128 B per weight tile: two vector loads of activations
+            //           per vector load of weights, whatever M is
+            //   block : the M rows copied ONCE per workgroup into LDS (LDS-DMA); needs K % 128 == 0 and M*K*2 <= 64 KiB; the per-tile
+            //           cost is the weight load alone, so one tile row per workgroup is affordable where two load the CUs unevenly
+            //   ring  : M <= 8: one LDS-DMA instruction per k tile and wave into the wave's own ring; any K, no copy up front
+            // The rule: pick_plan above.  EETQ_AMD_I8_STREAM_PLAN=form,nt,waves (rule|regs|block|ring, 1|2, 8|16; "rule" / 0 = as
+            // the rule says) overrides single fields for A/B runs and tests; EETQ_AMD_I8_STREAM_XLDS=0 switches both LDS forms off
+            // (the register form with its own tile rows per workgroup and workgroup size: the kernel of rounds 1-3).
+            StreamPlan plan = pick_plan(M, N, K, ncu, nt, eight);
+            static const StreamPlan forced = plan_from_env("EETQ_AMD_I8_STREAM_PLAN");
+            if (forced.form >= 0) plan.form = forced.form;
+            if (forced.nt) plan.nt = forced.nt;
+            if (forced.waves) plan.waves = forced.waves;
+            if (forced_waves) plan.waves = forced_waves;
+            if (plan.nt == 2 && N % (2 * kTileN) != 0) plan.nt = 1;
+            if (plan.form == 1 && (K % 128 != 0 || (long)M * K * 2 > 128 * 1024)) plan.form = 0;
+            if (plan.form == 2 && M > 8) plan.form = 0;
+            const bool e8 = plan.waves == 8;
+            if (plan.form == 2) {
+                if (plan.nt == 2)
+                    return e8 ? launch_inst<MT, 2, 8, 2, 4, 8, 2>(x, w, scales, ep, y, M, N, K, stream)
+                              : launch_inst<MT, 2, 16, 2, 4, 8, 2>(x, w, scales, ep, y, M, N, K, stream);
+                return e8 ? launch_inst<MT, 1, 8, 2, 4, 8, 2>(x, w, scales, ep, y, M, N, K, stream)
+                          : launch_inst<MT, 1, 16, 2, 4, 8, 2>(x, w, scales, ep, y, M, N, K, stream);
             }
-            if (xnt == 2 && N % (2 * kTileN) != 0) xnt = 1;
-            if (xnt) {
-                const bool e8 = forced_waves ? forced_waves == 8 : (M > 4 || xnt == 2 || N / (kTileN * xnt) > ncu);
-                if (xnt == 2)
-                    return e8 ? launch_inst<MT, 2, 8, 2, 4, 8, true>(x, w, scales, ep, y, M, N, K, stream)
-                              : launch_inst<MT, 2, 16, 2, 4, 8, true>(x, w, scales, ep, y, M, N, K, stream);
-                return e8 ? launch_inst<MT, 1, 8, 2, 4, 8, true>(x, w, scales, ep, y, M, N, K, stream)
-                          : launch_inst<MT, 1, 16, 2, 4, 8, true>(x, w, scales, ep, y, M, N, K, stream);
+            if (plan.form == 1) {
+                if (plan.nt == 2)
+                    return e8 ? launch_inst<MT, 2, 8, 2, 4, 8, 1>(x, w, scales, ep, y, M, N, K, stream)
+                              : launch_inst<MT, 2, 16, 2, 4, 8, 1>(x, w, scales, ep, y, M, N, K, stream);
+                return e8 ? launch_inst<MT, 1, 8, 2, 4, 8, 1>(x, w, scales, ep, y, M, N, K, stream)
+                          : launch_inst<MT, 1, 16, 2, 4, 8, 1>(x, w, scales, ep, y, M, N, K, stream);
             }
-            if (nt == 2)
-                return eight ? launch_inst<MT, 2, 8, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
-                             : launch_inst<MT, 2, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
-            if (eight) return launch_inst<MT, 1, 8, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+            if (plan.nt == 2)
+                return e8 ? launch_inst<MT, 2, 8, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
+                          : launch_inst<MT, 2, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+            return e8 ? launch_inst<MT, 1, 8, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
+                      : launch_inst<MT, 1, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
         }
         return launch_inst<MT, 1, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     }
@@ -130,41 +213,40 @@ int launch_mt_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
         // workgroups than CUs (N = 5120: 160 workgroups, 5.84 vs 6.29 us with 8 waves)
         const int  wgs   = N / (kTileN * nt);
         const bool eight = forced_waves ? forced_waves == 8 : wgs >= ncu;
-        // Activations staged once per workgroup in LDS (see launch_mt; four activation loads per weight load otherwise).
-        // profiles/r04_stream_xlds_i4_ab.txt: wins at K = 4096 with 2..4 tile rows per CU and M <= 4, one tile row per workgroup
-        // (4096 x 11008 M = 2 8.32 -> 6.79 us, M = 4 8.37 -> 7.39; 4096 x 12288 8.30 -> 6.96 / 8.34 -> 7.51), and with one
-        // workgroup per CU at M >= 8 (4096^2 M = 16 6.08 -> 5.29, M = 12 5.36 -> 4.93, M = 8 4.73 -> 4.63); neutral or slower
-        // elsewhere (K = 5120, 8192, 11008, 13824; N = 22016).  EETQ_AMD_I4_STREAM_XLDS = 0: never; = 1 (default): that rule;
-        // >= 1024: everywhere up to that many bytes of M*K*2, EETQ_AMD_I4_STREAM_XLDS_NT = tile rows per workgroup (A/B runs).
-        static const long xlds_mode = [] {
-            const char* e = getenv("EETQ_AMD_I4_STREAM_XLDS");
-            return e ? atol(e) : 1L;
-        }();
-        static const int xlds_nt = [] {
-            const char* e = getenv("EETQ_AMD_I4_STREAM_XLDS_NT");
-            return e ? atoi(e) : 0;
-        }();
-        const long xbytes = (long)M * K * 2;
-        const int  rows   = N / kTileN;
-        int        xnt    = 0;
-        if (xlds_mode >= 1024) {
-            if (xbytes <= xlds_mode) xnt = xlds_nt ? xlds_nt : nt;
-        } else if (xlds_mode == 1 && K <= 4096) {
-            if (rows > 2 * ncu && rows <= 4 * ncu && M <= 4) xnt = 1;
-            if (rows <= ncu && M >= 8 && xbytes <= 144 * 1024) xnt = 1;
+        // Where the activation fragments come from (see launch_mt / pick_plan): four activation loads per weight load in the
+        // register form.  EETQ_AMD_I4_STREAM_PLAN=form,nt,waves overrides (A/B runs), EETQ_AMD_I4_STREAM_XLDS=0: registers only.
+        StreamPlan plan = pick_plan_i4(M, N, K, ncu, nt, eight);
+        static const StreamPlan forced = plan_from_env("EETQ_AMD_I4_STREAM_PLAN");
+        if (forced.form >= 0) plan.form = forced.form;
+        if (forced.nt) plan.nt = forced.nt;
+        if (forced.waves) plan.waves = forced.waves;
+        if (forced_waves) plan.waves = forced_waves;
+        if (plan.nt == 2 && N % (2 * kTileN) != 0) plan.nt = 1;
+        if (plan.form == 1 && (long)M * K * 2 > 144 * 1024) plan.form = 0;
+        if (plan.form == 2 && M > 8) plan.form = 0;
+        const bool e8 = plan.waves == 8;
+        if (plan.form == 2 && M <= 4) {
+            if (plan.nt == 2) return e8 ? launch_inst<1, 2, 8, 2, 2, 4, 3>(x, w, scales, ep, y, M, N, K, stream)
+                                        : launch_inst<1, 2, 16, 2, 2, 4, 3>(x, w, scales, ep, y, M, N, K, stream);
+            return e8 ? launch_inst<1, 1, 8, 2, 2, 4, 3>(x, w, scales, ep, y, M, N, K, stream)
+                      : launch_inst<1, 1, 16, 2, 2, 4, 3>(x, w, scales, ep, y, M, N, K, stream);
         }
-        if (xnt == 2 && N % (2 * kTileN) != 0) xnt = 1;
-        if (xnt) {
-            const bool e8 = forced_waves ? forced_waves == 8 : N / (kTileN * xnt) >= ncu;
-            if (xnt == 2) return e8 ? launch_inst<1, 2, 8, 2, 2, 4, true>(x, w, scales, ep, y, M, N, K, stream)
-                                    : launch_inst<1, 2, 16, 2, 2, 4, true>(x, w, scales, ep, y, M, N, K, stream);
-            return e8 ? launch_inst<1, 1, 8, 2, 2, 4, true>(x, w, scales, ep, y, M, N, K, stream)
-                      : launch_inst<1, 1, 16, 2, 2, 4, true>(x, w, scales, ep, y, M, N, K, stream);
+        if (plan.form == 2) {
+            if (plan.nt == 2) return e8 ? launch_inst<1, 2, 8, 2, 2, 4, 2>(x, w, scales, ep, y, M, N, K, stream)
+                                        : launch_inst<1, 2, 16, 2, 2, 4, 2>(x, w, scales, ep, y, M, N, K, stream);
+            return e8 ? launch_inst<1, 1, 8, 2, 2, 4, 2>(x, w, scales, ep, y, M, N, K, stream)
+                      : launch_inst<1, 1, 16, 2, 2, 4, 2>(x, w, scales, ep, y, M, N, K, stream);
         }
-        if (nt == 2) return eight ? launch_inst<1, 2, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
-                                  : launch_inst<1, 2, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
-        return eight ? launch_inst<1, 1, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
-                     : launch_inst<1, 1, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+        if (plan.form == 1) {
+            if (plan.nt == 2) return e8 ? launch_inst<1, 2, 8, 2, 2, 4, 1>(x, w, scales, ep, y, M, N, K, stream)
+                                        : launch_inst<1, 2, 16, 2, 2, 4, 1>(x, w, scales, ep, y, M, N, K, stream);
+            return e8 ? launch_inst<1, 1, 8, 2, 2, 4, 1>(x, w, scales, ep, y, M, N, K, stream)
+                      : launch_inst<1, 1, 16, 2, 2, 4, 1>(x, w, scales, ep, y, M, N, K, stream);
+        }
+        if (plan.nt == 2) return e8 ? launch_inst<1, 2, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
+                                    : launch_inst<1, 2, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+        return e8 ? launch_inst<1, 1, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
+                  : launch_inst<1, 1, 16, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     }
     if (KT >= 16) return launch_inst<1, 1, 8, 2, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     if (KT >= 4) return launch_inst<1, 1, 4, 1, 1, 4>(x, w, scales, ep, y, M, N, K, stream);

@@ -25,14 +25,25 @@ typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
 // Dynamic LDS then: [roundup(M*K*2, 1024) activations] + the reduction floats.
 // BITS = 4 (W4A16): the 1 KiB tile holds 16 columns x 128 k, a lane's 16 bytes are 32 k values of its column (the int4
 // layout of int4.hip / gemv_kernel.hpp): four MFMAs and four activation vectors per tile instead of two.
-template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD, int BITS = 8, bool XLDS = false>
+// XM = 2 (MT = 1, M <= 8; any K): per-wave ring instead of a whole-x copy -- ONE LDS-DMA instruction per int8 k tile and wave (two
+// per int4 tile: 8 rows x 256 B) brings the activations the tile needs (lane = row * chunks + chunk, chunk xor row) into a slot of the
+// wave's own ring (2*D - 1 slots), issued right before the tile's weight load so the wait for the weights covers it; no barrier, no
+// up-front copy, half the activation load instructions of the register form.  XM = 3: int4 with M <= 4 -- 4 rows, one DMA per tile.
+template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD, int BITS = 8, int XM = 0>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, Epilogue ep)
 {
-    static_assert(!XLDS || MT == 1, "LDS-staged activations: one row tile");
+    constexpr bool XLDS = XM == 1, XRING = XM == 2 || XM == 3;
+    constexpr int  kRing     = 2 * D - 1;
+    constexpr int  kRowBytes = BITS == 8 ? 128 : 256;          // activation bytes per row and k tile
+    constexpr int  kRingRows = XM == 3 ? 4 : 8;
+    constexpr int  kSlot     = kRingRows * kRowBytes;          // 1 KiB; int4 with 8 rows: 2 KiB
+    constexpr int  kDma      = kSlot / 1024;
+    static_assert(XM == 0 || MT == 1, "LDS-staged activations: one row tile");
+    static_assert(XM != 3 || BITS == 4, "the 4-row ring is the int4 form for M <= 4");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const int xs_bytes = XLDS ? ((M * K * 2 + 1023) & ~1023) : 0;
+    const int xs_bytes = XLDS ? ((M * K * 2 + 1023) & ~1023) : XRING ? WAVES * kRing * kSlot : 0;
     float*    red      = reinterpret_cast<float*>(smem + xs_bytes);
 
     const int tid  = threadIdx.x;
@@ -90,15 +101,46 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
         for (int t = 0; t < NT; ++t) sraw[t] = reinterpret_cast<const uint16_t*>(scales)[(ntile0 + t) * 16 + c];
     }
 
+    __amdgpu_buffer_rsrc_t ring_rs;
+    int                    ring_voff[2] = {0, 0}, ring_rd[XQ];
+    uint8_t*               ring_wr      = smem;
+#pragma unroll
+    for (int q = 0; q < XQ; ++q) ring_rd[q] = 0;
+    if constexpr (XRING) {
+        constexpr int kChunks = kRowBytes / 16;
+        ring_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, M * K * 2, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < kDma; ++j) {  // DMA lane = (row, chunk): slot byte j*1024 + lane*16 <- row rr, chunk ^ rr
+            const int row = (j * 1024 + lane * 16) / kRowBytes;
+            const int rr  = row < M ? row : M - 1;
+            ring_voff[j]  = rr * K * 2 + (((lane & (kChunks - 1)) ^ (rr & (kChunks - 1))) << 4);
+        }
+        ring_wr        = smem + wave * (kRing * kSlot);
+        const int rc   = c < M ? c : M - 1;  // fragment lane (g, c): row rc, chunks XQ*g .. XQ*g + XQ - 1
+        const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem + wave * (kRing * kSlot);
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) ring_rd[q] = lds0 + rc * kRowBytes + (((XQ * g + q) ^ (rc & (kChunks - 1))) << 4);
+    }
+
     struct Stage {
         u32x4 wq[NT];
-        u32x4 xa[XLDS ? 1 : MT][XLDS ? 1 : XQ];
+        u32x4 xa[XM ? 1 : MT][XM ? 1 : XQ];
         int   kt;
     };
-    auto load_stage = [&](int kt, Stage& s) {
+    auto load_stage = [&](int kt, Stage& s, int slot) {
+        if constexpr (XRING)  // before the weights: whoever waits for this stage's weights has the activations too
+        {
+#pragma unroll
+            for (int j = 0; j < kDma; ++j)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(ring_rs, (lds_void*)(ring_wr + slot * kSlot + j * 1024), 16, ring_voff[j],
+                                                         kt * kRowBytes, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) s.wq[t] = gemv::load_w<true>(wp[t] + (size_t)kt * 64);
-        if constexpr (XLDS) {
+        if constexpr (XRING) {
+            s.kt = slot;
+        } else if constexpr (XLDS) {
             s.kt = kt;
         } else {
 #pragma unroll
@@ -122,9 +164,28 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
 #pragma unroll
             for (int q = 0; q < XQ; ++q) xa[q] = *(lds_cu32x4*)(uintptr_t)(uint32_t)(xl_base[q] + ko);
         }
+        if constexpr (XRING) {
+            // Hand-written LDS reads: hipcc tracks LDS-DMA against the LDS loads it can see and would wait for EVERY DMA in flight
+            // (the refill of the other stage included) before each fragment read, i.e. halve the prefetch depth.  The weight register
+            // among the inputs makes the compiler wait for this stage's weights first -- the DMA was issued before them and returns
+            // are in order, so the slot is complete.
+            const int ko = s.kt * kSlot;
+            if constexpr (BITS == 8) {
+                asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
+                             : "=&v"(xa[0]), "=&v"(xa[1])
+                             : "v"(ring_rd[0] + ko), "v"(ring_rd[1] + ko), "v"(s.wq[NT - 1].x)
+                             : "memory");
+            } else {
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(xa[0]), "=&v"(xa[1]), "=&v"(xa[2]), "=&v"(xa[3])
+                             : "v"(ring_rd[0] + ko), "v"(ring_rd[1] + ko), "v"(ring_rd[2] + ko), "v"(ring_rd[3] + ko), "v"(s.wq[NT - 1].x)
+                             : "memory");
+            }
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            if constexpr (BITS == 8 && XLDS) {
+            if constexpr (BITS == 8 && XM != 0) {
                 f16x2 wq[8];
                 dequant_16(s.wq[t], scale2[t], wq);
                 const f16x8 b0 = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
@@ -150,7 +211,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
                     f16x2 wq[4];
                     gemv::dequant_dword_i4(wd[d], scale2[t], wq);
                     const f16x8 b = {wq[0].x, wq[0].y, wq[1].x, wq[1].y, wq[2].x, wq[2].y, wq[3].x, wq[3].y};
-                    if constexpr (XLDS) {
+                    if constexpr (XM != 0) {
                         acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xa[d]), b, acc[0][t], 0, 0, 0);
                     } else {
 #pragma unroll
@@ -167,7 +228,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     const int n = (KT - wave + WAVES - 1) / WAVES;  // >= D
     Stage     st[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) load_stage(wave + d * WAVES, st[d]);
+    for (int d = 0; d < D; ++d) load_stage(wave + d * WAVES, st[d], d);
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         asm volatile("" : "+v"(sraw[t]));
@@ -184,7 +245,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             consume(st[d]);
-            load_stage(wave + (i + d + D) * WAVES, st[d]);
+            load_stage(wave + (i + d + D) * WAVES, st[d], d);
         }
     }
     const int r = n - (i + D);  // 0 <= r < D tiles remain beyond the D already loaded
@@ -192,7 +253,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
 #pragma unroll
     for (int d = 0; d < D - 1; ++d) {
         const int t = i + D + d;
-        load_stage(wave + (t < n ? t : n - 1) * WAVES, tail[d]);
+        load_stage(wave + (t < n ? t : n - 1) * WAVES, tail[d], D + d);
     }
 #pragma unroll
     for (int d = 0; d < D; ++d) consume(st[d]);

@@ -1,8 +1,9 @@
-"""Small batches (2 <= M <= 16) with the activations staged in LDS (eetq_amd/csrc/streamk_kernel.hpp, XLDS; round 4): the M rows are
-copied once per workgroup into LDS by LDS-DMA and the MFMA A fragments are LDS reads, instead of 16 clamped rows from L2 per
-weight tile.  The fragments, the MFMAs and their order are those of the register form, so the results must be BIT-IDENTICAL to it
-(checked against a second process that runs with EETQ_AMD_I8_STREAM_XLDS=0 / EETQ_AMD_I4_STREAM_XLDS=0) and tier A against the
-oracle.  Shapes: the reference's batched-GEMV range and the small-M end of its CUTLASS range on Llama-2-7B / 13B projections
+"""Small batches (2 <= M <= 16) with the activations staged in LDS (eetq_amd/csrc/streamk_kernel.hpp, XM = 1 / 2 / 3; round 4):
+either the M rows are copied once per workgroup into LDS by LDS-DMA ("block"), or every wave DMAs the rows of its next k tile into
+its own ring ("ring", M <= 8); the MFMA A fragments are LDS reads, instead of 16 clamped rows from L2 per weight tile.  The
+fragments, the MFMAs and their order are those of the register form at the same workgroup size, so the results must be
+BIT-IDENTICAL to it (checked against a second process that runs with EETQ_AMD_I8_STREAM_PLAN=regs / EETQ_AMD_I4_STREAM_PLAN=regs)
+and tier A against the oracle.  Shapes: the reference's batched-GEMV range and the small-M end of its CUTLASS range on Llama-2-7B / 13B projections
 (weightOnlyBatchedGemv/kernelLauncher.cu:165-192, fpA_intB_gemm_template.h dispatch)."""
 import os
 import subprocess
@@ -16,11 +17,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-# (bits, K, N, M): every case is one the dispatcher stages in LDS by default (streamk.hip: 2..4 tile rows per CU; one tile row
-# per CU at M <= 4; int4: K = 4096 only, and one workgroup per CU at M >= 8) -- on a 256-CU MI355X
+# (bits, K, N, M): every case is one the dispatcher stages in LDS by default on a 256-CU MI355X (streamk.hip::pick_plan /
+# pick_plan_i4) -- block copies, 8-row rings with one and two tile rows per workgroup, 8 and 16 waves, the int4 4-row ring
 CASES = [(8, 4096, 11008, 2), (8, 4096, 11008, 5), (8, 4096, 11008, 8), (8, 4096, 12288, 3), (8, 5120, 13824, 4), (8, 4096, 4096, 4),
-         (8, 11008, 4096, 2), (8, 8192, 1024, 4), (8, 2048, 8256, 7), (8, 3072, 9216, 8),
-         (4, 4096, 11008, 2), (4, 4096, 12288, 4), (4, 4096, 4096, 8), (4, 4096, 4096, 13), (4, 4096, 4096, 16)]
+         (8, 4096, 4096, 7), (8, 11008, 4096, 2), (8, 11008, 4096, 8), (8, 8192, 1024, 4), (8, 2048, 8256, 7), (8, 3072, 9216, 8),
+         (8, 3072, 9216, 2), (8, 4096, 22016, 3), (8, 4096, 22016, 6), (8, 8192, 8192, 5), (8, 4096, 14336, 2),
+         (4, 4096, 11008, 2), (4, 4096, 11008, 7), (4, 4096, 12288, 4), (4, 4096, 14336, 3), (4, 4096, 4096, 3), (4, 4096, 4096, 8),
+         (4, 4096, 4096, 13), (4, 4096, 4096, 16), (4, 11008, 4096, 6), (4, 13824, 5120, 5), (4, 5120, 27648, 4)]
 
 
 def _inputs(bits, K, N, M):
@@ -50,9 +53,10 @@ np.savez({dst!r}, **out)
 
 @pytest.fixture(scope="module")
 def register_form(tmp_path_factory, oracle):
-    """The same cases in a process that never stages in LDS."""
+    """The same cases in a process that takes the activation fragments straight from L2 into registers (the form of rounds 1-3),
+    with the tile rows per workgroup and the workgroup size the rule picks for the LDS forms."""
     dst = str(tmp_path_factory.mktemp("xlds") / "regs.npz")
-    env = dict(os.environ, EETQ_AMD_I8_STREAM_XLDS="0", EETQ_AMD_I4_STREAM_XLDS="0")
+    env = dict(os.environ, EETQ_AMD_I8_STREAM_PLAN="regs,0,0", EETQ_AMD_I4_STREAM_PLAN="regs,0,0")
     code = _CHILD.format(root=ROOT, tests=os.path.join(ROOT, "tests"), dst=dst)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
