@@ -308,28 +308,19 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
     switch (path) {
         case EETQ_PATH_AUTO:
             // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
-            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 10 (<= 12 / 16 for narrower / smaller weights) -> MFMA stream kernel
-            // (same weight stream, activations straight from L2 into MFMA operands); up to M = 128 -> split-K medium-batch
+            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 16 -> MFMA stream kernel (same weight stream, activation rows
+            // through a per-wave LDS ring or a per-workgroup copy); up to M = 128 -> split-K medium-batch
             // tile (M > 64 on wide N: the tiled kernel); larger M -> LDS-tiled MFMA GEMM (128 x 128 tiles, or 128 x 64 when
             // those fill the chip better).  Crossovers measured as graph-replayed chains: profiles/r03_path_compare_mid.jsonl.
             if (M == 1) return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
-            {
-                static const bool use_splitk = [] {
-                    const char* e = getenv("EETQ_AMD_SPLITK");
-                    return !(e && e[0] == '0');
-                }();
-                const bool fits = (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31);
-                // the register-streaming kernel re-reads the M x K activations per 16-column tile row: beyond 8 rows and 32 Mi
-                // weights the split-K tile (flat in M up to 32) is ahead -- M = 16: 4096 x 11008 12.2 vs 14.1 us, 11008 x 4096
-                // 12.5 vs 14.2, 5120 x 13824 15.5 vs 18.7, 13824 x 5120 19.5 vs 22.3; at 4096^2 (6.6 vs 7.3) and 5120^2 it is not
-                // round 4 (8-wave workgroups in the stream kernel, profiles/r04_stream_splitk_seam.jsonl): on those big weights the
-                // stream kernel now holds up to M = 10 (M = 9: 4096 x 11008 11.6 vs 12.6 us, 11008 x 4096 10.8 vs 12.5, 13824 x 5120
-                // 17.4 vs 20.4, 5120 x 13824 15.4 vs 15.6) and to M = 12 where N < 8192 (11008 x 4096 12.1 vs 12.6, 13824 x 5120 19.1 vs
-                // 20.4; 5120 x 13824 16.5 vs 15.6 the other way)
-                const bool big  = (size_t)K * N >= (32ull << 20);
-                const int  mmax = !(big && use_splitk && fits) ? 16 : (N < 8192 ? 12 : 10);
-                if (M <= mmax) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
-            }
+            // One row tile (M <= 16) stays on the stream kernel everywhere.  History of this seam: round 3 handed 9 <= M <= 16 on
+            // weights >= 32 Mi to the split-K tile (the register form re-read 16 activation rows per weight tile from L2); round 4's
+            // 8-wave workgroups moved it to M = 10 / 12; with the activation rows going through the per-wave LDS ring
+            // (streamk.hip::pick_plan) the stream kernel is ahead up to M = 16 on every shape measured
+            // (profiles/r04_stream_splitk_seam2.jsonl, us stream / split-K at M = 16: 4096 x 11008 12.60 / 12.74, 11008 x 4096 12.48 /
+            // 13.15, 4096 x 22016 18.4 / 21.4, 13824 x 5120 19.5 / 20.4, 8192^2 13.9 / 18.5, 28672 x 8192 41.8 / 46.9, 7168^2 11.9 /
+            // 13.8; the other way only 5120 x 27648 from M = 13, 29.9 / 29.0, and 5120 x 13824 at M = 16, 16.43 / 16.25).
+            if (M <= 16) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
             if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31)) {
                 // wide N, M > 64: the 128 x 64 tiles of the tiled kernel already give most CUs a workgroup and read the
                 // activations once per 64 columns (N = 11008: M = 96 21.0 vs 23.9 us split-K, M = 128 22.4 vs 28.2; up to

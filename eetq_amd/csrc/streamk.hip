@@ -18,7 +18,7 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     auto         kern = streamk::streamk_kernel<MT, NT, WAVES, D, OCC, BITS, XM>;
     const size_t smem = streamk::streamk_smem_bytes(MT, NT, WAVES) +
                         (XM == 1 ? (((size_t)M * K * 2 + 1023) & ~(size_t)1023)
-                                 : XM >= 2 ? (size_t)WAVES * (2 * D - 1) * (BITS == 4 && XM == 2 ? 2048 : 1024) : 0);
+                                 : XM >= 2 ? (size_t)WAVES * (2 * D - 1) * ((BITS == 4 && XM == 2) || XM == 4 ? 2048 : 1024) : 0);
     if (smem > 64 * 1024) {
         static std::atomic<unsigned long long> opted{0};
         int st = opt_in_large_lds(kern, opted);
@@ -63,7 +63,13 @@ inline StreamPlan plan_from_env(const char* name)
 //   rpc > 4           ring, 1 row, 16 waves while M <= K / 1024 - 1, else 2 rows, 8 waves
 //                                             8192 x 28672 M = 2 40.5 -> 35.0, M = 4 40.7 -> 35.9; 5120 x 27648 M = 4 24.8 -> 23.7,
 //                                             M = 8 27.6 -> 25.7; 4096 x 22016 M = 8 16.77 -> 16.27
-// M > 8: registers.  All forms are bit-identical at equal wave count, so a wrong pick costs time only.
+// 9 <= M <= 16 (profiles/r04_stream_plan_sweep_m9to16.txt; the ring holds 16 rows, two DMAs per tile):
+//   rpc <= 1          ring, 1 row, 16 waves to M = 11, 8 waves from M = 12   4096^2 M = 16 6.38 -> 5.86; 8192 x 1024 M = 16 10.1 -> 8.44;
+//                                                                            11008 x 4096 M = 16 13.9 -> 12.6
+//   1 < rpc <= 2      ring, 2 rows, 8 waves from M = 12 (5120^2 M = 16 9.79 -> 8.97; 13824 x 5120 M = 16 21.4 -> 19.5), registers below
+//   rpc > 2           ring, 2 rows, 8 waves    4096 x 11008 M = 12 12.33 -> 11.74, M = 16 13.45 -> 12.39; 5120 x 13824 M = 16 18.5 -> 16.5;
+//                                              8192 x 28672 M = 16 51.5 -> 44.9
+// All forms are bit-identical at equal wave count, so a wrong pick costs time only.
 inline StreamPlan pick_plan(int M, int N, int K, int ncu, int nt0, bool eight0)
 {
     static const bool lds_off = [] {
@@ -71,9 +77,14 @@ inline StreamPlan pick_plan(int M, int N, int K, int ncu, int nt0, bool eight0)
         return e && atoi(e) == 0;
     }();
     StreamPlan p{0, nt0, eight0 ? 8 : 16};
-    if (lds_off || M > 8) return p;
+    if (lds_off || M > 16) return p;
     const int  rows   = N / kTileN;
     const long xbytes = (long)M * K * 2;
+    if (M > 8) {
+        if (rows <= ncu) return StreamPlan{2, 1, M >= 12 ? 8 : 16};
+        if (N % (2 * kTileN) != 0 || (rows <= 2 * ncu && M < 12)) return p;
+        return StreamPlan{2, 2, 8};
+    }
     if (rows <= ncu) return StreamPlan{2, 1, 16};
     if (rows <= 2 * ncu) return (rows == 2 * ncu && K <= 8192 && M <= 5) ? StreamPlan{2, 1, 8} : p;
     if (rows <= 3 * ncu) return (K % 128 == 0 && xbytes <= 24 * 1024) ? StreamPlan{1, 1, 8} : StreamPlan{2, 1, 16};
@@ -161,8 +172,15 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
             if (forced_waves) plan.waves = forced_waves;
             if (plan.nt == 2 && N % (2 * kTileN) != 0) plan.nt = 1;
             if (plan.form == 1 && (K % 128 != 0 || (long)M * K * 2 > 128 * 1024)) plan.form = 0;
-            if (plan.form == 2 && M > 8) plan.form = 0;
+            if (plan.form == 2 && M > 16) plan.form = 0;
             const bool e8 = plan.waves == 8;
+            if (plan.form == 2 && M > 8) {  // 16-row ring: two DMAs per tile
+                if (plan.nt == 2)
+                    return e8 ? launch_inst<MT, 2, 8, 2, 4, 8, 4>(x, w, scales, ep, y, M, N, K, stream)
+                              : launch_inst<MT, 2, 16, 2, 4, 8, 4>(x, w, scales, ep, y, M, N, K, stream);
+                return e8 ? launch_inst<MT, 1, 8, 2, 4, 8, 4>(x, w, scales, ep, y, M, N, K, stream)
+                          : launch_inst<MT, 1, 16, 2, 4, 8, 4>(x, w, scales, ep, y, M, N, K, stream);
+            }
             if (plan.form == 2) {
                 if (plan.nt == 2)
                     return e8 ? launch_inst<MT, 2, 8, 2, 4, 8, 2>(x, w, scales, ep, y, M, N, K, stream)

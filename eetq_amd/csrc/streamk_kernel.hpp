@@ -34,14 +34,15 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, Epilogue ep)
 {
-    constexpr bool XLDS = XM == 1, XRING = XM == 2 || XM == 3;
+    constexpr bool XLDS = XM == 1, XRING = XM >= 2;
     constexpr int  kRing     = 2 * D - 1;
     constexpr int  kRowBytes = BITS == 8 ? 128 : 256;          // activation bytes per row and k tile
-    constexpr int  kRingRows = XM == 3 ? 4 : 8;
+    constexpr int  kRingRows = XM == 3 ? 4 : XM == 4 ? 16 : 8;    // XM = 4: int8 with 9 <= M <= 16, two DMAs per tile
     constexpr int  kSlot     = kRingRows * kRowBytes;          // 1 KiB; int4 with 8 rows: 2 KiB
     constexpr int  kDma      = kSlot / 1024;
     static_assert(XM == 0 || MT == 1, "LDS-staged activations: one row tile");
     static_assert(XM != 3 || BITS == 4, "the 4-row ring is the int4 form for M <= 4");
+    static_assert(XM != 4 || BITS == 8, "the 16-row ring is an int8 form");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int xs_bytes = XLDS ? ((M * K * 2 + 1023) & ~1023) : XRING ? WAVES * kRing * kSlot : 0;
     float*    red      = reinterpret_cast<float*>(smem + xs_bytes);

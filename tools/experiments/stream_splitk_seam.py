@@ -5,11 +5,11 @@ import torch
 import eetq_amd.ops as ops
 from sweep import chain_us
 dev = "cuda:0"
-for K, N in [(4096, 4096), (4096, 11008), (11008, 4096), (5120, 5120), (5120, 13824), (13824, 5120)]:
+for K, N in [(4096, 11008), (4096, 12288), (4096, 22016), (11008, 4096), (5120, 13824), (5120, 15360), (5120, 27648), (13824, 5120), (8192, 8192), (8192, 28672), (28672, 8192), (7168, 7168)]:
     L = max(4, int(640e6 // (K * N)))
     ws = [torch.randint(-128, 127, (K, N), dtype=torch.int8, device=dev) for _ in range(L)]
     s = torch.rand(N, dtype=torch.float16, device=dev) * 0.01
-    for M in (9, 12, 16, 17, 20, 24):
+    for M in (8, 9, 10, 11, 12, 13, 14, 16):
         x = torch.randn(M, K, dtype=torch.float16, device=dev)
         row = {"K": K, "N": N, "M": M}
         for path in ("auto", "stream", "splitk"):
