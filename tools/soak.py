@@ -70,6 +70,30 @@ for it in range(n_t):
 print("K-sliced tiled kernel: %d launches, %d mismatches" % (n_t, bad_t))
 bad += bad_t
 
+# ---- small-batch kernel with the activation rows in LDS (block copy, per-wave rings; W8A16 and W4A16): the ring slots are rewritten
+# by LDS-DMA while earlier reads of the same slot have only just retired -- a read that saw a half-written slot shows up as a mismatch
+bad_s, n_s = 0, max(1, iters // 2)
+scases = []
+for bits, M, K, N in ((8, 2, 4096, 11008), (8, 6, 4096, 11008), (8, 4, 4096, 4096), (8, 12, 4096, 4096), (8, 16, 5120, 13824), (8, 3, 11008, 4096),
+                      (8, 5, 8192, 8192), (4, 3, 4096, 11008), (4, 7, 11008, 4096), (4, 16, 4096, 4096), (4, 4, 5120, 27648)):
+    w = torch.randint(-128, 127, (K, N if bits == 8 else N // 2), dtype=torch.int8, device=dev)
+    s = torch.rand(N, dtype=torch.float16, device=dev) * 0.01
+    x = torch.randn(M, K, dtype=torch.float16, device=dev)
+    scases.append((x, w, s, ops.w8_a16_gemm(x, w, s).clone()))
+for it in range(n_s):
+    x, w, s, ref = scases[it % len(scases)]
+    st = streams[it % 3] if it % 4 == 0 else torch.cuda.current_stream()
+    st.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(st):
+        y = ops.w8_a16_gemm(x, w, s)
+    torch.cuda.current_stream().wait_stream(st)
+    if it % 7 == 0:
+        junk.add_(1)
+    if not torch.equal(y, ref):
+        bad_s += 1
+print("small-batch kernel (LDS forms): %d launches, %d mismatches" % (n_s, bad_s))
+bad += bad_s
+
 # ---- one-launch decode attention: fixed cache and token, the counter walks and is reset; tickets must stay zero ----
 B, H, Hkv, D, S = 2, 40, 8, 128, 600
 inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
