@@ -181,8 +181,8 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
                 return e8 ? launch_inst<MT, 1, 8, 2, 4, 8, 4>(x, w, scales, ep, y, M, N, K, stream)
                           : launch_inst<MT, 1, 16, 2, 4, 8, 4>(x, w, scales, ep, y, M, N, K, stream);
             }
-            // (three / four tiles in flight per wave in the ring forms: slower on every shape, geometric mean +6 % / +9 %,
-            // profiles/r04_stream_depth_ab.txt -- like the register form before, r04_int8_stream_waves_ab2.txt)
+            // (two tiles in flight per wave is the optimum of the ring forms too: one +4.8 %, three +6 %, four +9 % in geometric
+            // mean over the sweep's shapes -- profiles/r04_stream_depth_ab.txt, r04_stream_depth1_ab.txt)
             if (plan.form == 2) {
                 if (plan.nt == 2)
                     return e8 ? launch_inst<MT, 2, 8, 2, 4, 8, 2>(x, w, scales, ep, y, M, N, K, stream)
