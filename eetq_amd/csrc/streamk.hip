@@ -1,4 +1,4 @@
-// Medium-batch (2 <= M <= 64) W8A16 stream GEMM launcher; kernel in streamk_kernel.hpp.
+// Small-batch (AUTO: 2 <= M <= 16; by explicit path up to 64 rows) W8A16 / W4A16 stream GEMM launcher; kernel in streamk_kernel.hpp.
 // Covers the reference's batched-GEMV range (m <= 4, weightOnlyBatchedGemv/kernelLauncher.cu:165-192) and the
 // small-M end of its CUTLASS range, where the weight stream -- not the matrix cores -- bounds the time.
 #include <cstdio>

@@ -1,10 +1,13 @@
-// Kernel template of the medium-batch (M <= 128) W8A16 "stream" GEMM with register-resident activations.
+// Kernel template of the small-batch W8A16 / W4A16 "stream" GEMM (AUTO: 2 <= M <= 16; the template itself runs up to 64 rows).
 //
-// Same HBM-bound weight stream as the GEMV kernel (waves of a workgroup split K, 16 B/lane tile loads go
-// straight to registers and are MFMA B operands as they are), but the activation fragments are loaded straight from
-// global memory (they live in L2: M*K*2 bytes, re-read by every workgroup) instead of being staged in LDS, so M*K is
-// not limited by the 160 KiB LDS.  One workgroup owns NT adjacent 16-column tile rows so each activation fragment is
-// reused by NT weight tiles; MT = ceil(M/16) row tiles of v_mfma_f32_16x16x32_f16.
+// Same HBM-bound weight stream as the GEMV kernel: the waves of a workgroup split K, 16 B/lane tile loads go straight to registers
+// and are MFMA B operands as they are (after the exact dequantisation); one workgroup owns NT adjacent 16-column tile rows so each
+// activation fragment is reused by NT weight tiles; MT = ceil(M/16) row tiles of v_mfma_f32_16x16x32_f16; the waves' partial sums
+// meet in LDS at the end.  Where the activation (A) fragments come from is the template parameter XM:
+//   XM = 0  registers: straight from global memory (L2), 16 clamped rows x 128 B per weight tile and wave (any MT)
+//   XM = 1  block copy: the M rows once per workgroup into LDS (MT = 1, K % 128 == 0, M*K*2 bytes must fit)
+//   XM = 2  per-wave ring of 8 rows (M <= 8), XM = 3 of 4 rows (int4, M <= 4), XM = 4 of 16 rows (int8, M <= 16): LDS-DMA per k tile
+// All forms feed the same fragments to the same MFMAs in the same order: bit-identical results at equal WAVES.
 // Included by streamk.hip and tools/kbench.hip.
 #pragma once
 #include "common.hpp"
@@ -18,7 +21,7 @@ typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
 
 // grid.x = N / (16*NT); block = WAVES*64; wave w takes k tiles w, w+WAVES, ... (each >= D tiles by launch contract).
 // Dynamic LDS: WAVES * MT*NT*256 floats (cross-wave reduction only).
-// XLDS (MT = 1, K % 128 == 0, M*K*2 bytes fit): the M activation rows are copied ONCE per workgroup into LDS (LDS-DMA,
+// XM = 1 (MT = 1, K % 128 == 0, M*K*2 bytes fit): the M activation rows are copied ONCE per workgroup into LDS (LDS-DMA,
 // 16 B/lane, no VGPR round trip; the 16-byte chunk index within a row is xor-ed with the row number so that the 16 lanes of an MFMA
 // A fragment -- 16 rows, same k -- hit 16 different bank groups) and the A fragments are LDS reads: the vector-memory path then
 // carries the weight stream only, instead of 16 (clamped) rows x 128 B of activations from L2 per 1 KiB weight tile.
@@ -28,7 +31,8 @@ typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
 // XM = 2 (MT = 1, M <= 8; any K): per-wave ring instead of a whole-x copy -- ONE LDS-DMA instruction per int8 k tile and wave (two
 // per int4 tile: 8 rows x 256 B) brings the activations the tile needs (lane = row * chunks + chunk, chunk xor row) into a slot of the
 // wave's own ring (2*D - 1 slots), issued right before the tile's weight load so the wait for the weights covers it; no barrier, no
-// up-front copy, half the activation load instructions of the register form.  XM = 3: int4 with M <= 4 -- 4 rows, one DMA per tile.
+// up-front copy, half the activation load instructions of the register form.  XM = 3: int4 with M <= 4 -- 4 rows, one DMA per tile;
+// XM = 4: int8 with 9 <= M <= 16 -- 16 rows, two DMAs per tile.  Dynamic LDS then: [WAVES * (2*D - 1) slots] + the reduction floats.
 template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD, int BITS = 8, int XM = 0>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
