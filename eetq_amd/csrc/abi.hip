@@ -167,6 +167,15 @@ int eetq_diag_clock_stamp(unsigned long long* out, int grid, void* stream)
     return launch_clock_stamp(out, grid, static_cast<hipStream_t>(stream));
 }
 
+int eetq_diag_stream_plan(int bits, int M, int N, int K, int cus, int* form, int* tile_rows, int* waves)
+{
+    EETQ_REQUIRE(form && tile_rows && waves, "eetq_diag_stream_plan: null output pointer");
+    const int ncu = cus > 0 ? cus : device_cu_count();
+    if (stream_plan_query(bits, M, N, K, ncu, form, tile_rows, waves) != 0)
+        return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] eetq_diag_stream_plan: bits 4 / 8, 1 <= M <= 16, N % 16 == 0, K % 64 (128) == 0");
+    return EETQ_OK;
+}
+
 int eetq_device_supported(void)
 {
     int dev = 0;

@@ -259,6 +259,7 @@ int  launch_stream_read(const void* p, size_t bytes, unsigned* sink, hipStream_t
 int  launch_empty(unsigned* sink, int grid, int block, hipStream_t stream);
 int  launch_clock_stamp(unsigned long long* out, int grid, hipStream_t stream);
 
+int  stream_plan_query(int bits, int M, int N, int K, int ncu, int* form, int* nt, int* waves);
 int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                     hipStream_t stream);
 

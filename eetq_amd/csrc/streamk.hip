@@ -48,6 +48,37 @@ inline StreamPlan plan_from_env(const char* name)
     return p;
 }
 
+// The register form's plan.  int8: every workgroup re-reads the activations (M x K fp16 from L2) for its columns; with two tile
+// rows per workgroup each activation fragment feeds two weight tiles.  Cost per k tile in wave-load units: NT weight loads + 2
+// activation loads, times the workgroups the busiest CU gets.  N = 5120 (320 tile rows on 256 CUs): M = 8 10.0 -> 7.5 us, K = 13824
+// 23.6 -> 17.2 us; N = 22016: 24.5 -> 17.0 us; N = 4096 stays at NT = 1 (5.0 vs 5.8 us) -- profiles/r01_kbench_streamk_nt.txt.
+// Workgroup size (us with 16 / 8 waves): 5120^2 M = 4 7.59 / 7.08, 13824 x 5120 M = 4 17.03 / 15.26, 5120 x 13824 M = 8 15.69 / 14.67,
+// 4096^2 M = 8 5.66 / 5.32; one tile row per workgroup on <= one workgroup per CU at M <= 4 keeps 16 waves (11008 x 4096 M = 2 9.66 / 10.27).
+inline StreamPlan regs_plan_i8(int M, int N, int ncu)
+{
+    int nt = 1;
+    if (N % (2 * kTileN) == 0) {
+        const long cost1 = (long)((N / kTileN + ncu - 1) / ncu) * 3;
+        const long cost2 = (long)((N / (2 * kTileN) + ncu - 1) / ncu) * 4;
+        if (cost2 < cost1) nt = 2;
+    }
+    const int wgs = N / (kTileN * nt);
+    return StreamPlan{0, nt, (M > 4 || nt == 2 || wgs > ncu) ? 8 : 16};
+}
+
+// int4 (per k tile: NT weight loads + 4 activation loads): 4096 x 11008 M = 4 8.99 -> 8.34 us with 8 waves, 5120 x 13824 10.93 ->
+// 10.44, 11008 x 4096 8.46 -> 8.10; N = 5120: 160 two-row workgroups, 5.84 (16 waves) vs 6.29 us
+inline StreamPlan regs_plan_i4(int N, int ncu)
+{
+    int nt = 1;
+    if (N % (2 * kTileN) == 0) {
+        const long cost1 = (long)((N / kTileN + ncu - 1) / ncu) * 5;
+        const long cost2 = (long)((N / (2 * kTileN) + ncu - 1) / ncu) * 6;
+        if (cost2 < cost1) nt = 2;
+    }
+    return StreamPlan{0, nt, N / (kTileN * nt) >= ncu ? 8 : 16};
+}
+
 // The rule (int8, one row tile, K / 64 >= 32), read off profiles/r04_stream_plan_sweep.txt (21 shapes x M = 2..8 x 7 plans; "rpc" =
 // 16-column tile rows per CU) and checked against the register form of rounds 1-3 in the same run
 // (profiles/r04_stream_plan_rule_check.txt, us per launch, registers -> rule; geometric mean over the grid 0.943, worst +1.1 %).
@@ -130,30 +161,18 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
 {
     const int KT = K / kTileK;  // every wave must own >= D k tiles
     if (KT >= 32) {
-        // every workgroup re-reads the activations (M x K fp16 from L2) for its columns; with two tile rows per
-        // workgroup each activation fragment feeds two weight tiles.  Cost per k tile in wave-load units: NT weight loads
-        // + 2 activation loads, times the workgroups the busiest CU gets.  N = 5120 (320 tile rows on 256 CUs): M = 8
-        // 10.0 -> 7.5 us, K = 13824 23.6 -> 17.2 us; N = 22016: 24.5 -> 17.0 us; N = 4096 stays at NT = 1 (5.0 vs 5.8 us)
-        // -- profiles/r01_kbench_streamk_nt.txt
         static const int forced_waves = [] {  // EETQ_AMD_I8_STREAM_WAVES=8 / 16: force the workgroup size (A/B runs)
             const char* e = getenv("EETQ_AMD_I8_STREAM_WAVES");
             return e ? atoi(e) : 0;
         }();
         if constexpr (MT == 1) {
             const int ncu = device_cu_count();
-            int       nt  = 1;
-            if (N % (2 * kTileN) == 0) {
-                const long cost1 = (long)((N / kTileN + ncu - 1) / ncu) * 3;
-                const long cost2 = (long)((N / (2 * kTileN) + ncu - 1) / ncu) * 4;
-                if (cost2 < cost1) nt = 2;
-            }
-            // Workgroup size (round 4, profiles/r04_int8_stream_waves_ab.txt, us with 16 / 8 waves): 8-wave workgroups win
-            // wherever there are two tile rows per workgroup or more workgroups than CUs, and at M > 4 -- 5120^2 M = 4 7.59 /
-            // 7.08, 13824 x 5120 M = 4 17.03 / 15.26, 5120 x 13824 M = 8 15.69 / 14.67, 4096^2 M = 8 5.66 / 5.32; one tile row
-            // per workgroup on <= one workgroup per CU at M <= 4 keeps 16 waves (11008 x 4096 M = 2 9.66 / 10.27).  Four tiles
-            // in flight per wave instead of two lose (r04_int8_stream_waves_ab2.txt).
-            const int  wgs   = N / (kTileN * nt);
-            const bool eight = forced_waves ? forced_waves == 8 : (M > 4 || nt == 2 || wgs > ncu);
+            // the register form's own plan (regs_plan_i8): two tile rows per workgroup where that puts fewer loads on the busiest
+            // CU; 8-wave workgroups (round 4, profiles/r04_int8_stream_waves_ab.txt) wherever there are two tile rows per workgroup
+            // or more workgroups than CUs, and at M > 4
+            const StreamPlan regs  = regs_plan_i8(M, N, ncu);
+            const int        nt    = regs.nt;
+            const bool       eight = forced_waves ? forced_waves == 8 : regs.waves == 8;
             // Where the activation fragments come from (round 4; all three forms feed the same fragments to the same MFMAs in the
             // same order -- bit-identical results, tests/test_gpu_stream_xlds.py):
             //   regs  : straight from L2 into registers, 16 (clamped) rows x 128 B per weight tile: two vector loads of activations
@@ -221,18 +240,11 @@ int launch_mt_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
     }();
     if (KT >= 32) {
         const int ncu = device_cu_count();
-        int       nt  = 1;
-        if (N % (2 * kTileN) == 0) {
-            const long cost1 = (long)((N / kTileN + ncu - 1) / ncu) * 5;
-            const long cost2 = (long)((N / (2 * kTileN) + ncu - 1) / ncu) * 6;
-            if (cost2 < cost1) nt = 2;
-        }
-        // 8-wave workgroups when there are enough of them to give every CU one (round 4, profiles/r04_int4_stream_waves_ab.txt:
-        // 4096 x 11008 M = 4 8.99 -> 8.34 us, 5120 x 13824 10.93 -> 10.44, 11008 x 4096 8.46 -> 8.10; the int4 kernels are issue-
-        // and latency-bound and smaller workgroups overlap better); 16 waves when two tile rows per workgroup leave fewer
-        // workgroups than CUs (N = 5120: 160 workgroups, 5.84 vs 6.29 us with 8 waves)
-        const int  wgs   = N / (kTileN * nt);
-        const bool eight = forced_waves ? forced_waves == 8 : wgs >= ncu;
+        // the register form's own plan (regs_plan_i4): 8-wave workgroups when there are enough of them to give every CU one (round 4,
+        // profiles/r04_int4_stream_waves_ab.txt), 16 waves when two tile rows per workgroup leave fewer workgroups than CUs
+        const StreamPlan regs  = regs_plan_i4(N, ncu);
+        const int        nt    = regs.nt;
+        const bool       eight = forced_waves ? forced_waves == 8 : regs.waves == 8;
         // Where the activation fragments come from (see launch_mt / pick_plan): four activation loads per weight load in the
         // register form.  EETQ_AMD_I4_STREAM_PLAN=form,nt,waves overrides (A/B runs), EETQ_AMD_I4_STREAM_XLDS=0: registers only.
         StreamPlan plan = pick_plan_i4(M, N, K, ncu, nt, eight);
@@ -274,6 +286,35 @@ int launch_mt_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
 }
 
 }  // namespace
+
+// Which plan a small-batch launch takes (eetq_diag_stream_plan): pure host arithmetic, the same functions the launchers call.
+// Returns 0 and fills form (0 registers, 1 block copy, 2 ring), tile rows per workgroup, waves per workgroup, or -1 when the shape is
+// outside the kernel (M > 16 rows of one tile, K not a multiple of the tile depth).  Environment overrides are NOT applied.
+int stream_plan_query(int bits, int M, int N, int K, int ncu, int* form, int* nt, int* waves)
+{
+    const int tile_k = bits == 4 ? 128 : 64;
+    if ((bits != 4 && bits != 8) || M < 1 || M > 16 || N < kTileN || N % kTileN || K < tile_k || K % tile_k || ncu < 1) return -1;
+    const int  KT = K / tile_k;
+    StreamPlan p{0, 1, 16};
+    if (KT >= 32) {
+        if (bits == 8) {
+            const StreamPlan r = regs_plan_i8(M, N, ncu);
+            p                  = pick_plan(M, N, K, ncu, r.nt, r.waves == 8);
+            if (p.form == 1 && (K % 128 != 0 || (long)M * K * 2 > 128 * 1024)) p.form = 0;
+        } else {
+            const StreamPlan r = regs_plan_i4(N, ncu);
+            p                  = pick_plan_i4(M, N, K, ncu, r.nt, r.waves == 8);
+            if (p.form == 2 && M > 8) p.form = 0;
+        }
+        if (p.nt == 2 && N % (2 * kTileN) != 0) p.nt = 1;
+    } else {
+        p.waves = KT >= 16 ? 8 : KT >= 4 ? 4 : 1;
+    }
+    *form  = p.form;
+    *nt    = p.nt;
+    *waves = p.waves;
+    return 0;
+}
 
 int launch_streamk_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                       hipStream_t stream)

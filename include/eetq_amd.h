@@ -312,6 +312,13 @@ int eetq_diag_empty(void* sink, int grid, int block, void* stream);
  * the chip held over the chain, per XCD: d(memtime) / d(memrealtime) x 100 MHz (bench.py `effective_clock_mhz`: the
  * evidence for "power-bound").  Graph-capturable. */
 int eetq_diag_clock_stamp(unsigned long long* out, int grid, void* stream);
+/* Diagnostic, host arithmetic only (no launch; with cus > 0 no device either): which plan the small-batch kernel (1 <= M <= 16 rows;
+ * AUTO sends 2 <= M <= 16 there) takes for a weight of `bits` (8 / 4), K x N, on a chip with `cus` compute units (<= 0: the current
+ * device's).  *form = 0 activation fragments straight from L2 into registers, 1 rows copied once per workgroup into LDS, 2 per-wave
+ * LDS-DMA ring; *tile_rows = 16-column tile rows per workgroup (1 / 2); *waves = waves per workgroup.  All plans give the same bits
+ * at equal *waves.  The environment overrides (EETQ_AMD_I8_STREAM_PLAN ...) are not applied.  No reference counterpart: the
+ * reference picks its CUTLASS tile by a timing sweep at run time (cutlass_heuristic.cc), this library by a rule -- this entry shows it. */
+int eetq_diag_stream_plan(int bits, int M, int N, int K, int cus, int* form, int* tile_rows, int* waves);
 
 /* Decode steps on a pre-allocated KV cache (eetq_rope_decode_attention_f16, eetq_rotary_neox_kvcache_f16) whose new token
  * was NOT written because its cache row lies outside the cache (slot >= rows: the cache is full; or a negative position).

@@ -59,6 +59,48 @@ def test_argument_validation_without_gpu(lib):
     assert lib.eetq_rotary_neox_f16(p, p, p, p, 1, 1, 64, 63, None) == -1   # odd rot_dim
 
 
+def test_small_batch_plan_rule_on_a_256_cu_chip(lib):
+    """eetq_diag_stream_plan: host arithmetic only (cus given: no device needed).  Pins the rule of streamk.hip::pick_plan /
+    pick_plan_i4 as DESIGN.md 4.2 / 4.6 state it, for an MI355X (256 CUs): form 0 registers, 1 block copy, 2 per-wave ring."""
+    import ctypes
+
+    def plan(bits, M, N, K, cus=256):
+        f, t, w = ctypes.c_int(-9), ctypes.c_int(-9), ctypes.c_int(-9)
+        rc = lib.eetq_diag_stream_plan(bits, M, N, K, cus, ctypes.byref(f), ctypes.byref(t), ctypes.byref(w))
+        return None if rc != 0 else (f.value, t.value, w.value)
+
+    REGS, BLOCK, RING = 0, 1, 2
+    want8 = {
+        (4, 4096, 4096): (RING, 1, 16), (8, 4096, 4096): (RING, 1, 16), (10, 4096, 4096): (RING, 1, 16), (12, 4096, 4096): (RING, 1, 8),
+        (3, 4096, 11008): (RING, 1, 16),                                  # one tile row per CU, deep K
+        (2, 11008, 4096): (BLOCK, 1, 8), (4, 11008, 4096): (RING, 1, 16), (8, 11008, 4096): (RING, 1, 16), (12, 11008, 4096): (RING, 2, 8),
+        (2, 9216, 3072): (BLOCK, 1, 8), (8, 9216, 3072): (RING, 1, 16),
+        (4, 5120, 5120): (REGS, 2, 8), (10, 5120, 5120): (REGS, 2, 8), (12, 5120, 5120): (RING, 2, 8), (4, 5120, 13824): (REGS, 2, 8),
+        (4, 8192, 8192): (RING, 1, 8), (6, 8192, 8192): (REGS, 2, 8), (4, 8192, 28672): (REGS, 2, 8),     # N = 32 * CUs: K <= 8192, M <= 5
+        (8, 13824, 5120): (RING, 2, 8), (2, 14336, 4096): (RING, 2, 8), (4, 14352, 4096): (RING, 1, 16),  # 897 tile rows: odd
+        (2, 28672, 8192): (RING, 1, 16), (7, 28672, 8192): (RING, 1, 16), (8, 28672, 8192): (RING, 2, 8), (4, 22016, 4096): (RING, 2, 8),
+        (3, 22016, 4096): (RING, 1, 16), (16, 28672, 8192): (RING, 2, 8),
+        (4, 4096, 1024): (REGS, 1, 8), (4, 4096, 256): (REGS, 1, 4), (4, 64, 128): (REGS, 1, 1),         # K / 64 < 32: fixed instantiations
+    }
+    for (M, N, K), w in want8.items():
+        assert plan(8, M, N, K) == w, (8, M, N, K, plan(8, M, N, K), w)
+    want4 = {
+        (4, 4096, 11008): (RING, 1, 16), (8, 4096, 4096): (RING, 1, 16), (16, 4096, 4096): (BLOCK, 1, 8), (12, 1024, 4096): (BLOCK, 1, 16),
+        (2, 11008, 4096): (BLOCK, 1, 8), (5, 11008, 4096): (BLOCK, 1, 8), (7, 11008, 4096): (RING, 1, 8), (12, 11008, 4096): (REGS, 2, 8),
+        (4, 13824, 5120): (REGS, 2, 8), (4, 14336, 4096): (REGS, 2, 8), (4, 5120, 5120): (REGS, 2, 16),
+        (8, 5120, 13824): (RING, 2, 16), (4, 8192, 28672): (RING, 2, 16),
+        (4, 27648, 5120): (RING, 1, 8), (6, 27648, 5120): (REGS, 2, 8), (6, 28672, 8192): (RING, 2, 8), (4, 22016, 4096): (REGS, 2, 8),
+    }
+    for (M, N, K), w in want4.items():
+        assert plan(4, M, N, K) == w, (4, M, N, K, plan(4, M, N, K), w)
+    # another chip: the thresholds move with the CU count (4096 x 4096 on 128 CUs has two tile rows per CU: registers below M = 6 ...)
+    assert plan(8, 4, 4096, 4096, cus=128) == (RING, 1, 8) and plan(8, 6, 4096, 4096, cus=128) == (REGS, 2, 8)
+    # outside the kernel
+    for bad in ((8, 17, 4096, 4096), (8, 0, 4096, 4096), (8, 4, 4100, 4096), (8, 4, 4096, 4100), (4, 4, 4096, 4160), (5, 4, 4096, 4096)):
+        assert plan(*bad) is None
+    assert b"eetq_diag_stream_plan" in lib.eetq_last_error()
+
+
 def test_no_oracle_in_product():
     """The product path must never import or link the oracle (it is test infrastructure)."""
     pkg = os.path.join(ROOT, "eetq_amd")
