@@ -23,7 +23,7 @@ CASES = [(8, 4096, 11008, 2), (8, 4096, 11008, 5), (8, 4096, 11008, 8), (8, 4096
          (8, 4096, 4096, 7), (8, 11008, 4096, 2), (8, 11008, 4096, 8), (8, 8192, 1024, 4), (8, 2048, 8256, 7), (8, 3072, 9216, 8),
          (8, 3072, 9216, 2), (8, 4096, 22016, 3), (8, 4096, 22016, 6), (8, 8192, 8192, 5), (8, 4096, 14336, 2),
          (8, 4096, 4096, 16), (8, 4096, 4096, 9), (8, 4096, 11008, 12), (8, 11008, 4096, 11), (8, 5120, 5120, 13), (8, 2048, 8256, 16),
-         (4, 4096, 11008, 2), (4, 4096, 11008, 7), (4, 4096, 12288, 4), (4, 4096, 14336, 3), (4, 4096, 4096, 3), (4, 4096, 4096, 8),
+         (4, 4096, 11008, 2), (4, 4096, 11008, 7), (4, 4096, 12288, 4), (4, 8192, 1024, 6), (4, 4096, 4096, 3), (4, 4096, 4096, 8),
          (4, 4096, 4096, 13), (4, 4096, 4096, 16), (4, 11008, 4096, 6), (4, 13824, 5120, 5), (4, 5120, 27648, 4)]
 
 
@@ -122,3 +122,19 @@ def test_lds_staged_rows_bias_residual_glu_and_graph(oracle):
         g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out, ops.w8_a16_gemm(xd, pk, sd))
+
+
+def test_plan_query_uses_the_device_cu_count():
+    """eetq_diag_stream_plan with cus <= 0 asks the device: an MI355X has 256 CUs, so both calls agree (tests/test_abi.py pins the
+    256-CU table on the host)."""
+    import ctypes
+    from eetq_amd import _lib
+    lib = _lib.lib()
+    for bits, K, N, M in CASES:
+        got = []
+        for cus in (0, 256):
+            f, t, w = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            assert lib.eetq_diag_stream_plan(bits, M, N, K, cus, ctypes.byref(f), ctypes.byref(t), ctypes.byref(w)) == 0
+            got.append((f.value, t.value, w.value))
+        assert got[0] == got[1], (bits, M, N, K, got)
+        assert got[0][0] in (1, 2), (bits, M, N, K, got)          # every case of this file is one the rule stages in LDS
