@@ -17,6 +17,8 @@
 // (k0,k1), (k2,k3), (k4,k5), (k6,k7) that v_dot2 wants.  quant_weights in the native layout is two launches + a fill (column maxima,
 // then quant.hip's fused quantise + pack kernel); the other routes (sm80 layout, row-major copy, pack / unpack alone) are plain
 // one-thread-per-byte gathers, not tuned.
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 
 #include "common.hpp"
@@ -348,7 +350,29 @@ int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
         return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16: unknown or unimplemented GEMM path");
     const bool expand = path == EETQ_PATH_MFMA;
     // decode: the wave-reduction GEMV on int4 tiles (gemv_kernel<..., BITS = 4>)
-    if (M == 1 && !expand) return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
+    if (M == 1 && !expand) {
+        // Round 4: the MFMA small-batch kernel run with ONE row (its activation row in LDS, streamk.hip::pick_plan_i4) where it beats the
+        // dot-product GEMV.  The GEMV is VALU-bound (2.1 VALU operations per weight) and saturates near 3.5-4.4 TB/s of
+        // int4 weights; the MFMA form leaves the adds to the matrix cores and reaches 5.1 (profiles/r04_i4_gemv_vs_stream_m1.txt, us
+        // GEMV / stream): 8192 x 28672 33.9 / 22.9, 8192^2 10.86 / 8.81, 28672 x 8192 26.7 / 22.9, 5120 x 27648 18.3 / 15.7, 5120 x
+        // 15360 11.6 / 10.3, 8192 x 1024 5.54 / 4.94, 11008 x 4096 7.43 / 6.82.  Kept on the GEMV: the ties and losses -- 4096^2 4.02 /
+        // 4.07, 5120^2 5.61 / 5.76, 5120 x 13824 10.15 / 10.20, 4096 x 14336 8.45 / 8.57, 13824 x 5120 10.82 / 11.17 (1 < tile rows per
+        // CU < 2: the 8-column units balance those better).  EETQ_AMD_I4_M1=gemv|stream forces one (A/B runs).
+        static const int forced = [] {
+            const char* e = getenv("EETQ_AMD_I4_M1");
+            return !e ? 0 : !strcmp(e, "gemv") ? 1 : !strcmp(e, "stream") ? 2 : 0;
+        }();
+        bool stream_form = false;
+        if (K % 128 == 0 && K >= 4096) {
+            const int  ncu  = device_cu_count();
+            const int  rows = N / kTileN;
+            const bool deep = K >= 8192 && !(rows > ncu && rows < 2 * ncu);
+            const bool big  = (size_t)K * N >= (72ull << 20);
+            stream_form     = forced ? forced == 2 : (deep || big);
+        }
+        if (stream_form) return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
+        return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
+    }
     // batched decode, 2 <= M <= 16: the register-streaming MFMA kernel on int4 tiles (streamk_kernel<..., BITS = 4>) -- the
     // weight stream bounds these M, and it is half as long as the int8 one (M = 8, N = K = 4096: 4.5 vs 5.1 us; the dot2
     // GEMV at M = 4 needs 6.9).  Larger M are bound by the activation traffic / the matrix cores, where int4 buys nothing.

@@ -18,7 +18,7 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     auto         kern = streamk::streamk_kernel<MT, NT, WAVES, D, OCC, BITS, XM>;
     const size_t smem = streamk::streamk_smem_bytes(MT, NT, WAVES) +
                         (XM == 1 ? (((size_t)M * K * 2 + 1023) & ~(size_t)1023)
-                                 : XM >= 2 ? (size_t)WAVES * (2 * D - 1) * ((BITS == 4 && XM == 2) || XM == 4 ? 2048 : 1024) : 0);
+                                 : XM >= 2 ? (size_t)WAVES * (2 * D - 1) * (XM == 4 ? (BITS == 4 ? 4096 : 2048) : (BITS == 4 && XM == 2) ? 2048 : 1024) : 0);
     if (smem > 64 * 1024) {
         static std::atomic<unsigned long long> opted{0};
         int st = opt_in_large_lds(kern, opted);
@@ -127,7 +127,11 @@ inline StreamPlan pick_plan(int M, int N, int K, int ncu, int nt0, bool eight0)
 // the same run (profiles/r04_stream_plan_rule_check_i4.txt, us per launch, registers -> rule; geometric mean 0.963 at M <= 8, worst
 // +1.6 %).  The register form issues FOUR activation loads per weight load; the ring one DMA per tile at M <= 4, two at M <= 8.
 //   rpc <= 1, M <= 8     ring, 1 row, 16 waves   11008 x 4096 M = 4 7.98 -> 6.92; 8192 x 1024 M = 4 6.07 -> 5.02; 4096^2 M = 8 4.73 -> 4.46
-//   rpc <= 1, M >= 9     block copy while M*K*2 <= 144 KiB at K = 4096 (4096^2 M = 16 6.09 -> 5.32)
+//   rpc <= 1, M >= 9     16-row ring (four DMAs per tile), 1 row, 8 waves   11008 x 4096 M = 16 13.35 -> 10.02; 8192 x 1024 9.90 -> 7.22;
+//                        4096^2 M = 16 6.09 -> 5.23 (the block copy used before the ring existed: 5.32)
+//   1 < rpc <= 2, M >= 9 16-row ring, 2 rows, 8 waves from M = 12 (from M = 9 at K >= 6144): 13824 x 5120 M = 16 19.07 -> 14.95; 8192^2
+//                        12.14 -> 10.24; 5120^2 8.63 -> 7.67; 7168^2 11.5 -> 9.5; wider shapes stay on registers (ring 6-27 % slower at
+//                        M = 9..12) except M >= 15 at K >= 8192 (8192 x 28672 M = 16 39.7 -> 35.3)
 //   1 < rpc <= 2         ring, 2 rows, 16 waves above K = 8192 (13824 x 5120 M = 8 13.68 -> 12.32; 28672 x 8192 M = 4 25.5 -> 23.5)
 //   2 < rpc <= 3, K 4096 block copy, 1 row, at M <= 5 (4096 x 11008 M = 2 8.36 -> 6.87, M = 5 8.48 -> 7.64; 4096 x 12288 M = 4 8.45 ->
 //                        7.62), ring, 1 row, 8 waves above (M = 8 9.00 -> 8.68)
@@ -143,9 +147,12 @@ inline StreamPlan pick_plan_i4(int M, int N, int K, int ncu, int nt0, bool eight
     StreamPlan p{0, nt0, eight0 ? 8 : 16};
     if (lds_off) return p;
     const int  rows   = N / kTileN;
-    const long xbytes = (long)M * K * 2;
     const bool even   = N % (2 * kTileN) == 0;
-    if (M > 8) return (K <= 4096 && rows <= ncu && xbytes <= 144 * 1024) ? StreamPlan{1, 1, rows >= ncu ? 8 : 16} : p;
+    if (M > 8) {  // 16-row ring, 4 KiB slots, 8-wave workgroups (profiles/r04_stream_plan_sweep_i4_m9to16.txt)
+        if (rows <= ncu) return StreamPlan{2, 1, 8};
+        if (rows <= 2 * ncu) return (even && (M >= 12 || K >= 6144)) ? StreamPlan{2, 2, 8} : p;
+        return (even && M >= 15 && K >= 8192) ? StreamPlan{2, 2, 8} : p;
+    }
     if (rows <= ncu) return StreamPlan{2, 1, 16};
     if (rows <= 2 * ncu) return K > 8192 ? StreamPlan{2, even ? 2 : 1, 16} : p;
     if (rows <= 3 * ncu) return K > 4096 ? p : M <= 5 ? StreamPlan{1, 1, 8} : StreamPlan{2, 1, 8};
@@ -255,8 +262,12 @@ int launch_mt_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
         if (forced_waves) plan.waves = forced_waves;
         if (plan.nt == 2 && N % (2 * kTileN) != 0) plan.nt = 1;
         if (plan.form == 1 && (long)M * K * 2 > 144 * 1024) plan.form = 0;
-        if (plan.form == 2 && M > 8) plan.form = 0;
+        if (plan.form == 2 && M > 8) plan.waves = 8;
         const bool e8 = plan.waves == 8;
+        if (plan.form == 2 && M > 8) {  // 16-row ring: 4 KiB slots, 8-wave workgroups only (16 waves would need 192 KiB of LDS)
+            if (plan.nt == 2) return launch_inst<1, 2, 8, 2, 2, 4, 4>(x, w, scales, ep, y, M, N, K, stream);
+            return launch_inst<1, 1, 8, 2, 2, 4, 4>(x, w, scales, ep, y, M, N, K, stream);
+        }
         if (plan.form == 2 && M <= 4) {
             if (plan.nt == 2) return e8 ? launch_inst<1, 2, 8, 2, 2, 4, 3>(x, w, scales, ep, y, M, N, K, stream)
                                         : launch_inst<1, 2, 16, 2, 2, 4, 3>(x, w, scales, ep, y, M, N, K, stream);
@@ -304,7 +315,7 @@ int stream_plan_query(int bits, int M, int N, int K, int ncu, int* form, int* nt
         } else {
             const StreamPlan r = regs_plan_i4(N, ncu);
             p                  = pick_plan_i4(M, N, K, ncu, r.nt, r.waves == 8);
-            if (p.form == 2 && M > 8) p.form = 0;
+            if (p.form == 2 && M > 8) p.waves = 8;
         }
         if (p.nt == 2 && N % (2 * kTileN) != 0) p.nt = 1;
     } else {

@@ -6,7 +6,7 @@
 // meet in LDS at the end.  Where the activation (A) fragments come from is the template parameter XM:
 //   XM = 0  registers: straight from global memory (L2), 16 clamped rows x 128 B per weight tile and wave (any MT)
 //   XM = 1  block copy: the M rows once per workgroup into LDS (MT = 1, K % 128 == 0, M*K*2 bytes must fit)
-//   XM = 2  per-wave ring of 8 rows (M <= 8), XM = 3 of 4 rows (int4, M <= 4), XM = 4 of 16 rows (int8, M <= 16): LDS-DMA per k tile
+//   XM = 2  per-wave ring of 8 rows (M <= 8), XM = 3 of 4 rows (int4, M <= 4), XM = 4 of 16 rows (M <= 16): LDS-DMA per k tile
 // All forms feed the same fragments to the same MFMAs in the same order: bit-identical results at equal WAVES.
 // Included by streamk.hip and tools/kbench.hip.
 #pragma once
@@ -32,7 +32,7 @@ typedef __attribute__((address_space(3))) const u32x4 lds_cu32x4;
 // per int4 tile: 8 rows x 256 B) brings the activations the tile needs (lane = row * chunks + chunk, chunk xor row) into a slot of the
 // wave's own ring (2*D - 1 slots), issued right before the tile's weight load so the wait for the weights covers it; no barrier, no
 // up-front copy, half the activation load instructions of the register form.  XM = 3: int4 with M <= 4 -- 4 rows, one DMA per tile;
-// XM = 4: int8 with 9 <= M <= 16 -- 16 rows, two DMAs per tile.  Dynamic LDS then: [WAVES * (2*D - 1) slots] + the reduction floats.
+// XM = 4: 9 <= M <= 16 -- 16 rows, two DMAs per int8 tile (four per int4 tile: 4 KiB slots, 8-wave workgroups only).  Dynamic LDS then: [WAVES * (2*D - 1) slots] + the reduction floats.
 template <int MT, int NT, int WAVES, int D, int MIN_WAVES_PER_SIMD, int BITS = 8, int XM = 0>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
@@ -41,12 +41,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     constexpr bool XLDS = XM == 1, XRING = XM >= 2;
     constexpr int  kRing     = 2 * D - 1;
     constexpr int  kRowBytes = BITS == 8 ? 128 : 256;          // activation bytes per row and k tile
-    constexpr int  kRingRows = XM == 3 ? 4 : XM == 4 ? 16 : 8;    // XM = 4: int8 with 9 <= M <= 16, two DMAs per tile
+    constexpr int  kRingRows = XM == 3 ? 4 : XM == 4 ? 16 : 8;    // XM = 4: 9 <= M <= 16, two DMAs per int8 tile, four per int4 tile
     constexpr int  kSlot     = kRingRows * kRowBytes;          // 1 KiB; int4 with 8 rows: 2 KiB
     constexpr int  kDma      = kSlot / 1024;
     static_assert(XM == 0 || MT == 1, "LDS-staged activations: one row tile");
     static_assert(XM != 3 || BITS == 4, "the 4-row ring is the int4 form for M <= 4");
-    static_assert(XM != 4 || BITS == 8, "the 16-row ring is an int8 form");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int xs_bytes = XLDS ? ((M * K * 2 + 1023) & ~1023) : XRING ? WAVES * kRing * kSlot : 0;
     float*    red      = reinterpret_cast<float*>(smem + xs_bytes);
@@ -107,7 +106,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     }
 
     __amdgpu_buffer_rsrc_t ring_rs;
-    int                    ring_voff[2] = {0, 0}, ring_rd[XQ];
+    int                    ring_voff[4] = {0, 0, 0, 0}, ring_rd[XQ];
     uint8_t*               ring_wr      = smem;
 #pragma unroll
     for (int q = 0; q < XQ; ++q) ring_rd[q] = 0;

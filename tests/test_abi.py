@@ -85,7 +85,8 @@ def test_small_batch_plan_rule_on_a_256_cu_chip(lib):
     for (M, N, K), w in want8.items():
         assert plan(8, M, N, K) == w, (8, M, N, K, plan(8, M, N, K), w)
     want4 = {
-        (4, 4096, 11008): (RING, 1, 16), (8, 4096, 4096): (RING, 1, 16), (16, 4096, 4096): (BLOCK, 1, 8), (12, 1024, 4096): (BLOCK, 1, 16),
+        (4, 4096, 11008): (RING, 1, 16), (8, 4096, 4096): (RING, 1, 16), (16, 4096, 4096): (RING, 1, 8), (12, 1024, 4096): (RING, 1, 8), (12, 5120, 5120): (RING, 2, 8), (9, 5120, 5120): (REGS, 2, 16),
+        (9, 5120, 13824): (RING, 2, 8), (16, 28672, 8192): (RING, 2, 8), (12, 28672, 8192): (REGS, 2, 8),
         (2, 11008, 4096): (BLOCK, 1, 8), (5, 11008, 4096): (BLOCK, 1, 8), (7, 11008, 4096): (RING, 1, 8), (12, 11008, 4096): (REGS, 2, 8),
         (4, 13824, 5120): (REGS, 2, 8), (4, 14336, 4096): (REGS, 2, 8), (4, 5120, 5120): (REGS, 2, 16),
         (8, 5120, 13824): (RING, 2, 16), (4, 8192, 28672): (RING, 2, 16),

@@ -308,11 +308,13 @@ def test_w4a16_medium_batch_is_graph_capturable(ops, oracle):
     assert torch.equal(out, eager)
 
 
-@pytest.mark.parametrize("K,N", [(4096, 4096), (5120, 15360), (5120, 27648), (13824, 5120), (512, 64), (128, 16), (2048, 1024)])
-@pytest.mark.parametrize("M", [2, 5, 16])
+@pytest.mark.parametrize("K,N", [(4096, 4096), (5120, 15360), (5120, 27648), (13824, 5120), (512, 64), (128, 16), (2048, 1024),
+                                 (8192, 8192), (11008, 4096), (8192, 1024)])
+@pytest.mark.parametrize("M", [1, 2, 5, 16])
 def test_w4a16_stream_kernel_shapes(ops, oracle, M, K, N):
     """The int4 stream kernel over the decode shapes (every wave-count / depth instantiation of its launcher), against the
-    oracle GEMM on the exact integers (rows sampled)."""
+    oracle GEMM on the exact integers (rows sampled).  M = 1 through AUTO: the dot-product GEMV, or -- round 4, deep K and big
+    weights -- this kernel with one row; whichever AUTO takes must also agree (tier A) with the other one."""
     rng = np.random.default_rng(K + N + M)
     qp = rng.integers(-128, 128, (K, N // 2), dtype=np.int8)
     s = (rng.random(N) * 0.02 + 0.001).astype(np.float16)
@@ -323,6 +325,11 @@ def test_w4a16_stream_kernel_shapes(ops, oracle, M, K, N):
     cols = slice(0, min(N, 256))
     ref = oracle.w8a16_gemm(x[rows], np.ascontiguousarray(oracle.i4_values(qp)[:, cols]), s[cols])
     assert _tier_a(y[rows][:, cols], ref).all()
+    if M == 1 and K % 128 == 0:
+        for path in ("gemv", "stream"):
+            other = ops.w8_a16_gemm(torch.from_numpy(x).to(DEV), torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV),
+                                    torch.from_numpy(s).to(DEV), path=path).cpu().numpy()
+            assert _tier_a(other[:, cols], ref).all(), path
 
 
 def test_w4a16_linear_module(ops, oracle):
