@@ -138,6 +138,9 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
             for (int j = 0; j < kDma; ++j)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(ring_rs, (lds_void*)(ring_wr + slot * kSlot + j * 1024), 16, ring_voff[j],
                                                          kt * kRowBytes, 0, 0);
+            // the DMA must stay ahead of this stage's weight loads at every level of the compiler (the reads of the slot are ordered
+            // by the wait for those weights): a compiler barrier for the IR passes, a scheduling barrier for the machine scheduler
+            asm volatile("" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
         }
 #pragma unroll

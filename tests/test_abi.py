@@ -169,3 +169,45 @@ def test_store_hazard_checker_on_the_built_objects():
         assert chk.check(text, obj) == [], obj
     # the split-K kernel is the one with SGPR-soffset stores: the check is not vacuous
     assert chk.count_wide_sgpr_stores(chk.disassemble(os.path.join(_lib.CSRC_DIR, "gemm_splitk.o"))) > 0
+
+
+def test_ring_order_checker_on_the_built_object():
+    """tools/check_ring_order.py (run by the Makefile before linking): in every ring kernel of streamk.o the LDS-DMAs of a stage are
+    issued before its weight loads and no `ds_read_b128` runs while the slot's own DMA can still be in flight -- and the checker
+    does flag machine code in which a wait is dropped or a weight load is moved ahead of its DMA (mutations of the real
+    disassembly)."""
+    import importlib.util
+    import re
+    from eetq_amd import _lib
+    spec = importlib.util.spec_from_file_location("check_ring_order", os.path.join(ROOT, "tools", "check_ring_order.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    if not shutil.which("hipcc") and not os.path.exists(os.path.join(_lib.CSRC_DIR, "streamk.o")):
+        pytest.skip("no objects and no compiler on this machine")
+    _lib.build(force=False, verbose=False)
+    text = chk.disassemble(os.path.join(_lib.CSRC_DIR, "streamk.o"))
+    findings, seen = chk.check(text, "streamk.o")
+    assert seen >= 18 and findings == [], findings[:3]
+    # mutation 1: every vmcnt wait of the ring kernels relaxed to "wait for nothing" -> reads with the slot's DMA outstanding
+    relaxed = re.sub(r"s_waitcnt vmcnt\(\d+\)", "s_waitcnt vmcnt(63)", text)
+    f1, _ = chk.check(relaxed, "relaxed")
+    assert sum("rule 2" in f for f in f1) >= seen
+    # mutation 2: in each ring kernel the first LDS-DMA is moved behind the next weight load -> rule 1
+    lines, out, pending, in_ring = text.splitlines(), [], None, False
+    for ln in lines:
+        if re.match(r"^[0-9a-f]+ <", ln):
+            in_ring, moved = bool(chk.ring_params(ln)), False
+            if pending:
+                out.append(pending)
+                pending = None
+        if in_ring and not moved and pending is None and "buffer_load_dwordx4" in ln and " lds" in ln:
+            pending = ln
+            continue
+        out.append(ln)
+        if pending and "global_load_dwordx4" in ln:
+            out.append(pending)
+            pending, moved = None, True
+    f2, _ = chk.check("\n".join(out), "swapped")
+    # (a kernel whose compiler-hoisted DMAs of the NEXT stage already sit ahead of the first weight load keeps the count rule
+    # satisfied after this mutation: the int4 16-row ring, four DMAs per stage)
+    assert sum("rule 1" in f for f in f2) >= seen - 2
