@@ -87,6 +87,7 @@ inline StreamPlan regs_plan_i4(int N, int ncu)
 //                                             8192 x 1024 M = 4 7.04 -> 5.79, M = 8 7.51 -> 6.71; 4096 x 1024 M = 8 4.82 -> 4.21
 //   1 < rpc <= 2      registers               (5120^2, 13824 x 5120, 6144^2, 7168^2, 28672 x 8192: nothing beats them by > 2 %)
 //                     except N = 32 * CUs (rpc = 2) with K <= 8192 at M <= 5: ring, 1 row, 8 waves (8192^2 M = 4 12.73 -> 11.96)
+//                     and M = 2 on rpc <= 1.5: block copy, 1 row (5120^2 7.07 -> 6.74)
 //   2 < rpc <= 3      block copy, 1 row, while M*K*2 <= 24 KiB (4096 x 11008 M = 2 10.91 -> 8.94; 3072 x 9216 M = 2 8.43 -> 6.77),
 //                     then ring, 1 row, 16 waves (4096 x 11008 M = 4 11.10 -> 9.28, M = 6 11.19 -> 9.65, M = 8 11.41 -> 10.22; 4096 x
 //                     12288 M = 4 11.31 -> 9.84; the block copy falls off a cliff once its LDS leaves two workgroups per CU: M = 6 11.64)
@@ -117,7 +118,14 @@ inline StreamPlan pick_plan(int M, int N, int K, int ncu, int nt0, bool eight0)
         return StreamPlan{2, 2, 8};
     }
     if (rows <= ncu) return StreamPlan{2, 1, 16};
-    if (rows <= 2 * ncu) return (rows == 2 * ncu && K <= 8192 && M <= 5) ? StreamPlan{2, 1, 8} : p;
+    if (rows <= 2 * ncu) {
+        if (rows == 2 * ncu && K <= 8192 && M <= 5) return StreamPlan{2, 1, 8};
+        // two rows on up to 1.5 tile rows per CU, K <= 6144: the block copy with one tile row per workgroup (5120^2 7.04 -> 6.73, 4096 x
+        // 5120 6.05 -> 5.78, 4096 x 6144 6.35 -> 6.21; deeper K within +-1 %: 13824 x 5120 15.17 / 15.33; not at 1.75 rows per CU:
+        // 7168^2 9.78 -> 10.16; not from M = 3)
+        if (M == 2 && 2 * rows <= 3 * ncu && K <= 6144 && K % 128 == 0) return StreamPlan{1, 1, 8};
+        return p;
+    }
     if (rows <= 3 * ncu) return (K % 128 == 0 && xbytes <= 24 * 1024) ? StreamPlan{1, 1, 8} : StreamPlan{2, 1, 16};
     if (rows <= 4 * ncu) return N % (2 * kTileN) == 0 ? StreamPlan{2, 2, 8} : StreamPlan{2, 1, 16};
     return (M <= K / 1024 - 1 || N % (2 * kTileN) != 0) ? StreamPlan{2, 1, 16} : StreamPlan{2, 2, 8};

@@ -75,7 +75,8 @@ def test_small_batch_plan_rule_on_a_256_cu_chip(lib):
         (3, 4096, 11008): (RING, 1, 16),                                  # one tile row per CU, deep K
         (2, 11008, 4096): (BLOCK, 1, 8), (4, 11008, 4096): (RING, 1, 16), (8, 11008, 4096): (RING, 1, 16), (12, 11008, 4096): (RING, 2, 8),
         (2, 9216, 3072): (BLOCK, 1, 8), (8, 9216, 3072): (RING, 1, 16),
-        (4, 5120, 5120): (REGS, 2, 8), (10, 5120, 5120): (REGS, 2, 8), (12, 5120, 5120): (RING, 2, 8), (4, 5120, 13824): (REGS, 2, 8),
+        (4, 5120, 5120): (REGS, 2, 8), (2, 5120, 5120): (BLOCK, 1, 8), (2, 5120, 13824): (REGS, 2, 8), (2, 7168, 7168): (REGS, 2, 8),
+        (3, 5120, 5120): (REGS, 2, 8), (10, 5120, 5120): (REGS, 2, 8), (12, 5120, 5120): (RING, 2, 8), (4, 5120, 13824): (REGS, 2, 8),
         (4, 8192, 8192): (RING, 1, 8), (6, 8192, 8192): (REGS, 2, 8), (4, 8192, 28672): (REGS, 2, 8),     # N = 32 * CUs: K <= 8192, M <= 5
         (8, 13824, 5120): (RING, 2, 8), (2, 14336, 4096): (RING, 2, 8), (4, 14352, 4096): (RING, 1, 16),  # 897 tile rows: odd
         (2, 28672, 8192): (RING, 1, 16), (7, 28672, 8192): (RING, 1, 16), (8, 28672, 8192): (RING, 2, 8), (4, 22016, 4096): (RING, 2, 8),

@@ -39,6 +39,8 @@ if __name__ == "__main__":
         BITS = int(sys.argv[2])
         if BITS == 4:
             MS = (2, 3, 4, 5, 6, 8, 12, 16)
+        if os.environ.get("SWEEP_SHAPES"):   # "K1xN1,K2xN2"
+            SHAPES = [tuple(int(v) for v in a.split("x")) for a in os.environ["SWEEP_SHAPES"].split(",")]
         if os.environ.get("SWEEP_MS"):
             MS = tuple(int(a) for a in os.environ["SWEEP_MS"].split(","))
         child()
