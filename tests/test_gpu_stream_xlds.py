@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CASES = [(8, 4096, 11008, 2), (8, 4096, 11008, 5), (8, 4096, 11008, 8), (8, 4096, 12288, 3), (8, 5120, 13824, 4), (8, 4096, 4096, 4),
          (8, 4096, 4096, 7), (8, 11008, 4096, 2), (8, 11008, 4096, 8), (8, 8192, 1024, 4), (8, 2048, 8256, 7), (8, 3072, 9216, 8),
          (8, 3072, 9216, 2), (8, 4096, 22016, 3), (8, 4096, 22016, 6), (8, 8192, 8192, 5), (8, 4096, 14336, 2),
-         (8, 4096, 4096, 16), (8, 4096, 4096, 9), (8, 4096, 11008, 12), (8, 11008, 4096, 11), (8, 5120, 5120, 13), (8, 2048, 8256, 16),
+         (8, 4096, 4096, 16), (8, 4096, 4096, 9), (8, 5120, 5120, 2), (8, 4096, 11008, 12), (8, 11008, 4096, 11), (8, 5120, 5120, 13), (8, 2048, 8256, 16),
          (4, 4096, 11008, 2), (4, 4096, 11008, 7), (4, 4096, 12288, 4), (4, 8192, 1024, 6), (4, 4096, 4096, 3), (4, 4096, 4096, 8),
          (4, 4096, 4096, 13), (4, 4096, 4096, 16), (4, 11008, 4096, 6), (4, 13824, 5120, 5), (4, 5120, 27648, 4),
          (4, 11008, 4096, 12), (4, 5120, 5120, 14), (4, 8192, 1024, 9)]
