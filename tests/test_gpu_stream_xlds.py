@@ -139,3 +139,25 @@ def test_plan_query_uses_the_device_cu_count():
             got.append((f.value, t.value, w.value))
         assert got[0] == got[1], (bits, M, N, K, got)
         assert got[0][0] in (1, 2), (bits, M, N, K, got)          # every case of this file is one the rule stages in LDS
+
+
+def test_cold_graph_capture_of_the_large_lds_forms():
+    """The first launch of a kernel that needs > 64 KiB of dynamic LDS opts in (hipFuncSetAttribute) -- also when that first launch
+    happens INSIDE a graph capture, in a fresh process (9 <= M <= 11 on one tile row per CU: 16 waves x 3 slots x 2 KiB + reduction)."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import torch, eetq_amd.ops as ops\n"
+        "torch.manual_seed(0)\n"
+        "w = torch.randint(-128, 127, (4096, 4096), dtype=torch.int8, device='cuda:0')\n"
+        "s = torch.rand(4096, dtype=torch.float16, device='cuda:0') * 0.01\n"
+        "for M in (10, 12, 4):\n"
+        "    x = torch.randn(M, 4096, dtype=torch.float16, device='cuda:0')\n"
+        "    torch.cuda.synchronize()\n"
+        "    g = torch.cuda.CUDAGraph()\n"
+        "    with torch.cuda.graph(g):\n"
+        "        y = ops.w8_a16_gemm(x, w, s)\n"
+        "    g.replay(); torch.cuda.synchronize()\n"
+        "    assert torch.equal(y, ops.w8_a16_gemm(x, w, s)) and float(y.float().abs().max()) > 0, M\n"
+        "print('cold capture ok')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "cold capture ok" in r.stdout, r.stderr[-2000:]
