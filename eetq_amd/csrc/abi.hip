@@ -297,6 +297,66 @@ int eetq_unpack_i8_host(const int8_t* q_packed, size_t K, size_t N, int8_t* q_ra
     return relayout_host(q_packed, K, N, q_raw, layout, false);
 }
 
+// ---- what AUTO launches --------------------------------------------------------------------------------------------------
+// The reference switches on m alone (m <= 4: batched GEMV, else CUTLASS with a tile picked by occupancy queries at run time:
+// fpA_intB_gemm_wrapper.cu:149-162, cutlass_heuristic.cc:123-206).  Here one pure function of (M, N, K, epilogue) names the
+// kernel path; crossovers measured as graph-replayed chains (profiles/r03_path_compare_mid.jsonl, r04_stream_splitk_seam2.jsonl,
+// r05_auto_regret.jsonl).  No environment reads except the operational EETQ_AMD_SPLITK=0 (no library-owned scratch).
+struct AutoChoice {
+    int path;    // EETQ_PATH_*
+    int detail;  // TILESPLIT: K slices the launch uses (1 = the unsplit tiled kernel); otherwise 0
+};
+
+static AutoChoice auto_path_i8(int M, int N, int K, int act)
+{
+    // M = 1 -> wave-reduction GEMV (no MFMA)
+    if (M == 1) return {EETQ_PATH_GEMV, 0};
+    // One row tile (2 <= M <= 16): the MFMA stream kernel (same weight stream as the GEMV, activation rows through a per-wave
+    // LDS ring or a per-workgroup copy: streamk.hip::pick_plan) on every shape (us stream / split-K at M = 16: 4096 x 11008
+    // 12.60 / 12.74, 11008 x 4096 12.48 / 13.15, 8192^2 13.9 / 18.5, 28672 x 8192 41.8 / 46.9; the other way only 5120 x 27648
+    // from M = 13, 29.9 / 29.0)
+    if (M <= 16) return {EETQ_PATH_STREAM, 0};
+    static const bool use_splitk = [] {  // EETQ_AMD_SPLITK=0 keeps the unsplit kernels (the split forms own per-stream scratch)
+        const char* e = getenv("EETQ_AMD_SPLITK");
+        return !(e && e[0] == '0');
+    }();
+    if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31)) {
+        // wide N, M > 64: the 128 x 64 tiles of the tiled kernel already give most CUs a workgroup and read the activations
+        // once per 64 columns (N = 11008: M = 96 21.0 vs 23.9 us split-K, M = 128 22.4 vs 28.2; up to M = 64 the split-K tile
+        // is ahead: 17.6 vs 18.5)
+        if (M > 64 && (N + 63) / 64 >= 160 && K >= 320) return {EETQ_PATH_MFMA, 0};
+        // few tiles, deep K, M > 96 (the split-K tile needs four row blocks there): K slices of the tiled kernel's 128 x 64
+        // tile -- M = 128: 11008 x 4096 23.9 vs 27.1 us, 5120^2 20.1 vs 22.6 (tile_splitk_slices has the rule)
+        if (M > 96 && act == 0) {
+            const int S = tile_splitk_slices(M, N, K);
+            if (S > 1) return {EETQ_PATH_TILESPLIT, use_splitk ? S : 1};
+        }
+        // narrower N: the split-K tile (K slices + in-launch deterministic reduction; N = K = 4096: M = 64 8.8 vs 11.2 us)
+        return {use_splitk ? EETQ_PATH_SPLITK : EETQ_PATH_MID, 0};
+    }
+    // M > 128: the tiled kernel; with K slices when its tiles would leave most CUs idle (M = 256 at 11008 x 4096: 37.4 vs
+    // 54.7 us) -- launch_gemm_tile_splitk applies the same rule and runs the unsplit kernel otherwise
+    int S = (use_splitk && act == 0) ? tile_splitk_slices(M, N, K) : 1;
+    if (S == 1 && use_splitk && act == 0 && wide_tile_splitk_slices(M, N, K) == 2) S = 2;
+    return {EETQ_PATH_TILESPLIT, S};
+}
+
+int eetq_diag_auto_path(int bits, int M, int N, int K, int* path, int* detail)
+{
+    EETQ_REQUIRE(path && M >= 1 && N >= kTileN && K >= kTileK, "eetq_diag_auto_path: bad argument");
+    AutoChoice c{EETQ_PATH_AUTO, 0};
+    if (bits == 8) {
+        c = auto_path_i8(M, N, K, EETQ_ACT_IDENTITY);
+    } else if (bits == 4) {
+        c.path = w4a16_auto_path(M, N, K);
+    } else {
+        return fail(EETQ_ERR_INVALID, "[eetq_amd] eetq_diag_auto_path: bits must be 8 or 4");
+    }
+    *path = c.path;
+    if (detail) *detail = c.detail;
+    return EETQ_OK;
+}
+
 static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scales, const void* bias,
                          const void* residual, void* y, int M, int N, int K, int path, void* stream, int act = EETQ_ACT_IDENTITY)
 {
@@ -315,44 +375,19 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
     f16*           yp = static_cast<f16*>(y);
     hipStream_t    s  = static_cast<hipStream_t>(stream);
     switch (path) {
-        case EETQ_PATH_AUTO:
-            // reference: m <= SMALL_M_FAST_PATH (4) takes the GEMV kernel (fpA_intB_gemm_wrapper.cu:149-162)
-            // here: M = 1 -> wave-reduction GEMV (no MFMA); 2 <= M <= 16 -> MFMA stream kernel (same weight stream, activation rows
-            // through a per-wave LDS ring or a per-workgroup copy); up to M = 128 -> split-K medium-batch
-            // tile (M > 64 on wide N: the tiled kernel); larger M -> LDS-tiled MFMA GEMM (128 x 128 tiles, or 128 x 64 when
-            // those fill the chip better).  Crossovers measured as graph-replayed chains: profiles/r03_path_compare_mid.jsonl.
-            if (M == 1) return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
-            // One row tile (M <= 16) stays on the stream kernel everywhere.  History of this seam: round 3 handed 9 <= M <= 16 on
-            // weights >= 32 Mi to the split-K tile (the register form re-read 16 activation rows per weight tile from L2); round 4's
-            // 8-wave workgroups moved it to M = 10 / 12; with the activation rows going through the per-wave LDS ring
-            // (streamk.hip::pick_plan) the stream kernel is ahead up to M = 16 on every shape measured
-            // (profiles/r04_stream_splitk_seam2.jsonl, us stream / split-K at M = 16: 4096 x 11008 12.60 / 12.74, 11008 x 4096 12.48 /
-            // 13.15, 4096 x 22016 18.4 / 21.4, 13824 x 5120 19.5 / 20.4, 8192^2 13.9 / 18.5, 28672 x 8192 41.8 / 46.9, 7168^2 11.9 /
-            // 13.8; the other way only 5120 x 27648 from M = 13, 29.9 / 29.0, and 5120 x 13824 at M = 16, 16.43 / 16.25).
-            if (M <= 16) return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
-            if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31)) {
-                // wide N, M > 64: the 128 x 64 tiles of the tiled kernel already give most CUs a workgroup and read the
-                // activations once per 64 columns (N = 11008: M = 96 21.0 vs 23.9 us split-K, M = 128 22.4 vs 28.2; up to
-                // M = 64 the split-K tile is ahead: 17.6 vs 18.5, M = 48 16.2 vs 17.8; N = 13824 alike)
-                if (M > 64 && (N + 63) / 64 >= 160 && K >= 320) return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
-                // few tiles, deep K, M > 96 (the split-K tile needs four row blocks there and stops being flat in M): K slices of
-                // the tiled kernel's 128 x 64 tile -- M = 128: 11008 x 4096 23.9 vs 27.1 us, 5120^2 20.1 vs 22.6, 13824 x 5120
-                // 40.9 vs 46.8 (tile_splitk_slices has the rule and the cases it leaves alone); at M <= 96 the split-K tile is
-                // ahead (4096^2: 12.5 vs 13.1)
-                if (M > 96 && bp.act == 0 && tile_splitk_slices(M, N, K) > 1) return launch_gemm_tile_splitk(xp, wp, sp, bp, yp, M, N, K, s);
-                // narrower N: the split-K tile (K slices + in-launch deterministic reduction; N = K = 4096: M = 64 8.8 vs
-                // 11.2 us, M = 128 14.0 vs 20.2, K = 11008 16.3 vs 28.0; profiles/r02_kbench_splitk.txt).  EETQ_AMD_SPLITK=0
-                // keeps the unsplit tile (the split form owns per-stream scratch; see gemm_splitk.hip)
-                static const bool use_splitk = [] {
-                    const char* e = getenv("EETQ_AMD_SPLITK");
-                    return !(e && e[0] == '0');
-                }();
-                if (use_splitk) return launch_gemm_splitk(xp, wp, sp, bp, yp, M, N, K, s);
-                return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
+        case EETQ_PATH_AUTO: {
+            // ONE heuristic (auto_path_i8 above), like the reference's (cutlass_heuristic.cc:123-206) -- and visible from outside
+            // through eetq_diag_auto_path, which calls the same function
+            const AutoChoice c = auto_path_i8(M, N, K, act);
+            switch (c.path) {
+                case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
+                case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
+                case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
+                case EETQ_PATH_SPLITK: return launch_gemm_splitk(xp, wp, sp, bp, yp, M, N, K, s);
+                case EETQ_PATH_MID: return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
+                default: return launch_gemm_tile_splitk(xp, wp, sp, bp, yp, M, N, K, s);
             }
-            // M > 128: the tiled kernel; with K slices when its tiles would leave most CUs idle (M = 256 at 11008 x 4096: 37.4 vs
-            // 54.7 us) -- launch_gemm_tile_splitk decides and runs the unsplit kernel otherwise
-            return launch_gemm_tile_splitk(xp, wp, sp, bp, yp, M, N, K, s);
+        }
         case EETQ_PATH_GEMV: return launch_gemv(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_MFMA: return launch_gemm_mfma(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);

@@ -3,6 +3,7 @@
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <atomic>
 #include <string>
 
@@ -202,6 +203,22 @@ inline int opt_in_large_lds(Kern kern, std::atomic<unsigned long long>& done)
     return EETQ_OK;
 }
 
+// ---- A/B hooks ----------------------------------------------------------------------------------------
+// Every EETQ_AMD_* variable that steers kernel SELECTION (stream plans, workgroup sizes, column units, quantiser forms ...) is
+// an A/B hook for tools/ and tests/: it is read through tuning_env(), which answers only when the process also sets
+// EETQ_AMD_TUNING=1.  Without that switch a production process never looks at them, so a stray variable cannot change which
+// kernel runs (and with it the result bits: bit identity holds at equal wave count only).  Both the switch and the hooks are
+// read once per process.  Operational variables are not hooks and stay unconditional: EETQ_AMD_SPLITK=0 (no library-owned
+// scratch), EETQ_AMD_SPLITK_REGIONS (its size); EETQ_AMD_SPLITK_PLAN is honoured on the explicitly forced path only.
+inline const char* tuning_env(const char* name)
+{
+    static const bool on = [] {
+        const char* e = getenv("EETQ_AMD_TUNING");
+        return e && e[0] == '1';
+    }();
+    return on ? getenv(name) : nullptr;
+}
+
 // ---- kernel launchers (one per .hip file) ------------------------------------------------------------
 int launch_quantize(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
                     int layout, void* scales, float* workspace, size_t workspace_floats, hipStream_t stream);
@@ -285,6 +302,10 @@ int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, E
                             hipStream_t stream, int force_s = 0, int* used_s = nullptr);
 // slices launch_gemm_tile_splitk would use (1 = it would run the unsplit tiled kernel)
 int tile_splitk_slices(int M, int N, int K);
+// the same for the 128 x 128 tile (2 = two slices; 1 = unsplit)
+int wide_tile_splitk_slices(int M, int N, int K);
+// EETQ_PATH_* that W4A16 AUTO takes (int4.hip; MFMA = expansion to int8 tiles + the W8A16 kernels)
+int w4a16_auto_path(int M, int N, int K);
 // library-owned scratch (eetq_release_workspace): each frees its buffers on every device and adds the bytes to *freed
 int launch_quantize_pack_i4_native(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_packed, void* scales,
                                    const float* colmax, hipStream_t stream);  // quant.hip; UNSUPPORTED -> int4.hip's own route

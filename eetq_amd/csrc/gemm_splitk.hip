@@ -28,9 +28,10 @@ constexpr size_t kRegionTickets = 4096;         // tiles per launch (N <= 4096 *
 constexpr size_t kRegionBytes   = kRegionSlabs + 2 * kRegionTickets * sizeof(unsigned);
 
 struct Region {
-    uint8_t*    base  = nullptr;
-    hipStream_t owner = nullptr;
-    bool        used  = false;
+    uint8_t*           base  = nullptr;
+    hipStream_t        owner = nullptr;
+    bool               used  = false;
+    unsigned long long uses  = 0;  // launches handed this region (release_splitk_region: has the owner launched since its sync?)
 };
 struct Arena {
     Region r[kMaxRegions];
@@ -87,7 +88,16 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
         // every region taken: this stream runs unsplit.  Nothing is inferred about the owners (a stream that is capturing
         // on another thread, or a destroyed one whose captured graphs are still replayed, must keep its region):
         // regions come back only through eetq_release_stream_workspace / eetq_release_workspace.
-        if (!reg) return EETQ_ERR_UNSUPPORTED;
+        if (!reg) {
+            static std::atomic<bool> warned{false};
+            if (!warned.exchange(true))  // once per process: the fallback is correct but slower, and silent otherwise
+                fprintf(stderr,
+                        "[eetq_amd] all %d split-K scratch regions of device %d are owned by other streams: GEMMs at 17 <= M <= 128 "
+                        "(and K-sliced tiled launches) on further streams run unsplit.  Release a stream's region with "
+                        "eetq_release_stream_workspace (eetq_amd.ops.release_stream_workspace) before destroying the stream, or raise "
+                        "EETQ_AMD_SPLITK_REGIONS.\n", cap, dev);
+            return EETQ_ERR_UNSUPPORTED;
+        }
         if (!reg->base) EETQ_TRY_HIP(alloc_region(*reg));
         reg->used    = true;
         reg->owner   = stream;
@@ -106,6 +116,7 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
             a.need_spare = false;
         }
     }
+    ++reg->uses;
     *slabs   = reinterpret_cast<float*>(reg->base);
     *tickets = reinterpret_cast<unsigned*>(reg->base + kRegionSlabs);
     return EETQ_OK;
@@ -198,20 +209,35 @@ int release_splitk_region(hipStream_t stream)
 {
     int dev = 0;
     EETQ_TRY_HIP(hipGetDevice(&dev));
-    {
-        std::lock_guard<std::mutex> lock(g_mutex);
-        bool owns = false;
-        for (Region& r : g_arena[dev & 63].r) owns |= r.used && r.owner == stream;
-        if (!owns) return EETQ_OK;
-    }
-    EETQ_TRY_HIP(hipStreamSynchronize(stream));
-    std::lock_guard<std::mutex> lock(g_mutex);
-    for (Region& r : g_arena[dev & 63].r)
-        if (r.used && r.owner == stream) {
-            r.used  = false;
-            r.owner = nullptr;
+    // The stream is synchronised WITHOUT the lock (a blocked mutex would stall every other stream's launches); ownership and the
+    // region's launch count are re-checked after re-acquiring it: a launch that slipped in between (another host thread using the
+    // same stream) means the region is busy again, so synchronise once more instead of handing out a region with work in flight.
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        unsigned long long seen = 0;
+        {
+            std::lock_guard<std::mutex> lock(g_mutex);
+            bool owns = false;
+            for (Region& r : g_arena[dev & 63].r)
+                if (r.used && r.owner == stream) {
+                    owns = true;
+                    seen += r.uses;
+                }
+            if (!owns) return EETQ_OK;
         }
-    return EETQ_OK;
+        EETQ_TRY_HIP(hipStreamSynchronize(stream));
+        std::lock_guard<std::mutex> lock(g_mutex);
+        unsigned long long now = 0;
+        for (Region& r : g_arena[dev & 63].r)
+            if (r.used && r.owner == stream) now += r.uses;
+        if (now != seen) continue;  // launched again while we were waiting: not idle yet
+        for (Region& r : g_arena[dev & 63].r)
+            if (r.used && r.owner == stream) {
+                r.used  = false;
+                r.owner = nullptr;
+            }
+        return EETQ_OK;
+    }
+    return fail(EETQ_ERR_INVALID, "[eetq_amd] eetq_release_stream_workspace: the stream keeps launching split-K GEMMs from another thread");
 }
 
 int release_splitk_workspace(size_t* freed)

@@ -74,7 +74,7 @@ int launch_half_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue e
 bool mixed_units_pay(int N, int K)
 {
     static const bool allowed = [] {
-        const char* e = getenv("EETQ_AMD_GEMV_MIXED");
+        const char* e = tuning_env("EETQ_AMD_GEMV_MIXED");
         return !(e && e[0] == '0');
     }();
     const int KT = K / kTileK, ncu = device_cu_count();
@@ -109,7 +109,7 @@ bool half_units_pay(int N, int K)
     const int KT = K / kTileK;
     if (KT % 2 || KT < 32 || K > 32768) return false;  // pairs of k tiles, >= 2 pairs per wave in flight, x fits in LDS
     static const int forced = [] {  // EETQ_AMD_I8_UNITS=1: column units wherever they can run, =0: never (A/B runs)
-        const char* e = getenv("EETQ_AMD_I8_UNITS");
+        const char* e = tuning_env("EETQ_AMD_I8_UNITS");
         return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1;
     }();
     if (forced >= 0) return forced == 1;
@@ -154,7 +154,7 @@ int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16
         // (profiles/r04_i8_gemv_k4096_ab.txt); at one tile row per CU (4096^2) it loses (5.10 vs 4.69).
         // EETQ_AMD_I8_GEMV_K4096 = 16 / 82 / 88: force the straight-line form / 8 waves generic / 8 waves x 8 tiles (A/B runs)
         static const int forced64 = [] {
-            const char* e = getenv("EETQ_AMD_I8_GEMV_K4096");
+            const char* e = tuning_env("EETQ_AMD_I8_GEMV_K4096");
             return e ? atoi(e) : 0;
         }();
         if (KT == 64 && forced64 == 88) return launch_lds<M, 8, 8, true, 4>(x, w, scales, ep, y, N, K, stream, pro);
@@ -178,7 +178,7 @@ int launch_m(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16
         // 23.16 / 22.50 -- with one tile row per CU they starve it (11008 x 4096 9.37 / 10.28); 8192^2 is a wash.
         // EETQ_AMD_I8_GEMV_WAVES = 16 / 82 / 84 forces 16 waves / 8 waves with 2 / 4 tiles in flight (A/B runs)
         static const int forced = [] {
-            const char* e = getenv("EETQ_AMD_I8_GEMV_WAVES");
+            const char* e = tuning_env("EETQ_AMD_I8_GEMV_WAVES");
             return e ? atoi(e) : 0;
         }();
         if (KT >= 32 && forced == 84) return launch_lds<M, 8, 4, false, 8>(x, w, scales, ep, y, N, K, stream, pro);
@@ -240,7 +240,7 @@ bool half_units_pay_i4(int N, int K)
     const int KT = K / 128;
     if (KT % 2 || KT < 32 || K > 32768) return false;  // pairs of k tiles, >= 2 pairs per wave in flight (8 waves), x fits in LDS
     static const int forced = [] {  // EETQ_AMD_I4_UNITS=1: 8-column units wherever they can run, =0: never (A/B runs)
-        const char* e = getenv("EETQ_AMD_I4_UNITS");
+        const char* e = tuning_env("EETQ_AMD_I4_UNITS");
         return e ? (e[0] == '1' ? 1 : (e[0] == '0' ? 0 : -1)) : -1;
     }();
     if (forced >= 0) return forced == 1;
@@ -270,7 +270,7 @@ int launch_m_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         // 4096 x 22016 13.6 -> 11.8, 4096 x 12288 8.2 -> 7.2; 4096^2 keeps the straight-line form (4.04 vs 4.12)
         // (profiles/r04_i4_gemv_k4096_ab.txt).  EETQ_AMD_I4_GEMV_K4096 = 16 / 82 / 84 forces a form (A/B runs)
         static const int forced32 = [] {
-            const char* e = getenv("EETQ_AMD_I4_GEMV_K4096");
+            const char* e = tuning_env("EETQ_AMD_I4_GEMV_K4096");
             return e ? atoi(e) : 0;
         }();
         if (KT == 32 && forced32 == 84) return launch_lds_i4<M, 8, 4, 2>(x, w, scales, ep, y, N, K, stream);
@@ -336,7 +336,7 @@ int launch_gemv_grouped(const gemv::GroupedArgs& g, int K, int rows, hipStream_t
     // same bits from call to call; against separate launches it is tier A (another summation order) unless both take the same
     // body.  EETQ_AMD_GROUPED_WAVES = 16 / 8 forces a body (A/B runs).
     static const int forced = [] {
-        const char* e = getenv("EETQ_AMD_GROUPED_WAVES");
+        const char* e = tuning_env("EETQ_AMD_GROUPED_WAVES");
         return e ? atoi(e) : 0;
     }();
     const bool eight = forced ? forced == 8 : rows > 2 * device_cu_count();

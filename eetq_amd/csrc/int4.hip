@@ -335,6 +335,44 @@ int launch_unpack_i4(const int8_t* q_packed, size_t K, size_t N, int8_t* q_raw, 
     return check_hip(hipGetLastError(), "unpack_i4_kernel launch");
 }
 
+// What W4A16 AUTO launches (one pure function; eetq_diag_auto_path shows it).  Reference: m <= 4 batched GEMV, else CUTLASS
+// (fpA_intB_gemm_wrapper.cu:149-162).
+int w4a16_auto_path(int M, int N, int K)
+{
+    // decode: the wave-reduction GEMV on int4 tiles (gemv_kernel<..., BITS = 4>) ...
+    if (M == 1) {
+        // ... or (round 4) the MFMA small-batch kernel run with ONE row (its activation row in LDS, streamk.hip::pick_plan_i4) where
+        // it beats the dot-product GEMV.  The GEMV is VALU-bound (2.1 VALU operations per weight) and saturates near
+        // 3.5-4.4 TB/s of int4 weights; the MFMA form leaves the adds to the matrix cores and reaches 5.1
+        // (profiles/r04_i4_gemv_vs_stream_m1.txt, us GEMV / stream): 8192 x 28672 33.9 / 22.9, 8192^2 10.86 / 8.81, 28672 x 8192 26.7 /
+        // 22.9, 5120 x 27648 18.3 / 15.7, 5120 x 15360 11.6 / 10.3, 8192 x 1024 5.54 / 4.94, 11008 x 4096 7.43 / 6.82.  Kept on the
+        // GEMV: the ties and losses -- 4096^2 4.02 / 4.07, 5120^2 5.61 / 5.76, 5120 x 13824 10.15 / 10.20, 4096 x 14336 8.45 / 8.57,
+        // 13824 x 5120 10.82 / 11.17 (1 < tile rows per CU < 2: the 8-column units balance those better).
+        // EETQ_AMD_I4_M1=gemv|stream forces one (A/B runs; needs EETQ_AMD_TUNING=1).
+        static const int forced = [] {
+            const char* e = tuning_env("EETQ_AMD_I4_M1");
+            return !e ? 0 : !strcmp(e, "gemv") ? 1 : !strcmp(e, "stream") ? 2 : 0;
+        }();
+        bool stream_form = false;
+        if (K % 128 == 0 && K >= 4096) {
+            const int  ncu  = device_cu_count();
+            const int  rows = N / kTileN;
+            const bool deep = K >= 8192 && !(rows > ncu && rows < 2 * ncu);
+            const bool big  = (size_t)K * N >= (72ull << 20);
+            stream_form     = forced ? forced == 2 : (deep || big);
+        }
+        return stream_form ? EETQ_PATH_STREAM : EETQ_PATH_GEMV;
+    }
+    // batched decode, 2 <= M <= 16: the register-streaming MFMA kernel on int4 tiles (streamk_kernel<..., BITS = 4>) -- the
+    // weight stream bounds these M, and it is half as long as the int8 one (M = 8, N = K = 4096: 4.5 vs 5.1 us; the dot2
+    // GEMV at M = 4 needs 6.9).  Larger M are bound by the activation traffic / the matrix cores, where int4 buys nothing.
+    if (M <= 16) return EETQ_PATH_STREAM;
+    // 17 <= M <= 128: the split-K MFMA tile on int4 weight tiles (gemm_splitk_kernel<..., BITS = 4>; round 4) -- no expansion
+    // pass, no per-stream weight scratch, capturable into a HIP graph
+    if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K / 2 < (1ull << 31)) return EETQ_PATH_SPLITK;
+    return EETQ_PATH_MFMA;   // larger batches: the expansion route below
+}
+
 int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, hipStream_t stream,
                  int path)
 {
@@ -348,39 +386,10 @@ int launch_w4a16(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
     if (path == EETQ_PATH_SPLITK) return launch_gemm_splitk_i4(x, w, scales, ep, y, M, N, K, stream, /*env_plan=*/true);
     if (path != EETQ_PATH_AUTO && path != EETQ_PATH_MFMA)
         return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] W4A16: unknown or unimplemented GEMM path");
-    const bool expand = path == EETQ_PATH_MFMA;
-    // decode: the wave-reduction GEMV on int4 tiles (gemv_kernel<..., BITS = 4>)
-    if (M == 1 && !expand) {
-        // Round 4: the MFMA small-batch kernel run with ONE row (its activation row in LDS, streamk.hip::pick_plan_i4) where it beats the
-        // dot-product GEMV.  The GEMV is VALU-bound (2.1 VALU operations per weight) and saturates near 3.5-4.4 TB/s of
-        // int4 weights; the MFMA form leaves the adds to the matrix cores and reaches 5.1 (profiles/r04_i4_gemv_vs_stream_m1.txt, us
-        // GEMV / stream): 8192 x 28672 33.9 / 22.9, 8192^2 10.86 / 8.81, 28672 x 8192 26.7 / 22.9, 5120 x 27648 18.3 / 15.7, 5120 x
-        // 15360 11.6 / 10.3, 8192 x 1024 5.54 / 4.94, 11008 x 4096 7.43 / 6.82.  Kept on the GEMV: the ties and losses -- 4096^2 4.02 /
-        // 4.07, 5120^2 5.61 / 5.76, 5120 x 13824 10.15 / 10.20, 4096 x 14336 8.45 / 8.57, 13824 x 5120 10.82 / 11.17 (1 < tile rows per
-        // CU < 2: the 8-column units balance those better).  EETQ_AMD_I4_M1=gemv|stream forces one (A/B runs).
-        static const int forced = [] {
-            const char* e = getenv("EETQ_AMD_I4_M1");
-            return !e ? 0 : !strcmp(e, "gemv") ? 1 : !strcmp(e, "stream") ? 2 : 0;
-        }();
-        bool stream_form = false;
-        if (K % 128 == 0 && K >= 4096) {
-            const int  ncu  = device_cu_count();
-            const int  rows = N / kTileN;
-            const bool deep = K >= 8192 && !(rows > ncu && rows < 2 * ncu);
-            const bool big  = (size_t)K * N >= (72ull << 20);
-            stream_form     = forced ? forced == 2 : (deep || big);
-        }
-        if (stream_form) return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
-        return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
-    }
-    // batched decode, 2 <= M <= 16: the register-streaming MFMA kernel on int4 tiles (streamk_kernel<..., BITS = 4>) -- the
-    // weight stream bounds these M, and it is half as long as the int8 one (M = 8, N = K = 4096: 4.5 vs 5.1 us; the dot2
-    // GEMV at M = 4 needs 6.9).  Larger M are bound by the activation traffic / the matrix cores, where int4 buys nothing.
-    if (M <= 16 && !expand) return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
-    // 17 <= M <= 128: the split-K MFMA tile on int4 weight tiles (gemm_splitk_kernel<..., BITS = 4>; round 4) -- no expansion
-    // pass, no per-stream weight scratch, capturable into a HIP graph
-    if (!expand && M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K / 2 < (1ull << 31))
-        return launch_gemm_splitk_i4(x, w, scales, ep, y, M, N, K, stream);
+    if (path == EETQ_PATH_AUTO) path = w4a16_auto_path(M, N, K);
+    if (path == EETQ_PATH_GEMV) return launch_gemv_i4(x, w, scales, ep, y, M, N, K, stream);
+    if (path == EETQ_PATH_STREAM) return launch_streamk_i4(x, w, scales, ep, y, M, N, K, stream);
+    if (path == EETQ_PATH_SPLITK) return launch_gemm_splitk_i4(x, w, scales, ep, y, M, N, K, stream);
     // larger batches: expand the nibbles to the int8 tile layout once per call (K*N/2 bytes read, K*N written; the GEMM that
     // follows is MFMA- or x-bound at these M) and run the W8A16 kernels on it -- same integers, same scales, same contract
     uint8_t* w8 = nullptr;

@@ -692,7 +692,7 @@ int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_
     // folds them into row 0 with a small launch of their own first (measured slower: one more launch costs more than the
     // reads it saves, profiles/r03_quant_sweep.txt)
     static const bool fold = [] {
-        const char* e = getenv("EETQ_AMD_QUANT_FOLD");
+        const char* e = tuning_env("EETQ_AMD_QUANT_FOLD");
         return e && *e == '1';
     }();
     unsigned rows = P;
@@ -707,19 +707,19 @@ int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_
     // tiles per workgroup: 1 (most workgroups in flight) for short K, 4 once the P rows of maxima a workgroup reduces
     // outweigh one tile (K > 8192: 13824 x 5120 94 vs 113 us); EETQ_AMD_QUANT_STRIP = 1 / 2 / 4 overrides (tuning hook)
     static const int forced = [] {
-        const char* e = getenv("EETQ_AMD_QUANT_STRIP");
+        const char* e = tuning_env("EETQ_AMD_QUANT_STRIP");
         const int   v = e ? atoi(e) : 0;
         return v == 1 || v == 2 || v == 4 ? v : 0;
     }();
     const int strip = forced ? forced : (K > 8192 ? 4 : 1);
     static const bool nt = [] {
-        const char* e = getenv("EETQ_AMD_QUANT_NT");
+        const char* e = tuning_env("EETQ_AMD_QUANT_NT");
         return e && *e == '1';
     }();
     // native layout, no row-major copy asked for: the column-major kernel (EETQ_AMD_QUANT_KERNEL=strip keeps the older one
     // for A/B runs); it indexes with 32-bit row offsets
     static const bool old_kernel = [] {
-        const char* e = getenv("EETQ_AMD_QUANT_KERNEL");
+        const char* e = tuning_env("EETQ_AMD_QUANT_KERNEL");
         return e && e[0] == 's';
     }();
     const bool colmajor = p && !sm80 && !raw_out && !old_kernel && layout == EETQ_LAYOUT_GFX950 && rows * N < 0xffffffffull &&
@@ -729,7 +729,7 @@ int launch_quantize_typed(const T* w, size_t K, size_t N, int8_t* raw_out, int8_
         // measured 20.1 vs 20.9 us at 4096^2 against 2048 workgroups of 2 tiles), never fewer than two tiles each (one tile =
         // no overlap of loads and arithmetic), at most 16; EETQ_AMD_QUANT_TILES overrides (tuning hook)
         static const int forced_tiles = [] {
-            const char* e = getenv("EETQ_AMD_QUANT_TILES");
+            const char* e = tuning_env("EETQ_AMD_QUANT_TILES");
             const int   v = e ? atoi(e) : 0;
             return v >= 1 && v <= 64 ? v : 0;
         }();

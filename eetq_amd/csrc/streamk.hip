@@ -33,10 +33,19 @@ struct StreamPlan {
     int form, nt, waves;
 };
 
+// The block copy keeps M x K fp16 (rounded up to 1 KiB) in dynamic LDS NEXT TO the cross-wave reduction area (WAVES x NT KiB for one
+// row tile): the launch fits only while the SUM stays within the CU's 160 KiB -- for the NT and WAVES the plan actually uses.  The
+// launchers and stream_plan_query share this check; a plan that does not fit falls back to the register form (same bits).
+inline bool block_copy_fits(int M, int K, int nt, int waves)
+{
+    const size_t xs = ((size_t)M * K * 2 + 1023) & ~(size_t)1023;
+    return xs + streamk::streamk_smem_bytes(1, nt, waves) <= (size_t)kMaxDynamicLds;
+}
+
 inline StreamPlan plan_from_env(const char* name)
 {
     StreamPlan  p{-1, 0, 0};
-    const char* e = getenv(name);
+    const char* e = tuning_env(name);
     if (!e) return p;
     char form[16] = {0};
     int  nt = 0, waves = 0;
@@ -105,7 +114,7 @@ inline StreamPlan regs_plan_i4(int N, int ncu)
 inline StreamPlan pick_plan(int M, int N, int K, int ncu, int nt0, bool eight0)
 {
     static const bool lds_off = [] {
-        const char* e = getenv("EETQ_AMD_I8_STREAM_XLDS");
+        const char* e = tuning_env("EETQ_AMD_I8_STREAM_XLDS");
         return e && atoi(e) == 0;
     }();
     StreamPlan p{0, nt0, eight0 ? 8 : 16};
@@ -149,7 +158,7 @@ inline StreamPlan pick_plan(int M, int N, int K, int ncu, int nt0, bool eight0)
 inline StreamPlan pick_plan_i4(int M, int N, int K, int ncu, int nt0, bool eight0)
 {
     static const bool lds_off = [] {
-        const char* e = getenv("EETQ_AMD_I4_STREAM_XLDS");
+        const char* e = tuning_env("EETQ_AMD_I4_STREAM_XLDS");
         return e && atoi(e) == 0;
     }();
     StreamPlan p{0, nt0, eight0 ? 8 : 16};
@@ -177,7 +186,7 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
     const int KT = K / kTileK;  // every wave must own >= D k tiles
     if (KT >= 32) {
         static const int forced_waves = [] {  // EETQ_AMD_I8_STREAM_WAVES=8 / 16: force the workgroup size (A/B runs)
-            const char* e = getenv("EETQ_AMD_I8_STREAM_WAVES");
+            const char* e = tuning_env("EETQ_AMD_I8_STREAM_WAVES");
             return e ? atoi(e) : 0;
         }();
         if constexpr (MT == 1) {
@@ -205,7 +214,7 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
             if (forced.waves) plan.waves = forced.waves;
             if (forced_waves) plan.waves = forced_waves;
             if (plan.nt == 2 && N % (2 * kTileN) != 0) plan.nt = 1;
-            if (plan.form == 1 && (K % 128 != 0 || (long)M * K * 2 > 128 * 1024)) plan.form = 0;
+            if (plan.form == 1 && (K % 128 != 0 || (long)M * K * 2 > 128 * 1024 || !block_copy_fits(M, K, plan.nt, plan.waves))) plan.form = 0;
             if (plan.form == 2 && M > 16) plan.form = 0;
             const bool e8 = plan.waves == 8;
             if (plan.form == 2 && M > 8) {  // 16-row ring: two DMAs per tile
@@ -250,7 +259,7 @@ int launch_mt_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
 {
     const int KT = K / 128;
     static const int forced_waves = [] {  // EETQ_AMD_I4_STREAM_WAVES=8 / 16: force the workgroup size (A/B runs)
-        const char* e = getenv("EETQ_AMD_I4_STREAM_WAVES");
+        const char* e = tuning_env("EETQ_AMD_I4_STREAM_WAVES");
         return e ? atoi(e) : 0;
     }();
     if (KT >= 32) {
@@ -269,8 +278,8 @@ int launch_mt_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep,
         if (forced.waves) plan.waves = forced.waves;
         if (forced_waves) plan.waves = forced_waves;
         if (plan.nt == 2 && N % (2 * kTileN) != 0) plan.nt = 1;
-        if (plan.form == 1 && (long)M * K * 2 > 144 * 1024) plan.form = 0;
         if (plan.form == 2 && M > 8) plan.waves = 8;
+        if (plan.form == 1 && ((long)M * K * 2 > 144 * 1024 || !block_copy_fits(M, K, plan.nt, plan.waves))) plan.form = 0;
         const bool e8 = plan.waves == 8;
         if (plan.form == 2 && M > 8) {  // 16-row ring: 4 KiB slots, 8-wave workgroups only (16 waves would need 192 KiB of LDS)
             if (plan.nt == 2) return launch_inst<1, 2, 8, 2, 2, 4, 4>(x, w, scales, ep, y, M, N, K, stream);
@@ -319,11 +328,14 @@ int stream_plan_query(int bits, int M, int N, int K, int ncu, int* form, int* nt
         if (bits == 8) {
             const StreamPlan r = regs_plan_i8(M, N, ncu);
             p                  = pick_plan(M, N, K, ncu, r.nt, r.waves == 8);
-            if (p.form == 1 && (K % 128 != 0 || (long)M * K * 2 > 128 * 1024)) p.form = 0;
+            if (p.nt == 2 && N % (2 * kTileN) != 0) p.nt = 1;
+            if (p.form == 1 && (K % 128 != 0 || (long)M * K * 2 > 128 * 1024 || !block_copy_fits(M, K, p.nt, p.waves))) p.form = 0;
         } else {
             const StreamPlan r = regs_plan_i4(N, ncu);
             p                  = pick_plan_i4(M, N, K, ncu, r.nt, r.waves == 8);
             if (p.form == 2 && M > 8) p.waves = 8;
+            if (p.nt == 2 && N % (2 * kTileN) != 0) p.nt = 1;
+            if (p.form == 1 && ((long)M * K * 2 > 144 * 1024 || !block_copy_fits(M, K, p.nt, p.waves))) p.form = 0;
         }
         if (p.nt == 2 && N % (2 * kTileN) != 0) p.nt = 1;
     } else {

@@ -51,7 +51,8 @@ else:
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_", "layernorm_forward",
            "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention",
-           "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped", "decode_dropped_steps", "BOUNDARY"]
+           "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped", "decode_dropped_steps",
+           "release_stream_workspace", "release_workspace", "BOUNDARY"]
 
 
 def decode_dropped_steps(reset=True, device=None):
@@ -65,6 +66,33 @@ def decode_dropped_steps(reset=True, device=None):
     n = ctypes.c_ulonglong(0)
     with torch.cuda.device(device if device is not None else torch.cuda.current_device()):
         _lib.check(_lib.lib().eetq_decode_dropped_steps(ctypes.byref(n), 1 if reset else 0))
+    return int(n.value)
+
+
+def release_stream_workspace(stream=None):
+    """Hand the split-K scratch region a stream owns (40 MiB; 17 <= M <= 128 GEMMs and the K-sliced tiled kernel take one per
+    launch stream, at most 16 per device) back to the pool -- the library never reclaims one on its own, so a server that
+    creates and destroys streams calls this before destroying one (unless HIP graphs captured on it are still replayed).
+    Synchronises the stream.  ``stream``: a ``torch.cuda.Stream`` (default: the current one).  eetq_release_stream_workspace."""
+    import ctypes
+
+    import torch
+
+    from . import _lib
+    stream = stream if stream is not None else torch.cuda.current_stream()
+    with torch.cuda.device(stream.device):
+        _lib.check(_lib.lib().eetq_release_stream_workspace(ctypes.c_void_p(stream.cuda_stream)))
+
+
+def release_workspace():
+    """Free ALL library-owned scratch on every device (split-K regions, W4A16 expansion buffers, the quantiser's NULL-workspace
+    buffer); returns the bytes freed.  Not while a HIP graph that captured a split-K / W4A16 launch is still going to be
+    replayed.  eetq_release_workspace."""
+    import ctypes
+
+    from . import _lib
+    n = ctypes.c_size_t(0)
+    _lib.check(_lib.lib().eetq_release_workspace(ctypes.byref(n)))
     return int(n.value)
 
 

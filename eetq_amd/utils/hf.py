@@ -15,8 +15,12 @@ bytes EETQ checkpoints hold are the reference's ``sm80`` layout (eetq_amd/checkp
 the helper keeps the disk format the reference's:
   * every ``EetqLinear`` it sees gets the ``state_dict`` hook of eetq_amd/checkpoint.py, so ``save_pretrained`` writes
     sm80 bytes (``get_wire_layout()``), readable by CUDA-EETQ / TGI;
-  * after a PRE-QUANTISED checkpoint has been loaded, the int8 parameters are re-encoded wire -> gfx950 in place
-    (``convert_model_layout_``), so NVIDIA-written EETQ checkpoints load as they are.
+  * after a PRE-QUANTISED checkpoint has been loaded, the int8 parameters are re-encoded to gfx950 in place
+    (``convert_model_layout_``) FROM THE LAYOUT THE CHECKPOINT NAMES: ``quantization_config["layout"]`` in its config.json
+    (``convert_checkpoint(dst="gfx950")``, ``save_quantized`` and ``save_pretrained`` under a non-sm80 wire layout write
+    it; the same tag ``models.from_quantized`` honours), ``sm80`` when there is none -- so NVIDIA-written EETQ checkpoints
+    load as they are and gfx950-tagged ones are not re-encoded a second time;
+  * ``save_pretrained`` under ``wire_layout("gfx950")`` writes that tag (transformers' ``EetqConfig`` would drop it).
 Quantise-on-load (fp16 checkpoint + ``EetqConfig``) produces gfx950 bytes directly and needs no re-encode.
 """
 import functools
@@ -83,9 +87,37 @@ def use_with_transformers(wire=True):
 
         def _process_model_after_weight_loading(self, model, **kwargs):
             out = after(self, model, **kwargs)
-            if self.pre_quantized and get_wire_layout() != "gfx950":
-                convert_model_layout_(model, get_wire_layout(), "gfx950")
+            if self.pre_quantized:
+                # the layout of the bytes just assigned to the parameters: the checkpoint's own tag (config.json's
+                # quantization_config["layout"], kept on the EetqConfig by the __init__ wrapper below; written by
+                # convert_checkpoint / models.save_quantized / save_pretrained under a non-sm80 wire layout) -- a
+                # reference-written checkpoint has none and is sm80 -- and only without a tag the process-wide wire layout
+                src = getattr(self.quantization_config, "layout", None) or get_wire_layout()
+                if src != "gfx950":
+                    convert_model_layout_(model, src, "gfx950")
             return out
+        # transformers' EetqConfig swallows unknown keys (``**kwargs`` dropped), so a ``layout`` tag in config.json would be
+        # lost on load and never written on save: keep it on the object, and let to_dict() -- what save_pretrained serialises
+        # into config.json -- name the layout the state_dict hook writes (absent for sm80: the reference's config, byte for byte)
+        from transformers.utils.quantization_config import EetqConfig
+        from ..checkpoint import _check
+        cfg_init, cfg_to_dict = EetqConfig.__init__, EetqConfig.to_dict
+
+        @functools.wraps(cfg_init)
+        def __init__(self, *args, layout=None, **kwargs):
+            cfg_init(self, *args, **kwargs)
+            if layout is not None:
+                self.layout = _check(layout)
+
+        @functools.wraps(cfg_to_dict)
+        def to_dict(self):
+            d = cfg_to_dict(self)
+            d.pop("layout", None)
+            if get_wire_layout() != "sm80":
+                d["layout"] = get_wire_layout()
+            return d
+        EetqConfig.__init__ = __init__
+        EetqConfig.to_dict = to_dict
         cls._process_model_before_weight_loading = _process_model_before_weight_loading
         cls._process_model_after_weight_loading = _process_model_after_weight_loading
     return EETQ

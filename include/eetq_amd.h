@@ -319,6 +319,14 @@ int eetq_diag_clock_stamp(unsigned long long* out, int grid, void* stream);
  * at equal *waves.  The environment overrides (EETQ_AMD_I8_STREAM_PLAN ...) are not applied.  No reference counterpart: the
  * reference picks its CUTLASS tile by a timing sweep at run time (cutlass_heuristic.cc), this library by a rule -- this entry shows it. */
 int eetq_diag_stream_plan(int bits, int M, int N, int K, int cus, int* form, int* tile_rows, int* waves);
+/* Diagnostic, host arithmetic only (no launch): which kernel path EETQ_PATH_AUTO takes for an M x K activation against a K x N
+ * weight of `bits` (8 / 4) on the current device.  *path = EETQ_PATH_* (for bits = 4: GEMV, STREAM, SPLITK, or MFMA = expansion to
+ * int8 tiles + the W8A16 kernels); *detail (may be NULL) = K slices per tile when *path is EETQ_PATH_TILESPLIT (1 = the unsplit
+ * tiled kernel), else 0.  It calls the function the launchers call.  Replaces, as far as anything does, the reference's run-time
+ * choice: the m <= 4 switch (fpA_intB_gemm_wrapper.cu:149-162) and the occupancy-scored tile pick
+ * (cutlass_kernels/cutlass_heuristic.cc:123-206) -- one rule here, printed by bench.py's `config4` block per point and measured
+ * against every forced path by tools/auto_regret.py. */
+int eetq_diag_auto_path(int bits, int M, int N, int K, int* path, int* detail);
 
 /* Decode steps on a pre-allocated KV cache (eetq_rope_decode_attention_f16, eetq_rotary_neox_kvcache_f16) whose new token
  * was NOT written because its cache row lies outside the cache (slot >= rows: the cache is full; or a negative position).

@@ -58,7 +58,7 @@ def register_form(tmp_path_factory, oracle):
     """The same cases in a process that takes the activation fragments straight from L2 into registers (the form of rounds 1-3),
     with the tile rows per workgroup and the workgroup size the rule picks for the LDS forms."""
     dst = str(tmp_path_factory.mktemp("xlds") / "regs.npz")
-    env = dict(os.environ, EETQ_AMD_I8_STREAM_PLAN="regs,0,0", EETQ_AMD_I4_STREAM_PLAN="regs,0,0")
+    env = dict(os.environ, EETQ_AMD_TUNING="1", EETQ_AMD_I8_STREAM_PLAN="regs,0,0", EETQ_AMD_I4_STREAM_PLAN="regs,0,0")
     code = _CHILD.format(root=ROOT, tests=os.path.join(ROOT, "tests"), dst=dst)
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
@@ -77,6 +77,43 @@ def test_lds_staged_rows_equal_register_form_and_oracle(oracle, register_form, b
     ref = oracle.w8a16_gemm(x, np.ascontiguousarray(vals[:, cols]), s[cols]).astype(np.float32)
     got = y[:, cols].astype(np.float32)
     assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref))   # tier A
+
+
+_CHILD_ONE = """
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+sys.path.insert(0, {tests!r})
+import oracle
+from test_gpu_stream_xlds import _inputs
+import eetq_amd.ops as ops
+q, s, x = _inputs(8, 4096, 4096, 4)
+y = ops.w8_a16_gemm(torch.from_numpy(x).cuda(), torch.from_numpy(oracle.gfx950_pack(q)).cuda(), torch.from_numpy(s).cuda())
+np.save({dst!r}, y.cpu().numpy())
+"""
+
+
+def test_stray_tuning_variables_do_not_reach_production_launches(oracle, tmp_path):
+    """The A/B hooks change the kernel (and, through the wave count, the summation order): they answer only under
+    EETQ_AMD_TUNING=1.  A process that merely has EETQ_AMD_I8_STREAM_PLAN / _WAVES in its environment must produce the bits of a
+    clean process; with the switch the forced 8-wave register form runs (tier A, another summation order)."""
+    import eetq_amd.ops as ops
+    q, s, x = _inputs(8, 4096, 4096, 4)
+    clean = ops.w8_a16_gemm(torch.from_numpy(x).to(DEV), torch.from_numpy(oracle.gfx950_pack(q)).to(DEV),
+                            torch.from_numpy(s).to(DEV)).cpu().numpy()
+    outs = {}
+    for name, extra in (("stray", {}), ("tuning", {"EETQ_AMD_TUNING": "1"})):
+        dst = str(tmp_path / (name + ".npy"))
+        env = dict(os.environ, EETQ_AMD_I8_STREAM_PLAN="regs,1,8", EETQ_AMD_I8_STREAM_WAVES="8", **extra)
+        env.pop("EETQ_AMD_TUNING", None) if name == "stray" else None
+        code = _CHILD_ONE.format(root=ROOT, tests=os.path.join(ROOT, "tests"), dst=dst)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-3000:]
+        outs[name] = np.load(dst)
+    assert np.array_equal(outs["stray"], clean)                     # the variables were never read
+    ref = oracle.w8a16_gemm(x, q, s).astype(np.float32)
+    got = outs["tuning"].astype(np.float32)
+    assert np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref))
+    assert not np.array_equal(outs["tuning"], clean)                # 8 waves x registers: a different summation order
 
 
 def test_lds_staged_rows_rows_do_not_leak(oracle):

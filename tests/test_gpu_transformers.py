@@ -152,6 +152,41 @@ def test_save_pretrained_writes_reference_bytes_and_reloads(oracle, eetq_model, 
         assert torch.equal(eetq_model(ids).logits, again(ids).logits)
 
 
+def test_layout_tag_is_honoured_and_written_through_transformers(oracle, eetq_model, tmp_path):
+    """Round-4 ADVICE (medium): the transformers loader must take the source layout from the checkpoint's own tag, like
+    models.from_quantized does -- a directory rewritten by convert_checkpoint(dst="gfx950") carries
+    quantization_config["layout"] = "gfx950" and must NOT be re-encoded sm80 -> gfx950 a second time; and save_pretrained under
+    a non-sm80 wire layout must write the tag (transformers' EetqConfig drops unknown keys)."""
+    from eetq_amd.checkpoint import checkpoint_layout, convert_checkpoint, wire_layout
+    d_sm80, d_native, d_saved = str(tmp_path / "sm80"), str(tmp_path / "native"), str(tmp_path / "saved_native")
+    eetq_model.save_pretrained(d_sm80)
+    assert "layout" not in json.load(open(os.path.join(d_sm80, "config.json")))["quantization_config"]   # the reference's config
+    assert convert_checkpoint(d_sm80, d_native, dst="gfx950") == 14
+    assert checkpoint_layout(json.load(open(os.path.join(d_native, "config.json")))) == "gfx950"
+    ids = torch.randint(0, 1000, (1, 16), generator=torch.Generator().manual_seed(6)).to(DEV)
+    with torch.no_grad():
+        want = eetq_model(ids).logits
+    a = _eetq_linears(eetq_model)
+    for d in (d_native, d_sm80):
+        again = transformers.AutoModelForCausalLM.from_pretrained(d, device_map=DEV, dtype=torch.float16).eval()
+        b = _eetq_linears(again)
+        for n in a:
+            assert torch.equal(a[n].weight.data, b[n].weight.data), (d, n)    # gfx950 bytes in memory whatever the disk held
+        with torch.no_grad():
+            assert torch.equal(again(ids).logits, want), d
+    # saving under a gfx950 wire layout: native bytes on disk AND the tag in config.json; reloads bit-identically
+    with wire_layout("gfx950"):
+        eetq_model.save_pretrained(d_saved)
+    assert json.load(open(os.path.join(d_saved, "config.json")))["quantization_config"]["layout"] == "gfx950"
+    from safetensors import safe_open
+    with safe_open(os.path.join(d_saved, "model.safetensors"), "pt") as f:
+        k = "model.layers.0.self_attn.q_proj.weight"
+        assert torch.equal(f.get_tensor(k), a["model.layers.0.self_attn.q_proj"].weight.data.cpu())
+    again = transformers.AutoModelForCausalLM.from_pretrained(d_saved, device_map=DEV, dtype=torch.float16).eval()
+    with torch.no_grad():
+        assert torch.equal(again(ids).logits, want)
+
+
 def test_tgi_layer_call_pattern(oracle):
     """text-generation-inference's EETQ layer (server/text_generation_server/layers/eetq.py, `from EETQ import quant_weights,
     w8_a16_gemm`): fp16 weight -> `torch.t(w).contiguous().cpu()` -> `quant_weights(w, torch.int8, False)` -> `.cuda(device)`;

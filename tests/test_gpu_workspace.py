@@ -129,6 +129,57 @@ def test_quantize_workspace_contract_of_both_abi_revisions(oracle, K, N):
     assert bool((ws == guard).all()) and not q.any()                      # rejected before any launch
 
 
+@pytest.mark.parametrize("dtype", ["f16", "f32"])
+def test_both_quantiser_routes_agree_on_special_values(oracle, dtype):
+    """Round-4 ADVICE: revision 1's entry (atomicMax maxima, `colmax_kernel<..., false>`) and revision 2's sized entry (row-block
+    maxima) feed the scales from DIFFERENT column-maximum kernels.  They must give byte-identical weights and scales -- also on
+    columns holding NaN, +-Inf, zeros only, subnormals and the largest finite value (the reference's std::max / std::min NaN
+    order, cutlass_preprocessors.cc:619-648) -- and both must equal the oracle."""
+    from eetq_amd import _lib
+    L = _lib.lib()
+    K, N = 512, 256
+    tdt = torch.float16 if dtype == "f16" else torch.float32
+    torch.manual_seed(3)
+    w = ((torch.rand(K, N) - 0.5) * 0.3).to(tdt)
+    big = torch.finfo(tdt).max
+    w[:, 0] = 0                                    # zero column: scale 0, q = 127 by the NaN order
+    w[5, 1] = float("nan")
+    w[:, 2] = float("nan")                         # all-NaN column
+    w[7, 3] = float("inf")
+    w[9, 4] = float("-inf")
+    w[11, 5], w[12, 5] = float("inf"), float("nan")
+    w[13, 6] = big
+    w[14, 7] = -big
+    w[:, 8] = torch.finfo(tdt).tiny / 4            # subnormal column
+    w[300, 9] = float("nan")                       # NaN in a later 128-row block only
+    w[200, 10], w[400, 10] = float("-inf"), float("inf")
+    q_ref, s_ref = oracle.quantize(w.numpy())
+    wd = w.to(DEV)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    code = _lib.DTYPE_F16 if dtype == "f16" else _lib.DTYPE_F32
+    full = L.eetq_quantize_workspace_floats(K, N)
+    outs = []
+    for entry, floats in (("v1", N), ("v2", N), ("v2", full), ("v2-null", 0)):
+        ws = torch.zeros(full, dtype=torch.float32, device=DEV)
+        raw = torch.zeros(K, N, dtype=torch.int8, device=DEV)
+        q = torch.zeros(K, N, dtype=torch.int8, device=DEV)
+        sc = torch.zeros(N, dtype=tdt, device=DEV)
+        if entry == "v1":
+            st = L.eetq_quantize_i8(p(wd), code, K, N, p(raw), p(q), _lib.LAYOUT_GFX950, p(sc), p(ws), stream)
+        elif entry == "v2":
+            st = L.eetq_quantize_i8_ws(p(wd), code, K, N, p(raw), p(q), _lib.LAYOUT_GFX950, p(sc), p(ws), floats, stream)
+        else:
+            st = L.eetq_quantize_i8_ws(p(wd), code, K, N, p(raw), p(q), _lib.LAYOUT_GFX950, p(sc), None, 0, stream)
+        torch.cuda.synchronize()
+        assert st == 0, (entry, L.eetq_last_error())
+        outs.append((entry, floats, raw.cpu().numpy(), q.cpu().numpy(), sc.cpu().numpy()))
+    for entry, floats, raw, q, sc in outs:
+        assert np.array_equal(raw, q_ref), (entry, floats, np.argwhere(raw != q_ref)[:4])
+        assert np.array_equal(q, oracle.gfx950_pack(q_ref)), (entry, floats)
+        assert sc.tobytes() == s_ref.tobytes(), (entry, floats)          # NaN scales compare by their bytes
+
+
 def test_release_stream_workspace_returns_a_region_to_the_pool(ops):
     """Regions are never reclaimed by guessing (a stream that is capturing elsewhere, or a destroyed stream whose graphs are
     still replayed, keeps its region): a stream that found none runs unsplit until some owner hands its region back with

@@ -14,7 +14,9 @@ this script checks the machine code those sources compile to, so a compiler upgr
           next 2 wait states (what LLVM inserts for gfx940+ when it does see the hazard).
 
 usage: check_store_hazard.py a.o [b.o ...]     (host objects with an embedded gfx950 bundle, or .s / .txt disassembly)
-exit status 1 and one line per finding when a rule is violated.  Linear scan per function (branches are not followed: a
+exit status 1 and one line per finding when a rule is violated -- or when an object holds FEWER stores / functions than the floors
+committed in check_store_hazard.floors.json (fail closed: a toolchain change that makes the rules match nothing is a failure, not a
+pass; `--print-floors a.o ...` prints the current counts in that file's format).  Linear scan per function (branches are not followed: a
 region that crosses one is still checked in address order, which can only over-report).
 """
 import os
@@ -150,27 +152,71 @@ def check(text, name="<input>"):
     return findings
 
 
-def count_wide_sgpr_stores(text):
-    n = 0
-    for ins in parse(text).values():
+def count_wide_stores(text):
+    """(12/16-byte stores with an SGPR soffset -- rule A's subjects, all 12/16-byte stores -- rule B's subjects, functions)"""
+    sgpr = wide = 0
+    funcs = parse(text)
+    for ins in funcs.values():
         for mnem, ops, _ in ins:
             info = store_info(mnem, ops)
-            if info and info[1]:
-                n += 1
-    return n
+            if info:
+                wide += 1
+                sgpr += bool(info[1])
+    return sgpr, wide, len(funcs)
+
+
+def count_wide_sgpr_stores(text):
+    return count_wide_stores(text)[0]
+
+
+FLOORS_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "check_store_hazard.floors.json")
+
+
+def load_floors(path=FLOORS_FILE):
+    import json
+    with open(path) as f:
+        return {k: v for k, v in json.load(f).items() if not k.startswith("_")}
+
+
+def below_floor(name, text, floors):
+    """The guard fails CLOSED: an object this script is told to check must still contain at least the stores it was written
+    against (floors committed next to the script: today's counts).  A hipcc that renames a mnemonic, changes the operand syntax
+    or the disassembly format would otherwise make both rules match nothing and turn the Makefile step into a no-op.  An object
+    without an entry in the floors file is an error too (add one with --print-floors)."""
+    fl = floors.get(name)
+    if fl is None:
+        return ["%s: no entry in %s: the guard cannot tell a clean object from one it no longer understands"
+                % (name, os.path.basename(FLOORS_FILE))]
+    sgpr, wide, nfunc = count_wide_stores(text)
+    out = []
+    for key, got in (("sgpr_soffset_stores", sgpr), ("wide_stores", wide), ("functions", nfunc)):
+        if got < fl.get(key, 0):
+            out.append("%s: fail closed: %d %s matched, floor %d (did hipcc / llvm-objdump change a mnemonic or the operand "
+                       "syntax?  update the parser, then the floors file)" % (name, got, key, fl[key]))
+    return out
 
 
 def main(argv):
     if not argv:
         print(__doc__)
         return 2
+    if argv[0] == "--print-floors":
+        import json
+        doc = {}
+        for path in argv[1:]:
+            sgpr, wide, nfunc = count_wide_stores(disassemble(path))
+            doc[os.path.basename(path)] = {"sgpr_soffset_stores": sgpr, "wide_stores": wide, "functions": nfunc}
+        print(json.dumps(doc, indent=1))
+        return 0
+    floors = load_floors()
     bad = []
     for path in argv:
         text = disassemble(path)
-        f = check(text, os.path.basename(path))
+        name = os.path.basename(path)
+        f = check(text, name) + below_floor(name, text, floors)
         bad += f
-        print("check_store_hazard: %s: %d wide stores with an SGPR soffset, %d finding(s)"
-              % (os.path.basename(path), count_wide_sgpr_stores(text), len(f)))
+        sgpr, wide, _ = count_wide_stores(text)
+        print("check_store_hazard: %s: %d wide stores (%d with an SGPR soffset), %d finding(s)" % (name, wide, sgpr, len(f)))
     for line in bad:
         print(line, file=sys.stderr)
     return 1 if bad else 0

@@ -1,6 +1,7 @@
 """int4 M = 1 GEMV at K = 4096: straight-line 16-wave form (shipping) vs the 8-wave generic form with 2 / 4 tiles in flight
 (EETQ_AMD_I4_GEMV_K4096 = 82 / 84, one process per arm), graph-replayed chains, us per call."""
 import json, os, subprocess, sys
+os.environ["EETQ_AMD_TUNING"] = "1"   # the A/B hooks this script sets answer only with this switch (csrc/common.hpp: tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -1,4 +1,5 @@
 import json, os, subprocess, sys
+os.environ["EETQ_AMD_TUNING"] = "1"   # the A/B hooks this script sets answer only with this switch (csrc/common.hpp: tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

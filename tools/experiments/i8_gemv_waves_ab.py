@@ -1,6 +1,7 @@
 """int8 M = 1 GEMV, generic-K form: 16-wave workgroups (shipping) vs 8-wave workgroups with 2 / 4 tiles in flight
 (EETQ_AMD_I8_GEMV_WAVES = 82 / 84, read once: one process per arm), graph-replayed chains, us per call."""
 import json, os, subprocess, sys
+os.environ["EETQ_AMD_TUNING"] = "1"   # the A/B hooks this script sets answer only with this switch (csrc/common.hpp: tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

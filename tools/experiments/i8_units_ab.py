@@ -1,6 +1,7 @@
 """int8 M = 1 GEMV: 8-column units (gemv_half_kernel / gemv_mixed_kernel) forced everywhere vs never (EETQ_AMD_I8_UNITS, read once:
 two processes), graph-replayed chains over rotating weights, us per call.  usage: python tools/experiments/i8_units_ab.py"""
 import json, os, subprocess, sys
+os.environ["EETQ_AMD_TUNING"] = "1"   # the A/B hooks this script sets answer only with this switch (csrc/common.hpp: tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

@@ -2,6 +2,7 @@
 processes (EETQ_AMD_GEMV_MIXED is read once), graph-replayed chains over rotating weights, us per call.
 usage: python tools/experiments/mixed_units_check.py"""
 import json, os, subprocess, sys
+os.environ["EETQ_AMD_TUNING"] = "1"   # the A/B hooks this script sets answer only with this switch (csrc/common.hpp: tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "--one":
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))

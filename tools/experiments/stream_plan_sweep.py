@@ -2,6 +2,7 @@
 (the switch is read once), us per launch in graph-replayed chains over rotating weights, a hash of the outputs (all plans with the
 same wave count must agree bit for bit).  Output: one JSON line per (shape, M) with every plan's time, and the rule's."""
 import hashlib, json, os, subprocess, sys
+os.environ["EETQ_AMD_TUNING"] = "1"   # the A/B hooks this script sets answer only with this switch (csrc/common.hpp: tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [(4096, 4096), (4096, 11008), (4096, 12288), (4096, 14336), (4096, 22016), (5120, 5120), (5120, 13824), (5120, 15360), (5120, 27648),
           (8192, 8192), (8192, 1024), (4096, 1024), (11008, 4096), (13824, 5120), (8192, 28672), (28672, 8192), (3072, 9216), (2048, 8192),

@@ -3,6 +3,7 @@ Runs itself once per setting (the switch is read once per process), prints us pe
 weights) and a hash of the outputs: the LDS form feeds the same fragments to the same MFMAs in the same order, so the hashes must
 be equal to the register form's."""
 import hashlib, json, os, subprocess, sys
+os.environ["EETQ_AMD_TUNING"] = "1"   # the A/B hooks this script sets answer only with this switch (csrc/common.hpp: tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES = [(4096, 4096), (4096, 11008), (4096, 12288), (4096, 22016), (5120, 5120), (5120, 13824), (5120, 15360), (8192, 8192),
           (11008, 4096), (13824, 5120)]

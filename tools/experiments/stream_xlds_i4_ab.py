@@ -2,6 +2,7 @@
 adopted W8A16 rule (EETQ_AMD_I8_STREAM_XLDS = 0 against the default) through the AUTO dispatcher.  One process per setting;
 us per launch in graph-replayed chains over rotating weights + a hash of the outputs (must not depend on the setting)."""
 import hashlib, json, os, subprocess, sys
+os.environ["EETQ_AMD_TUNING"] = "1"   # the A/B hooks this script sets answer only with this switch (csrc/common.hpp: tuning_env)
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 SHAPES4 = [(4096, 4096), (4096, 11008), (4096, 12288), (4096, 22016), (5120, 5120), (5120, 13824), (8192, 8192), (11008, 4096), (13824, 5120)]
 SHAPES8 = [(4096, 4096), (4096, 11008), (4096, 12288), (4096, 14336), (4096, 22016), (4096, 1024), (8192, 1024), (5120, 5120),

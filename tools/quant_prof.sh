@@ -1,6 +1,7 @@
 #!/bin/bash
 # per-kernel split of quant_weights under rocprofv3 (new column-major kernel, then the older row-major one)
 # usage (GPU box): bash tools/quant_prof.sh > gpurun_out/quant_prof.txt
+export EETQ_AMD_TUNING=1   # the EETQ_AMD_QUANT_* A/B hooks answer only with this switch (csrc/common.hpp: tuning_env)
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 export TMPDIR=/tmp
 cd /tmp
