@@ -28,6 +28,9 @@ A "step" is one w8_a16_gemm call (one pass of the decode hot path over one batch
              roofline.gemm_m1024: the other half of the metric, fused dequant-GEMM at M=1024 (MFMA roofline), same method.
   cpu_baseline  the oracle's scalar C port of the same GEMV on one host core (bounded sample); beside it
              (cpu_linear_fp16) the north star's CPU torch.nn.Linear fp16 forward, best over a sweep of thread counts.
+  config4    BASELINE configs[3]: the Llama-2-7B projection shapes x M in {1, 8, 64, 1024} (+ 32 / 128 / 256 at
+             4096^2) through AUTO, each chain-timed like the headline, with the path AUTO took, both roofline fractions and a
+             tier-A check against the oracle (skip with --no-config4).  Reported beside the headline, never as `value`.
   config5    BASELINE configs[4] on the same box (skip with --no-config5): Llama-2-13B shapes, prompt 1024 + 50 new tokens,
              one replica per GPU, whole-job tokens/s.  Reported beside the headline, never as `value`.
 Multi-GPU: replicas only (model replicated, no data-path collective); rank 0 fans the activations out with one
@@ -318,6 +321,100 @@ def config5_leg(grp, prompt_len=1024, new_tokens=50):
     return res
 
 
+PATH_NAMES = {0: "auto", 1: "gemv", 2: "mfma", 3: "stream", 4: "mid", 5: "splitk", 6: "tilesplit"}
+
+
+def auto_path_name(bits, M, N, K):
+    """What EETQ_PATH_AUTO launches for this problem (eetq_diag_auto_path: the function the launchers call, host arithmetic)."""
+    from eetq_amd import _lib
+    p, d = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().eetq_diag_auto_path(bits, M, N, K, ctypes.byref(p), ctypes.byref(d)))
+    name = PATH_NAMES.get(p.value, str(p.value))
+    if p.value == 6:
+        name = "tilesplit/S=%d" % d.value if d.value > 1 else "tile"
+    if p.value == 2:
+        name = "tile"
+    if p.value == 3:
+        f, t, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
+        if M <= 16 and _lib.lib().eetq_diag_stream_plan(bits, M, N, K, 0, ctypes.byref(f), ctypes.byref(t), ctypes.byref(w)) == 0:
+            name = "stream/%s,%d,%d" % (("regs", "block", "ring")[f.value], t.value, w.value)
+    return name
+
+
+CONFIG4_SHAPES = ((4096, 4096), (4096, 11008), (11008, 4096))          # (K, N): q/k/v/o, gate/up, down of Llama-2-7B
+CONFIG4_MS = {(4096, 4096): (1, 8, 32, 64, 128, 256, 1024)}           # SURVEY 8(d): M in {1, 8, 64, 1024}; 4096^2 also 32 / 128 / 256
+CONFIG4_DEFAULT_MS = (1, 8, 64, 1024)
+
+
+def config4_leg(grp, ops, oracle, sets4096, min_s=0.03):
+    """BASELINE configs[3] (SURVEY 8(d) "Config 4 sweep"): the Llama-2-7B projection shapes x M in {1, 8, 64, 1024}, plus
+    M in {32, 128, 256} at 4096^2, through EETQ_PATH_AUTO -- every point timed like the headline (ONE HIP graph of >= 1000
+    dependent launches -- >= 200 at M = 1024 -- over rotating weight sets larger than the Infinity Cache, replayed for >= 30 ms),
+    with the path AUTO took, both roofline fractions and a tier-A check of the point's own output against the oracle on the
+    last 256 columns (the oracle quantises those columns of the fp16 weight itself, so the GPU quantiser is in the loop).
+    Labelled extra, never `value`.  Every rank runs it (the timed regions hold barriers); rank 0 reports."""
+    dev = grp.device
+    t_start = time.perf_counter()
+    points = []
+    g = torch.Generator(device=dev)
+    g.manual_seed(4321)
+    for (K, N) in CONFIG4_SHAPES:
+        bound = 1.0 / (K ** 0.5)
+        w_first = ((torch.rand(K, N, device=dev, generator=g) * 2 - 1) * bound).half()
+        if (K, N) == (4096, 4096):
+            sets = [ops.quant_weights(w_first, torch.int8, False)] + list(sets4096[1:])
+        else:   # 16 x 43 MiB = 688 MiB > Infinity Cache
+            sets = [ops.quant_weights(w_first, torch.int8, False)]
+            for _ in range(15):
+                sets.append(ops.quant_weights(((torch.rand(K, N, device=dev, generator=g) * 2 - 1) * bound).half(), torch.int8, False))
+        nbuf = len(sets)
+        cols = slice(N - 256, N)
+        w_cols = w_first[:, cols].cpu().numpy() if oracle is not None else None
+        del w_first
+        q_cols = s_cols = None
+        if oracle is not None:
+            q_cols, s_cols = oracle.quantize(np.ascontiguousarray(w_cols))
+        for M in CONFIG4_MS.get((K, N), CONFIG4_DEFAULT_MS):
+            torch.manual_seed(100 + M)
+            x = torch.rand(M, K, dtype=torch.float16).to(dev)
+            grp.fan_out(x)
+            outs = [torch.empty(M, N, dtype=torch.float16, device=dev) for _ in range(2)]
+
+            def steps(first, count, x=x, outs=outs, sets=sets, nbuf=nbuf, M=M, N=N, K=K):
+                for i in range(first, first + count):
+                    w, sc = sets[i % nbuf]
+                    ops.w8_a16_gemm_(x, w, sc, outs[i % 2], M, N, K)
+            steps(0, 2 * nbuf if M < 1024 else nbuf)     # warm-up: kernel selection, scratch, clocks
+            grp.synchronize()
+            launches = 1000 if M < 1024 else 200
+            launches = -(-launches // nbuf) * nbuf       # whole passes over the weight sets
+            graphs, glen = capture_graphs(steps, launches, nbuf, launches)
+            secs, replays = timed_replays(grp, graphs, launches, min_s)
+            us = secs * 1e6 / (replays * glen)
+            del graphs
+            pt = {"K": K, "N": N, "M": M, "us": round(us, 3), "path": auto_path_name(8, M, N, K),
+                  "hbm_frac": round(gemv_bytes(M, N, K) / (us * 1e-6) / 1e9 / HBM_PEAK_GBPS, 4),
+                  "mfma_frac": round(2.0 * M * N * K / (us * 1e-6) / 1e12 / MFMA_F16_PEAK_TFLOPS, 4),
+                  "GBps": round(gemv_bytes(M, N, K) / (us * 1e-6) / 1e9, 1),
+                  "TFLOPS": round(2.0 * M * N * K / (us * 1e-6) / 1e12, 2), "launches_timed": replays * glen}
+            if oracle is not None:
+                rows = list(range(min(M, 8))) + list(range(max(M - 8, 8), M))          # first and last rows of the batch
+                ops.w8_a16_gemm_(x, sets[0][0], sets[0][1], outs[0], M, N, K)
+                got = outs[0][rows][:, cols].float().cpu().numpy()
+                ref = oracle.w8a16_gemm(x[rows].cpu().numpy(), q_cols, s_cols).astype(np.float32)
+                pt["tier_a_ok"] = bool(np.all(np.abs(got - ref) <= 1e-3 * np.abs(ref).max() + 2e-3 * np.abs(ref)))
+            points.append(pt)
+        del sets
+        torch.cuda.empty_cache()
+    return {"what": "BASELINE configs[3] / SURVEY 8(d) config-4 sweep through EETQ_PATH_AUTO: (K, N) in {(4096, 4096), (4096, 11008), "
+                    "(11008, 4096)} x M in {1, 8, 64, 1024} (+ M in {32, 128, 256} at 4096^2); per point one HIP graph of >= 1000 "
+                    "dependent launches (>= 200 at M = 1024) over rotating weight sets (40 x 16 MiB / 16 x 43 MiB), replayed >= 30 ms; "
+                    "hbm_frac = (K*N + 2*M*K + 2*N + 2*M*N) B / us / 8 TB/s, mfma_frac = 2*M*N*K / us / 2.5 PF; tier_a_ok = this "
+                    "point's output vs the oracle on the last 256 columns, first and last 8 rows",
+            "points": points, "all_tier_a_ok": all(p.get("tier_a_ok", True) for p in points),
+            "seconds": round(time.perf_counter() - t_start, 2)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -329,6 +426,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-config5", action="store_true",
                     help="skip the BASELINE configs[4] leg (Llama-2-13B shapes, prompt 1024 + 50 new tokens, one replica per GPU)")
+    ap.add_argument("--no-config4", action="store_true",
+                    help="skip the BASELINE configs[3] sweep (7B projection shapes x M in {1, 8, 64, 1024}, + 32 / 128 / 256 at 4096^2)")
     ap.add_argument("--no-power-check", action="store_true",
                     help="skip the zero-operand / Gaussian-weight GEMM chains (tools/profile_bench.sh: the rocprofv3 average of "
                          "gemm_tile_kernel must cover the BASELINE operands only)")
@@ -400,10 +499,23 @@ def main():
         r = rocprof_doc.get(key)
         if not r:
             return None
-        return {"avg_us": r.get("avg_us"), "calls": r.get("calls"), "min_us": r.get("min_us"),
-                "frac": round(work / (r["avg_us"] * 1e-6) / peak_scale, 4) if r.get("avg_us") else None,
-                "file": rocprof_doc.get("file"), "head": rocprof_doc.get("head"),
-                "kernel_sources_unchanged_since": rocprof_doc.get("kernel_src_sha16") == src_sha}
+        out = {"avg_us": r.get("avg_us"), "calls": r.get("calls"), "min_us": r.get("min_us"),
+               "frac": round(work / (r["avg_us"] * 1e-6) / peak_scale, 4) if r.get("avg_us") else None,
+               # the SAME profiled process's own chain step (bench.py's timed region while rocprofv3 was attached) and the
+               # un-profiled chain step of the same script run: the attached tool stretches every dispatch, so the profiled
+               # average is explained by chain_us_same_process (>= avg_us: a chain step is the kernel plus the inter-dispatch
+               # gap), never by the un-profiled step of another process; profiler_offset_us = the difference of the two chains
+               "chain_us_same_process": r.get("chain_us_same_process"),
+               "chain_us_unprofiled_same_run": r.get("chain_us_unprofiled"),
+               "profiler_offset_us": r.get("profiler_offset_us"),
+               "file": rocprof_doc.get("file"), "head": rocprof_doc.get("head"),
+               "kernel_sources_unchanged_since": rocprof_doc.get("kernel_src_sha16") == src_sha}
+        if r.get("avg_us") and r.get("chain_us_same_process"):
+            out["avg_le_chain_same_process"] = bool(r["avg_us"] <= r["chain_us_same_process"] * 1.005)
+            if not out["avg_le_chain_same_process"]:
+                print("warning: profiles/%s: rocprofv3 average of %s (%.3f us) exceeds the profiled process's own chain step "
+                      "(%.3f us)" % (rocprof_doc.get("file"), key, r["avg_us"], r["chain_us_same_process"]), file=sys.stderr)
+        return out
 
     # diagnostic only: HIP event pairs on each dispatch packet, with the method's own floor (empty kernel, same geometry)
     n_ev = max(nbuf, (min(max(steps, 400), 2000) // nbuf) * nbuf)
@@ -599,6 +711,11 @@ def main():
                      "us_per_call": round(q_us, 1), "moved_GBps": round((K * N * 2 * 2 + K * N) / q_us / 1e3)}
         del srcs
 
+    # ---- BASELINE configs[3]: the 7B-shape sweep through AUTO (reported beside the headline, never as `value`) ----
+    config4 = None
+    if not args.no_config4:
+        config4 = config4_leg(grp, ops, oracle, sets)
+
     # ---- BASELINE configs[4]: the whole decode path on the same box (reported beside the headline, never as `value`) ----
     config5 = None
     if not args.no_config5:
@@ -620,7 +737,7 @@ def main():
                        "graph_launches": graph_len,
                        "timed_steps": timed_steps, "timed_ms": round(seconds * 1e3, 3)},
             "roofline": roofline, "secondary": gemm, "cpu_baseline": cpu_baseline, "cpu_linear_fp16": cpu_linear,
-            "parity": parity, "quantizer": quantizer, "config5": config5,
+            "parity": parity, "quantizer": quantizer, "config4": config4, "config5": config5,
         }
         print(json.dumps(line))
     grp.close()

@@ -25,7 +25,7 @@ $PY bench.py "$@" > "$OUT/${TAG}_bench.json" 2> "$OUT/${TAG}_bench.err" || echo 
 
 echo "== 2. rocprofv3 --kernel-trace --stats of the same command" >&2
 rm -rf /tmp/prof_bench
-( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- $PY "$ROOT/bench.py" "$@" --no-cpu-baseline --no-config5 --no-power-check \
+( cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_bench -- $PY "$ROOT/bench.py" "$@" --no-cpu-baseline --no-config5 --no-config4 --no-power-check \
     > "$OUT/${TAG}_bench_under_rocprof.json" 2> "$OUT/${TAG}_rocprof.err" ) || echo "rocprofv3 stats run failed" >&2
 STATS=$(find /tmp/prof_bench -name '*kernel_stats.csv' | head -1)
 if [ -n "$STATS" ]; then
@@ -41,7 +41,7 @@ for r in rows[1:]:
 PYEOF
 fi
 if [ -s "$OUT/${TAG}_bench_kernel_stats.csv" ]; then
-    $PY - "$OUT/${TAG}_bench_kernel_stats.csv" "profiles/${TAG}_bench_kernel_stats.csv" > "$OUT/bench_rocprof.json" <<'PYEOF'
+    $PY - "$OUT/${TAG}_bench_kernel_stats.csv" "profiles/${TAG}_bench_kernel_stats.csv" "$OUT/${TAG}_bench_under_rocprof.json" "$OUT/${TAG}_bench.json" > "$OUT/bench_rocprof.json" <<'PYEOF'
 import csv, json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import bench
@@ -52,6 +52,24 @@ for r in csv.DictReader(open(sys.argv[1])):
         if pat in r["Name"] and key not in doc:
             doc[key] = {"avg_us": round(float(r["AverageNs"]) / 1e3, 3), "calls": int(r["Calls"]),
                         "min_us": round(float(r["MinNs"]) / 1e3, 3), "max_us": round(float(r["MaxNs"]) / 1e3, 3)}
+# The profiled process's OWN chain step (bench.py's timed region while rocprofv3 was attached) next to the tool's average, and
+# the un-profiled chain of step 1 of this script: avg_us must not exceed chain_us_same_process (a chain step is the kernel plus
+# the inter-dispatch gap); profiler_offset_us = what the attached tool adds to a step.
+def chain(path):
+    try:
+        line = [l for l in open(path).read().splitlines() if l.startswith("{")][-1]
+        d = json.loads(line)
+        return {"gemv": d["ms_per_step"] * 1e3, "gemm_m1024": d["secondary"]["ms_per_step"] * 1e3}
+    except Exception as e:
+        return {}
+prof, plain = chain(sys.argv[3]), chain(sys.argv[4])
+for key in ("gemv", "gemm_m1024"):
+    if key in doc and key in prof:
+        doc[key]["chain_us_same_process"] = round(prof[key], 3)
+        if key in plain:
+            doc[key]["chain_us_unprofiled"] = round(plain[key], 3)
+            doc[key]["profiler_offset_us"] = round(prof[key] - plain[key], 3)
+        doc[key]["avg_le_chain_same_process"] = bool(doc[key]["avg_us"] <= prof[key] * 1.005)
 print(json.dumps(doc, indent=1))
 PYEOF
 fi
