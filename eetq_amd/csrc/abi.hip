@@ -393,7 +393,7 @@ static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scal
         case EETQ_PATH_STREAM: return launch_streamk(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_MID: return launch_gemm_mid(xp, wp, sp, bp, yp, M, N, K, s);
         case EETQ_PATH_SPLITK: return launch_gemm_splitk(xp, wp, sp, bp, yp, M, N, K, s, 0, 0, /*env_plan=*/true);
-        case EETQ_PATH_TILESPLIT: return launch_gemm_tile_splitk(xp, wp, sp, bp, yp, M, N, K, s);
+        case EETQ_PATH_TILESPLIT: return launch_gemm_tile_splitk(xp, wp, sp, bp, yp, M, N, K, s, 0, nullptr, /*env_plan=*/true);
         default: return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] unknown or unimplemented GEMM path");
     }
 }

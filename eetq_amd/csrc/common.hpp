@@ -283,6 +283,7 @@ int  launch_streamk(const f16* x, const uint8_t* w, const f16* scales, Epilogue 
 constexpr int kGemvMaxM   = 4;
 constexpr int kStreamMaxM = 64;
 constexpr int kMidMaxM    = 128;
+constexpr int kSplitkMaxM = 1024;  // the split-K tile with row groups (round 5): up to 32 groups of <= 128 rows
 int launch_gemm_mid(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                     hipStream_t stream);
 // split-K form of the medium-batch tile (gemm_splitk.hip); force_nb / force_s (0 = planned) are tuning hooks; `env_plan`:
@@ -292,14 +293,15 @@ int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilog
                        hipStream_t stream, int force_nb = 0, int force_s = 0, bool env_plan = false);
 int launch_gemm_splitk_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                           hipStream_t stream, bool env_plan = false);
-void splitk_plan(int M, int N, int K, int* nb, int* s, int* stages);
+// *r (optional): row groups the batch is cut into (gemm_splitk_kernel.hpp: R); nb / s / stages are planned for ceil(M / r) rows
+void splitk_plan(int M, int N, int K, int* nb, int* s, int* stages, int* r = nullptr);
 // the calling stream's own split-K scratch region (gemm_splitk.hip): slabs (*slab_bytes of them), one ticket array per slice
 // count (2 and 4), *max_tiles tickets each.  EETQ_ERR_UNSUPPORTED (no message) when the stream cannot have one right now.
 int splitk_region(hipStream_t stream, float** slabs, size_t* slab_bytes, unsigned** tickets2, unsigned** tickets4, size_t* max_tiles);
 // split-K form of the tiled MFMA GEMM (gemm.hip): K slices of the 128 x 64 tile when whole tiles leave CUs idle; falls back
 // to launch_gemm_mfma when it does not apply.  *used_s (optional) reports the slice count that ran.
 int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
-                            hipStream_t stream, int force_s = 0, int* used_s = nullptr);
+                            hipStream_t stream, int force_s = 0, int* used_s = nullptr, bool env_plan = false);
 // slices launch_gemm_tile_splitk would use (1 = it would run the unsplit tiled kernel)
 int tile_splitk_slices(int M, int N, int K);
 // the same for the 128 x 128 tile (2 = two slices; 1 = unsplit)

@@ -24,20 +24,29 @@ __device__ unsigned long long* g_gemm_stamps = nullptr;
 
 constexpr int BM = 128, BK = 64;
 constexpr int A_STAGE_BYTES = BM * BK * 2;  // 16 KiB of fp16 activations per K step
-constexpr int STAGES        = 6;
+constexpr int STAGES        = 6;            // ring depth of the unsplit kernel (and the default of the K-sliced one)
 constexpr int kMinKSteps    = STAGES - 1;   // the statically unrolled drain needs K/64 >= 5
 // J = 32-column blocks per wave: J = 2 -> 128 x 128 tile (the MFMA-bound shape), J = 1 -> 128 x 64 tile (twice the
 // workgroups: fills the chip at 129 <= M <= 512 and trims the last partial round of tiles on other shapes)
 // CW = waves across the tile's columns (each owns 32*J of them); 2*CW waves per workgroup.  CW = 2: the round-1 geometry,
 // one wave per SIMD.  (J, CW) = (1, 4): the 128 x 128 tile on EIGHT waves, two per SIMD -- half the accumulators and half the
 // DMA pieces per wave, and a second wave on every SIMD to issue MFMAs while the first sits in an LDS-DMA issue or a barrier.
-template <int J, int CW = 2>
+// ST = ring depth.  6 (the unsplit kernel): five stages in flight cover the HBM latency of a 64-step loop.  3 / 4 (round 5, K slices
+// of 8..32 steps): a short slice spends as long filling and draining a 6-deep ring as it spends in it -- a shallower ring starts
+// multiplying after ONE stage has landed with 40-60 KiB less requested up front, and its 60 / 80 KiB of LDS lets two workgroups
+// share a CU, so one's fill / hand-over / store phases run under the other's loop.
+template <int J, int CW = 2, int ST = STAGES>
 struct TileCfg {
+    static_assert(ST >= 3 && ST <= 6, "ring depths with a wait schedule: 3..6");
     static constexpr int BN            = 32 * J * CW;
     static constexpr int WAVES         = 2 * CW;
     static constexpr int B_STAGE_BYTES = BN * BK;  // BN/16 native 1 KiB tiles per K step
     static constexpr int STAGE_BYTES   = A_STAGE_BYTES + B_STAGE_BYTES;
-    static constexpr int SMEM_BYTES    = STAGES * STAGE_BYTES;  // 144 / 120 KiB (also covers the end-of-kernel reduction)
+    static constexpr int RING_BYTES    = ST * STAGE_BYTES;      // 144 / 120 KiB at ST = 6
+    // end of kernel: the second K half's parked accumulators, the fp16 image of the tile behind them, the ticket word
+    static constexpr int EPI_BYTES     = CW * (16 * J) * 64 * 16 + BM * (BN + 8) * 2 + 16;
+    static constexpr int SMEM_BYTES    = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
+    static constexpr int kMinKSteps    = ST - 1;                // the statically unrolled drain
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -95,7 +104,18 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // tiles meet in `slabs` ([tile][slice][BM * BN] floats, accumulator order) and the workgroup that draws the last of the tile's
 // S tickets adds them IN SLICE ORDER (replicas stay bit-identical) and runs the ordinary epilogue.  Same hand-over as
 // gemm_splitk_kernel.hpp: write-through stores, every wave drains them, barrier, one relaxed agent-scope ticket.
-template <int ABLATE, int J, bool ACT, int CW, bool SPLIT>
+template <int N_, typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
+{
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N_, typename F>
+__device__ __forceinline__ void static_for(F&& f)
+{
+    static_for_impl<N_>(f, std::make_integer_sequence<int, N_>{});
+}
+
+template <int ABLATE, int J, bool ACT, int CW, bool SPLIT, int ST = STAGES>
 __device__ __forceinline__ void gemm_tile_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep, int S, float* __restrict__ slabs,
@@ -103,8 +123,8 @@ __device__ __forceinline__ void gemm_tile_body(
 {
     // N = columns of THIS launch (w, scales, y, ep.* already point at its first column); ldc = row stride of y / residual
     EETQ_GEMM_STAMP(0);
-    using Cfg = TileCfg<J, CW>;
-    constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES, NW = Cfg::WAVES;
+    using Cfg = TileCfg<J, CW, ST>;
+    constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES, RING_BYTES = Cfg::RING_BYTES, NW = Cfg::WAVES;
     constexpr int APW = 16 / NW;  // activation DMA pieces (8 rows each) per wave and stage: 4 or 2
     constexpr int WN_COLS = 32 * J, PIECES = APW + J, NMFMA = 8 * J;
     static_assert(J == 1 || J == 2, "slot tables exist for J = 1 and J = 2");
@@ -209,7 +229,7 @@ __device__ __forceinline__ void gemm_tile_body(
 
     // ring state of the step about to run (wave-uniform): rd = LDS offset of the stage whose fragments it reads
     // (stage kt+1), wr = LDS offset its DMA fills (stage kt+5), ka / kb = source offsets of that stage
-    int rd = STAGE_BYTES, wr = (STAGES - 1) * STAGE_BYTES, ka = (k0 + STAGES - 1) * BK * 2, kb = (k0 + STAGES - 1) * kTileBytes;
+    int rd = STAGE_BYTES, wr = (ST - 1) * STAGE_BYTES, ka = (k0 + ST - 1) * BK * 2, kb = (k0 + ST - 1) * kTileBytes;
     int ra0 = rd + c_a0, ra1 = rd + c_a1, rb0 = rd + c_b0, rb1 = rd + c_b1;
 
     auto dma_piece = [&](auto itag) {
@@ -306,11 +326,11 @@ __device__ __forceinline__ void gemm_tile_body(
                 // ring state and read addresses of the next step, in the gaps that carry little else
                 // (after the step's last fragment read / last DMA piece: J = 2 gaps 12..15, J = 1 gaps 5..7)
                 if (i == (J == 2 ? 12 : 5)) {
-                    rd = rd + STAGE_BYTES == SMEM_BYTES ? 0 : rd + STAGE_BYTES;
+                    rd = rd + STAGE_BYTES == RING_BYTES ? 0 : rd + STAGE_BYTES;
                     asm volatile("" : "+s"(rd));
                 }
                 if (i == (J == 2 ? 13 : 6)) {
-                    wr = wr + STAGE_BYTES == SMEM_BYTES ? 0 : wr + STAGE_BYTES;
+                    wr = wr + STAGE_BYTES == RING_BYTES ? 0 : wr + STAGE_BYTES;
                     ka += BK * 2;
                     kb += kTileBytes;
                     asm volatile("" : "+s"(wr), "+s"(ka), "+s"(kb));
@@ -345,7 +365,7 @@ __device__ __forceinline__ void gemm_tile_body(
     {
         int pwr = 0, pka = k0 * BK * 2, pkb = k0 * kTileBytes;
 #pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s) {  // KT >= STAGES - 1 by launch contract
+        for (int s = 0; s < ST - 1; ++s) {  // KT >= ST - 1 by launch contract
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {  // plain form: voff carries -IMM, so the LDS address gets it back here
                 if (i < APW)
@@ -358,7 +378,7 @@ __device__ __forceinline__ void gemm_tile_body(
             pkb += kTileBytes;
         }
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PIECES) : "memory");  // stage 0 landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PIECES) : "memory");  // stage 0 landed
     __builtin_amdgcn_s_barrier();
     EETQ_GEMM_STAMP(1);
     Frags f0, f1;
@@ -385,23 +405,36 @@ __device__ __forceinline__ void gemm_tile_body(
     auto k_step = [&](auto rem_tag, const WFrag& wcur, const Frags& fcur, WFrag& wnext, Frags& fnext) {
         constexpr int REM = decltype(rem_tag)::value;
         if constexpr (REM >= 1) {
-            constexpr int younger = (REM - 1) < (STAGES - 3) ? (REM - 1) : (STAGES - 3);
+            constexpr int younger = (REM - 1) < (ST - 3) ? (REM - 1) : (ST - 3);
             if constexpr (!(ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger * PIECES) : "memory");
             if constexpr (!(ABLATE & 16)) __builtin_amdgcn_s_barrier();
-            step(wcur, fcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= STAGES - 1)>{});
+            step(wcur, fcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= ST - 1)>{});
         } else {
             step(wcur, fcur, std::false_type{}, fnext, wnext, std::false_type{});
         }
     };
-    using Steady = std::integral_constant<int, STAGES - 1>;
-    const int tail = (ksteps & 1) ? 5 : 6;
+    using Steady = std::integral_constant<int, ST - 1>;
+    // the steady loop runs pairs of steps (the fragment buffers alternate); the drain is ST - 1 steps, plus one steady step when
+    // the pairs do not come out even
+    const int tail = ((ksteps - (ST - 1)) & 1) ? ST : ST - 1;
     int       kt   = 0;
     for (; kt < ksteps - tail; kt += 2) {
         k_step(Steady{}, w0, f0, w1, f1);
         k_step(Steady{}, w1, f1, w0, f0);
     }
     EETQ_GEMM_STAMP(2);
-    if (tail == 6) {
+    if constexpr (ST != 6) {
+        auto drain = [&](auto n_tag) {  // n steps with REM = n - 1 .. 0, buffers alternating from (w0, f0)
+            constexpr int n = decltype(n_tag)::value;
+            static_for<n>([&](auto i_tag) {
+                constexpr int i = decltype(i_tag)::value;
+                if constexpr (i % 2 == 0) k_step(std::integral_constant<int, n - 1 - i>{}, w0, f0, w1, f1);
+                else k_step(std::integral_constant<int, n - 1 - i>{}, w1, f1, w0, f0);
+            });
+        };
+        if (tail == ST) drain(std::integral_constant<int, ST>{});
+        else drain(std::integral_constant<int, ST - 1>{});
+    } else if (tail == 6) {
         k_step(std::integral_constant<int, 5>{}, w0, f0, w1, f1);
         k_step(std::integral_constant<int, 4>{}, w1, f1, w0, f0);
         k_step(std::integral_constant<int, 3>{}, w0, f0, w1, f1);
@@ -523,7 +556,7 @@ __device__ __forceinline__ void gemm_tile_body(
     }
     constexpr int kRowHalfs = BN + 8;                       // row stride of the image: 272 / 144 bytes (bank shift per row)
     f16* image = reinterpret_cast<f16*>(smem + CW * (16 * J) * 64 * 16);  // behind every column part's parked accumulators
-    static_assert(CW * (16 * J) * 64 * 16 + BM * kRowHalfs * 2 <= SMEM_BYTES, "the output image must fit behind the parked halves");
+    static_assert(CW * (16 * J) * 64 * 16 + BM * kRowHalfs * 2 + 16 <= SMEM_BYTES, "the output image must fit behind the parked halves");
     // who rounds which row blocks into the image: the K-half-0 waves all four -- or, after a split read-back, every wave the two
     // it summed (held in acc[0], acc[1])
     const bool summed = SPLIT && S > 1;
@@ -592,15 +625,16 @@ __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
     gemm_tile_body<ABLATE, J, ACT, CW, false>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
 }
 
-// grid = tiles * S workgroups; every slice must own >= kMinKSteps K steps; counters: one per tile, shared only by launches
-// with the same S (they grow by S per launch; "last" is (old & (S-1)) == S-1), S in {2, 4} for J = 1, S = 2 for J = 2
-template <int J>
-__global__ __launch_bounds__(256, 1) void gemm_tile_splitk_kernel(
+// grid = tiles * S workgroups; every slice must own >= ST - 1 K steps; counters: one per tile, shared only by launches
+// with the same S (they grow by S per launch; "last" is (old & (S-1)) == S-1), S in {2, 4} for J = 1, S = 2 for J = 2.
+// ST = ring depth (TileCfg), OCC = workgroups the register budget lets share a CU (2: <= 256 registers per lane, J = 1 only)
+template <int J, int ST = STAGES, int OCC = 1>
+__global__ __launch_bounds__(256, OCC) void gemm_tile_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep, int S, float* __restrict__ slabs,
     unsigned* __restrict__ counters)
 {
-    gemm_tile_body<0, J, false, 2, true>(x, w, scales, y, M, N, K, ldc, ep, S, slabs, counters);
+    gemm_tile_body<0, J, false, 2, true, ST>(x, w, scales, y, M, N, K, ldc, ep, S, slabs, counters);
 }
 
 }  // namespace gemm

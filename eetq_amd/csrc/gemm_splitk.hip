@@ -126,6 +126,7 @@ template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4, int BITS = 8>
 int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int S,
                 hipStream_t stream)
 {
+    const int R = (M + 32 * MT - 1) / (32 * MT);  // row groups of 32*MT rows (1 unless the plan cut the batch along M)
     using C   = gemm_splitk::Cfg<MT, NB, SA, SB, W, BITS>;
     auto kern = gemm_splitk::gemm_splitk_kernel<MT, NB, SA, SB, KFULL, W, false, BITS>;
     if (C::kSmem > 64 * 1024) {
@@ -133,7 +134,7 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         int st = opt_in_large_lds(kern, opted);
         if (st != EETQ_OK) return st;
     }
-    const int tiles = (N + C::kBN - 1) / C::kBN;
+    const int tiles = ((N + C::kBN - 1) / C::kBN) * R;  // slab / ticket units: one per (row group, column tile)
     float*    slabs   = nullptr;
     unsigned* tickets = nullptr;
     if (S > 1) {
@@ -152,7 +153,7 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     // With that fixed both occupancies are exact (tools/deepk_check.py: 812 forced plans, 0 wrong either way;
     // tools/experiments/sk_debug.py) and equally fast (tools/splitk_occupancy.py), so a split launch asks for what it uses.
     const size_t lds = C::kSmem;
-    launch_kernel(kern, dim3(tiles * S), dim3(C::kThreads), lds, stream, x, w, scales, y, M, N, K, S, slabs,
+    launch_kernel(kern, dim3(tiles * S), dim3(C::kThreads), lds, stream, x, w, scales, y, M, N, K, S, R, slabs,
                   tickets, ep);
     return check_hip(hipGetLastError(), "gemm_splitk_kernel launch");
 }
@@ -268,9 +269,11 @@ int release_splitk_workspace(size_t* freed)
 // Reading: a slice costs about (its K steps) x (16*MT + 8*NB KiB per step at ~70 GB/s per CU) plus ~2 us for a 2-way and
 // ~3 us for a 4-way in-launch reduction, on top of ~2.3 us of launch + first-data latency; wide column blocks pay off when
 // the K loop is long (fewer re-reads of x) or the row tile is tall, narrow ones when the loop is short.
-void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out)
+void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out, int* r_out)
 {
-    const int MT    = (M + 31) / 32;
+    const int r0 = (M + 127) / 128;  // a row group holds at most 128 rows (MT <= 4)
+    if (r_out) *r_out = r0;
+    const int MT    = (M + 32 * r0 - 1) / (32 * r0);
     const int ncu   = device_cu_count();
     const int steps = (K / 64 + 3) / 4;
     double    best  = 1e30;
@@ -307,27 +310,33 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out)
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                        hipStream_t stream, int force_nb, int force_s, bool env_plan)
 {
-    if (M < 1 || M > kMidMaxM) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] split-K tile path supports 1 <= M <= 128");
+    if (M < 1 || M > kSplitkMaxM) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] split-K tile path supports 1 <= M <= 1024");
     EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31),
                  "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
-    int nb, s, stages;
-    splitk_plan(M, N, K, &nb, &s, &stages);
+    int nb, s, stages, r = 1;
+    splitk_plan(M, N, K, &nb, &s, &stages, &r);
     if (force_nb) nb = force_nb;
     if (force_s) s = force_s;
-    if (force_nb || force_s) stages = ((M + 31) / 32 <= 2 && ((N + 32 * nb - 1) / (32 * nb)) * s <= device_cu_count()) ? 3 : 2;
+    if (force_nb || force_s) {
+        r      = 1;
+        stages = ((M + 31) / 32 <= 2 && ((N + 32 * nb - 1) / (32 * nb)) * s <= device_cu_count()) ? 3 : 2;
+    }
     int ring = 11 * stages;  // shared ring of round 2: SA = SB = stages
-    // EETQ_AMD_SPLITK_PLAN="nb,s,ring" (ring = 10 * SA + SB) overrides the plan of the FORCED path only (EETQ_PATH_SPLITK:
-    // tuning and tests of every instantiation); production (AUTO) launches never read the environment
+    // EETQ_AMD_SPLITK_PLAN="nb,s,ring[,r]" (ring = 10 * SA + SB; r = row groups, default 1) overrides the plan of the FORCED path
+    // only (EETQ_PATH_SPLITK: tuning and tests of every instantiation); production (AUTO) launches never read the environment
     if (const char* e = env_plan ? getenv("EETQ_AMD_SPLITK_PLAN") : nullptr) {
-        int a = 0, b = 0, c = 0;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
+        int a = 0, b = 0, c = 0, d = 1;
+        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3) {
             nb   = a;
             s    = b;
             ring = c;
+            r    = d;
         }
     }
-    EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4), "invalid split-K plan");
-    switch ((M + 31) / 32) {
+    EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4) && r >= 1 && r <= 32, "invalid split-K plan");
+    EETQ_REQUIRE((M + 32 * r - 1) / (32 * r) <= 4, "split-K plan: a row group holds at most 128 rows");
+    // r row groups of 32 * MT rows each (launch_full derives the group count back from MT): MT = ceil(M / (32 r))
+    switch ((M + 32 * r - 1) / (32 * r)) {
         case 1: return launch_mt<1>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
         case 2: return launch_mt<2>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
         case 3: return launch_mt<3>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
@@ -346,19 +355,20 @@ int launch_gemm_splitk_i4(const f16* x, const uint8_t* w, const f16* scales, Epi
     EETQ_REQUIRE(K % 128 == 0 && N % 16 == 0, "W4A16 needs K % 128 == 0 and N % 16 == 0");
     EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K / 2 < (1ull << 31),
                  "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
-    int nb, s, stages;
-    splitk_plan(M, N, K, &nb, &s, &stages);
+    int nb, s, stages, r = 1;
+    splitk_plan(M, N, K, &nb, &s, &stages, &r);
     int ring = 11 * stages;
     if (const char* e = env_plan ? getenv("EETQ_AMD_SPLITK_PLAN") : nullptr) {
-        int a = 0, b = 0, c = 0;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) {
+        int a = 0, b = 0, c = 0, d = 1;
+        if (sscanf(e, "%d,%d,%d,%d", &a, &b, &c, &d) >= 3) {
             nb   = a;
             s    = b;
             ring = c;
+            r    = d;
         }
     }
-    EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4), "invalid split-K plan");
-    switch ((M + 31) / 32) {
+    EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4) && r >= 1 && r <= 4, "invalid split-K plan");
+    switch ((M + 32 * r - 1) / (32 * r)) {
         case 1: return launch_mt<1, 4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
         case 2: return launch_mt<2, 4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
         case 3: return launch_mt<3, 4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);

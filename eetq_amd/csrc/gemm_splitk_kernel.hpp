@@ -83,14 +83,17 @@ struct Cfg {
     static constexpr int kSlabFloats = kRows * kBN;                      // fp32 partial tile of one slice
 };
 
-// grid = tiles_n * S workgroups (all of M in one row tile: M <= 32*MT).  slabs: [tiles_n][S][kSlabFloats] floats,
-// counters: [tiles_n] unsigned (both unused when S == 1).
+// grid = tiles_n * R * S workgroups: R row groups of 32*MT rows each (R = 1: all of M in one row tile, M <= 32*MT -- rounds 2-4;
+// R > 1, round 5: the batch is cut along M instead of -- or on top of -- K, so a launch fills the chip WITHOUT a cross-workgroup
+// reduction: M = 64 at N = 4096 is 2 row groups x 128 column tiles = 256 workgroups of 32 rows x all of K; the price is that
+// each weight tile is pulled out of L2 by R workgroups, which the block-id map below makes neighbours on one XCD).
+// slabs: [R * tiles_n][S][kSlabFloats] floats, counters: [R * tiles_n] unsigned (both unused when S == 1).
 // INTER: the DMA pieces of the stage being refilled are issued BETWEEN the MFMA groups of the step (a few right after the
 // fragment reads, to cover their latency) instead of all of them before the first dequant.
 template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4, bool INTER = false, int BITS = 8>
 __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
-    int N, int K, int S, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
+    int N, int K, int S, int R, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
 {
     using C = Cfg<MT, NB, SA, SB, W, BITS>;
     constexpr int TPS = C::kTilesPerStep;  // weight tiles per 16 columns and step
@@ -107,16 +110,27 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
 
     // ---- block id -> (column tile, K slice): a tile's slices are consecutive ids on one XCD when tiles_n % 8 == 0 ----
     const int tiles_n = (N + C::kBN - 1) / C::kBN;
-    int       tile, slice;
+    int       tile, slice, rg;
     if ((tiles_n & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         slice = j % S;
-        tile  = (j / S) * 8 + xcd;
+        rg    = (j / S) % R;
+        tile  = (j / (S * R)) * 8 + xcd;
     } else {
         slice = blockIdx.x % S;
-        tile  = blockIdx.x / S;
+        rg    = (blockIdx.x / S) % R;
+        tile  = blockIdx.x / (S * R);
     }
     const int n0 = tile * C::kBN;
+    // row group rg: rows [rg * kRows, min(M, (rg + 1) * kRows)) of the batch -- from here on the kernel sees its own rows only
+    {
+        const int m_first = rg * C::kRows;
+        x += (size_t)m_first * K;
+        y += (size_t)m_first * N;
+        if (ep.residual) ep.residual += (size_t)m_first * N;
+        M = M - m_first < C::kRows ? M - m_first : C::kRows;
+    }
+    const int vtile = rg * tiles_n + tile;  // slab / ticket index
     // K steps of this slice: [s0, s1); slices differ by at most one step
     const int s0 = (int)(((long)steps_total * slice) / S), s1 = (int)(((long)steps_total * (slice + 1)) / S);
     const int n_tiles_total = N >> 4;
@@ -368,7 +382,7 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         // ---- publish this slice's partial tile (write-through), take a ticket ----
         const size_t tile_floats = (size_t)S * C::kSlabFloats;
         const __amdgpu_buffer_rsrc_t s_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            slabs + (size_t)tile * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
+            slabs + (size_t)vtile * tile_floats, 0, (int)(tile_floats * 4), 0x00020000);
         // float4 index inside a slab: ((mt*NB + nb)*4 + wave)*64 + lane
         const int lane_off = (wave * 64 + lane) * 16;
         u32x4     pub[MT][NB];
@@ -397,7 +411,7 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         __syncthreads();
         unsigned* flag = reinterpret_cast<unsigned*>(smem + C::kSmem - 16);  // inside the one dynamic LDS array
         if (tid == 0)
-            *flag = __hip_atomic_fetch_add(counters + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *flag = __hip_atomic_fetch_add(counters + vtile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
         const unsigned ticket = *flag;
         if ((ticket & (unsigned)(S - 1)) != (unsigned)(S - 1)) return;  // not the last slice of this tile
