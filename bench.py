@@ -334,6 +334,8 @@ def auto_path_name(bits, M, N, K):
         name = "tilesplit/S=%d" % d.value if d.value > 1 else "tile"
     if p.value == 2:
         name = "tile"
+    if p.value == 5 and d.value > 0:
+        name = "splitk/rows=%d" % d.value
     if p.value == 3:
         f, t, w = ctypes.c_int(0), ctypes.c_int(0), ctypes.c_int(0)
         if M <= 16 and _lib.lib().eetq_diag_stream_plan(bits, M, N, K, 0, ctypes.byref(f), ctypes.byref(t), ctypes.byref(w)) == 0:

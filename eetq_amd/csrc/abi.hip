@@ -304,7 +304,7 @@ int eetq_unpack_i8_host(const int8_t* q_packed, size_t K, size_t N, int8_t* q_ra
 // r05_auto_regret.jsonl).  No environment reads except the operational EETQ_AMD_SPLITK=0 (no library-owned scratch).
 struct AutoChoice {
     int path;    // EETQ_PATH_*
-    int detail;  // TILESPLIT: K slices the launch uses (1 = the unsplit tiled kernel); otherwise 0
+    int detail;  // TILESPLIT: K slices the launch uses (1 = the unsplit tiled kernel); SPLITK: row groups of the row-group plan (0 = K-slice plan); otherwise 0
 };
 
 static AutoChoice auto_path_i8(int M, int N, int K, int act)
@@ -324,15 +324,30 @@ static AutoChoice auto_path_i8(int M, int N, int K, int act)
         // wide N, M > 64: the 128 x 64 tiles of the tiled kernel already give most CUs a workgroup and read the activations
         // once per 64 columns (N = 11008: M = 96 21.0 vs 23.9 us split-K, M = 128 22.4 vs 28.2; up to M = 64 the split-K tile
         // is ahead: 17.6 vs 18.5)
-        if (M > 64 && (N + 63) / 64 >= 160 && K >= 320) return {EETQ_PATH_MFMA, 0};
+        // ... and from M = 33 once the narrow tiles alone give EVERY CU a workgroup (round 5, held-out shapes of
+        // tools/auto_regret.py, us split-K / tiled at M = 48 and 64: 3584 x 18944 34.2 / 24.2, 35.3 / 24.9; 4096 x 28672 40.5 / 33.9,
+        // 43.4 / 35.1; 8192 x 57344 153 / 127, 169 / 128 -- the split-K tile doubles its row blocks at M = 33 and needs a second
+        // round of workgroups there; below 256 narrow tiles it stays ahead: 5120 x 13824 M = 64 22.7 / 25.9, 8192 x 10240 32.0 / 33.0)
+        const int tiles1 = (N + 63) / 64;
+        if (K >= 320 && ((M > 64 && tiles1 >= 160) || (M > 32 && tiles1 >= device_cu_count()))) return {EETQ_PATH_MFMA, 0};
         // few tiles, deep K, M > 96 (the split-K tile needs four row blocks there): K slices of the tiled kernel's 128 x 64
         // tile -- M = 128: 11008 x 4096 23.9 vs 27.1 us, 5120^2 20.1 vs 22.6 (tile_splitk_slices has the rule)
         if (M > 96 && act == 0) {
             const int S = tile_splitk_slices(M, N, K);
             if (S > 1) return {EETQ_PATH_TILESPLIT, use_splitk ? S : 1};
         }
+        // (few tiles, shallow K: the split-K tile cuts the batch into row groups instead -- splitk_plan / splitk_rows_plan)
         // narrower N: the split-K tile (K slices + in-launch deterministic reduction; N = K = 4096: M = 64 8.8 vs 11.2 us)
-        return {use_splitk ? EETQ_PATH_SPLITK : EETQ_PATH_MID, 0};
+        int r = 0;
+        if (!(use_splitk && splitk_rows_plan(M, N, K, &r))) r = 0;
+        return {use_splitk ? EETQ_PATH_SPLITK : EETQ_PATH_MID, r};
+    }
+    // 128 < M <= 1024 on few-tile shapes with a K too shallow to slice: the split-K tile with the batch cut into row groups of
+    // <= 64 rows, one round of workgroups, no reduction (gemm_splitk.hip::splitk_rows_plan: 4096^2 M = 256 20.8 -> 17.0 us,
+    // 5120^2 M = 192 22.6 -> 21.3); needs no scratch, so EETQ_AMD_SPLITK=0 does not switch it off
+    {
+        int r = 0;
+        if (splitk_rows_plan(M, N, K, &r) && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31)) return {EETQ_PATH_SPLITK, r};
     }
     // M > 128: the tiled kernel; with K slices when its tiles would leave most CUs idle (M = 256 at 11008 x 4096: 37.4 vs
     // 54.7 us) -- launch_gemm_tile_splitk applies the same rule and runs the unsplit kernel otherwise

@@ -295,6 +295,9 @@ int launch_gemm_splitk_i4(const f16* x, const uint8_t* w, const f16* scales, Epi
                           hipStream_t stream, bool env_plan = false);
 // *r (optional): row groups the batch is cut into (gemm_splitk_kernel.hpp: R); nb / s / stages are planned for ceil(M / r) rows
 void splitk_plan(int M, int N, int K, int* nb, int* s, int* stages, int* r = nullptr);
+// true (and *r = row groups) when the row-group plan of the split-K tile applies: 97 <= M <= 1024, its workgroups fit the chip at
+// once and the tiled kernel would not K-slice the shape (gemm_splitk.hip)
+bool splitk_rows_plan(int M, int N, int K, int* r = nullptr);
 // the calling stream's own split-K scratch region (gemm_splitk.hip): slabs (*slab_bytes of them), one ticket array per slice
 // count (2 and 4), *max_tiles tickets each.  EETQ_ERR_UNSUPPORTED (no message) when the stream cannot have one right now.
 int splitk_region(hipStream_t stream, float** slabs, size_t* slab_bytes, unsigned** tickets2, unsigned** tickets4, size_t* max_tiles);

@@ -269,8 +269,40 @@ int release_splitk_workspace(size_t* freed)
 // Reading: a slice costs about (its K steps) x (16*MT + 8*NB KiB per step at ~70 GB/s per CU) plus ~2 us for a 2-way and
 // ~3 us for a 4-way in-launch reduction, on top of ~2.3 us of launch + first-data latency; wide column blocks pay off when
 // the K loop is long (fewer re-reads of x) or the row tile is tall, narrow ones when the loop is short.
+// Row groups instead of K slices (round 5): the batch is cut along M into r groups of <= 64 rows, 64-column blocks, all of K per
+// workgroup -- (N / 64) * r workgroups, NO cross-workgroup reduction, the 3-deep ring (MT <= 2).  It applies when those
+// workgroups fit the chip at once and the K-sliced tiled kernel would not slice (few tiles but a shallow K: tile_splitk_slices
+// == 1); 32-row groups when even that leaves half the CUs idle.  Measured on two boxes (profiles/r05_splitk_rows_scan*.jsonl,
+// r05_tilesplit_forms_scan*.jsonl; us, AUTO before -> this plan): 4096^2 M = 112 14.85 -> 12.35, M = 128 15.29 -> 12.42,
+// M = 256 20.76 -> 17.04 (the tiled kernel K-sliced 2 x 32 steps: 17.2-17.6); 4096 x 6144 M = 128 19.98 -> 16.86; 5120^2
+// M = 160 22.38 -> 20.93, M = 192 22.63 -> 21.26; 4096^2 M = 160 / 192 16.45 / 16.92 -> 16.37 / 16.41.  Where it loses it is
+// not eligible: more than one round of workgroups (4096 x 6144 M = 160: 22.2 vs 18.7; 8192^2 M = 192: 45.8 vs 41.1) or a K the
+// tiled kernel slices (8192^2 M = 128: 32.4 vs 30.6 K-sliced; 11008 x 4096 M = 128: 25.4 vs 23.7).
+bool splitk_rows_plan(int M, int N, int K, int* r_out)
+{
+    if (M <= 96 || M > kSplitkMaxM || K % 64 != 0 || tile_splitk_slices(M, N, K) != 1 || wide_tile_splitk_slices(M, N, K) != 1)
+        return false;
+    const int ncu = device_cu_count(), tiles2 = (N + 63) / 64;
+    int       r   = (M + 63) / 64;  // 64-row groups (MT = 2)
+    if (tiles2 * r > ncu) return false;
+    const int r32 = (M + 31) / 32;  // 32-row groups when the 64-row ones leave half the chip idle
+    if (tiles2 * r * 2 <= ncu && tiles2 * r32 <= ncu) r = r32;
+    if (r_out) *r_out = r;
+    return true;
+}
+
 void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out, int* r_out)
 {
+    {
+        int r = 1;
+        if (r_out && splitk_rows_plan(M, N, K, &r)) {  // callers that cannot run row groups (no r_out) keep the K-slice plans
+            *nb_out     = 2;
+            *s_out      = 1;
+            *stages_out = 3;
+            *r_out      = r;
+            return;
+        }
+    }
     const int r0 = (M + 127) / 128;  // a row group holds at most 128 rows (MT <= 4)
     if (r_out) *r_out = r0;
     const int MT    = (M + 32 * r0 - 1) / (32 * r0);
@@ -356,7 +388,7 @@ int launch_gemm_splitk_i4(const f16* x, const uint8_t* w, const f16* scales, Epi
     EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K / 2 < (1ull << 31),
                  "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
     int nb, s, stages, r = 1;
-    splitk_plan(M, N, K, &nb, &s, &stages, &r);
+    splitk_plan(M, N, K, &nb, &s, &stages);  // (the row-group plan is measured for int8 tiles only: K slices here, r = 1)
     int ring = 11 * stages;
     if (const char* e = env_plan ? getenv("EETQ_AMD_SPLITK_PLAN") : nullptr) {
         int a = 0, b = 0, c = 0, d = 1;

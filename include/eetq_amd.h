@@ -322,7 +322,7 @@ int eetq_diag_stream_plan(int bits, int M, int N, int K, int cus, int* form, int
 /* Diagnostic, host arithmetic only (no launch): which kernel path EETQ_PATH_AUTO takes for an M x K activation against a K x N
  * weight of `bits` (8 / 4) on the current device.  *path = EETQ_PATH_* (for bits = 4: GEMV, STREAM, SPLITK, or MFMA = expansion to
  * int8 tiles + the W8A16 kernels); *detail (may be NULL) = K slices per tile when *path is EETQ_PATH_TILESPLIT (1 = the unsplit
- * tiled kernel), else 0.  It calls the function the launchers call.  Replaces, as far as anything does, the reference's run-time
+ * tiled kernel), row groups when *path is EETQ_PATH_SPLITK and its row-group plan applies (0 = a K-slice plan), else 0.  It calls the function the launchers call.  Replaces, as far as anything does, the reference's run-time
  * choice: the m <= 4 switch (fpA_intB_gemm_wrapper.cu:149-162) and the occupancy-scored tile pick
  * (cutlass_kernels/cutlass_heuristic.cc:123-206) -- one rule here, printed by bench.py's `config4` block per point and measured
  * against every forced path by tools/auto_regret.py. */

@@ -121,8 +121,16 @@ def test_auto_path_rule_on_a_256_cu_chip(lib):
             assert auto(8, M, N, K)[0] == STREAM
     assert auto(8, 17, 4096, 4096)[0] == SPLITK and auto(8, 64, 4096, 4096)[0] == SPLITK
     assert auto(8, 64, 11008, 4096)[0] == SPLITK and auto(8, 96, 11008, 4096)[0] == MFMA     # wide N, M > 64: the tiled kernel
+    # ... and from M = 33 once the 128 x 64 tiles alone give every CU a workgroup (N >= 64 * 256)
+    assert auto(8, 32, 18944, 3584)[0] == SPLITK and auto(8, 48, 18944, 3584)[0] == MFMA and auto(8, 64, 28672, 4096)[0] == MFMA
+    assert auto(8, 64, 13824, 5120)[0] == SPLITK
     assert auto(8, 128, 4096, 11008) == (TILESPLIT, 4) and auto(8, 128, 5120, 5120) == (TILESPLIT, 2)
     assert auto(8, 256, 4096, 11008) == (TILESPLIT, 2)
+    # few tiles, K too shallow to slice: the split-K tile with the batch cut into row groups (one round of workgroups, no reduction)
+    assert auto(8, 128, 4096, 4096) == (SPLITK, 4) and auto(8, 100, 4096, 4096) == (SPLITK, 4) and auto(8, 256, 4096, 4096) == (SPLITK, 4)
+    assert auto(8, 128, 6144, 4096) == (SPLITK, 2) and auto(8, 192, 5120, 5120) == (SPLITK, 3)
+    assert auto(8, 96, 4096, 4096) == (SPLITK, 0) and auto(8, 384, 4096, 4096) == (TILESPLIT, 1) and auto(8, 160, 6144, 4096) == (TILESPLIT, 1)
+    assert auto(8, 128, 8192, 8192) == (TILESPLIT, 2)                                            # a K the tiled kernel slices
     assert auto(8, 1024, 4096, 4096) == (TILESPLIT, 1) and auto(8, 4096, 4096, 4096) == (TILESPLIT, 1)   # unsplit tiled kernel
     assert auto(4, 1, 4096, 4096)[0] == GEMV and auto(4, 1, 8192, 8192)[0] == STREAM and auto(4, 8, 4096, 4096)[0] == STREAM
     assert auto(4, 64, 4096, 4096)[0] == SPLITK and auto(4, 1024, 4096, 4096)[0] == MFMA
@@ -137,7 +145,8 @@ def test_production_launches_read_no_tuning_variables():
     common.hpp::tuning_env (round-4 ADVICE / verdict weak 6)."""
     import re
     csrc = os.path.join(ROOT, "eetq_amd", "csrc")
-    allowed = {"EETQ_AMD_SPLITK", "EETQ_AMD_SPLITK_REGIONS", "EETQ_AMD_SPLITK_PLAN", "EETQ_AMD_TUNING"}
+    # (the two *_PLAN variables are honoured on the explicitly FORCED paths only: `env_plan`, checked below)
+    allowed = {"EETQ_AMD_SPLITK", "EETQ_AMD_SPLITK_REGIONS", "EETQ_AMD_SPLITK_PLAN", "EETQ_AMD_TILESPLIT_PLAN", "EETQ_AMD_TUNING"}
     hooks = set()
     for fn in sorted(os.listdir(csrc)):
         if not fn.endswith((".hip", ".hpp", ".cpp")):
@@ -153,6 +162,8 @@ def test_production_launches_read_no_tuning_variables():
     # the forced split-K plan is read on the explicitly forced path only (env_plan)
     sk = open(os.path.join(csrc, "gemm_splitk.hip")).read()
     assert sk.count('env_plan ? getenv("EETQ_AMD_SPLITK_PLAN")') == sk.count('getenv("EETQ_AMD_SPLITK_PLAN")') == 2
+    tk = open(os.path.join(csrc, "gemm.hip")).read()
+    assert tk.count('(env_plan && allowed) ? getenv("EETQ_AMD_TILESPLIT_PLAN")') == tk.count('getenv("EETQ_AMD_TILESPLIT_PLAN")') == 1
     # INTEGRATION.md lists every hook
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "EETQ_AMD_TUNING" in doc

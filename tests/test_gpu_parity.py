@@ -440,6 +440,84 @@ def test_splitk_every_plan(ops, oracle, K, N, M, plans):
         assert _tier_a(got, whole).all(), (nb, S, ring, np.abs(got.astype(np.float32) - whole.astype(np.float32)).max())
 
 
+@pytest.mark.parametrize("K,N,M,plans", [
+    # plans = (column blocks, K slices, ring, ROW GROUPS): the batch cut along M (round 5, gemm_splitk_kernel.hpp "R"): r groups of
+    # 32 * ceil(M / (32 r)) rows, each with its own slab / ticket unit when the plan also slices K
+    (4096, 4096, 128, [(2, 1, 33, 4), (1, 1, 33, 2), (2, 2, 33, 2), (2, 2, 22, 4), (1, 4, 22, 4)]),
+    (4096, 4096, 256, [(2, 1, 33, 4), (2, 1, 22, 8), (2, 2, 22, 2), (1, 2, 22, 3)]),
+    (4096, 4096, 100, [(2, 1, 33, 4), (2, 1, 33, 2), (1, 2, 22, 2)]),            # last group ragged: rows 96..99
+    (4096, 6144, 130, [(2, 1, 22, 2), (2, 1, 33, 3), (2, 2, 22, 5)]),            # last group: 2 rows / 34 rows
+    (4160, 4112, 200, [(1, 1, 22, 2), (2, 4, 22, 4), (1, 2, 33, 4)]),            # K % 256 != 0, N % 32 != 0
+    (2048, 1024, 512, [(2, 1, 22, 4), (2, 2, 22, 8), (1, 1, 33, 16)]),
+    (1024, 2048, 1000, [(2, 1, 22, 8), (2, 2, 33, 16), (1, 4, 22, 32)]),         # up to 32 groups (M <= 1024)
+])
+def test_splitk_row_groups(ops, oracle, K, N, M, plans):
+    """Row groups of the split-K tile, every combination with column blocks / K slices forced through
+    EETQ_AMD_SPLITK_PLAN="nb,s,ring,r": tier A against the oracle on rows of the first, a middle and the last group, tier A against
+    the tiled kernel on the whole output, the same bits from two launches, and the fused bias + residual epilogue bit-identical to
+    the separate adds (the residual pointer moves with the row group)."""
+    w, x = _rand_case(K, N, M, seed=K + N + M)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    rows = sorted(set([0, 31, 32, M // 2, M - 33 if M > 40 else 0, M - 1]))
+    ref = oracle.w8a16_gemm(x[rows], q, s)
+    whole = ops.w8_a16_gemm(xd, processed, scales, path="mfma").cpu().numpy()
+    torch.manual_seed(M)
+    bias = torch.randn(N, dtype=torch.float16, device=DEV)
+    res = torch.randn(M, N, dtype=torch.float16, device=DEV)
+    for nb, S, ring, r in plans:
+        os.environ["EETQ_AMD_SPLITK_PLAN"] = "%d,%d,%d,%d" % (nb, S, ring, r)
+        try:
+            y1 = ops.w8_a16_gemm(xd, processed, scales, path="splitk")
+            y2 = ops.w8_a16_gemm(xd, processed, scales, path="splitk")
+            y3 = ops.w8_a16_gemm(xd, processed, scales, path="splitk", bias=bias, residual=res)
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("EETQ_AMD_SPLITK_PLAN", None)
+        got = y1.cpu().numpy()
+        assert torch.equal(y1, y2), (nb, S, ring, r)
+        assert torch.equal(y3, (y1 + bias) + res), (nb, S, ring, r)
+        assert _tier_a(got[rows], ref).all(), (nb, S, ring, r)
+        assert _tier_a(got, whole).all(), (nb, S, ring, r, np.abs(got.astype(np.float32) - whole.astype(np.float32)).max())
+
+
+@pytest.mark.parametrize("K,N,M", [(4096, 4096, 100), (4096, 4096, 128), (4096, 4096, 256), (4096, 6144, 128), (5120, 5120, 192),
+                                   (4096, 4096, 192)])
+def test_auto_takes_the_row_group_plan_and_matches_the_oracle(ops, oracle, K, N, M):
+    """AUTO on few-tile shapes with a K too shallow to slice (eetq_diag_auto_path: SPLITK with row groups): oracle on sampled rows,
+    the tiled kernel on everything, graph capture (the plan needs no scratch) and bit-identical replays."""
+    import ctypes
+    from eetq_amd import _lib
+    p, d = ctypes.c_int(0), ctypes.c_int(0)
+    _lib.check(_lib.lib().eetq_diag_auto_path(8, M, N, K, ctypes.byref(p), ctypes.byref(d)))
+    assert (p.value, d.value > 0) == (5, True), (p.value, d.value)
+    w, x = _rand_case(K, N, M, seed=K + N + M)
+    q, s = oracle.quantize(w)
+    processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
+    scales = torch.from_numpy(s).to(DEV)
+    xd = torch.from_numpy(x).to(DEV)
+    rows = sorted(set([0, M // 3, M - 1]))
+    y = ops.w8_a16_gemm(xd, processed, scales)
+    assert _tier_a(y.cpu().numpy()[rows], oracle.w8a16_gemm(x[rows], q, s)).all()
+    assert _tier_a(y.cpu().numpy(), ops.w8_a16_gemm(xd, processed, scales, path="mfma").cpu().numpy()).all()
+    out = torch.empty_like(y)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ops.w8_a16_gemm_(xd, processed, scales, out, M, N, K)
+    torch.cuda.current_stream().wait_stream(side)
+    with torch.cuda.graph(g):
+        ops.w8_a16_gemm_(xd, processed, scales, out, M, N, K)
+    for _ in range(3):
+        out.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, y)
+
+
 @pytest.mark.parametrize("M,K,N", [(5, 64, 16), (8, 256, 128), (17, 128, 144), (64, 1024, 256), (128, 512, 128),
                                    (130, 192, 272), (300, 2048, 384), (8, 4096, 4096), (64, 4096, 1024),
                                    # narrow (128 x 64) and wide tiles with ragged edges: N below / not a multiple of the

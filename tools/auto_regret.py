@@ -46,7 +46,7 @@ def candidate_paths(M):
         out.append("gemv")
     if M <= 64:
         out.append("stream")
-    if 2 <= M <= 128:
+    if 2 <= M <= 1024:
         out.append("splitk")
     if 17 <= M <= 128:
         out.append("mid")
@@ -62,7 +62,7 @@ def measure(K, N, M, ws, s, min_seconds):
     x = torch.randn(M, K, dtype=torch.float16, device="cuda:0")
     row = {"K": K, "N": N, "M": M}
     name, detail = auto_path(M, N, K)
-    row["auto_path"] = name + ("/S=%d" % detail if name == "tilesplit" else "")
+    row["auto_path"] = name + ("/S=%d" % detail if name == "tilesplit" else "/rows=%d" % detail if name == "splitk" and detail else "")
     calls = max(2 * L, 40 if M <= 256 else 8)
     for path in ["auto"] + candidate_paths(M):
         def step(i, path=path):
