@@ -118,6 +118,20 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
             launch_kernel(kern, dim3(tiles), dim3(256), smem, stream, x + (size_t)m * K, wc, scales + c0, y + (size_t)m * N + c0,
                           rows, cols, K, N, e);
         };
+        // More wide tiles than CUs (M >= 2048 at N = 4096; M = 1024 at N = 11008): the persistent form -- one workgroup per CU
+        // walks its tiles and overlaps each tile's fixed cost with its neighbours' (gemm_kernel.hpp: PERSIST).
+        // EETQ_AMD_TILE_PERSIST=0 (with EETQ_AMD_TUNING=1) keeps one workgroup per tile (A/B runs).
+        static const bool persist_on = [] {
+            const char* en = tuning_env("EETQ_AMD_TILE_PERSIST");
+            return !(en && en[0] == '0');
+        }();
+        if (!narrow && e.act == 0 && persist_on && tiles2 > n_cu && K / BK >= PersistCfg::kMinKSteps && n_cu >= 8) {
+            static std::atomic<unsigned long long> opted_p{0};
+            int st = opt_in_large_lds(gemm_tile_persistent_kernel<2>, opted_p);
+            if (st != EETQ_OK) return st;
+            go(gemm_tile_persistent_kernel<2>, n_cu & ~7, PersistCfg::SMEM_BYTES);
+            return check_hip(hipGetLastError(), "gemm_tile_persistent_kernel launch");
+        }
         if (narrow && e.act == 0) go(gemm_tile_kernel<0, 1>, tiles1, TileCfg<1>::SMEM_BYTES);
         else if (narrow) go(gemm_tile_kernel<0, 1, true>, tiles1, TileCfg<1>::SMEM_BYTES);
         else if (e.act == 0) go(gemm_tile_kernel<0, 2>, tiles2, TileCfg<2>::SMEM_BYTES);

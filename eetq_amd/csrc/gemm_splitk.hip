@@ -134,7 +134,8 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         int st = opt_in_large_lds(kern, opted);
         if (st != EETQ_OK) return st;
     }
-    const int tiles = ((N + C::kBN - 1) / C::kBN) * R;  // slab / ticket units: one per (row group, column tile)
+    const int tiles_n = (N + C::kBN - 1) / C::kBN;
+    const int tiles   = tiles_n * R;  // slab / ticket units: one per (row group, column tile)
     float*    slabs   = nullptr;
     unsigned* tickets = nullptr;
     if (S > 1) {
@@ -153,7 +154,7 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     // With that fixed both occupancies are exact (tools/deepk_check.py: 812 forced plans, 0 wrong either way;
     // tools/experiments/sk_debug.py) and equally fast (tools/splitk_occupancy.py), so a split launch asks for what it uses.
     const size_t lds = C::kSmem;
-    launch_kernel(kern, dim3(tiles * S), dim3(C::kThreads), lds, stream, x, w, scales, y, M, N, K, S, R, slabs,
+    launch_kernel(kern, dim3(tiles_n * S, R), dim3(C::kThreads), lds, stream, x, w, scales, y, M, N, K, S, slabs,
                   tickets, ep);
     return check_hip(hipGetLastError(), "gemm_splitk_kernel launch");
 }

@@ -83,7 +83,7 @@ struct Cfg {
     static constexpr int kSlabFloats = kRows * kBN;                      // fp32 partial tile of one slice
 };
 
-// grid = tiles_n * R * S workgroups: R row groups of 32*MT rows each (R = 1: all of M in one row tile, M <= 32*MT -- rounds 2-4;
+// grid = (tiles_n * S, R) workgroups: R row groups of 32*MT rows each (R = 1: all of M in one row tile, M <= 32*MT -- rounds 2-4;
 // R > 1, round 5: the batch is cut along M instead of -- or on top of -- K, so a launch fills the chip WITHOUT a cross-workgroup
 // reduction: M = 64 at N = 4096 is 2 row groups x 128 column tiles = 256 workgroups of 32 rows x all of K; the price is that
 // each weight tile is pulled out of L2 by R workgroups, which the block-id map below makes neighbours on one XCD).
@@ -93,7 +93,7 @@ struct Cfg {
 template <int MT, int NB, int SA, int SB, bool KFULL, int W = 4, bool INTER = false, int BITS = 8>
 __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kSmem <= 80 * 1024 && MT * NB <= 4) ? 2 : 1) void gemm_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales, f16* __restrict__ y, int M,
-    int N, int K, int S, int R, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
+    int N, int K, int S, float* __restrict__ slabs, unsigned* __restrict__ counters, Epilogue ep)
 {
     using C = Cfg<MT, NB, SA, SB, W, BITS>;
     constexpr int TPS = C::kTilesPerStep;  // weight tiles per 16 columns and step
@@ -110,16 +110,19 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
 
     // ---- block id -> (column tile, K slice): a tile's slices are consecutive ids on one XCD when tiles_n % 8 == 0 ----
     const int tiles_n = (N + C::kBN - 1) / C::kBN;
-    int       tile, slice, rg;
+    // (shifts and masks only: S is 1, 2 or 4 and the row group is blockIdx.y.  The divisions by run-time S and R that stood here --
+    // two of them 64-bit -- were ~330 dependent scalar instructions ahead of the first DMA request, 0.7-1 us of every launch:
+    // gemm_mid_kernel, the same tile without them, ran 8.9 us where this kernel's unsplit plan ran 10.1, 4096 x 6144, M = 24)
+    const int sh = S == 4 ? 2 : (S == 2 ? 1 : 0);
+    const int rg = blockIdx.y;  // row group (gridDim.y = R); the groups of a column tile share block id % 8, i.e. an XCD
+    int       tile, slice;
     if ((tiles_n & 7) == 0) {
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-        slice = j % S;
-        rg    = (j / S) % R;
-        tile  = (j / (S * R)) * 8 + xcd;
+        slice = j & (S - 1);
+        tile  = (j >> sh) * 8 + xcd;
     } else {
-        slice = blockIdx.x % S;
-        rg    = (blockIdx.x / S) % R;
-        tile  = blockIdx.x / (S * R);
+        slice = blockIdx.x & (S - 1);
+        tile  = blockIdx.x >> sh;
     }
     const int n0 = tile * C::kBN;
     // row group rg: rows [rg * kRows, min(M, (rg + 1) * kRows)) of the batch -- from here on the kernel sees its own rows only
@@ -132,7 +135,7 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
     }
     const int vtile = rg * tiles_n + tile;  // slab / ticket index
     // K steps of this slice: [s0, s1); slices differ by at most one step
-    const int s0 = (int)(((long)steps_total * slice) / S), s1 = (int)(((long)steps_total * (slice + 1)) / S);
+    const int s0 = (steps_total * slice) >> sh, s1 = (steps_total * (slice + 1)) >> sh;
     const int n_tiles_total = N >> 4;
 
     const __amdgpu_buffer_rsrc_t x_rsrc =

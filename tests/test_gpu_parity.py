@@ -821,7 +821,8 @@ def test_fused_residual_is_bit_identical_to_separate_adds(ops, oracle, M, path):
                                                 ctypes.c_void_p(out.data_ptr()), M, N, K, 0,
                                                 ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)))
     torch.cuda.synchronize()
-    assert torch.equal(out, res + plain)
+    # (the C entry runs EETQ_PATH_AUTO, which need not be the kernel `path` names: M = 130 takes the row-group plan of the split-K tile)
+    assert torch.equal(out, res + ops.w8_a16_gemm(xd, processed, scales))
     with pytest.raises(RuntimeError):
         ops.w8_a16_gemm(xd, processed, scales, residual=res[:, :-16].contiguous())
 

@@ -214,4 +214,19 @@ def test_release_stream_workspace_returns_a_region_to_the_pool(ops):
         keep = ops.w8_a16_gemm(x, qw, s)
     torch.cuda.synchronize()
     assert torch.equal(late, ref) and torch.equal(keep, ref)
+    # the same through the Python operator surface (round-4 ADVICE: the release must be reachable from the bindings): stream 2 hands
+    # its region back, a stream that had none takes it over and runs the split plan
+    import eetq_amd.ops as top
+    fresh = torch.cuda.Stream()
+    fresh.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(fresh):
+        before = ops.w8_a16_gemm(x, qw, s)
+    torch.cuda.synchronize()
+    top.release_stream_workspace(streams[2])
+    top.release_stream_workspace()                         # current stream: owns region 0; released, re-acquired by the next call
+    with torch.cuda.stream(fresh):
+        after = ops.w8_a16_gemm(x, qw, s)
+    torch.cuda.synchronize()
+    assert _close(before, ref) and torch.equal(after, ref)
+    assert top.release_workspace() >= 40 << 20
     _lib.check(L.eetq_release_workspace(None))

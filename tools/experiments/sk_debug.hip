@@ -16,7 +16,7 @@ static int go(const f16* x, const uint8_t* w, const f16* scales, f16* y, int M, 
     auto kern = gemm_splitk::gemm_splitk_kernel<2, 1, 2, 2, KFULL, 4, false>;
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
     const int tiles = (N + C::kBN - 1) / C::kBN;
-    hipLaunchKernelGGL(kern, dim3(tiles * S), dim3(C::kThreads), lds, st, x, w, scales, y, M, N, K, S, 1, slabs, counters, Epilogue{});
+    hipLaunchKernelGGL(kern, dim3(tiles * S), dim3(C::kThreads), lds, st, x, w, scales, y, M, N, K, S, slabs, counters, Epilogue{});
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

@@ -362,13 +362,13 @@ static void bench_splitk(const char* name, int M, int N, int K, int S, const std
     auto st = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
             hipExtLaunchKernelGGL(kern, dim3(tiles * S), dim3(C::kThreads), C::kSmem, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, S, 1, slabs, tickets, eetq::Epilogue{});
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, M, N, K, S, slabs, tickets, eetq::Epilogue{});
         },
         200);
     const double g = time_graph(
         [&](int i, hipStream_t s) {
             hipLaunchKernelGGL(kern, dim3(tiles * S), dim3(C::kThreads), C::kSmem, s, x, (const uint8_t*)bufs[i % bufs.size()],
-                               scales, y, M, N, K, S, 1, slabs, tickets, eetq::Epilogue{});
+                               scales, y, M, N, K, S, slabs, tickets, eetq::Epilogue{});
         },
         200);
     printf("%-26s N=%5d K=%5d M=%3d BN=%2d S=%d ring %dx%d w%d wg=%4d | disp mean %6.2f med %6.2f min %6.2f | graph step %6.2f us -> %6.0f GB/s %6.1f TF (graph)\n",
