@@ -118,20 +118,6 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
             launch_kernel(kern, dim3(tiles), dim3(256), smem, stream, x + (size_t)m * K, wc, scales + c0, y + (size_t)m * N + c0,
                           rows, cols, K, N, e);
         };
-        // More wide tiles than CUs (M >= 2048 at N = 4096; M = 1024 at N = 11008): the persistent form -- one workgroup per CU
-        // walks its tiles and overlaps each tile's fixed cost with its neighbours' (gemm_kernel.hpp: PERSIST).
-        // EETQ_AMD_TILE_PERSIST=0 (with EETQ_AMD_TUNING=1) keeps one workgroup per tile (A/B runs).
-        static const bool persist_on = [] {
-            const char* en = tuning_env("EETQ_AMD_TILE_PERSIST");
-            return !(en && en[0] == '0');
-        }();
-        if (!narrow && e.act == 0 && persist_on && tiles2 > n_cu && K / BK >= PersistCfg::kMinKSteps && n_cu >= 8) {
-            static std::atomic<unsigned long long> opted_p{0};
-            int st = opt_in_large_lds(gemm_tile_persistent_kernel<2>, opted_p);
-            if (st != EETQ_OK) return st;
-            go(gemm_tile_persistent_kernel<2>, n_cu & ~7, PersistCfg::SMEM_BYTES);
-            return check_hip(hipGetLastError(), "gemm_tile_persistent_kernel launch");
-        }
         if (narrow && e.act == 0) go(gemm_tile_kernel<0, 1>, tiles1, TileCfg<1>::SMEM_BYTES);
         else if (narrow) go(gemm_tile_kernel<0, 1, true>, tiles1, TileCfg<1>::SMEM_BYTES);
         else if (e.act == 0) go(gemm_tile_kernel<0, 2>, tiles2, TileCfg<2>::SMEM_BYTES);
@@ -206,33 +192,6 @@ int wide_tile_splitk_slices(int M, int N, int K)
     return (tiles * 2 <= ncu && tiles * 4 > ncu && KT / 2 >= 80) ? 2 : 1;
 }
 
-namespace {
-// one (ring depth, workgroups per CU) form of the K-sliced 128 x 64 tile
-template <int ST, int OCC>
-int launch_tile_splitk_form(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K, int tiles,
-                            int S, float* slabs, unsigned* tickets, hipStream_t stream)
-{
-    auto kern = gemm_tile_splitk_kernel<1, ST, OCC>;
-    using C   = TileCfg<1, 2, ST>;
-    if (C::SMEM_BYTES > 64 * 1024) {
-        static std::atomic<unsigned long long> opted{0};
-        int st = opt_in_large_lds(kern, opted);
-        if (st != EETQ_OK) return st;
-    }
-    launch_kernel(kern, dim3(tiles * S), dim3(256), C::SMEM_BYTES, stream, x, w, scales, y, M, N, K, N, ep, S, slabs, tickets);
-    return check_hip(hipGetLastError(), "gemm_tile_splitk_kernel launch");
-}
-}  // namespace
-
-// ring depth / occupancy of a K-sliced launch of the 128 x 64 tile: slices of >= 40 steps keep the 6-deep ring of the unsplit
-// kernel (rounds 3-4); shorter slices take the short ring (TileCfg).  *st / *occ filled; see tile_splitk_slices for S.
-void tile_splitk_form(int steps_per_slice, int* st, int* occ)
-{
-    *st  = 6;
-    *occ = 1;
-    (void)steps_per_slice;
-}
-
 int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                             hipStream_t stream, int force_s, int* used_s, bool env_plan)
 {
@@ -248,21 +207,17 @@ int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, E
         wide = true;
     }
     const int KT = K / BK;
-    int ST = 6, OCC = 1;
-    if (!wide && S > 1) tile_splitk_form(KT / S, &ST, &OCC);
-    // EETQ_AMD_TILESPLIT_PLAN="S,ring,occ" overrides slices / ring depth / workgroups per CU on the explicitly FORCED path only
-    // (EETQ_PATH_TILESPLIT: tuning and tests of every instantiation, read per call); AUTO launches never read it
+    // EETQ_AMD_TILESPLIT_PLAN="S" overrides the slice count of the 128 x 64 tile on the explicitly FORCED path only
+    // (EETQ_PATH_TILESPLIT: tuning and tests, read per call); AUTO launches never read it
     if (const char* e = (env_plan && allowed) ? getenv("EETQ_AMD_TILESPLIT_PLAN") : nullptr) {
-        int a = 0, b = 6, c = 1;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &c) >= 1) {
+        int a = 0;
+        if (sscanf(e, "%d", &a) == 1) {
             S    = a;
-            ST   = b;
-            OCC  = c;
             wide = false;
         }
     }
     const bool fits = (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31);
-    if ((S != 2 && S != 4) || ep.act != 0 || !fits || K % BK != 0 || KT / S < ST - 1)
+    if ((S != 2 && S != 4) || ep.act != 0 || !fits || K % BK != 0 || KT / S < kMinKSteps)
         return launch_gemm_mfma(x, w, scales, ep, y, M, N, K, stream);
     const int BN    = wide ? TileCfg<2>::BN : TileCfg<1>::BN;
     const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
@@ -273,22 +228,16 @@ int launch_gemm_tile_splitk(const f16* x, const uint8_t* w, const f16* scales, E
     if (st == EETQ_ERR_UNSUPPORTED || (st == EETQ_OK && ((size_t)tiles > max_tiles || (size_t)tiles * S * BM * BN * 4 > slab_bytes)))
         return launch_gemm_mfma(x, w, scales, ep, y, M, N, K, stream);  // no scratch of its own for this stream: unsplit
     if (st != EETQ_OK) return st;
-    if (wide) {
-        static std::atomic<unsigned long long> opted_wide{0};
-        st = opt_in_large_lds(gemm_tile_splitk_kernel<2>, opted_wide);
-        if (st != EETQ_OK) return st;
+    static std::atomic<unsigned long long> opted{0}, opted_wide{0};
+    st = wide ? opt_in_large_lds(gemm_tile_splitk_kernel<2>, opted_wide) : opt_in_large_lds(gemm_tile_splitk_kernel<1>, opted);
+    if (st != EETQ_OK) return st;
+    if (wide)
         launch_kernel(gemm_tile_splitk_kernel<2>, dim3(tiles * S), dim3(256), TileCfg<2>::SMEM_BYTES, stream, x, w, scales, y, M, N, K, N,
                       ep, S, slabs, t2);
-        st = check_hip(hipGetLastError(), "gemm_tile_splitk_kernel launch");
-    } else {
-        unsigned* tk = S == 2 ? t2 : t4;
-        if (ST == 6 && OCC == 1) st = launch_tile_splitk_form<6, 1>(x, w, scales, ep, y, M, N, K, tiles, S, slabs, tk, stream);
-        else if (ST == 4 && OCC == 1) st = launch_tile_splitk_form<4, 1>(x, w, scales, ep, y, M, N, K, tiles, S, slabs, tk, stream);
-        else if (ST == 3 && OCC == 1) st = launch_tile_splitk_form<3, 1>(x, w, scales, ep, y, M, N, K, tiles, S, slabs, tk, stream);
-        else if (ST == 4 && OCC == 2) st = launch_tile_splitk_form<4, 2>(x, w, scales, ep, y, M, N, K, tiles, S, slabs, tk, stream);
-        else if (ST == 3 && OCC == 2) st = launch_tile_splitk_form<3, 2>(x, w, scales, ep, y, M, N, K, tiles, S, slabs, tk, stream);
-        else return fail(EETQ_ERR_INVALID, "[eetq_amd] tile split-K: no instantiation for this (ring depth, occupancy)");
-    }
+    else
+        launch_kernel(gemm_tile_splitk_kernel<1>, dim3(tiles * S), dim3(256), TileCfg<1>::SMEM_BYTES, stream, x, w, scales, y, M, N, K, N,
+                      ep, S, slabs, S == 2 ? t2 : t4);
+    st = check_hip(hipGetLastError(), "gemm_tile_splitk_kernel launch");
     if (st == EETQ_OK && used_s) *used_s = S;
     return st;
 }

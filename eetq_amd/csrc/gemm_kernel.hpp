@@ -24,36 +24,20 @@ __device__ unsigned long long* g_gemm_stamps = nullptr;
 
 constexpr int BM = 128, BK = 64;
 constexpr int A_STAGE_BYTES = BM * BK * 2;  // 16 KiB of fp16 activations per K step
-constexpr int STAGES        = 6;            // ring depth of the unsplit kernel (and the default of the K-sliced one)
+constexpr int STAGES        = 6;
 constexpr int kMinKSteps    = STAGES - 1;   // the statically unrolled drain needs K/64 >= 5
 // J = 32-column blocks per wave: J = 2 -> 128 x 128 tile (the MFMA-bound shape), J = 1 -> 128 x 64 tile (twice the
 // workgroups: fills the chip at 129 <= M <= 512 and trims the last partial round of tiles on other shapes)
 // CW = waves across the tile's columns (each owns 32*J of them); 2*CW waves per workgroup.  CW = 2: the round-1 geometry,
 // one wave per SIMD.  (J, CW) = (1, 4): the 128 x 128 tile on EIGHT waves, two per SIMD -- half the accumulators and half the
 // DMA pieces per wave, and a second wave on every SIMD to issue MFMAs while the first sits in an LDS-DMA issue or a barrier.
-// ST = ring depth.  6 (the unsplit kernel): five stages in flight cover the HBM latency of a 64-step loop.  3 / 4 (round 5, K slices
-// of 8..32 steps): a short slice spends as long filling and draining a 6-deep ring as it spends in it -- a shallower ring starts
-// multiplying after ONE stage has landed with 40-60 KiB less requested up front, and its 60 / 80 KiB of LDS lets two workgroups
-// share a CU, so one's fill / hand-over / store phases run under the other's loop.
-template <int J, int CW = 2, int ST = STAGES>
+template <int J, int CW = 2>
 struct TileCfg {
-    static_assert(ST >= 3 && ST <= 6, "ring depths with a wait schedule: 3..6");
     static constexpr int BN            = 32 * J * CW;
     static constexpr int WAVES         = 2 * CW;
     static constexpr int B_STAGE_BYTES = BN * BK;  // BN/16 native 1 KiB tiles per K step
     static constexpr int STAGE_BYTES   = A_STAGE_BYTES + B_STAGE_BYTES;
-    static constexpr int RING_BYTES    = ST * STAGE_BYTES;      // 144 / 120 KiB at ST = 6
-    // end of kernel: the second K half's parked accumulators, the fp16 image of the tile behind them, the ticket word
-    static constexpr int EPI_BYTES     = CW * (16 * J) * 64 * 16 + BM * (BN + 8) * 2 + 16;
-    static constexpr int SMEM_BYTES    = RING_BYTES > EPI_BYTES ? RING_BYTES : EPI_BYTES;
-    static constexpr int kMinKSteps    = ST - 1;                // the statically unrolled drain
-};
-
-// the persistent form of the wide tile: the six-slot ring, and behind slot 3 the scratch of its two-pass epilogue
-struct PersistCfg {
-    static constexpr int kMinKSteps = 16;
-    static constexpr int SMEM_BYTES = 4 * TileCfg<2>::STAGE_BYTES + 2 * (8 * 2) * 64 * 16 + 64 * (TileCfg<2>::BN + 8) * 2;  // 145 KiB
-    static_assert(SMEM_BYTES >= TileCfg<2>::RING_BYTES && SMEM_BYTES <= 160 * 1024, "ring and scratch within the CU's LDS");
+    static constexpr int SMEM_BYTES    = STAGES * STAGE_BYTES;  // 144 / 120 KiB (also covers the end-of-kernel reduction)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -111,24 +95,7 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // tiles meet in `slabs` ([tile][slice][BM * BN] floats, accumulator order) and the workgroup that draws the last of the tile's
 // S tickets adds them IN SLICE ORDER (replicas stay bit-identical) and runs the ordinary epilogue.  Same hand-over as
 // gemm_splitk_kernel.hpp: write-through stores, every wave drains them, barrier, one relaxed agent-scope ticket.
-template <int N_, typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>)
-{
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N_, typename F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    static_for_impl<N_>(f, std::make_integer_sequence<int, N_>{});
-}
-
-// PERSIST (gemm_tile_persistent_kernel below, round 5): ONE workgroup per CU walks the tiles b, b + G, b + 2G ... of the same
-// XCD-grouped order, and the fixed cost of a tile that a one-tile workgroup cannot hide -- the wait for the first stage (2.1 us of a
-// 35 us tile, tools/kbench_stamps gemmstamps), the completion of its row stores, the exit / dispatch of workgroups -- overlaps with
-// its neighbours: right behind the drain the next tile's first FOUR stages are requested into ring slots 0..3, the epilogue works
-// in two passes of 64 rows in a scratch area BEHIND those slots (slots 4, 5 and the 16 KiB above the ring: 32 KiB of parked
-// accumulators + a 17 KiB image per pass), the row stores of a tile complete under the first steps of the next.
-template <int ABLATE, int J, bool ACT, int CW, bool SPLIT, int ST = STAGES, bool PERSIST = false>
+template <int ABLATE, int J, bool ACT, int CW, bool SPLIT>
 __device__ __forceinline__ void gemm_tile_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep, int S, float* __restrict__ slabs,
@@ -136,8 +103,8 @@ __device__ __forceinline__ void gemm_tile_body(
 {
     // N = columns of THIS launch (w, scales, y, ep.* already point at its first column); ldc = row stride of y / residual
     EETQ_GEMM_STAMP(0);
-    using Cfg = TileCfg<J, CW, ST>;
-    constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES, RING_BYTES = Cfg::RING_BYTES, NW = Cfg::WAVES;
+    using Cfg = TileCfg<J, CW>;
+    constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES, NW = Cfg::WAVES;
     constexpr int APW = 16 / NW;  // activation DMA pieces (8 rows each) per wave and stage: 4 or 2
     constexpr int WN_COLS = 32 * J, PIECES = APW + J, NMFMA = 8 * J;
     static_assert(J == 1 || J == 2, "slot tables exist for J = 1 and J = 2");
@@ -153,35 +120,31 @@ __device__ __forceinline__ void gemm_tile_body(
     const int tiles_m = (M + BM - 1) / BM;
     const int tiles_n = (N + BN - 1) / BN;
     const int T       = tiles_m * tiles_n;
-    static_assert(!PERSIST || (J == 2 && CW == 2 && ST == 6 && !SPLIT && !ACT && ABLATE == 0), "the persistent form exists for the wide tile, identity epilogue");
     int       tile, slice = 0, k0 = 0, ksteps = KT;  // this workgroup's K steps: [k0, k0 + ksteps)
-    int       m0, n0;                                 // first row / column of the tile being multiplied
-    int       vnext = blockIdx.x;                     // PERSIST: position in the tile order of the tile to set up next
-    // position v in the XCD-grouped order -> tile -> (m0, n0).  SPLIT: T * S virtual tiles in the same order, a tile's slices next
-    // to each other (one XCD, one L2).  Tile order: row tiles in chunks of kGroupM, inside a chunk column-major.  The 32 workgroups
-    // resident on an XCD at a time are consecutive tiles = 4 row tiles x 8 column tiles: the footprint its L2 fetches over the
-    // fabric per K step (4 x 16 KiB activations + 8 x 8 KiB weights) is the smallest any 32-tile set has -- 64 MB per launch at
-    // M = 1024, N = K = 4096 instead of 84 MB for whole columns of row tiles.
-    auto place_tile = [&](int v, int& m_first, int& n_first) {
+    {
+        // SPLIT: T * S virtual tiles in the same XCD-grouped order, a tile's slices next to each other (one XCD, one L2)
         const int TT = SPLIT ? T * S : T;
-        const int q = TT >> 3, r = TT & 7, xcd = v & 7, idx = v >> 3;
+        const int b = blockIdx.x, q = TT >> 3, r = TT & 7, xcd = b & 7, idx = b >> 3;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        if constexpr (SPLIT) {  // S is 2 or 4: shifts, no run-time division (two 64-bit ones stood here: ~300 scalar instructions
-            const int sh = S == 4 ? 2 : 1;  // ahead of the first DMA request)
+        if constexpr (SPLIT) {  // S is 2 or 4: shifts, no run-time division (two 64-bit ones stood here until round 5: ~300
+            const int sh = S == 4 ? 2 : 1;  // dependent scalar instructions ahead of the first DMA request)
             const int vt = tile;
             tile   = vt >> sh;
             slice  = vt & (S - 1);
             k0     = (KT * slice) >> sh;
             ksteps = ((KT * (slice + 1)) >> sh) - k0;
         }
-        constexpr int kGroupM = 4;
-        const int chunk   = tile / (kGroupM * tiles_n);
-        const int in_ch   = tile - chunk * (kGroupM * tiles_n);
-        const int ch_rows = tiles_m - chunk * kGroupM < kGroupM ? tiles_m - chunk * kGroupM : kGroupM;
-        m_first = (chunk * kGroupM + in_ch % ch_rows) * BM;
-        n_first = (in_ch / ch_rows) * BN;
-    };
-    place_tile(vnext, m0, n0);
+    }
+    // tile order: row tiles in chunks of kGroupM, inside a chunk column-major.  The 32 workgroups resident on an
+    // XCD at a time are consecutive tiles = 4 row tiles x 8 column tiles: the footprint its L2 fetches over the fabric
+    // per K step (4 x 16 KiB activations + 8 x 8 KiB weights) is the smallest any 32-tile set has -- 64 MB per launch
+    // at M = 1024, N = K = 4096 instead of 84 MB for whole columns of row tiles.
+    constexpr int kGroupM = 4;
+    const int chunk   = tile / (kGroupM * tiles_n);
+    const int in_ch   = tile - chunk * (kGroupM * tiles_n);
+    const int ch_rows = tiles_m - chunk * kGroupM < kGroupM ? tiles_m - chunk * kGroupM : kGroupM;
+    const int m0 = (chunk * kGroupM + in_ch % ch_rows) * BM;
+    const int n0 = (in_ch / ch_rows) * BN;
 
     // descriptors start kShift bytes below the operands: a piece's voff is pre-compensated by -(its instruction
     // offset), and must stay non-negative for the hardware's range check
@@ -194,24 +157,21 @@ __device__ __forceinline__ void gemm_tile_body(
     // J*wave + i - APW of the stage's BN/16
     int       dma_voff[PIECES];
     const int n_tiles_total = N >> 4;
-    auto set_dma_offsets = [&]() {  // of the tile at (m0, n0)
 #pragma unroll
-        for (int i = 0; i < APW; ++i) {
-            const int p    = wave * APW + i;
-            const int row  = p * 8 + (lane >> 3);
-            const int slot = (lane & 7) ^ ((row >> 1) & 7);
-            int       gm   = m0 + row;
-            gm             = gm < M ? gm : M - 1;
-            dma_voff[i]    = (gm * K + slot * 8) * 2 + kShift - i * 1024;
-        }
+    for (int i = 0; i < APW; ++i) {
+        const int p    = wave * APW + i;
+        const int row  = p * 8 + (lane >> 3);
+        const int slot = (lane & 7) ^ ((row >> 1) & 7);
+        int       gm   = m0 + row;
+        gm             = gm < M ? gm : M - 1;
+        dma_voff[i]    = (gm * K + slot * 8) * 2 + kShift - i * 1024;
+    }
 #pragma unroll
-        for (int i = APW; i < PIECES; ++i) {
-            int nt      = (n0 >> 4) + wave * J + (i - APW);
-            nt          = nt < n_tiles_total ? nt : n_tiles_total - 1;
-            dma_voff[i] = nt * KT * kTileBytes + lane * 16 + kShift - (i - APW) * 1024;
-        }
-    };
-    set_dma_offsets();
+    for (int i = APW; i < PIECES; ++i) {
+        int nt      = (n0 >> 4) + wave * J + (i - APW);
+        nt          = nt < n_tiles_total ? nt : n_tiles_total - 1;
+        dma_voff[i] = nt * KT * kTileBytes + lane * 16 + kShift - (i - APW) * 1024;
+    }
     const int dma_lds_a = wave * APW * 1024;                  // + i * 1024
     const int dma_lds_b = A_STAGE_BYTES + wave * J * 1024;    // + (i - APW) * 1024
 
@@ -225,26 +185,20 @@ __device__ __forceinline__ void gemm_tile_body(
     const int c_b1 = c_b0 + 2048;
 
     f16x2 scale2[J];
-    auto load_scales = [&](f16x2 (&dst)[J]) {  // of the tile at n0
 #pragma unroll
-        for (int j = 0; j < J; ++j) {
-            const int ncol = n0 + wn * WN_COLS + 32 * j + fn;
-            const f16 sc   = scales[ncol < N ? ncol : N - 1];
-            dst[j]         = f16x2{sc, sc};
-        }
-    };
-    load_scales(scale2);
+    for (int j = 0; j < J; ++j) {
+        const int ncol = n0 + wn * WN_COLS + 32 * j + fn;
+        const f16 sc   = scales[ncol < N ? ncol : N - 1];
+        scale2[j]      = f16x2{sc, sc};
+    }
 
     f32x16 acc[4][J];
-    auto zero_acc = [&]() {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-            for (int j = 0; j < J; ++j)
+        for (int j = 0; j < J; ++j)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.f;
-    };
-    zero_acc();
+            for (int i = 0; i < 16; ++i) acc[mt][j][i] = 0.f;
 
     struct Frags {
         u32x4 wq[J];
@@ -256,7 +210,7 @@ __device__ __forceinline__ void gemm_tile_body(
 
     // ring state of the step about to run (wave-uniform): rd = LDS offset of the stage whose fragments it reads
     // (stage kt+1), wr = LDS offset its DMA fills (stage kt+5), ka / kb = source offsets of that stage
-    int rd = STAGE_BYTES, wr = (ST - 1) * STAGE_BYTES, ka = (k0 + ST - 1) * BK * 2, kb = (k0 + ST - 1) * kTileBytes;
+    int rd = STAGE_BYTES, wr = (STAGES - 1) * STAGE_BYTES, ka = (k0 + STAGES - 1) * BK * 2, kb = (k0 + STAGES - 1) * kTileBytes;
     int ra0 = rd + c_a0, ra1 = rd + c_a1, rb0 = rd + c_b0, rb1 = rd + c_b1;
 
     auto dma_piece = [&](auto itag) {
@@ -353,11 +307,11 @@ __device__ __forceinline__ void gemm_tile_body(
                 // ring state and read addresses of the next step, in the gaps that carry little else
                 // (after the step's last fragment read / last DMA piece: J = 2 gaps 12..15, J = 1 gaps 5..7)
                 if (i == (J == 2 ? 12 : 5)) {
-                    rd = rd + STAGE_BYTES == RING_BYTES ? 0 : rd + STAGE_BYTES;
+                    rd = rd + STAGE_BYTES == SMEM_BYTES ? 0 : rd + STAGE_BYTES;
                     asm volatile("" : "+s"(rd));
                 }
                 if (i == (J == 2 ? 13 : 6)) {
-                    wr = wr + STAGE_BYTES == RING_BYTES ? 0 : wr + STAGE_BYTES;
+                    wr = wr + STAGE_BYTES == SMEM_BYTES ? 0 : wr + STAGE_BYTES;
                     ka += BK * 2;
                     kb += kTileBytes;
                     asm volatile("" : "+s"(wr), "+s"(ka), "+s"(kb));
@@ -389,12 +343,10 @@ __device__ __forceinline__ void gemm_tile_body(
 
     // ---- prologue: STAGES-1 stages in flight; stage 0 -> fragments ----
     asm volatile("" ::"v"(scale2[0]));
-    // stages [S0, S1) of the tile dma_voff describes, into ring slots S0 .. S1 - 1 (KT >= ST - 1 by launch contract)
-    auto issue_stages = [&](auto s0_tag, auto s1_tag) {
-        constexpr int S0 = decltype(s0_tag)::value, S1 = decltype(s1_tag)::value;
-        int pwr = S0 * STAGE_BYTES, pka = (k0 + S0) * BK * 2, pkb = (k0 + S0) * kTileBytes;
+    {
+        int pwr = 0, pka = k0 * BK * 2, pkb = k0 * kTileBytes;
 #pragma unroll
-        for (int s = S0; s < S1; ++s) {
+        for (int s = 0; s < STAGES - 1; ++s) {  // KT >= STAGES - 1 by launch contract
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {  // plain form: voff carries -IMM, so the LDS address gets it back here
                 if (i < APW)
@@ -406,32 +358,12 @@ __device__ __forceinline__ void gemm_tile_body(
             pka += BK * 2;
             pkb += kTileBytes;
         }
-    };
-    issue_stages(std::integral_constant<int, 0>{}, std::integral_constant<int, ST - 1>{});
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PIECES) : "memory");  // stage 0 landed
-    Frags f0, f1;
-    WFrag w0, w1;
-    f16x2 scale2_next[J];  // PERSIST: the next tile's scales, requested while this tile multiplies
-    bool  first_tile = true;
-    for (;;) {  // PERSIST: one pass per tile of this workgroup; otherwise a single pass (break at the end)
-    if constexpr (PERSIST) {
-        if (!first_tile) {  // everything below was set up for this tile before the previous epilogue
-            zero_acc();
-            rd = STAGE_BYTES, wr = (ST - 1) * STAGE_BYTES, ka = (k0 + ST - 1) * BK * 2, kb = (k0 + ST - 1) * kTileBytes;
-            ra0 = rd + c_a0, ra1 = rd + c_a1, rb0 = rd + c_b0, rb1 = rd + c_b1;
-        }
     }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PIECES) : "memory");  // stage 0 landed
     __builtin_amdgcn_s_barrier();
     EETQ_GEMM_STAMP(1);
-    if constexpr (PERSIST) {
-        if (vnext + (int)gridDim.x < T) {  // the next tile's scales: two loads that return while this tile multiplies
-            const int keep_n0 = n0;
-            int       unused_m;
-            place_tile(vnext + (int)gridDim.x, unused_m, n0);
-            load_scales(scale2_next);
-            n0 = keep_n0;
-        }
-    }
+    Frags f0, f1;
+    WFrag w0, w1;
     {
         f0.wq[0] = lds_read16(c_b0);
         if constexpr (J == 2) f0.wq[1] = lds_read16(c_b1);
@@ -451,52 +383,26 @@ __device__ __forceinline__ void gemm_tile_body(
     }
 
     // REM = K steps after this one, clamped to STAGES-1.  REM >= STAGES-1: steady state (DMA for stage kt+STAGES-1).
-    // REM < 0 (PERSIST, steps 0..2 of a later tile): a steady step WITHOUT the wait -- its stage landed before the previous tile's
-    // row stores were issued, and those stores must not be waited for here
     auto k_step = [&](auto rem_tag, const WFrag& wcur, const Frags& fcur, WFrag& wnext, Frags& fnext) {
-        constexpr bool NOWAIT = decltype(rem_tag)::value < 0;
-        constexpr int  REM    = NOWAIT ? ST - 1 : decltype(rem_tag)::value;
+        constexpr int REM = decltype(rem_tag)::value;
         if constexpr (REM >= 1) {
-            constexpr int younger = (REM - 1) < (ST - 3) ? (REM - 1) : (ST - 3);
-            if constexpr (!(ABLATE & 1) && !NOWAIT) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger * PIECES) : "memory");
+            constexpr int younger = (REM - 1) < (STAGES - 3) ? (REM - 1) : (STAGES - 3);
+            if constexpr (!(ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger * PIECES) : "memory");
             if constexpr (!(ABLATE & 16)) __builtin_amdgcn_s_barrier();
-            step(wcur, fcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= ST - 1)>{});
+            step(wcur, fcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= STAGES - 1)>{});
         } else {
             step(wcur, fcur, std::false_type{}, fnext, wnext, std::false_type{});
         }
     };
-    using Steady = std::integral_constant<int, ST - 1>;
-    // the steady loop runs pairs of steps (the fragment buffers alternate); the drain is ST - 1 steps, plus one steady step when
-    // the pairs do not come out even
-    const int tail = ((ksteps - (ST - 1)) & 1) ? ST : ST - 1;
+    using Steady = std::integral_constant<int, STAGES - 1>;
+    const int tail = (ksteps & 1) ? 5 : 6;
     int       kt   = 0;
-    if constexpr (PERSIST) {
-        if (!first_tile) {  // stages 0..3 are in LDS, stage 4 was requested behind the previous tile's row stores (KT >= 16)
-            using NoWait = std::integral_constant<int, -1>;
-            k_step(NoWait{}, w0, f0, w1, f1);
-            k_step(NoWait{}, w1, f1, w0, f0);
-            k_step(NoWait{}, w0, f0, w1, f1);
-            k_step(Steady{}, w1, f1, w0, f0);
-            kt = 4;
-        }
-    }
     for (; kt < ksteps - tail; kt += 2) {
         k_step(Steady{}, w0, f0, w1, f1);
         k_step(Steady{}, w1, f1, w0, f0);
     }
     EETQ_GEMM_STAMP(2);
-    if constexpr (ST != 6) {
-        auto drain = [&](auto n_tag) {  // n steps with REM = n - 1 .. 0, buffers alternating from (w0, f0)
-            constexpr int n = decltype(n_tag)::value;
-            static_for<n>([&](auto i_tag) {
-                constexpr int i = decltype(i_tag)::value;
-                if constexpr (i % 2 == 0) k_step(std::integral_constant<int, n - 1 - i>{}, w0, f0, w1, f1);
-                else k_step(std::integral_constant<int, n - 1 - i>{}, w1, f1, w0, f0);
-            });
-        };
-        if (tail == ST) drain(std::integral_constant<int, ST>{});
-        else drain(std::integral_constant<int, ST - 1>{});
-    } else if (tail == 6) {
+    if (tail == 6) {
         k_step(std::integral_constant<int, 5>{}, w0, f0, w1, f1);
         k_step(std::integral_constant<int, 4>{}, w1, f1, w0, f0);
         k_step(std::integral_constant<int, 3>{}, w0, f0, w1, f1);
@@ -518,94 +424,6 @@ __device__ __forceinline__ void gemm_tile_body(
     // bytes per lane, whole 256-byte rows (4 rows per wave instruction), adding the residual on the way. ----
     EETQ_GEMM_STAMP(3);
     __builtin_amdgcn_s_barrier();
-    if constexpr (PERSIST) {
-        // ---- persistent form: set the next tile up and request its first four stages, then this tile's epilogue in two passes
-        // of 64 rows in the scratch area behind ring slot 3 ----
-        const int em0 = m0, en0 = n0;  // the tile just multiplied
-        vnext += (int)gridDim.x;
-        const bool has_next = vnext < T;  // wave-uniform
-        if (has_next) {
-            // (the compiler's wait for the two scale loads of this tile's first step lands here, where no DMA is in flight)
-            asm volatile("" ::"v"(scale2_next[0]), "v"(scale2_next[1]));
-            place_tile(vnext, m0, n0);
-            set_dma_offsets();
-#pragma unroll
-            for (int j = 0; j < J; ++j) scale2[j] = scale2_next[j];
-            issue_stages(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{});
-        }
-        constexpr int kScr       = 4 * STAGE_BYTES;          // ring slots 4, 5 and the 4.4 KiB above the ring
-        constexpr int kParkBytes = CW * (8 * J) * 64 * 16;    // two row blocks of the second K half: 32 KiB
-        constexpr int kRowHalfs  = BN + 8;
-        static_assert(kScr + kParkBytes + 64 * kRowHalfs * 2 <= PersistCfg::SMEM_BYTES, "scratch of the two-pass epilogue");
-        f32x4* red4  = reinterpret_cast<f32x4*>(smem + kScr) + (size_t)wn * (8 * J) * 64;  // [block][quad][lane]
-        f16*   image = reinterpret_cast<f16*>(smem + kScr + kParkBytes);
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {  // rows 64 p .. 64 p + 63 of the tile
-            if (p == 1) __syncthreads();  // pass 0's row stores have read the image
-            if (grp == 1) {
-#pragma unroll
-                for (int mt_ = 0; mt_ < 2; ++mt_)
-#pragma unroll
-                    for (int j = 0; j < J; ++j)
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            red4[((mt_ * J + j) * 4 + q) * 64 + lane] =
-                                f32x4{acc[2 * p + mt_][j][4 * q], acc[2 * p + mt_][j][4 * q + 1], acc[2 * p + mt_][j][4 * q + 2],
-                                      acc[2 * p + mt_][j][4 * q + 3]};
-            }
-            __syncthreads();
-            if (grp == 0) {
-#pragma unroll
-                for (int mt_ = 0; mt_ < 2; ++mt_)
-#pragma unroll
-                    for (int j = 0; j < J; ++j) {
-                        const int ncol = wn * WN_COLS + 32 * j + 4 * fh;  // tile-local column of quad 0
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const f32x4 o     = red4[((mt_ * J + j) * 4 + q) * 64 + lane];
-                            const float a4[4] = {acc[2 * p + mt_][j][4 * q + 0] + o.x, acc[2 * p + mt_][j][4 * q + 1] + o.y,
-                                                 acc[2 * p + mt_][j][4 * q + 2] + o.z, acc[2 * p + mt_][j][4 * q + 3] + o.w};
-                            // identity epilogue: round to fp16, then the fp16 bias add (the reference's `output + bias`)
-                            f16x2 lo = f16x2{(f16)a4[0], (f16)a4[1]}, hi = f16x2{(f16)a4[2], (f16)a4[3]};
-                            if (ep.bias && en0 + ncol + 8 * q < N) {
-                                const u32x2 b = *reinterpret_cast<const u32x2*>(ep.bias + en0 + ncol + 8 * q);
-                                lo            = lo + as_f16x2(b.x);
-                                hi            = hi + as_f16x2(b.y);
-                            }
-                            *reinterpret_cast<u32x2*>(image + (mt_ * 32 + fn) * kRowHalfs + ncol + 8 * q) = u32x2{as_u32(lo), as_u32(hi)};
-                        }
-                    }
-            }
-            __syncthreads();
-            // the prefetched stages have landed (requested a park + merge ago): from here on only row stores are in flight
-            if (p == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            constexpr int kLanesPerRow = BN / 8, kRowsPerWave = 64 / kLanesPerRow, kRowsPerRound = NW * kRowsPerWave;
-            const int     c            = (lane % kLanesPerRow) * 8;
-#pragma unroll
-            for (int r0 = 0; r0 < 64; r0 += kRowsPerRound) {
-                const int r = r0 + wave * kRowsPerWave + lane / kLanesPerRow;
-                const int m = em0 + 64 * p + r;
-                if (m < M && en0 + c < N) {
-                    u32x4 v = *reinterpret_cast<const u32x4*>(image + r * kRowHalfs + c);
-                    if (ep.residual) {
-                        const u32x4 rr = *reinterpret_cast<const u32x4*>(ep.residual + (size_t)m * ldc + en0 + c);
-                        v.x = as_u32(as_f16x2(v.x) + as_f16x2(rr.x));
-                        v.y = as_u32(as_f16x2(v.y) + as_f16x2(rr.y));
-                        v.z = as_u32(as_f16x2(v.z) + as_f16x2(rr.z));
-                        v.w = as_u32(as_f16x2(v.w) + as_f16x2(rr.w));
-                    }
-                    *reinterpret_cast<u32x4*>(y + (size_t)m * ldc + en0 + c) = v;
-                }
-            }
-        }
-        if (!has_next) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            return;
-        }
-        __syncthreads();  // every wave has read the image: ring slots 4 and 5 may be refilled
-        issue_stages(std::integral_constant<int, 4>{}, std::integral_constant<int, 5>{});
-        first_tile = false;
-    } else {
     f32x4* red4 = reinterpret_cast<f32x4*>(smem) + (size_t)wn * (16 * J) * 64;  // [block][quad][lane]
     if (grp == 1) {
 #pragma unroll
@@ -706,7 +524,7 @@ __device__ __forceinline__ void gemm_tile_body(
     }
     constexpr int kRowHalfs = BN + 8;                       // row stride of the image: 272 / 144 bytes (bank shift per row)
     f16* image = reinterpret_cast<f16*>(smem + CW * (16 * J) * 64 * 16);  // behind every column part's parked accumulators
-    static_assert(CW * (16 * J) * 64 * 16 + BM * kRowHalfs * 2 + 16 <= SMEM_BYTES, "the output image must fit behind the parked halves");
+    static_assert(CW * (16 * J) * 64 * 16 + BM * kRowHalfs * 2 <= SMEM_BYTES, "the output image must fit behind the parked halves");
     // who rounds which row blocks into the image: the K-half-0 waves all four -- or, after a split read-back, every wave the two
     // it summed (held in acc[0], acc[1])
     const bool summed = SPLIT && S > 1;
@@ -765,9 +583,6 @@ __device__ __forceinline__ void gemm_tile_body(
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     EETQ_GEMM_STAMP(5);
-    break;
-    }  // one tile per workgroup
-    }  // tiles of this workgroup
 }
 
 template <int ABLATE, int J, bool ACT = false, int CW = 2>
@@ -778,26 +593,19 @@ __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
     gemm_tile_body<ABLATE, J, ACT, CW, false>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
 }
 
-// One workgroup per CU (grid = min(tiles, CUs), a multiple of 8 or the tile count itself), each walking tiles b, b + grid, ...;
-// K / 64 >= 16; identity epilogue (bias / residual); LDS = PersistCfg::SMEM_BYTES.
-template <int J = 2>
-__global__ __launch_bounds__(256, 1) void gemm_tile_persistent_kernel(
-    const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
-{
-    gemm_tile_body<0, J, false, 2, false, STAGES, true>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
-}
-
-// grid = tiles * S workgroups; every slice must own >= ST - 1 K steps; counters: one per tile, shared only by launches
-// with the same S (they grow by S per launch; "last" is (old & (S-1)) == S-1), S in {2, 4} for J = 1, S = 2 for J = 2.
-// ST = ring depth (TileCfg), OCC = workgroups the register budget lets share a CU (2: <= 256 registers per lane, J = 1 only)
-template <int J, int ST = STAGES, int OCC = 1>
-__global__ __launch_bounds__(256, OCC) void gemm_tile_splitk_kernel(
+// Round 5, measured and shelved with their patch (tools/experiments/tile_ring_depth_and_persistent.patch): the
+// ring depth as a template parameter (3 / 4 slots with one or two workgroups per CU for short K slices: 3 slots 30-60 % slower,
+// 4 slots within +-2 % of 6) and a persistent form of the wide tile (one workgroup per CU walks its tiles, the next tile's stages
+// requested under a two-pass epilogue: bit-identical, 57.9 k cycles per tile against 58.0 k, 0.98-1.00 x the time).
+// grid = tiles * S workgroups; every slice must own >= kMinKSteps K steps; counters: one per tile, shared only by launches
+// with the same S (they grow by S per launch; "last" is (old & (S-1)) == S-1), S in {2, 4} for J = 1, S = 2 for J = 2
+template <int J>
+__global__ __launch_bounds__(256, 1) void gemm_tile_splitk_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep, int S, float* __restrict__ slabs,
     unsigned* __restrict__ counters)
 {
-    gemm_tile_body<0, J, false, 2, true, ST>(x, w, scales, y, M, N, K, ldc, ep, S, slabs, counters);
+    gemm_tile_body<0, J, false, 2, true>(x, w, scales, y, M, N, K, ldc, ep, S, slabs, counters);
 }
 
 }  // namespace gemm
