@@ -340,15 +340,16 @@ static AutoChoice auto_path_i8(int M, int N, int K, int act)
         // narrower N: the split-K tile (K slices + in-launch deterministic reduction; N = K = 4096: M = 64 8.8 vs 11.2 us)
         int r = 0;
         if (!(use_splitk && splitk_rows_plan(M, N, K, &r))) r = 0;
-        if (use_splitk && r == 0) {
-            // ... unless its plan is the round-1 tile's own decomposition -- 32-column blocks, all of K, all of M per workgroup, one
-            // round of workgroups: then gemm_mid_kernel, the same tile without the slicing machinery, is the leaner kernel (round 5,
-            // tools/auto_regret.py on three boxes, us split-K / mid: 4096 x 6144 M = 17 9.7-10.1 / 8.9, M = 64 12.8 / 12.1; 4096 x 5120
-            // M = 17 10.0 / 8.7; 4096 x 8192 10.4 / 9.3; 3584 x 18944 M = 17 18.0 / 17.2.  With more workgroups than CUs the
-            // split-K kernel's two-per-CU form is ahead instead: 4096 x 28672 M = 17 23.9 / 32.0)
-            int nb = 0, s = 0, stages = 0, rr = 1;
-            splitk_plan(M, N, K, &nb, &s, &stages, &rr);
-            if (nb == 1 && s == 1 && rr == 1 && (N + 31) / 32 <= device_cu_count()) return {EETQ_PATH_MID, 0};
+        // ... except where the round-1 tile's own decomposition -- 32-column blocks, all of K and all of M per workgroup --
+        // already gives more than half the CUs a workgroup in ONE round and K is too shallow for slices to pay (<= 16 steps of
+        // 256): gemm_mid_kernel runs that decomposition without the slicing machinery.  Round 5, tools/auto_regret.py on three
+        // boxes, us split-K / mid: 4096 x 5120 M = 17 9.6 / 8.7, M = 48 12.0 / 11.0; 4096 x 6144 M = 24 9.7 / 9.0, M = 64 12.7 /
+        // 12.1; 4096 x 8192 M = 32 10.4 / 9.9, M = 64 14.4 / 12.8.  Not at N = 4096 (128 blocks: two K slices fill the chip, 7.6 /
+        // 8.9), not at K = 5120 (5120 x 6144 M = 32 11.1 / 11.5) or deeper (7168^2 13.2 / 14.0), not above M = 64 (4096 x 6144
+        // M = 96 16.9 / 18.9).
+        if (r == 0 && M <= 64 && K <= 4096) {
+            const int blocks = (N + 31) / 32, ncu = device_cu_count();
+            if (2 * blocks > ncu && blocks <= ncu) return {EETQ_PATH_MID, 0};
         }
         return {use_splitk ? EETQ_PATH_SPLITK : EETQ_PATH_MID, r};
     }

@@ -389,7 +389,7 @@ int launch_gemm_splitk_i4(const f16* x, const uint8_t* w, const f16* scales, Epi
     EETQ_REQUIRE((size_t)M * K * 2 < (1ull << 31) && (size_t)N * K / 2 < (1ull << 31),
                  "operand larger than 2 GiB is not supported by the buffer-addressed DMA path");
     int nb, s, stages, r = 1;
-    splitk_plan(M, N, K, &nb, &s, &stages);  // (the row-group plan is measured for int8 tiles only: K slices here, r = 1)
+    splitk_plan(M, N, K, &nb, &s, &stages, &r);  // (incl. the row-group plan: the int4 tile has the int8 tile's geometry)
     int ring = 11 * stages;
     if (const char* e = env_plan ? getenv("EETQ_AMD_SPLITK_PLAN") : nullptr) {
         int a = 0, b = 0, c = 0, d = 1;

@@ -124,6 +124,9 @@ def test_auto_path_rule_on_a_256_cu_chip(lib):
     # ... and from M = 33 once the 128 x 64 tiles alone give every CU a workgroup (N >= 64 * 256)
     assert auto(8, 32, 18944, 3584)[0] == SPLITK and auto(8, 48, 18944, 3584)[0] == MFMA and auto(8, 64, 28672, 4096)[0] == MFMA
     assert auto(8, 64, 13824, 5120)[0] == SPLITK
+    # shallow K, more than half the CUs busy with 32-column blocks in one round, M <= 64: the round-1 tile without slicing machinery
+    assert auto(8, 24, 6144, 4096)[0] == MID and auto(8, 64, 8192, 4096)[0] == MID and auto(8, 48, 5120, 4096)[0] == MID
+    assert auto(8, 32, 4096, 4096)[0] == SPLITK and auto(8, 32, 6144, 5120)[0] == SPLITK and auto(8, 96, 6144, 4096)[0] == SPLITK
     assert auto(8, 128, 4096, 11008) == (TILESPLIT, 4) and auto(8, 128, 5120, 5120) == (TILESPLIT, 2)
     assert auto(8, 256, 4096, 11008) == (TILESPLIT, 2)
     # few tiles, K too shallow to slice: the split-K tile with the batch cut into row groups (one round of workgroups, no reduction)

@@ -284,6 +284,39 @@ def test_w4a16_splitk_every_plan(ops, oracle, K, N, M, plans):
         assert _tier_a(got, whole).all(), (nb, S, ring, np.abs(got.astype(np.float32) - whole.astype(np.float32)).max())
 
 
+@pytest.mark.parametrize("K,N,M,plans", [
+    (4096, 4096, 128, [(2, 1, 33, 4), (1, 1, 33, 2), (2, 2, 22, 4), None]),       # None = AUTO (takes the row-group plan here)
+    (4096, 6144, 100, [(2, 1, 33, 2), (1, 2, 22, 4), None]),
+    (2176, 1040, 120, [(2, 1, 22, 2), (1, 4, 22, 4), None]),                     # K % 256 != 0 (last step 128 deep), ragged N
+])
+def test_w4a16_splitk_row_groups(ops, oracle, K, N, M, plans):
+    """Row groups on int4 tiles (the int8 tile's geometry, gemm_splitk_kernel<..., BITS = 4>, blockIdx.y = row group): tier A against
+    the oracle on sampled rows, against the expansion route on the whole output, launch-to-launch bit identity."""
+    rng = np.random.default_rng(K + N + M)
+    qp = rng.integers(-128, 128, (K, N // 2), dtype=np.int8)
+    s = (rng.random(N) * 0.02 + 0.001).astype(np.float16)
+    x = (rng.random((M, K)) - 0.5).astype(np.float16)
+    pk = torch.from_numpy(oracle.gfx950_pack_i4(qp)).to(DEV)
+    xd, sd = torch.from_numpy(x).to(DEV), torch.from_numpy(s).to(DEV)
+    whole = ops.w8_a16_gemm(xd, pk, sd, path="mfma").cpu().numpy()
+    rows = sorted(set([0, 33, M // 2, M - 1]))
+    cols = slice(0, 256)
+    ref = oracle.w8a16_gemm(x[rows], np.ascontiguousarray(oracle.i4_values(qp)[:, cols]), s[cols])
+    for plan in plans:
+        if plan is not None:
+            os.environ["EETQ_AMD_SPLITK_PLAN"] = "%d,%d,%d,%d" % plan
+        try:
+            y1 = ops.w8_a16_gemm(xd, pk, sd, path="splitk" if plan is not None else "auto")
+            y2 = ops.w8_a16_gemm(xd, pk, sd, path="splitk" if plan is not None else "auto")
+            torch.cuda.synchronize()
+        finally:
+            os.environ.pop("EETQ_AMD_SPLITK_PLAN", None)
+        got = y1.cpu().numpy()
+        assert torch.equal(y1, y2), plan
+        assert _tier_a(got[rows][:, cols], ref).all(), plan
+        assert _tier_a(got, whole).all(), (plan, np.abs(got.astype(np.float32) - whole.astype(np.float32)).max())
+
+
 def test_w4a16_medium_batch_is_graph_capturable(ops, oracle):
     """The expansion route needed a per-stream scratch that cannot be created during capture; the int4 tile does not."""
     K, N, M = 2048, 1024, 64
