@@ -2,6 +2,7 @@
 //   (a) per-dispatch begin/end timestamps (hipExtLaunchKernelGGL start/stop events == what rocprof reports),
 //   (b) wall time per step of a HIP graph holding a chain of dependent launches.
 // Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-kernarg-preload-count=16 tools/kbench.hip -o tools/kbench
+//   (tools/kbench_stamps: the same with -DEETQ_KBENCH_STAMPS -- device-clock stamps inside the kernels)
 #include <hip/hip_ext.h>
 #include <hip/hip_runtime.h>
 
