@@ -254,12 +254,21 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         if (s0 + v + SB - 1 < s1) issue_b((v + SB - 1) % SB, s0 + v + SB - 1);
     }
     int bufa = 0, bufb = 0;
-    for (int step = s0; step < s1; ++step) {
+    int step = s0;
+    // One K step.  STEADY (shared rings, SA == SB; every step that still refills both rings): the wait is a CONSTANT and the DMA
+    // issue unconditional -- the general form below walks a compare-and-branch chain to pick its s_waitcnt and tests do_a / do_b
+    // every step, ~22 scalar instructions and up to seven branches in a step of ~600 cycles: against gemm_mid_kernel (the same
+    // tile, one branch per step) that was +13 % wave cycles on the same decomposition (profiles/r05_pmc_medium.txt: 4.26 M vs
+    // 3.77 M SQ_WAVE_CYCLES, 806 k vs 536 k scalar instructions; 10.9-11.4 vs 10.3-10.6 us per dispatch, 4096 x 6144, M = 24).
+    auto k_step = [&](auto steady_tag) {
+        constexpr bool STEADY = decltype(steady_tag)::value;
         // this wave's pieces of A(step) and B(step) have landed; everything issued after the later of the two may stay in
         // flight.  R = steps after this one.  SB > SA: the later one is A(step), issued one virtual step before B(step+SB-SA)
         // ...: younger = A(step+1 .. step+SA-2) and B(step+SB-SA .. step+SB-2), as far as they exist.  SB == SA: the later one
         // is B(step); younger = A and B of steps step+1 .. step+SA-2.
-        {
+        if constexpr (STEADY) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SA - 2) * (C::kAPW + C::kBPW)) : "memory");
+        } else {
             const int R  = s1 - 1 - step;
             const int ya = R < SA - 2 ? R : SA - 2;
             int       yb;
@@ -295,7 +304,7 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         }
         __builtin_amdgcn_sched_barrier(0);
         const int  bufa_next = bufa == 0 ? SA - 1 : bufa - 1, bufb_next = bufb == 0 ? SB - 1 : bufb - 1;  // buffers of step - 1
-        const bool do_a = step + SA - 1 < s1, do_b = step + SB - 1 < s1;
+        const bool do_a = STEADY || step + SA - 1 < s1, do_b = STEADY || step + SB - 1 < s1;
         constexpr int NC  = SN * NB * 2;                          // MFMA groups of a step (MT MFMAs each)
         constexpr int PPS = (C::kPieces + NC) / (NC + 1);         // DMA pieces per slot: slot 0 before the first group
         auto dma_slot = [&](int slot) {
@@ -352,7 +361,11 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         }
         bufa = bufa + 1 == SA ? 0 : bufa + 1;
         bufb = bufb + 1 == SB ? 0 : bufb + 1;
+    };
+    if constexpr (SA == SB) {
+        for (; step + SA - 1 < s1; ++step) k_step(std::true_type{});
     }
+    for (; step < s1; ++step) k_step(std::false_type{});
 
     // ---- add the W partial tiles through LDS; wave q < 4 then owns accumulator registers 4q..4q+3 of every block ----
     __syncthreads();
