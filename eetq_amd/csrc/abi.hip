@@ -342,11 +342,12 @@ static AutoChoice auto_path_i8(int M, int N, int K, int act)
         if (!(use_splitk && splitk_rows_plan(M, N, K, &r))) r = 0;
         // ... except where the round-1 tile's own decomposition -- 32-column blocks, all of K and all of M per workgroup --
         // already gives more than half the CUs a workgroup in ONE round and K is too shallow for slices to pay (<= 16 steps of
-        // 256): gemm_mid_kernel runs that decomposition without the slicing machinery.  Round 5, tools/auto_regret.py on three
-        // boxes, us split-K / mid: 4096 x 5120 M = 17 9.6 / 8.7, M = 48 12.0 / 11.0; 4096 x 6144 M = 24 9.7 / 9.0, M = 64 12.7 /
-        // 12.1; 4096 x 8192 M = 32 10.4 / 9.9, M = 64 14.4 / 12.8.  Not at N = 4096 (128 blocks: two K slices fill the chip, 7.6 /
-        // 8.9), not at K = 5120 (5120 x 6144 M = 32 11.1 / 11.5) or deeper (7168^2 13.2 / 14.0), not above M = 64 (4096 x 6144
-        // M = 96 16.9 / 18.9).
+        // 256): gemm_mid_kernel runs that decomposition without slicing machinery.  Round 5, tools/auto_regret.py
+        // (profiles/r05_auto_regret_midrule.jsonl, after the split-K tile's K loop lost its per-step branch chain), us split-K /
+        // mid: 4096 x 8192 M = 48 13.4 / 12.1, M = 64 14.3 / 12.9; 4096 x 7168 M = 64 13.1 / 12.3; 4096 x 6144 M = 48 11.8 /
+        // 11.3; 2048 x 8192 M = 64 7.9 / 7.7; equal within 1 % at M <= 32.  Not at N = 4096 (128 blocks: two K slices fill the
+        // chip, 7.3 / 8.9), not at K = 5120 (5120^2 M = 32 10.5 / 11.1) or deeper (7168^2 13.2 / 14.0), not above M = 64
+        // (4096 x 6144 M = 96 16.2 / 18.7).
         if (r == 0 && M <= 64 && K <= 4096) {
             const int blocks = (N + 31) / 32, ncu = device_cu_count();
             if (2 * blocks > ncu && blocks <= ncu) return {EETQ_PATH_MID, 0};

@@ -26,7 +26,7 @@ POINTS = [
     (4096, 4096, 256, "splitk"),         # row groups: 17.2 vs 20.7
     (4096, 6144, 8, "stream"),           # 6.6 vs 9.9
     (14336, 4096, 2, "stream"),          # 11.4 vs 12.2 (GEMV) / 14.1
-    (28672, 8192, 16, "stream"),         # 40.5 vs 44.5
+    (28672, 8192, 8, "stream"),          # 37.1 vs 43.0
 ]
 
 
