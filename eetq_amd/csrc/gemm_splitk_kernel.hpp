@@ -177,7 +177,8 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         for (int i = C::kAPW; i < C::kPieces; ++i) {
             const int b    = wave * C::kBPW + (i - C::kAPW);
             const int kt   = step * TPS + b % TPS;
-            const int back = kt < KTW ? 0 : (kt - (KTW - 1)) * kTileBytes;  // clamp to the last valid weight tile
+            // clamp to the last valid weight tile (KFULL: every step is whole, nothing to clamp -- and nothing to compute per step)
+            const int back = (KFULL || kt < KTW) ? 0 : (kt - (KTW - 1)) * kTileBytes;
             gemm::dma16(w_rsrc, dma_voff[i] - back, step * TPS * kTileBytes, sb + b * 1024);
         }
     };
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         } else if (do_b) {
             const int b    = wave * C::kBPW + (i - C::kAPW);
             const int kt   = (step + SB - 1) * TPS + b % TPS;
-            const int back = kt < KTW ? 0 : (kt - (KTW - 1)) * kTileBytes;
+            const int back = (KFULL || kt < KTW) ? 0 : (kt - (KTW - 1)) * kTileBytes;
             gemm::dma16(w_rsrc, dma_voff[i] - back, (step + SB - 1) * TPS * kTileBytes, smem + C::kARing + bufb_next * C::kBBytes + b * 1024);
         }
     };
