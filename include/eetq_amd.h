@@ -46,7 +46,8 @@ enum { EETQ_LAYOUT_ROW_MAJOR = 0, EETQ_LAYOUT_GFX950 = 1, EETQ_LAYOUT_SM80 = 2 }
 /* Kernel selection for eetq_w8a16_gemm_ex (tests and tuning).  AUTO is what eetq_w8a16_gemm uses. */
 enum { EETQ_PATH_AUTO = 0, EETQ_PATH_GEMV = 1 /* M <= 4 */, EETQ_PATH_MFMA = 2 /* LDS-tiled */, EETQ_PATH_STREAM = 3 /* M <= 64; AUTO uses it for 2..16 */,
        EETQ_PATH_MID = 4 /* M <= 128: 32-column tiles, 256-deep K steps */,
-       EETQ_PATH_SPLITK = 5 /* M <= 128: split-K tiles with an in-launch deterministic reduction */,
+       EETQ_PATH_SPLITK = 5 /* W8A16: M <= 1024 -- split-K tiles: K slices with an in-launch deterministic reduction and / or row groups
+                               of <= 128 rows (AUTO: 17 <= M <= 128, and the row-group plan on few-tile shapes up to M = 1024); W4A16: M <= 128 */,
        EETQ_PATH_TILESPLIT = 6 /* the LDS-tiled kernel with K slices per 128 x 64 tile (few tiles, deep K); unsplit when that does not apply */ };
 
 /* Activation of the fused bias + activation epilogue (eetq_w8a16_gemm_act).  Reference: ActivationType
