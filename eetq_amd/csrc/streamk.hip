@@ -101,7 +101,7 @@ inline StreamPlan regs_plan_i4(int N, int ncu)
 //                     then ring, 1 row, 16 waves (4096 x 11008 M = 4 11.10 -> 9.28, M = 6 11.19 -> 9.65, M = 8 11.41 -> 10.22; 4096 x
 //                     12288 M = 4 11.31 -> 9.84; the block copy falls off a cliff once its LDS leaves two workgroups per CU: M = 6 11.64)
 //   3 < rpc <= 4      ring, 2 rows, 8 waves   5120 x 13824 M = 4 14.16 -> 13.36, M = 8 14.97 -> 14.21; 4096 x 14336 M = 8 11.96 -> 11.60
-//   rpc > 4           ring, 1 row, 16 waves while M <= K / 1024 - 1, else 2 rows, 8 waves
+//   rpc > 4           ring, 1 row, 16 waves while M <= max(4, K / 1024 - 1), else 2 rows, 8 waves
 //                                             8192 x 28672 M = 2 40.5 -> 35.0, M = 4 40.7 -> 35.9; 5120 x 27648 M = 4 24.8 -> 23.7,
 //                                             M = 8 27.6 -> 25.7; 4096 x 22016 M = 8 16.77 -> 16.27
 // 9 <= M <= 16 (profiles/r04_stream_plan_sweep_m9to16.txt; the ring holds 16 rows, two DMAs per tile):
@@ -137,7 +137,10 @@ inline StreamPlan pick_plan(int M, int N, int K, int ncu, int nt0, bool eight0)
     }
     if (rows <= 3 * ncu) return (K % 128 == 0 && xbytes <= 24 * 1024) ? StreamPlan{1, 1, 8} : StreamPlan{2, 1, 16};
     if (rows <= 4 * ncu) return N % (2 * kTileN) == 0 ? StreamPlan{2, 2, 8} : StreamPlan{2, 1, 16};
-    return (M <= K / 1024 - 1 || N % (2 * kTileN) != 0) ? StreamPlan{2, 1, 16} : StreamPlan{2, 2, 8};
+    // (round 5: at least up to M = 4 whatever K is -- held-out shapes, tools/experiments/stream_plan_sweep.py, profiles/r05_stream_plan_heldout.jsonl:
+    // 3584 x 18944 M = 4 ring,1,16 12.69 vs ring,2,8 13.65 us; 4096 x 28672 M = 4 19.88 vs 20.50; costs 4096 x 22016 M = 4 16.02 vs 15.88)
+    const int m_one_row = K / 1024 - 1 > 4 ? K / 1024 - 1 : 4;
+    return (M <= m_one_row || N % (2 * kTileN) != 0) ? StreamPlan{2, 1, 16} : StreamPlan{2, 2, 8};
 }
 
 // W4A16 (K / 128 >= 32, i.e. K >= 4096), read off profiles/r04_stream_plan_sweep_i4.txt and checked against the register form in

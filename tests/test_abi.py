@@ -80,7 +80,8 @@ def test_small_batch_plan_rule_on_a_256_cu_chip(lib):
         (3, 5120, 5120): (REGS, 2, 8), (10, 5120, 5120): (REGS, 2, 8), (12, 5120, 5120): (RING, 2, 8), (4, 5120, 13824): (REGS, 2, 8),
         (4, 8192, 8192): (RING, 1, 8), (6, 8192, 8192): (REGS, 2, 8), (4, 8192, 28672): (REGS, 2, 8),     # N = 32 * CUs: K <= 8192, M <= 5
         (8, 13824, 5120): (RING, 2, 8), (2, 14336, 4096): (RING, 2, 8), (4, 14352, 4096): (RING, 1, 16),  # 897 tile rows: odd
-        (2, 28672, 8192): (RING, 1, 16), (7, 28672, 8192): (RING, 1, 16), (8, 28672, 8192): (RING, 2, 8), (4, 22016, 4096): (RING, 2, 8),
+        (2, 28672, 8192): (RING, 1, 16), (7, 28672, 8192): (RING, 1, 16), (8, 28672, 8192): (RING, 2, 8), (4, 22016, 4096): (RING, 1, 16),
+        (5, 22016, 4096): (RING, 2, 8), (4, 18944, 3584): (RING, 1, 16), (4, 28672, 4096): (RING, 1, 16), (8, 28672, 4096): (RING, 2, 8),
         (3, 22016, 4096): (RING, 1, 16), (16, 28672, 8192): (RING, 2, 8),
         (4, 4096, 1024): (REGS, 1, 8), (4, 4096, 256): (REGS, 1, 4), (4, 64, 128): (REGS, 1, 1),         # K / 64 < 32: fixed instantiations
     }
