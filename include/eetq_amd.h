@@ -76,7 +76,10 @@ enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SIL
  * eetq_quantize_i8 (ABI revision 1, kept): no size argument, and revision 1 documented the workspace as N floats -- a
  *   caller-provided workspace is therefore treated as exactly N floats (the atomicMax route); NULL as above.  Callers that
  *   allocate eetq_quantize_workspace_floats() floats should move to eetq_quantize_i8_ws to get the faster route. */
-#define EETQ_AMD_ABI_VERSION 2
+/* Revision history: 1 = round 1-2; 2 = eetq_quantize_i8_ws (sized workspace), eetq_release_stream_workspace, eetq_w4a16_gemm_ex;
+ * 3 = eetq_diag_auto_path, EETQ_PATH_SPLITK accepts M <= 1024 (row groups).  Revisions only ADD entry points: a caller built
+ * against an older header keeps working. */
+#define EETQ_AMD_ABI_VERSION 3
 int eetq_abi_version(void);   /* EETQ_AMD_ABI_VERSION of the loaded library */
 int eetq_quantize_i8_ws(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
                         int layout, void* scales, float* workspace, size_t workspace_floats, void* stream);
