@@ -309,18 +309,11 @@ struct AutoChoice {
 
 static AutoChoice auto_path_i8(int M, int N, int K, int act)
 {
-    // M = 1 -> wave-reduction GEMV (no MFMA) ...
-    if (M == 1) {
-        // ... except K = 4096 with 1.3 < tile rows per CU <= 2 (N = 6144 ... 8192 on 256 CUs: Llama-3-8B's fused q|k|v): the
-        // GEMV's straight-line 16-wave form needs a second, partly empty round of workgroups there and its 8-column units only
-        // balance 1.5 rows per CU (N = 6144 6.4-6.6 us, but N = 7168 / 8192 7.6 / 7.6 vs 7.1 / 7.3); the small-batch kernel run
-        // with one row takes all three: tools/auto_regret.py on three boxes, us GEMV / stream: 4096 x 6144 6.78-6.86 / 6.37-6.43,
-        // 4096 x 7168 7.02-7.09 / 6.79-7.07, 4096 x 8192 7.28-7.33 / 7.10-7.17 (profiles/r05_m1_default.jsonl, r05_auto_regret_*).
-        // Other K keep the GEMV (5120 x 6144 7.32 / 7.42, 8192 x 6144 10.2 / 10.4).
-        const int rows = N / kTileN, ncu = device_cu_count();
-        if (K == 4096 && N % kTileN == 0 && 10 * rows > 13 * ncu && rows <= 2 * ncu) return {EETQ_PATH_STREAM, 0};
-        return {EETQ_PATH_GEMV, 0};
-    }
+    // M = 1 -> wave-reduction GEMV (no MFMA).  (Round 5 tried the small-batch kernel for K = 4096 with 1.3 < tile rows per CU <= 2 --
+    // Llama-3-8B's fused q|k|v, 4096 x 6144: 6.8 -> 6.4 us, the one M = 1 point above 5 % in tools/auto_regret.py -- and took it
+    // back: the GEMV entry points with fused prologues / epilogues (norm, glu8, the compiled decode layer) promise the bits of the
+    // plain M = 1 projection, which therefore has to stay on the GEMV kernel too: tests/test_gpu_glu.py.)
+    if (M == 1) return {EETQ_PATH_GEMV, 0};
     // One row tile (2 <= M <= 16): the MFMA stream kernel (same weight stream as the GEMV, activation rows through a per-wave
     // LDS ring or a per-workgroup copy: streamk.hip::pick_plan) on every shape (us stream / split-K at M = 16: 4096 x 11008
     // 12.60 / 12.74, 11008 x 4096 12.48 / 13.15, 8192^2 13.9 / 18.5, 28672 x 8192 41.8 / 46.9; the other way only 5120 x 27648

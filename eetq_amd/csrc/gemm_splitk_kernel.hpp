@@ -256,7 +256,7 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
     }
     int bufa = 0, bufb = 0;
     int step = s0;
-    // One K step.  STEADY (shared rings, SA == SB; every step that still refills both rings): the wait is a CONSTANT and the DMA
+    // One K step.  STEADY (every step that still refills both rings): the wait is a CONSTANT and the DMA
     // issue unconditional -- the general form below walks a compare-and-branch chain to pick its s_waitcnt and tests do_a / do_b
     // every step, ~22 scalar instructions and up to seven branches in a step of ~600 cycles: against gemm_mid_kernel (the same
     // tile, one branch per step) that was +13 % wave cycles on the same decomposition (profiles/r05_pmc_medium.txt: 4.26 M vs
@@ -267,8 +267,8 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         // flight.  R = steps after this one.  SB > SA: the later one is A(step), issued one virtual step before B(step+SB-SA)
         // ...: younger = A(step+1 .. step+SA-2) and B(step+SB-SA .. step+SB-2), as far as they exist.  SB == SA: the later one
         // is B(step); younger = A and B of steps step+1 .. step+SA-2.
-        if constexpr (STEADY) {
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SA - 2) * (C::kAPW + C::kBPW)) : "memory");
+        if constexpr (STEADY) {  // R >= SB - 1: ya = SA - 2, yb = SA - 2 (shared rings) / SA - 1 (deeper weight ring)
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((SA - 2) * C::kAPW + (SB > SA ? SA - 1 : SA - 2) * C::kBPW) : "memory");
         } else {
             const int R  = s1 - 1 - step;
             const int ya = R < SA - 2 ? R : SA - 2;
@@ -363,9 +363,7 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         bufa = bufa + 1 == SA ? 0 : bufa + 1;
         bufb = bufb + 1 == SB ? 0 : bufb + 1;
     };
-    if constexpr (SA == SB) {
-        for (; step + SA - 1 < s1; ++step) k_step(std::true_type{});
-    }
+    for (; step + SB - 1 < s1; ++step) k_step(std::true_type{});  // (SB >= SA: both rings are still being refilled)
     for (; step < s1; ++step) k_step(std::false_type{});
 
     // ---- add the W partial tiles through LDS; wave q < 4 then owns accumulator registers 4q..4q+3 of every block ----
