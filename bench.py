@@ -105,6 +105,8 @@ def capture_graphs(fn, nsteps, nbuf, min_launches=GRAPH_MIN_LAUNCHES):
         fn(0, 3)  # warm the capture stream / lazy init outside capture
     torch.cuda.current_stream().wait_stream(s)
     torch.cuda.synchronize()
+    from eetq_amd import ops as _ops
+    _ops.release_stream_workspace(s)   # the warm-up stream's split-K scratch region, if it took one (config4 captures 15 graphs)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for first in range(0, length, nsteps):

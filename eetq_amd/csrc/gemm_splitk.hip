@@ -186,11 +186,6 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
         EETQ_RING(1, 3, 3)
         EETQ_RING(2, 3, 3)
     }
-    if constexpr (BITS == 8 && MT <= 2) {  // deeper WEIGHT rings (forced plans only, round 5: tools/experiments/splitk_deep_rings.py)
-        EETQ_RING(1, 3, 8)
-        EETQ_RING(2, 3, 4)
-        if constexpr (MT == 1) { EETQ_RING(2, 3, 6) }
-    }
 #undef EETQ_RING
     return fail(EETQ_ERR_INVALID, "[eetq_amd] split-K: no instantiation for this (column blocks, ring) plan");
 }

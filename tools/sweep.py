@@ -29,6 +29,9 @@ def chain_us(step, calls_per_graph, min_seconds=0.03):
             step(i)
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
+    # the warm-up stream took a split-K scratch region if `step` runs a K-sliced kernel: hand it back (16 regions per device, never
+    # reclaimed by the library on its own; the captured launches below run on torch's one capture stream, which keeps its region)
+    ops.release_stream_workspace(side)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for i in range(calls_per_graph):
