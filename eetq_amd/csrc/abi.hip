@@ -318,11 +318,21 @@ static AutoChoice auto_path_i8(int M, int N, int K, int act)
     // LDS ring or a per-workgroup copy: streamk.hip::pick_plan) on every shape (us stream / split-K at M = 16: 4096 x 11008
     // 12.60 / 12.74, 11008 x 4096 12.48 / 13.15, 8192^2 13.9 / 18.5, 28672 x 8192 41.8 / 46.9; the other way only 5120 x 27648
     // from M = 13, 29.9 / 29.0)
-    if (M <= 16) return {EETQ_PATH_STREAM, 0};
     static const bool use_splitk = [] {  // EETQ_AMD_SPLITK=0 keeps the unsplit kernels (the split forms own per-stream scratch)
         const char* e = getenv("EETQ_AMD_SPLITK");
         return !(e && e[0] == '0');
     }();
+    if (M <= 16) {
+        // ... except a narrow, deep weight from M = 9 (a GQA k / v projection: Llama-3-70B 8192 x 1024): the stream kernel has one
+        // workgroup per 16 columns -- N <= 2048 leaves at least half the CUs without one -- and walks all of K in each, while the
+        // split-K tile cuts K and fills the chip; from M = 9 the stream kernel also needs its 16-row ring.  tools/auto_regret.py
+        // (profiles/r05_auto_regret_small_n.jsonl), us stream / split-K: 8192 x 1024 M = 9 7.4 / 6.8, M = 16 8.3 / 6.8; 7168 x 1024
+        // M = 12 7.2 / 6.5; 14336 x 1024 M = 9 11.3 / 9.0, M = 16 13.2 / 9.0; 8192 x 2048 M = 12 8.0 / 7.6, M = 16 8.7 / 7.7.  A shallow
+        // K keeps the stream kernel (4096 x 1024 M = 16 5.3 / 6.3, 5120 x 1280 M = 12 5.9 / 5.9), as does M <= 8 (8192 x 1024 6.6 / 6.8).
+        if (M >= 9 && use_splitk && K >= 7168 && 2 * (N / kTileN) <= device_cu_count() && (size_t)N * K < (1ull << 31))
+            return {EETQ_PATH_SPLITK, 0};
+        return {EETQ_PATH_STREAM, 0};
+    }
     if (M <= kMidMaxM && (size_t)M * K * 2 < (1ull << 31) && (size_t)N * K < (1ull << 31)) {
         // wide N, M > 64: the 128 x 64 tiles of the tiled kernel already give most CUs a workgroup and read the activations
         // once per 64 columns (N = 11008: M = 96 21.0 vs 23.9 us split-K, M = 128 22.4 vs 28.2; up to M = 64 the split-K tile

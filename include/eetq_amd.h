@@ -317,7 +317,7 @@ int eetq_diag_empty(void* sink, int grid, int block, void* stream);
  * evidence for "power-bound").  Graph-capturable. */
 int eetq_diag_clock_stamp(unsigned long long* out, int grid, void* stream);
 /* Diagnostic, host arithmetic only (no launch; with cus > 0 no device either): which plan the small-batch kernel (1 <= M <= 16 rows;
- * AUTO sends 2 <= M <= 16 there) takes for a weight of `bits` (8 / 4), K x N, on a chip with `cus` compute units (<= 0: the current
+ * AUTO sends 2 <= M <= 16 there, except narrow deep W8A16 weights from M = 9: eetq_diag_auto_path) takes for a weight of `bits` (8 / 4), K x N, on a chip with `cus` compute units (<= 0: the current
  * device's).  *form = 0 activation fragments straight from L2 into registers, 1 rows copied once per workgroup into LDS, 2 per-wave
  * LDS-DMA ring; *tile_rows = 16-column tile rows per workgroup (1 / 2); *waves = waves per workgroup.  All plans give the same bits
  * at equal *waves.  The environment overrides (EETQ_AMD_I8_STREAM_PLAN ...) are not applied.  No reference counterpart: the

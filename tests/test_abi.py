@@ -121,6 +121,9 @@ def test_auto_path_rule_on_a_256_cu_chip(lib):
         assert auto(8, 1, N, K)[0] == GEMV
         for M in (2, 4, 8, 16):
             assert auto(8, M, N, K)[0] == STREAM
+    # a narrow, deep weight (GQA k / v projection) from M = 9: K slices fill the chip where N / 16 workgroups cannot
+    assert auto(8, 9, 1024, 8192)[0] == SPLITK and auto(8, 16, 2048, 8192)[0] == SPLITK and auto(8, 12, 1024, 14336)[0] == SPLITK
+    assert auto(8, 8, 1024, 8192)[0] == STREAM and auto(8, 16, 1024, 4096)[0] == STREAM and auto(8, 16, 3072, 8192)[0] == STREAM
     assert auto(8, 17, 4096, 4096)[0] == SPLITK and auto(8, 64, 4096, 4096)[0] == SPLITK
     assert auto(8, 64, 11008, 4096)[0] == SPLITK and auto(8, 96, 11008, 4096)[0] == MFMA     # wide N, M > 64: the tiled kernel
     # ... and from M = 33 once the 128 x 64 tiles alone give every CU a workgroup (N >= 64 * 256)
