@@ -51,7 +51,12 @@ __global__ __launch_bounds__(kThreads, (STAGES == 2 && MT <= 2) ? 2 : 1) void ge
     const int steps = (KT + 3) >> 2;
 
     const int tiles_n = (N + kBN - 1) / kBN;
-    const int n0      = (blockIdx.x % tiles_n) * kBN;
+    // block b runs on XCD b % 8 (when the dispatcher deals them round-robin): every XCD takes one contiguous eighth of the column
+    // tiles, as in gemm_splitk_kernel.hpp (round 5; together with the scale wait below -0.4 .. -2.9 % on the shapes AUTO runs
+    // here, tools/experiments/ab_lib.py on one box: 4096 x 6144 M = 24 9.13 -> 8.86 us, 2048 x 8192 M = 64 7.95 -> 7.78)
+    int ct = blockIdx.x % tiles_n;
+    if ((tiles_n & 7) == 0) ct = (ct & 7) * (tiles_n >> 3) + (ct >> 3);
+    const int n0      = ct * kBN;
     const int m0      = (blockIdx.x / tiles_n) * C::kRows;
     const int n_tiles_total = N >> 4;
 
@@ -118,8 +123,11 @@ __global__ __launch_bounds__(kThreads, (STAGES == 2 && MT <= 2) ? 2 : 1) void ge
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[mt][i] = 0.f;
 
-    asm volatile("" ::"v"(scale2));
     issue_stage(0, 0);
+    // (the scales were asked for ahead of the first stage and return ahead of it: the wait for them -- the K loop below must not
+    // contain one the compiler counts -- stands BEHIND the stage's requests, so a cold scale read runs under the stage's latency
+    // instead of in front of it; gemm_splitk_kernel.hpp has the measurement)
+    asm volatile("" ::"v"(scale2));
     if (C::kStages == 3 && steps > 1) issue_stage(1, 1);
     int buf = 0;
     for (int step = 0; step < steps; ++step) {

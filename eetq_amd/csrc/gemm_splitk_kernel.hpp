@@ -117,9 +117,13 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
     const int rg = blockIdx.y;  // row group (gridDim.y = R); the groups of a column tile share block id % 8, i.e. an XCD
     int       tile, slice;
     if ((tiles_n & 7) == 0) {
+        // ... and every XCD takes ONE CONTIGUOUS eighth of the column tiles, i.e. of the weight (round 5; rounds 2-4 dealt the tiles
+        // round-robin, tile % 8 = XCD): same box, same binary otherwise (tools/experiments/ab_lib.py), 8192^2 M = 17 / 32 / 64
+        // 19.5 / 18.1 / 22.7 -> 16.1 / 17.0 / 21.4 us, 8192 x 10240 M = 64 30.5 -> 28.6, 4096 x 12288 -3 %, within +-1 % elsewhere.
+        // (The GEMV kernel is the other way round: round-robin tile rows are 3 % ahead of contiguous ones there.)
         const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
         slice = j & (S - 1);
-        tile  = (j >> sh) * 8 + xcd;
+        tile  = xcd * (tiles_n >> 3) + (j >> sh);
     } else {
         slice = blockIdx.x & (S - 1);
         tile  = blockIdx.x >> sh;
@@ -245,14 +249,24 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[mt][nb][i] = 0.f;
 
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(scale2[nb]));
     // Issue order, kept by the prologue and by every step i (relative to s0): A(i + SA - 1) then B(i + SB - 1).  The prologue
     // plays the "virtual" steps -(SB-1) .. -1.
 #pragma unroll
     for (int v = -(SB - 1); v < 0; ++v) {
-        if (v + SA - 1 >= 0 && s0 + v + SA - 1 < s1) issue_a((v + SA - 1) % SA, s0 + v + SA - 1);
-        if (s0 + v + SB - 1 < s1) issue_b((v + SB - 1) % SB, s0 + v + SB - 1);
+        // (the first virtual step asks for step s0 itself: s0 < s1 always, so no test and no branch -- the compiler can then COUNT
+        // the requests between the scale loads and the wait below)
+        if (v + SA - 1 >= 0 && (v == -(SB - 1) || s0 + v + SA - 1 < s1)) issue_a((v + SA - 1) % SA, s0 + v + SA - 1);
+        if (v == -(SB - 1) || s0 + v + SB - 1 < s1) issue_b((v + SB - 1) % SB, s0 + v + SB - 1);
+        if (v == -(SB - 1)) {
+            // The scales must be in their registers before the K loop (a wait inside it would be one the compiler inserts, and it
+            // cannot count the ring), but not before the FIRST DMA requests: the scale loads were issued ahead of them and return
+            // ahead of them, so their latency runs under the first stage's instead of in front of it.  Round 5; before, every launch
+            // waited for its scales -- a cold HBM read in a real model, where every layer has its own -- and only then asked for
+            // its first tile: tools/experiments/ab_lib.py with one scale vector per weight set, -0.1 .. -0.35 us per launch
+            // (4096^2 M = 32 7.45 -> 7.20, M = 128 11.51 -> 11.16); unchanged when the scales are L2-resident.
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) asm volatile("" ::"v"(scale2[nb]));
+        }
     }
     int bufa = 0, bufb = 0;
     int step = s0;
