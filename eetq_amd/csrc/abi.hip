@@ -343,16 +343,15 @@ static AutoChoice auto_path_i8(int M, int N, int K, int act)
         // round of workgroups there; below 256 narrow tiles it stays ahead: 5120 x 13824 M = 64 22.7 / 25.9, 8192 x 10240 32.0 / 33.0)
         const int tiles1 = (N + 63) / 64;
         if (K >= 320 && ((M > 64 && tiles1 >= 160) || (M > 32 && tiles1 >= device_cu_count()))) return {EETQ_PATH_MFMA, 0};
-        // few tiles, deep K, M > 96 (the split-K tile needs four row blocks there): K slices of the tiled kernel's 128 x 64
-        // tile -- M = 128: 11008 x 4096 23.9 vs 27.1 us, 5120^2 20.1 vs 22.6 (tile_splitk_slices has the rule)
-        if (M > 96 && act == 0) {
+        // few tiles, M > 96, K deeper than 8192: K slices of the tiled kernel's 128 x 64 tile -- M = 128: 13824 x 5120 40.7 vs
+        // 41.9 us the best split-K plan, 28672 x 8192 89 vs 98, 11008 x 4096 23.3 vs 23.6 (tile_splitk_slices has the rule).  Up to
+        // K = 8192 the split-K tile's plans with row groups are ahead (profiles/r05_splitk_plan_regret_after.jsonl, us K-sliced
+        // tiled kernel / split-K plan: 5120^2 19.9 / 18.4, 8192 x 4096 20.1 / 18.6, 4096 x 2048 10.8 / 8.3, 8192 x 2048 16.1 / 12.3).
+        if (M > 96 && act == 0 && K > 8192) {
             const int S = tile_splitk_slices(M, N, K);
             if (S > 1) return {EETQ_PATH_TILESPLIT, use_splitk ? S : 1};
         }
-        // (few tiles, shallow K: the split-K tile cuts the batch into row groups instead -- splitk_plan / splitk_rows_plan)
         // narrower N: the split-K tile (K slices + in-launch deterministic reduction; N = K = 4096: M = 64 8.8 vs 11.2 us)
-        int r = 0;
-        if (!(use_splitk && splitk_rows_plan(M, N, K, &r))) r = 0;
         // ... except where the round-1 tile's own decomposition -- 32-column blocks, all of K and all of M per workgroup --
         // already gives more than half the CUs a workgroup in ONE round and K is too shallow for slices to pay (<= 16 steps of
         // 256): gemm_mid_kernel runs that decomposition without slicing machinery.  Round 5, tools/auto_regret.py
@@ -361,11 +360,15 @@ static AutoChoice auto_path_i8(int M, int N, int K, int act)
         // 11.3; 2048 x 8192 M = 64 7.9 / 7.7; equal within 1 % at M <= 32.  Not at N = 4096 (128 blocks: two K slices fill the
         // chip, 7.3 / 8.9), not at K = 5120 (5120^2 M = 32 10.5 / 11.1) or deeper (7168^2 13.2 / 14.0), not above M = 64
         // (4096 x 6144 M = 96 16.2 / 18.7).
-        if (r == 0 && M <= 64 && K <= 4096) {
+        if (M <= 64 && K <= 4096) {
             const int blocks = (N + 31) / 32, ncu = device_cu_count();
             if (2 * blocks > ncu && blocks <= ncu) return {EETQ_PATH_MID, 0};
         }
-        return {use_splitk ? EETQ_PATH_SPLITK : EETQ_PATH_MID, r};
+        if (!use_splitk) return {EETQ_PATH_MID, 0};
+        // (the split-K launcher's plan may cut the batch into row groups on top of -- or instead of -- K slices: splitk_plan)
+        int nb = 1, s = 1, stages = 2, rp = 1;
+        splitk_plan(M, N, K, &nb, &s, &stages, &rp);
+        return {EETQ_PATH_SPLITK, rp > 1 ? rp : 0};
     }
     // 128 < M <= 1024 on few-tile shapes with a K too shallow to slice: the split-K tile with the batch cut into row groups of
     // <= 64 rows, one round of workgroups, no reduction (gemm_splitk.hip::splitk_rows_plan: 4096^2 M = 256 20.8 -> 17.0 us,

@@ -281,7 +281,8 @@ int release_splitk_workspace(size_t* freed)
 // tiled kernel slices (8192^2 M = 128: 32.4 vs 30.6 K-sliced; 11008 x 4096 M = 128: 25.4 vs 23.7).
 bool splitk_rows_plan(int M, int N, int K, int* r_out)
 {
-    if (M <= 96 || M > kSplitkMaxM || K % 64 != 0 || tile_splitk_slices(M, N, K) != 1 || wide_tile_splitk_slices(M, N, K) != 1)
+    // (M <= 128: splitk_plan's search covers row groups together with K slices and both column-block widths)
+    if (M <= kMidMaxM || M > kSplitkMaxM || K % 64 != 0 || tile_splitk_slices(M, N, K) != 1 || wide_tile_splitk_slices(M, N, K) != 1)
         return false;
     const int ncu = device_cu_count(), tiles2 = (N + 63) / 64;
     int       r   = (M + 63) / 64;  // 64-row groups (MT = 2)
@@ -304,40 +305,52 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out, 
             return;
         }
     }
-    const int r0 = (M + 127) / 128;  // a row group holds at most 128 rows (MT <= 4)
-    if (r_out) *r_out = r0;
-    const int MT    = (M + 32 * r0 - 1) / (32 * r0);
+    // K slices AND row groups (round 5, second half): for M > 32 the search also cuts the batch into r <= 4 groups of
+    // 32 * ceil(M / 32r) rows -- fewer rows per workgroup (a lighter K step: 16 KiB of x per 32 rows), r times the workgroups, no
+    // more hand-over.  Same cost model, + 0.3 us per extra group (each weight tile is pulled out of L2 r times); checked against
+    // every plan's measured time on 12 shapes x 7 batch sizes (profiles/r05_splitk_plan_regret.jsonl: the model's pick is within
+    // 0.7 % of the best measured plan on average, 4 of 84 points above 5 %), us before -> after: 5120^2 M = 96 18.5 -> 14.5
+    // (2,1,33 x 3 groups), 4096^2 M = 48 8.73 -> 8.33, M = 64 9.05 -> 8.80, M = 96 11.96 -> 11.03, 4096 x 6144 M = 96 15.9 -> 15.0.
+    const int r_lo = (M + 127) / 128;  // a row group holds at most 128 rows (MT <= 4)
+    const int r_hi = (r_out && M > 32) ? (M + 31) / 32 : r_lo;  // (<= 4; callers without r_out cannot run row groups)
     const int ncu   = device_cu_count();
     const int steps = (K / 64 + 3) / 4;
     double    best  = 1e30;
-    int       bnb = 1, bs = 1, bst = 2;
-    for (int nb = 1; nb <= 2; ++nb) {
-        const int tiles = (N + 32 * nb - 1) / (32 * nb);
-        for (int s = 1; s <= gemm_splitk::kMaxSlices; s *= 2) {
-            if (s > 1 && steps / s < 2) continue;
-            const int wgs = tiles * s;
-            // ring depth 3 (120..144 KiB: one workgroup per CU) when that many workgroups fit anyway, else depth 2 (two per CU at MT <= 2)
-            const int stages  = (MT <= 2 && wgs <= ncu) ? 3 : 2;
-            // the model counts on two workgroups per CU only for unsplit plans (split ones time the same at one and two per CU)
-            const int per_cu  = (s == 1 && stages == 2 && MT <= 2 && (16 * MT + 8 * nb) * 2 <= 80) ? 2 : 1;
-            const int rounds  = (wgs + ncu * per_cu - 1) / (ncu * per_cu);
-            const int my_steps = (steps + s - 1) / s;
-            // microseconds: per-step ingest at ~70 GB/s per CU (shared by the workgroups on the CU), shallower ring ~15 % slower
-            double t = my_steps * (16.0 * MT + 8.0 * nb) * 0.014 * per_cu * (stages == 3 ? 1.0 : 1.15);
-            t += s == 1 ? 0.0 : (s == 2 ? 2.0 : 3.6) + 0.05 * MT * nb * s;   // reduction: publish + ticket + slab reads
-            t = 2.3 + rounds * t;
-            if (wgs * 2 <= ncu) t *= 1.25;                                      // half the chip idle: the weight stream thins out
-            if (t < best) {
-                best = t;
-                bnb  = nb;
-                bs   = s;
-                bst  = stages;
+    int       bnb = 1, bs = 1, bst = 2, br = r_lo;
+    for (int r = r_lo; r <= (r_hi > r_lo ? r_hi : r_lo); ++r) {
+        const int MT = (M + 32 * r - 1) / (32 * r);
+        if (MT > 4 || (M + 32 * MT - 1) / (32 * MT) != r) continue;  // (this r collapses to a smaller one)
+        for (int nb = 1; nb <= 2; ++nb) {
+            const int tiles = (N + 32 * nb - 1) / (32 * nb);
+            for (int s = 1; s <= gemm_splitk::kMaxSlices; s *= 2) {
+                if (s > 1 && steps / s < 2) continue;
+                const int wgs = tiles * s * r;
+                // ring depth 3 (120..144 KiB: one workgroup per CU) when that many workgroups fit anyway, else depth 2 (two per CU at MT <= 2)
+                const int stages  = (MT <= 2 && wgs <= ncu) ? 3 : 2;
+                // the model counts on two workgroups per CU only for plans without a hand-over (split ones time the same at one and two per CU)
+                const int per_cu  = ((s == 1 || r > 1) && stages == 2 && MT <= 2 && (16 * MT + 8 * nb) * 2 <= 80) ? 2 : 1;
+                const int rounds  = (wgs + ncu * per_cu - 1) / (ncu * per_cu);
+                const int my_steps = (steps + s - 1) / s;
+                // microseconds: per-step ingest at ~70 GB/s per CU (shared by the workgroups on the CU), shallower ring ~15 % slower
+                double t = my_steps * (16.0 * MT + 8.0 * nb) * 0.014 * per_cu * (stages == 3 ? 1.0 : 1.15);
+                t += s == 1 ? 0.0 : (s == 2 ? 2.0 : 3.6) + 0.05 * MT * nb * s;   // reduction: publish + ticket + slab reads
+                t = 2.3 + rounds * t;
+                if (wgs * 2 <= ncu) t *= 1.25;                                      // half the chip idle: the weight stream thins out
+                t += 0.3 * (r - 1);
+                if (t < best) {
+                    best = t;
+                    bnb  = nb;
+                    bs   = s;
+                    bst  = stages;
+                    br   = r;
+                }
             }
         }
     }
     *nb_out     = bnb;
     *s_out      = bs;
     *stages_out = bst;
+    if (r_out) *r_out = br;
 }
 
 int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,

@@ -132,13 +132,19 @@ def test_auto_path_rule_on_a_256_cu_chip(lib):
     # shallow K, more than half the CUs busy with 32-column blocks in one round, M <= 64: the round-1 tile without slicing machinery
     assert auto(8, 24, 6144, 4096)[0] == MID and auto(8, 64, 8192, 4096)[0] == MID and auto(8, 48, 5120, 4096)[0] == MID
     assert auto(8, 32, 4096, 4096)[0] == SPLITK and auto(8, 32, 6144, 5120)[0] == SPLITK and auto(8, 96, 6144, 4096)[0] == SPLITK
-    assert auto(8, 128, 4096, 11008) == (TILESPLIT, 4) and auto(8, 128, 5120, 5120) == (TILESPLIT, 2)
+    # few tiles, 97 <= M <= 128: the K-sliced tiled kernel only for K deeper than 8192 ...
+    assert auto(8, 128, 4096, 11008) == (TILESPLIT, 4) and auto(8, 128, 5120, 13824) == (TILESPLIT, 2) and auto(8, 128, 8192, 28672) == (TILESPLIT, 2)
     assert auto(8, 256, 4096, 11008) == (TILESPLIT, 2)
-    # few tiles, K too shallow to slice: the split-K tile with the batch cut into row groups (one round of workgroups, no reduction)
-    assert auto(8, 128, 4096, 4096) == (SPLITK, 4) and auto(8, 100, 4096, 4096) == (SPLITK, 4) and auto(8, 256, 4096, 4096) == (SPLITK, 4)
-    assert auto(8, 128, 6144, 4096) == (SPLITK, 2) and auto(8, 192, 5120, 5120) == (SPLITK, 3)
-    assert auto(8, 96, 4096, 4096) == (SPLITK, 0) and auto(8, 384, 4096, 4096) == (TILESPLIT, 1) and auto(8, 160, 6144, 4096) == (TILESPLIT, 1)
-    assert auto(8, 128, 8192, 8192) == (TILESPLIT, 2)                                            # a K the tiled kernel slices
+    # ... up to there the split-K tile, whose plan (splitk_plan: K slices x row groups x column-block width, one cost model) may cut
+    # the batch into row groups from M = 33 on: detail = the groups (0 = K slices only)
+    assert auto(8, 128, 5120, 5120) == (SPLITK, 2) and auto(8, 128, 8192, 8192) == (SPLITK, 2) and auto(8, 128, 2048, 4096) == (SPLITK, 4)
+    assert auto(8, 128, 4096, 4096) == (SPLITK, 4) and auto(8, 100, 4096, 4096) == (SPLITK, 4) and auto(8, 128, 6144, 4096) == (SPLITK, 2)
+    assert auto(8, 32, 4096, 4096) == (SPLITK, 0) and auto(8, 48, 4096, 4096) == (SPLITK, 2) and auto(8, 64, 4096, 4096) == (SPLITK, 2)
+    assert auto(8, 96, 4096, 4096) == (SPLITK, 3) and auto(8, 96, 5120, 5120) == (SPLITK, 3) and auto(8, 64, 5120, 5120) == (SPLITK, 0)
+    assert auto(8, 64, 11008, 4096) == (SPLITK, 0) and auto(8, 96, 6144, 4096) == (SPLITK, 0)
+    # M > 128, few tiles, K too shallow to slice: 64-row groups, one round of workgroups, no reduction (splitk_rows_plan)
+    assert auto(8, 256, 4096, 4096) == (SPLITK, 4) and auto(8, 192, 5120, 5120) == (SPLITK, 3)
+    assert auto(8, 384, 4096, 4096) == (TILESPLIT, 1) and auto(8, 160, 6144, 4096) == (TILESPLIT, 1)
     assert auto(8, 1024, 4096, 4096) == (TILESPLIT, 1) and auto(8, 4096, 4096, 4096) == (TILESPLIT, 1)   # unsplit tiled kernel
     assert auto(4, 1, 4096, 4096)[0] == GEMV and auto(4, 1, 8192, 8192)[0] == STREAM and auto(4, 8, 4096, 4096)[0] == STREAM
     assert auto(4, 64, 4096, 4096)[0] == SPLITK and auto(4, 1024, 4096, 4096)[0] == MFMA

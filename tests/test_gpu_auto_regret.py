@@ -21,7 +21,7 @@ POINTS = [
     (14336, 4096, 128, "tilesplit"),     # deep K, few tiles: four K slices, 27.6 vs 30.0 (split-K) / 68 (unsplit)
     (8192, 10240, 32, "splitk"),         # 23.5 vs 28.8 (mid) / 31.5 (tiled)
     (8192, 10240, 96, "mfma"),           # 38.7 vs 44.5 (split-K)
-    (7168, 7168, 128, "tilesplit"),      # 25.8 vs 28.6
+    (7168, 7168, 128, "splitk"),         # two 64-row groups 25.2 vs 26.4 (K-sliced tiled kernel; it keeps K > 8192: point 4)
     (4096, 4096, 128, "splitk"),         # row groups: 12.5 vs 20.5 (tiled, K-sliced tiled)
     (4096, 4096, 256, "splitk"),         # row groups: 17.2 vs 20.7
     (4096, 6144, 8, "stream"),           # 6.6 vs 9.9

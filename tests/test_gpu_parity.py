@@ -368,7 +368,8 @@ def test_tile_splitk_is_deterministic_across_launches_streams_and_graphs(ops, or
     """The split form of the tiled kernel shares the split-K tickets (one array per slice count, monotonic): interleaved with
     split-K launches of the same slice counts, on two streams, and replayed from a HIP graph, every result is bit-identical
     to the first."""
-    w, x = _rand_case(8192, 4096, 128, seed=11)   # four slices (the split-K launches below run with two)
+    w, x = _rand_case(11008, 4096, 128, seed=11)   # four slices, like the split-K launches below: the SAME ticket array (K > 8192:
+                                                   # AUTO, which the graph below launches, takes the K-sliced tiled kernel too)
     q, s = oracle.quantize(w)
     processed = torch.from_numpy(oracle.gfx950_pack(q)).to(DEV)
     scales = torch.from_numpy(s).to(DEV)
@@ -391,7 +392,7 @@ def test_tile_splitk_is_deterministic_across_launches_streams_and_graphs(ops, or
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for _ in range(4):
-            ops.w8_a16_gemm_(xd, processed, scales, y, 128, 4096, 8192)
+            ops.w8_a16_gemm_(xd, processed, scales, y, 128, 4096, 11008)
     for _ in range(10):
         y.zero_()
         g.replay()
@@ -450,6 +451,11 @@ def test_splitk_every_plan(ops, oracle, K, N, M, plans):
     (4160, 4112, 200, [(1, 1, 22, 2), (2, 4, 22, 4), (1, 2, 33, 4)]),            # K % 256 != 0, N % 32 != 0
     (2048, 1024, 512, [(2, 1, 22, 4), (2, 2, 22, 8), (1, 1, 33, 16)]),
     (1024, 2048, 1000, [(2, 1, 22, 8), (2, 2, 33, 16), (1, 4, 22, 32)]),         # up to 32 groups (M <= 1024)
+    # M <= 96 (the planner's search cuts rows from M = 33 on): 32-row groups, with and without K slices, a ragged last group
+    (4096, 4096, 64, [(1, 1, 33, 2), (2, 1, 33, 2), (2, 2, 22, 2), (1, 4, 22, 2)]),
+    (5120, 5120, 96, [(2, 1, 33, 3), (2, 2, 22, 3), (1, 1, 22, 3), (2, 4, 22, 2)]),
+    (8192, 2048, 70, [(2, 4, 22, 3), (1, 2, 33, 3), (2, 2, 33, 2)]),             # last group: 6 rows / 22 rows
+    (4096, 2048, 112, [(1, 1, 33, 4), (2, 2, 33, 4), (1, 2, 33, 2)]),
 ])
 def test_splitk_row_groups(ops, oracle, K, N, M, plans):
     """Row groups of the split-K tile, every combination with column blocks / K slices forced through
@@ -484,10 +490,13 @@ def test_splitk_row_groups(ops, oracle, K, N, M, plans):
 
 
 @pytest.mark.parametrize("K,N,M", [(4096, 4096, 100), (4096, 4096, 128), (4096, 4096, 256), (4096, 6144, 128), (5120, 5120, 192),
-                                   (4096, 4096, 192)])
+                                   (4096, 4096, 192),
+                                   # M <= 128 through the planner's search (gemm_splitk.hip::splitk_plan): 32- and 64-row groups
+                                   (4096, 4096, 48), (4096, 4096, 64), (4096, 4096, 96), (5120, 5120, 96), (5120, 5120, 128),
+                                   (8192, 8192, 128), (4096, 2048, 112), (8192, 2048, 128)])
 def test_auto_takes_the_row_group_plan_and_matches_the_oracle(ops, oracle, K, N, M):
-    """AUTO on few-tile shapes with a K too shallow to slice (eetq_diag_auto_path: SPLITK with row groups): oracle on sampled rows,
-    the tiled kernel on everything, graph capture (the plan needs no scratch) and bit-identical replays."""
+    """AUTO where its split-K plan cuts the batch into row groups (eetq_diag_auto_path: SPLITK, detail = groups): oracle on sampled
+    rows, the tiled kernel on everything, graph capture and bit-identical replays."""
     import ctypes
     from eetq_amd import _lib
     p, d = ctypes.c_int(0), ctypes.c_int(0)
