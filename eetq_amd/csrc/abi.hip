@@ -342,7 +342,11 @@ static AutoChoice auto_path_i8(int M, int N, int K, int act)
         // 43.4 / 35.1; 8192 x 57344 153 / 127, 169 / 128 -- the split-K tile doubles its row blocks at M = 33 and needs a second
         // round of workgroups there; below 256 narrow tiles it stays ahead: 5120 x 13824 M = 64 22.7 / 25.9, 8192 x 10240 32.0 / 33.0)
         const int tiles1 = (N + 63) / 64;
-        if (K >= 320 && ((M > 64 && tiles1 >= 160) || (M > 32 && tiles1 >= device_cu_count()))) return {EETQ_PATH_MFMA, 0};
+        // (... except 65 <= M <= 96 on a deep K where three 32-row groups of the split-K tile's 64-column blocks still fit the chip
+        // two per CU -- Llama-3-70B's fused q|k|v, 8192 x 10240: M = 80 35.6 tiled vs 33.9 us, M = 96 39.1 vs 33.7-34.7,
+        // profiles/r05_splitk_plan_regret_fitted.jsonl; 4096 x 11008 M = 96 stays: 21.4 vs 23.5)
+        const bool rows3 = M > 64 && M <= 96 && K >= 8192 && tiles1 * 3 <= 2 * device_cu_count() && use_splitk;
+        if (K >= 320 && !rows3 && ((M > 64 && tiles1 >= 160) || (M > 32 && tiles1 >= device_cu_count()))) return {EETQ_PATH_MFMA, 0};
         // few tiles, M > 96, K deeper than 8192: K slices of the tiled kernel's 128 x 64 tile -- M = 128: 13824 x 5120 40.7 vs
         // 41.9 us the best split-K plan, 28672 x 8192 89 vs 98, 11008 x 4096 23.3 vs 23.6 (tile_splitk_slices has the rule).  Up to
         // K = 8192 the split-K tile's plans with row groups are ahead (profiles/r05_splitk_plan_regret_after.jsonl, us K-sliced
@@ -351,19 +355,13 @@ static AutoChoice auto_path_i8(int M, int N, int K, int act)
             const int S = tile_splitk_slices(M, N, K);
             if (S > 1) return {EETQ_PATH_TILESPLIT, use_splitk ? S : 1};
         }
-        // narrower N: the split-K tile (K slices + in-launch deterministic reduction; N = K = 4096: M = 64 8.8 vs 11.2 us)
-        // ... except where the round-1 tile's own decomposition -- 32-column blocks, all of K and all of M per workgroup --
-        // already gives more than half the CUs a workgroup in ONE round and K is too shallow for slices to pay (<= 16 steps of
-        // 256): gemm_mid_kernel runs that decomposition without slicing machinery.  Round 5, tools/auto_regret.py
-        // (profiles/r05_auto_regret_midrule.jsonl, after the split-K tile's K loop lost its per-step branch chain), us split-K /
-        // mid: 4096 x 8192 M = 48 13.4 / 12.1, M = 64 14.3 / 12.9; 4096 x 7168 M = 64 13.1 / 12.3; 4096 x 6144 M = 48 11.8 /
-        // 11.3; 2048 x 8192 M = 64 7.9 / 7.7; equal within 1 % at M <= 32.  Not at N = 4096 (128 blocks: two K slices fill the
-        // chip, 7.3 / 8.9), not at K = 5120 (5120^2 M = 32 10.5 / 11.1) or deeper (7168^2 13.2 / 14.0), not above M = 64
-        // (4096 x 6144 M = 96 16.2 / 18.7).
-        if (M <= 64 && K <= 4096) {
-            const int blocks = (N + 31) / 32, ncu = device_cu_count();
-            if (2 * blocks > ncu && blocks <= ncu) return {EETQ_PATH_MID, 0};
-        }
+        // narrower N: the split-K tile (K slices + in-launch deterministic reduction, and / or the batch cut into row groups:
+        // splitk_plan; N = K = 4096: M = 64 8.7 us vs 11.2 round-1 tile).  (Until the planner learnt row groups, shallow-K shapes
+        // with 128 < N / 32 <= 256 column blocks went to the round-1 tile at M <= 64 -- the same decomposition without slicing
+        // machinery, 5-10 % ahead of the K-slice plans at M = 48 / 64.  Two 32-row groups are ahead of it now -- us round-1 tile /
+        // split-K plan, profiles/r05_splitk_plan_regret_fitted.jsonl: 4096 x 6144 M = 48 11.2 / 10.9, M = 64 12.0 / 11.5; 4096 x 8192
+        // M = 48 12.1 / 11.5; 3584 x 4608 M = 64 11.4 / 10.6 -- and at M <= 32 the two were within 1 % of each other: the rule is gone,
+        // the round-1 tile stays as the path without library-owned scratch, EETQ_AMD_SPLITK=0.)
         if (!use_splitk) return {EETQ_PATH_MID, 0};
         // (the split-K launcher's plan may cut the batch into row groups on top of -- or instead of -- K slices: splitk_plan)
         int nb = 1, s = 1, stages = 2, rp = 1;

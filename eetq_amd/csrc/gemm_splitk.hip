@@ -269,7 +269,8 @@ int release_splitk_workspace(size_t* freed)
 //   K = 11008, M = 64: BN 64, S 4: 16.3 [28.0] (BN 32, S 2: 24.5);  N = 11008, M = 64: BN 64, S 1: 17.1 [20.0].
 // Reading: a slice costs about (its K steps) x (16*MT + 8*NB KiB per step at ~70 GB/s per CU) plus ~2 us for a 2-way and
 // ~3 us for a 4-way in-launch reduction, on top of ~2.3 us of launch + first-data latency; wide column blocks pay off when
-// the K loop is long (fewer re-reads of x) or the row tile is tall, narrow ones when the loop is short.
+// the K loop is long (fewer re-reads of x) or the row tile is tall, narrow ones when the loop is short.  (Round 5 refitted the
+// constants on every plan's time: the model in splitk_plan below.)
 // Row groups instead of K slices (round 5): the batch is cut along M into r groups of <= 64 rows, 64-column blocks, all of K per
 // workgroup -- (N / 64) * r workgroups, NO cross-workgroup reduction, the 3-deep ring (MT <= 2).  It applies when those
 // workgroups fit the chip at once and the K-sliced tiled kernel would not slice (few tiles but a shallow K: tile_splitk_slices
@@ -331,12 +332,14 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out, 
                 const int per_cu  = ((s == 1 || r > 1) && stages == 2 && MT <= 2 && (16 * MT + 8 * nb) * 2 <= 80) ? 2 : 1;
                 const int rounds  = (wgs + ncu * per_cu - 1) / (ncu * per_cu);
                 const int my_steps = (steps + s - 1) / s;
-                // microseconds: per-step ingest at ~70 GB/s per CU (shared by the workgroups on the CU), shallower ring ~15 % slower
-                double t = my_steps * (16.0 * MT + 8.0 * nb) * 0.014 * per_cu * (stages == 3 ? 1.0 : 1.15);
-                t += s == 1 ? 0.0 : (s == 2 ? 2.0 : 3.6) + 0.05 * MT * nb * s;   // reduction: publish + ticket + slab reads
-                t = 2.3 + rounds * t;
-                if (wgs * 2 <= ncu) t *= 1.25;                                      // half the chip idle: the weight stream thins out
-                t += 0.3 * (r - 1);
+                // microseconds per K step: 0.30 per 32 rows of x + 0.14 per 32 columns of weights (shared by the workgroups on the
+                // CU), the shallower ring 20 % slower; the hand-over: publish + ticket + slab reads; 0.3 per extra row group (each
+                // weight tile is pulled out of L2 r times).  The constants are a least-regret fit to the measured time of EVERY plan
+                // on 24 shapes x 6-7 batch sizes (profiles/r05_splitk_plan_regret*.jsonl, 349 points: the pick is within 0.85 % of the
+                // best measured plan on average, 17 points above 5 %; the round-2 constants: 1.5 %, 39).
+                double t = my_steps * (0.30 * MT + 0.14 * nb) * per_cu * (stages == 3 ? 1.0 : 1.2);
+                t += s == 1 ? 0.0 : (s == 2 ? 2.4 : 3.6) + 0.084 * MT * nb * s;
+                t = 1.5 + rounds * t + 0.3 * (r - 1);
                 if (t < best) {
                     best = t;
                     bnb  = nb;

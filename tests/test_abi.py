@@ -129,8 +129,11 @@ def test_auto_path_rule_on_a_256_cu_chip(lib):
     # ... and from M = 33 once the 128 x 64 tiles alone give every CU a workgroup (N >= 64 * 256)
     assert auto(8, 32, 18944, 3584)[0] == SPLITK and auto(8, 48, 18944, 3584)[0] == MFMA and auto(8, 64, 28672, 4096)[0] == MFMA
     assert auto(8, 64, 13824, 5120)[0] == SPLITK
-    # shallow K, more than half the CUs busy with 32-column blocks in one round, M <= 64: the round-1 tile without slicing machinery
-    assert auto(8, 24, 6144, 4096)[0] == MID and auto(8, 64, 8192, 4096)[0] == MID and auto(8, 48, 5120, 4096)[0] == MID
+    # ... except 65 <= M <= 96 on a deep K where three 32-row groups of 64-column blocks fit the chip two per CU (70B's fused q|k|v)
+    assert auto(8, 96, 10240, 8192) == (SPLITK, 3) and auto(8, 97, 10240, 8192)[0] == MFMA and auto(8, 96, 28672, 8192)[0] == MFMA
+    # (shallow K, 128 < N / 32 <= 256: the round-1 tile's rule of the first half of round 5 is gone -- the split-K plans with row
+    # groups are ahead of it; MID is what EETQ_AMD_SPLITK=0 falls back to)
+    assert auto(8, 24, 6144, 4096) == (SPLITK, 0) and auto(8, 64, 8192, 4096) == (SPLITK, 2) and auto(8, 48, 5120, 4096) == (SPLITK, 2)
     assert auto(8, 32, 4096, 4096)[0] == SPLITK and auto(8, 32, 6144, 5120)[0] == SPLITK and auto(8, 96, 6144, 4096)[0] == SPLITK
     # few tiles, 97 <= M <= 128: the K-sliced tiled kernel only for K deeper than 8192 ...
     assert auto(8, 128, 4096, 11008) == (TILESPLIT, 4) and auto(8, 128, 5120, 13824) == (TILESPLIT, 2) and auto(8, 128, 8192, 28672) == (TILESPLIT, 2)
@@ -141,7 +144,7 @@ def test_auto_path_rule_on_a_256_cu_chip(lib):
     assert auto(8, 128, 4096, 4096) == (SPLITK, 4) and auto(8, 100, 4096, 4096) == (SPLITK, 4) and auto(8, 128, 6144, 4096) == (SPLITK, 2)
     assert auto(8, 32, 4096, 4096) == (SPLITK, 0) and auto(8, 48, 4096, 4096) == (SPLITK, 2) and auto(8, 64, 4096, 4096) == (SPLITK, 2)
     assert auto(8, 96, 4096, 4096) == (SPLITK, 3) and auto(8, 96, 5120, 5120) == (SPLITK, 3) and auto(8, 64, 5120, 5120) == (SPLITK, 0)
-    assert auto(8, 64, 11008, 4096) == (SPLITK, 0) and auto(8, 96, 6144, 4096) == (SPLITK, 0)
+    assert auto(8, 64, 11008, 4096) == (SPLITK, 0) and auto(8, 96, 6144, 4096) == (SPLITK, 2) and auto(8, 96, 8192, 8192) == (SPLITK, 0)
     # M > 128, few tiles, K too shallow to slice: 64-row groups, one round of workgroups, no reduction (splitk_rows_plan)
     assert auto(8, 256, 4096, 4096) == (SPLITK, 4) and auto(8, 192, 5120, 5120) == (SPLITK, 3)
     assert auto(8, 384, 4096, 4096) == (TILESPLIT, 1) and auto(8, 160, 6144, 4096) == (TILESPLIT, 1)

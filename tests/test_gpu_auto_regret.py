@@ -17,10 +17,10 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 POINTS = [
     (4096, 28672, 64, "mfma"),           # wide N from M = 33: tiled kernel 35 us, split-K 43
     (3584, 18944, 48, "mfma"),           # 24 vs 34
-    (4096, 6144, 24, "mid"),             # split-K would plan the round-1 decomposition: the leaner kernel, 8.9 vs 9.7
+    (4096, 6144, 24, "splitk"),          # 32-column blocks, all of K: 9.0 = the round-1 tile on the same decomposition (9.1)
     (14336, 4096, 128, "tilesplit"),     # deep K, few tiles: four K slices, 27.6 vs 30.0 (split-K) / 68 (unsplit)
     (8192, 10240, 32, "splitk"),         # 23.5 vs 28.8 (mid) / 31.5 (tiled)
-    (8192, 10240, 96, "mfma"),           # 38.7 vs 44.5 (split-K)
+    (8192, 10240, 96, "splitk"),         # three 32-row groups, two workgroups per CU: 34 vs 39 (tiled kernel)
     (7168, 7168, 128, "splitk"),         # two 64-row groups 25.2 vs 26.4 (K-sliced tiled kernel; it keeps K > 8192: point 4)
     (4096, 4096, 128, "splitk"),         # row groups: 12.5 vs 20.5 (tiled, K-sliced tiled)
     (4096, 4096, 256, "splitk"),         # row groups: 17.2 vs 20.7
