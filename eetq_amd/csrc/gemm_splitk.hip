@@ -335,8 +335,9 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out, 
                 // microseconds per K step: 0.30 per 32 rows of x + 0.14 per 32 columns of weights (shared by the workgroups on the
                 // CU), the shallower ring 20 % slower; the hand-over: publish + ticket + slab reads; 0.3 per extra row group (each
                 // weight tile is pulled out of L2 r times).  The constants are a least-regret fit to the measured time of EVERY plan
-                // on 24 shapes x 6-7 batch sizes (profiles/r05_splitk_plan_regret*.jsonl, 349 points: the pick is within 0.85 % of the
-                // best measured plan on average, 17 points above 5 %; the round-2 constants: 1.5 %, 39).
+                // on 27 shapes x 6-7 batch sizes (profiles/r05_splitk_plan_regret*.jsonl through tools/experiments/splitk_plan_fit.py,
+                // 510 points: the pick is within 0.8 % of the best measured plan on average, 26 points above 5 %; the round-2
+                // constants: 1.5 %, 63).
                 double t = my_steps * (0.30 * MT + 0.14 * nb) * per_cu * (stages == 3 ? 1.0 : 1.2);
                 t += s == 1 ? 0.0 : (s == 2 ? 2.4 : 3.6) + 0.084 * MT * nb * s;
                 t = 1.5 + rounds * t + 0.3 * (r - 1);
