@@ -342,10 +342,11 @@ static AutoChoice auto_path_i8(int M, int N, int K, int act)
         // 43.4 / 35.1; 8192 x 57344 153 / 127, 169 / 128 -- the split-K tile doubles its row blocks at M = 33 and needs a second
         // round of workgroups there; below 256 narrow tiles it stays ahead: 5120 x 13824 M = 64 22.7 / 25.9, 8192 x 10240 32.0 / 33.0)
         const int tiles1 = (N + 63) / 64;
-        // (... except 65 <= M <= 96 on a deep K where three 32-row groups of the split-K tile's 64-column blocks still fit the chip
-        // two per CU -- Llama-3-70B's fused q|k|v, 8192 x 10240: M = 80 35.6 tiled vs 33.9 us, M = 96 39.1 vs 33.7-34.7,
-        // profiles/r05_splitk_plan_regret_fitted.jsonl; 4096 x 11008 M = 96 stays: 21.4 vs 23.5)
-        const bool rows3 = M > 64 && M <= 96 && K >= 8192 && tiles1 * 3 <= 2 * device_cu_count() && use_splitk;
+        // (... except 65 <= M <= 96 where three 32-row groups of the split-K tile's 64-column blocks still fit the chip two per
+        // CU, i.e. N <= 10880 -- Llama-3-70B's fused q|k|v, 8192 x 10240: M = 80 35.6 tiled vs 33.9 us, M = 96 39.1 vs 33.7-34.7;
+        // 2560 x 10240 M = 72 14.5 vs 12.7, M = 96 16.2 vs 13.0 (profiles/r05_splitk_plan_regret_fitted.jsonl, ..._share.jsonl);
+        // 4096 x 11008 does not fit and stays: M = 96 21.4 vs 23.5)
+        const bool rows3 = M > 64 && M <= 96 && tiles1 * 3 <= 2 * device_cu_count() && use_splitk;
         if (K >= 320 && !rows3 && ((M > 64 && tiles1 >= 160) || (M > 32 && tiles1 >= device_cu_count()))) return {EETQ_PATH_MFMA, 0};
         // few tiles, M > 96, K deeper than 8192: K slices of the tiled kernel's 128 x 64 tile -- M = 128: 13824 x 5120 40.7 vs
         // 41.9 us the best split-K plan, 28672 x 8192 89 vs 98, 11008 x 4096 23.3 vs 23.6 (tile_splitk_slices has the rule).  Up to

@@ -308,10 +308,9 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out, 
     }
     // K slices AND row groups (round 5, second half): for M > 32 the search also cuts the batch into r <= 4 groups of
     // 32 * ceil(M / 32r) rows -- fewer rows per workgroup (a lighter K step: 16 KiB of x per 32 rows), r times the workgroups, no
-    // more hand-over.  Same cost model, + 0.3 us per extra group (each weight tile is pulled out of L2 r times); checked against
-    // every plan's measured time on 12 shapes x 7 batch sizes (profiles/r05_splitk_plan_regret.jsonl: the model's pick is within
-    // 0.7 % of the best measured plan on average, 4 of 84 points above 5 %), us before -> after: 5120^2 M = 96 18.5 -> 14.5
-    // (2,1,33 x 3 groups), 4096^2 M = 48 8.73 -> 8.33, M = 64 9.05 -> 8.80, M = 96 11.96 -> 11.03, 4096 x 6144 M = 96 15.9 -> 15.0.
+    // more hand-over.  One cost model for all of it (below); us before -> after the row groups joined the search: 5120^2 M = 96
+    // 18.5 -> 14.2 (2,1,33 x 3 groups), 4096^2 M = 48 8.73 -> 8.3, M = 64 9.05 -> 8.7, M = 96 11.96 -> 10.9, 4096 x 6144 M = 96
+    // 15.9 -> 15.0, 4096 x 2048 M = 128 10.8 -> 8.3.
     const int r_lo = (M + 127) / 128;  // a row group holds at most 128 rows (MT <= 4)
     const int r_hi = (r_out && M > 32) ? (M + 31) / 32 : r_lo;  // (<= 4; callers without r_out cannot run row groups)
     const int ncu   = device_cu_count();
@@ -332,15 +331,18 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out, 
                 const int per_cu  = ((s == 1 || r > 1) && stages == 2 && MT <= 2 && (16 * MT + 8 * nb) * 2 <= 80) ? 2 : 1;
                 const int rounds  = (wgs + ncu * per_cu - 1) / (ncu * per_cu);
                 const int my_steps = (steps + s - 1) / s;
-                // microseconds per K step: 0.30 per 32 rows of x + 0.14 per 32 columns of weights (shared by the workgroups on the
-                // CU), the shallower ring 20 % slower; the hand-over: publish + ticket + slab reads; 0.3 per extra row group (each
-                // weight tile is pulled out of L2 r times).  The constants are a least-regret fit to the measured time of EVERY plan
-                // on 27 shapes x 6-7 batch sizes (profiles/r05_splitk_plan_regret*.jsonl through tools/experiments/splitk_plan_fit.py,
-                // 510 points: the pick is within 0.8 % of the best measured plan on average, 26 points above 5 %; the round-2
-                // constants: 1.5 %, 63).
-                double t = my_steps * (0.30 * MT + 0.14 * nb) * per_cu * (stages == 3 ? 1.0 : 1.2);
-                t += s == 1 ? 0.0 : (s == 2 ? 2.4 : 3.6) + 0.084 * MT * nb * s;
-                t = 1.5 + rounds * t + 0.3 * (r - 1);
+                // microseconds per K step: 0.27 per 32 rows of x + 0.14 per 32 columns of weights, x 1.3 when two workgroups share
+                // the CU (they hide each other's latencies: not x 2), the shallower ring 20 % slower; the hand-over: publish +
+                // ticket + slab reads; 0.27 per extra row group (each weight tile is pulled out of L2 r times).  The constants are a
+                // least-regret fit to the measured time of EVERY plan on 27 shapes x 6-7 batch sizes
+                // (profiles/r05_splitk_plan_regret*.jsonl through tools/experiments/splitk_plan_fit.py, 510 points: the pick is
+                // within 0.5 % of the best measured plan on average, 12 points above 5 %; fitted on three of the five tables it
+                // scores 0.5 % / 8 on the other two; the round-2 constants: 1.5 %, 63 points).  Out of sample -- a sixth table
+                // measured AFTER the fit, 22 shapes (5 new) at batch sizes none of the five used, AUTO against the best forced
+                // plan: 1.3 % on average, 12 of 154 points above 5 % (narrow N at M = 72 .. 120).
+                double t = my_steps * (0.27 * MT + 0.14 * nb) * (per_cu == 2 ? 1.3 : 1.0) * (stages == 3 ? 1.0 : 1.2);
+                t += s == 1 ? 0.0 : (s == 2 ? 2.2 : 2.9) + 0.077 * MT * nb * s;
+                t = 1.6 + rounds * t + 0.27 * (r - 1);
                 if (t < best) {
                     best = t;
                     bnb  = nb;

@@ -129,8 +129,9 @@ def test_auto_path_rule_on_a_256_cu_chip(lib):
     # ... and from M = 33 once the 128 x 64 tiles alone give every CU a workgroup (N >= 64 * 256)
     assert auto(8, 32, 18944, 3584)[0] == SPLITK and auto(8, 48, 18944, 3584)[0] == MFMA and auto(8, 64, 28672, 4096)[0] == MFMA
     assert auto(8, 64, 13824, 5120)[0] == SPLITK
-    # ... except 65 <= M <= 96 on a deep K where three 32-row groups of 64-column blocks fit the chip two per CU (70B's fused q|k|v)
+    # ... except 65 <= M <= 96 where three 32-row groups of 64-column blocks fit the chip two per CU (N <= 10880: 70B's fused q|k|v)
     assert auto(8, 96, 10240, 8192) == (SPLITK, 3) and auto(8, 97, 10240, 8192)[0] == MFMA and auto(8, 96, 28672, 8192)[0] == MFMA
+    assert auto(8, 72, 10240, 2560) == (SPLITK, 3) and auto(8, 96, 11008, 4096)[0] == MFMA
     # (shallow K, 128 < N / 32 <= 256: the round-1 tile's rule of the first half of round 5 is gone -- the split-K plans with row
     # groups are ahead of it; MID is what EETQ_AMD_SPLITK=0 falls back to)
     assert auto(8, 24, 6144, 4096) == (SPLITK, 0) and auto(8, 64, 8192, 4096) == (SPLITK, 2) and auto(8, 48, 5120, 4096) == (SPLITK, 2)

@@ -9,7 +9,7 @@ import glob, json, math, os, random, sys
 
 NCU = 256
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHIPPED = {"a": 0.30, "b": 0.14, "shallow": 1.2, "r2": 2.4, "r4": 3.6, "slab": 0.084, "fix": 1.5, "rowpen": 0.3}
+SHIPPED = {"a": 0.27, "b": 0.14, "shallow": 1.2, "r2": 2.2, "r4": 2.9, "slab": 0.077, "fix": 1.6, "rowpen": 0.27, "share": 1.3}
 ROUND2 = {"a": 16 * 0.014, "b": 8 * 0.014, "shallow": 1.15, "r2": 2.0, "r4": 3.6, "slab": 0.05, "fix": 2.3, "rowpen": 0.3, "idle": 1.25}
 
 
@@ -30,7 +30,7 @@ def model(M, N, K, nb, s, ring, r, P):
     MT, steps, wgs, stages = geometry(M, N, K, nb, s, r)
     per_cu = 2 if ((s == 1 or r > 1) and stages == 2 and MT <= 2 and (16 * MT + 8 * nb) * 2 <= 80) else 1
     rounds = -(-wgs // (NCU * per_cu))
-    t = -(-steps // s) * (P["a"] * MT + P["b"] * nb) * per_cu * (1.0 if stages == 3 else P["shallow"])
+    t = -(-steps // s) * (P["a"] * MT + P["b"] * nb) * (P.get("share", 2.0) if per_cu == 2 else 1.0) * (1.0 if stages == 3 else P["shallow"])
     t += 0.0 if s == 1 else ((P["r2"] if s == 2 else P["r4"]) + P["slab"] * MT * nb * s)
     t = P["fix"] + rounds * t
     if wgs * 2 <= NCU:
