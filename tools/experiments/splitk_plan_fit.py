@@ -67,9 +67,14 @@ def score(data, P, verbose=False):
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if a != "--fit"]
-    files = args or sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_splitk_plan_regret*.jsonl")))
+    AFTER = os.path.join(ROOT, "profiles", "r05_splitk_plan_regret_share.jsonl")   # measured after the fit: never fitted on
+    files = args or [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_splitk_plan_regret*.jsonl"))) if f != AFTER]
     data = load(files)
     print("%d points from %d tables" % (len(data), len(files)))
+    if not args and os.path.exists(AFTER):
+        held = load([AFTER])
+        print("table measured after the fit (%d points; its `auto` column is the planner itself on the GPU): model pick vs best plan "
+              "%.2f %%, %d above 5 %%" % ((len(held),) + (lambda m, b: (100 * m, b))(*score(held, SHIPPED))))
     print("round-2 constants: mean regret %.2f %%, %d points above 5 %%" % ((lambda m, b: (100 * m, b))(*score(data, ROUND2))))
     print("shipped constants: mean regret %.2f %%, %d points above 5 %%" % ((lambda m, b: (100 * m, b))(*score(data, SHIPPED))))
     score(data, SHIPPED, verbose=True)
