@@ -45,7 +45,7 @@ enum { EETQ_LAYOUT_ROW_MAJOR = 0, EETQ_LAYOUT_GFX950 = 1, EETQ_LAYOUT_SM80 = 2 }
 
 /* Kernel selection for eetq_w8a16_gemm_ex (tests and tuning).  AUTO is what eetq_w8a16_gemm uses. */
 enum { EETQ_PATH_AUTO = 0, EETQ_PATH_GEMV = 1 /* M <= 4 */, EETQ_PATH_MFMA = 2 /* LDS-tiled */, EETQ_PATH_STREAM = 3 /* M <= 64; AUTO uses it for 2..16 */,
-       EETQ_PATH_MID = 4 /* M <= 128: 32-column tiles, 256-deep K steps */,
+       EETQ_PATH_MID = 4 /* M <= 128: 32-column tiles, 256-deep K steps; what AUTO runs for 17..128 under EETQ_AMD_SPLITK=0 */,
        EETQ_PATH_SPLITK = 5 /* W8A16: M <= 1024 -- split-K tiles: K slices with an in-launch deterministic reduction and / or row groups
                                of <= 128 rows (AUTO: 17 <= M <= 128, and the row-group plan on few-tile shapes up to M = 1024); W4A16: M <= 128 */,
        EETQ_PATH_TILESPLIT = 6 /* the LDS-tiled kernel with K slices per 128 x 64 tile (few tiles, deep K); unsplit when that does not apply */ };
@@ -326,7 +326,7 @@ int eetq_diag_stream_plan(int bits, int M, int N, int K, int cus, int* form, int
 /* Diagnostic, host arithmetic only (no launch): which kernel path EETQ_PATH_AUTO takes for an M x K activation against a K x N
  * weight of `bits` (8 / 4) on the current device.  *path = EETQ_PATH_* (for bits = 4: GEMV, STREAM, SPLITK, or MFMA = expansion to
  * int8 tiles + the W8A16 kernels); *detail (may be NULL) = K slices per tile when *path is EETQ_PATH_TILESPLIT (1 = the unsplit
- * tiled kernel), row groups when *path is EETQ_PATH_SPLITK and its row-group plan applies (0 = a K-slice plan), else 0.  It calls the function the launchers call.  Replaces, as far as anything does, the reference's run-time
+ * tiled kernel), the row groups of the plan when *path is EETQ_PATH_SPLITK (0 = K slices only), else 0.  It calls the function the launchers call.  Replaces, as far as anything does, the reference's run-time
  * choice: the m <= 4 switch (fpA_intB_gemm_wrapper.cu:149-162) and the occupancy-scored tile pick
  * (cutlass_kernels/cutlass_heuristic.cc:123-206) -- one rule here, printed by bench.py's `config4` block per point and measured
  * against every forced path by tools/auto_regret.py. */
