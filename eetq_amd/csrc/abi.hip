@@ -399,6 +399,16 @@ int eetq_diag_auto_path(int bits, int M, int N, int K, int* path, int* detail)
     return EETQ_OK;
 }
 
+int eetq_diag_splitk_plan(int M, int N, int K, int* column_blocks, int* k_slices, int* ring, int* row_groups)
+{
+    EETQ_REQUIRE(column_blocks && k_slices && ring && row_groups, "eetq_diag_splitk_plan: null pointer");
+    EETQ_REQUIRE(M >= 1 && M <= kSplitkMaxM && N >= kTileN && K >= kTileK && K % 64 == 0, "eetq_diag_splitk_plan: bad argument");
+    int stages = 2;
+    splitk_plan(M, N, K, column_blocks, k_slices, &stages, row_groups);
+    *ring = 11 * stages;
+    return EETQ_OK;
+}
+
 static int gemm_dispatch(const void* x, const int8_t* w_packed, const void* scales, const void* bias,
                          const void* residual, void* y, int M, int N, int K, int path, void* stream, int act = EETQ_ACT_IDENTITY)
 {

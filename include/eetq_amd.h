@@ -77,9 +77,9 @@ enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SIL
  *   caller-provided workspace is therefore treated as exactly N floats (the atomicMax route); NULL as above.  Callers that
  *   allocate eetq_quantize_workspace_floats() floats should move to eetq_quantize_i8_ws to get the faster route. */
 /* Revision history: 1 = round 1-2; 2 = eetq_quantize_i8_ws (sized workspace), eetq_release_stream_workspace, eetq_w4a16_gemm_ex;
- * 3 = eetq_diag_auto_path, EETQ_PATH_SPLITK accepts M <= 1024 (row groups).  Revisions only ADD entry points: a caller built
+ * 3 = eetq_diag_auto_path, EETQ_PATH_SPLITK accepts M <= 1024 (row groups); 4 = eetq_diag_splitk_plan.  Revisions only ADD entry points: a caller built
  * against an older header keeps working. */
-#define EETQ_AMD_ABI_VERSION 3
+#define EETQ_AMD_ABI_VERSION 4
 int eetq_abi_version(void);   /* EETQ_AMD_ABI_VERSION of the loaded library */
 int eetq_quantize_i8_ws(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
                         int layout, void* scales, float* workspace, size_t workspace_floats, void* stream);
@@ -331,6 +331,14 @@ int eetq_diag_stream_plan(int bits, int M, int N, int K, int cus, int* form, int
  * (cutlass_kernels/cutlass_heuristic.cc:123-206) -- one rule here, printed by bench.py's `config4` block per point and measured
  * against every forced path by tools/auto_regret.py. */
 int eetq_diag_auto_path(int bits, int M, int N, int K, int* path, int* detail);
+
+/* Diagnostic, host arithmetic only: the plan the split-K medium-batch tile (EETQ_PATH_SPLITK, W8A16 and W4A16 alike) runs an M x K
+ * activation against a K x N weight with -- *column_blocks (32-column blocks per workgroup: 1 or 2), *k_slices (1, 2 or 4; > 1
+ * needs the stream's scratch region), *ring (10 * activation stages + weight stages: 22 or 33), *row_groups (the batch cut along
+ * M; M <= 32 * 4 * row_groups).  It calls the planner the launcher calls (gemm_splitk.hip::splitk_plan: one cost model over every
+ * combination, its constants fitted on the measured time of every plan -- profiles/r05_splitk_plan_regret*.jsonl), so
+ * tests/test_abi.py can hold the planner against those tables without a GPU.  1 <= M <= 1024, K % 64 == 0. */
+int eetq_diag_splitk_plan(int M, int N, int K, int* column_blocks, int* k_slices, int* ring, int* row_groups);
 
 /* Decode steps on a pre-allocated KV cache (eetq_rope_decode_attention_f16, eetq_rotary_neox_kvcache_f16) whose new token
  * was NOT written because its cache row lies outside the cache (slot >= rows: the cache is full; or a negative position).
