@@ -327,22 +327,25 @@ void splitk_plan(int M, int N, int K, int* nb_out, int* s_out, int* stages_out, 
                 const int wgs = tiles * s * r;
                 // ring depth 3 (120..144 KiB: one workgroup per CU) when that many workgroups fit anyway, else depth 2 (two per CU at MT <= 2)
                 const int stages  = (MT <= 2 && wgs <= ncu) ? 3 : 2;
-                // the model counts on two workgroups per CU only for plans without a hand-over (split ones time the same at one and two per CU)
-                const int per_cu  = ((s == 1 || r > 1) && stages == 2 && MT <= 2 && (16 * MT + 8 * nb) * 2 <= 80) ? 2 : 1;
-                const int rounds  = (wgs + ncu * per_cu - 1) / (ncu * per_cu);
+                // workgroups that can share a CU: plans without a hand-over on the 2-deep ring, as many as the 160 KiB of LDS hold,
+                // three at most (split ones time the same at one and two per CU) ...
+                const int lds_kib = stages * (16 * MT + 8 * nb);
+                const int cap     = ((s == 1 || r > 1) && stages == 2 && MT <= 2 && lds_kib <= 80) ? (160 / lds_kib < 3 ? 160 / lds_kib : 3) : 1;
+                const int rounds  = (wgs + ncu * cap - 1) / (ncu * cap);
+                // ... and that DO share one in the fullest round
+                const int per_cu  = rounds == 1 ? ((wgs + ncu - 1) / ncu < cap ? (wgs + ncu - 1) / ncu : cap) : cap;
                 const int my_steps = (steps + s - 1) / s;
-                // microseconds per K step: 0.27 per 32 rows of x + 0.14 per 32 columns of weights, x 1.3 when two workgroups share
-                // the CU (they hide each other's latencies: not x 2), the shallower ring 20 % slower; the hand-over: publish +
-                // ticket + slab reads; 0.27 per extra row group (each weight tile is pulled out of L2 r times).  The constants are a
-                // least-regret fit to the measured time of EVERY plan on 27 shapes x 6-7 batch sizes
-                // (profiles/r05_splitk_plan_regret*.jsonl through tools/experiments/splitk_plan_fit.py, 510 points: the pick is
-                // within 0.5 % of the best measured plan on average, 12 points above 5 %; fitted on three of the five tables it
-                // scores 0.5 % / 8 on the other two; the round-2 constants: 1.5 %, 63 points).  Out of sample -- a sixth table
-                // measured AFTER the fit, 22 shapes (5 new) at batch sizes none of the five used, AUTO against the best forced
-                // plan: 1.3 % on average, 12 of 154 points above 5 % (narrow N at M = 72 .. 120).
-                double t = my_steps * (0.27 * MT + 0.14 * nb) * (per_cu == 2 ? 1.3 : 1.0) * (stages == 3 ? 1.0 : 1.2);
-                t += s == 1 ? 0.0 : (s == 2 ? 2.2 : 2.9) + 0.077 * MT * nb * s;
-                t = 1.6 + rounds * t + 0.27 * (r - 1);
+                // microseconds per K step: 0.27 per 32 rows of x + 0.14 per 32 columns of weights, x 1.22 / 1.6 when two / three
+                // workgroups share the CU (they hide each other's latencies: not x 2 / x 3), the shallower ring 30 % slower; the
+                // hand-over: publish + ticket + slab reads; 0.27 per extra row group (each weight tile is pulled out of L2 r
+                // times).  The constants are a least-regret fit to the measured time of EVERY plan on 27 shapes x 6-7 batch sizes
+                // (profiles/r05_splitk_plan_regret*.jsonl through tools/experiments/splitk_plan_fit.py; tests/test_abi.py holds the
+                // planner against the same tables): over 664 points the pick is within 0.4 % of the best measured plan on average,
+                // 16 points above 5 % (the round-2 constants: 1.7 %, 88).  Out of sample, before the last refit: a table measured
+                // AFTER a fit on the others -- 22 shapes (5 new) at batch sizes none of them used -- scored 1.3 % / 12 of 154.
+                double t = my_steps * (0.27 * MT + 0.14 * nb) * (per_cu == 3 ? 1.6 : per_cu == 2 ? 1.22 : 1.0) * (stages == 3 ? 1.0 : 1.3);
+                t += s == 1 ? 0.0 : (s == 2 ? 2.2 : 2.8) + 0.088 * MT * nb * s;
+                t = 1.45 + rounds * t + 0.27 * (r - 1);
                 if (t < best) {
                     best = t;
                     bnb  = nb;

