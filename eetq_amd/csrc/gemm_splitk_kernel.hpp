@@ -125,8 +125,13 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         slice = j & (S - 1);
         tile  = xcd * (tiles_n >> 3) + (j >> sh);
     } else {
-        slice = blockIdx.x & (S - 1);
-        tile  = blockIdx.x >> sh;
+        // the same for any tile count (the tiled kernel's formula): tiles_n * S virtual tiles, XCD x takes q or q + 1 consecutive
+        // ones (N = 11008 is 172 column tiles; round-robin until the end of round 5: 4096 x 11008 M = 64 17.2 -> 16.8 us,
+        // 8192 x 11008 M = 64 30.2 -> 28.6, profiles/r05_ab_xcd_contiguous_any.jsonl)
+        const int TT = tiles_n << sh, q = TT >> 3, r = TT & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        const int vt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        slice = vt & (S - 1);
+        tile  = vt >> sh;
     }
     const int n0 = tile * C::kBN;
     // row group rg: rows [rg * kRows, min(M, (rg + 1) * kRows)) of the batch -- from here on the kernel sees its own rows only
