@@ -734,9 +734,17 @@ int eetq_diag_attn_stamps(unsigned long long* stamps)
 int eetq_decode_attention_splits(int batch, int heads, int positions)
 {
     if (batch <= 0 || heads <= 0 || positions <= 0) return 1;
-    const long bh     = (long)batch * heads;
-    const long target = (15L * device_cu_count() / 8 + bh / 2) / bh;  // round(1.875 * CUs / (batch * heads))
-    long       splits = target < 8 ? target : 8;
+    const long bh = (long)batch * heads, cus = device_cu_count();
+    // about 0.85 workgroups per CU -- a bare read of the same 21 MB: 200 / 240 workgroups 4.7 - 4.8 us, 320 (a quarter of the CUs
+    // with two) 5.7, 400 5.5 (profiles/r06_attn_probe.txt); the kernel itself at 40 heads: 5 chunks 9.5, 6 9.9, 8 11.7 us -- and
+    // twice / four times that when a chunk would otherwise hold more than 512 rows (batch 4: 3 chunks 20.5 us, 2 23.5, 4 23.3)
+    long splits = 1;
+    for (long k = 1; k <= 4; k *= 2) {
+        splits = (17 * k * cus / 20 + bh / 2) / bh;  // round(0.85 k CUs / (batch heads))
+        if (splits < 1) splits = 1;
+        if (((long)positions + splits - 1) / splits <= 512) break;
+    }
+    if (splits > 16) splits = 16;
     const long cap    = ((long)positions + 63) / 64;
     if (splits > cap) splits = cap;
     return (int)(splits < 1 ? 1 : splits);

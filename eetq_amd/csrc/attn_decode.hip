@@ -6,10 +6,11 @@
 // of eet_accelerator's attention block uses this split-KV form instead: HBM/L2-bound byte work, no MFMA.
 //
 // Two-launch form (eetq_decode_attention_f16):
-//   phase 1  grid (splits, heads, batch), 256 threads: a workgroup owns a contiguous chunk of the VALID cache positions; a
-//            group of D/8 lanes owns one position at a time (16-byte loads of its k and v rows, fully coalesced across the
-//            wave), keeps an online-softmax state (m, l) and 8 output channels per lane; groups and waves are merged
-//            through LDS and the chunk's (m, l, o[D]) goes to an fp32 workspace;
+//   phase 1  grid (splits, heads, batch), 256 threads: a workgroup owns every splits-th 16-row block of the VALID cache
+//            positions (round 6: "Work assignment" below) and has all of them in flight before it consumes any; a group of
+//            D/8 lanes owns one position at a time (16-byte loads of its k and v rows, fully coalesced across the wave),
+//            keeps an online-softmax state (m, l) and 8 output channels per lane; the groups of a wave are merged by lane
+//            swaps, the waves through LDS, and the chunk's (m, l, o[D]) goes to an fp32 workspace;
 //   phase 2  grid (heads, batch), 256 threads: merges the chunks (attn_merge), normalises, writes fp16.
 // One-launch form (eetq_rope_decode_attention_f16), the decode step of a static cache: the same phase 1 with the NeoX
 // rotation of the new token's q and k done in registers on the way in (the arithmetic of rotary_neox_kvcache_kernel, fp16
@@ -17,9 +18,11 @@
 // kv head, every workgroup taking the new row from registers rather than from the cache (so nothing in the launch reads
 // what the launch writes), and phase 2 done by whichever workgroup of a head finishes last: partials are published with
 // write-through stores, a ticket per head decides "last" (the in-launch hand-off of gemm_splitk_kernel.hpp), and the last
-// head to finish advances the cache's token counter.  Three launches (15.0 us per layer at 13B shapes, 1 k rows) become one
-// (10.9 us).  Both forms run the
-// same chunk code and the same merge arithmetic: their outputs are bit-identical.
+// head to finish advances the cache's token counter.  Three launches (15.0 us per layer at 13B shapes, 1 k rows) became one
+// (10.9 - 11.6 us, rounds 2-5; 9.5 us with the round-6 chunk code, of which 8.7 are there with an almost empty cache: launch
+// gap 1.1, scalar reads 0.35, new token + rotation 0.8, the chunk's arithmetic 1.5, workgroup merge 0.4, publish 0.5, ticket
+// 0.75, head merge 1.6, store 0.2 -- profiles/r06_attn_stamps.txt, r06_attn_bench.jsonl).  Both forms run the same chunk code
+// and the same merge arithmetic: their outputs are bit-identical.
 #include <type_traits>
 
 #include "common.hpp"
@@ -39,32 +42,61 @@ constexpr int kAttnThreads = 256;
 constexpr int kRecPad = 4;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// One "trip" of a wave through the cache: U position groups, i.e. 2U independent 16-byte loads per lane in flight (the
-// loop is latency-bound otherwise).  The FIRST trip of a workgroup is loaded by the caller before anything else it has to
-// do (scalar setup, the rotation of the new token), so the cache rows are in flight while that runs.
-constexpr int kTripU = 4;
-template <int D>
-struct KvTrip {
-    f16x8 k[kTripU], v[kTripU];
-    int   jj[kTripU];
-    bool  valid[kTripU];
-};
+// Work assignment (round 6).  The cache rows of a (batch row, kv head) are cut into BLOCKS of BLK = 16 (D = 128) or 32 (D = 64)
+// consecutive rows -- one wave-wide 16-byte load per wave covers its share of a block, the workgroup's four waves the whole
+// block, 4 or 8 KiB of contiguous bytes -- and chunk `split` of `splits` owns blocks split, split + splits, split + 2 splits, ...:
+// all chunks of a head carry the same number of rows to within one block whatever the valid length is.
+// A workgroup requests its first kUA + kUB blocks before it consumes anything: at <= (kUA + kUB) * BLK * splits valid rows
+// (1536 at 6 chunks, D = 128) every row of the launch is in flight at once and the launch pays the memory latency once
+// (rounds 2-5: trips of 4 blocks one ahead -- 5.4 vs 4.7 us for the same bytes as a bare read kernel,
+// profiles/r06_attn_probe.txt).  LONG launches (the cache can hold more rows than that) continue in software-pipelined trips
+// of kUL blocks.
+// Every cache load is an unconditional buffer load, nt (a row is read once per token), through descriptors that END AT THE
+// VALID LENGTH: a row that does not count is out of range and comes back as zeros without touching memory -- no load behind a
+// branch, no clamped duplicate rows, no select on the way in.  An out-of-range load is not free, though (0.5 us per launch for
+// one per block, same probe): the mask loads exist only in the MASK instantiation, the further trips only in the LONG one.
+// The running softmax state is rescaled once per trip (A, B, then each further trip), not once per position.
+constexpr int kUA = 8, kUB = 8, kUL = 4, kUG = 4;
+constexpr int kNt = 2;  // aux bits of a buffer load: nt
 
 template <int D>
-__device__ __forceinline__ void load_trip(KvTrip<D>& t, const f16* __restrict__ kbase, const f16* __restrict__ vbase, long k_ss,
-                                          long v_ss, int jb, int j1)
+struct AttnGeo {
+    static constexpr int LPP = D / 8;                        // lanes per position
+    static constexpr int PPW = 64 / LPP;                     // positions per wave instruction
+    static constexpr int BLK = (kAttnThreads / 64) * PPW;    // positions per block
+};
+
+struct KvSrc {
+    __amdgpu_buffer_rsrc_t k, v, m;   // the valid rows of one (batch row, kv head); m: the additive mask row (MASK only)
+    unsigned               k_row, v_row;  // bytes between cache rows
+    unsigned               d0b;           // this lane's channel offset in bytes
+};
+
+template <int U>
+struct KvBlocks {
+    f16x8          k[U], v[U];
+    unsigned short m[U];
+};
+
+// blocks blk0 + u * dblk for u in [U0, U0 + UN) of the U a KvBlocks holds: this lane's row of each, K and V of a block back
+// to back (returns are in order: a block is complete when its V row is)
+template <int D, int U0, int UN, bool MASK, int U>
+__device__ __forceinline__ void load_range(KvBlocks<U>& t, const KvSrc& s, int blk0, int dblk, int rib)
 {
-    constexpr int LPP = D / 8, STEP = (kAttnThreads / 64) * (64 / LPP);
-    const int     grp = (threadIdx.x & 63) / LPP;
+    constexpr int BLK = AttnGeo<D>::BLK;
+    static_assert(U0 + UN <= U, "range");
 #pragma unroll
-    for (int u = 0; u < kTripU; ++u) {
-        const int j = jb + u * STEP + grp;
-        t.valid[u]  = j < j1;
-        t.jj[u]     = t.valid[u] ? j : max(j1 - 1, 0);  // clamped, predicated use: no load behind a branch
-        t.k[u]      = *reinterpret_cast<const f16x8*>(kbase + (long)t.jj[u] * k_ss);
+    for (int u = U0; u < U0 + UN; ++u) {
+        const unsigned j = (unsigned)((blk0 + u * dblk) * BLK + rib);
+        t.k[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(s.k, (int)(j * s.k_row + s.d0b), 0, kNt));
+        t.v[u] = __builtin_bit_cast(f16x8, __builtin_amdgcn_raw_buffer_load_b128(s.v, (int)(j * s.v_row + s.d0b), 0, kNt));
+        if constexpr (MASK) t.m[u] = __builtin_amdgcn_raw_buffer_load_b16(s.m, (int)(j * 2u), 0, 0);
     }
-#pragma unroll
-    for (int u = 0; u < kTripU; ++u) t.v[u] = *reinterpret_cast<const f16x8*>(vbase + (long)t.jj[u] * v_ss);
+}
+template <int D, int U, bool MASK>
+__device__ __forceinline__ void load_blocks(KvBlocks<U>& t, const KvSrc& s, int blk0, int dblk, int rib)
+{
+    load_range<D, 0, U, MASK>(t, s, blk0, dblk, rib);
 }
 
 // Sum over the LPP = 8 or 16 consecutive lanes that share a position, by DPP (no LDS traffic): quad swaps, then the
@@ -87,97 +119,190 @@ __device__ __forceinline__ float group_sum(float v)
     return v;
 }
 
-// The chunk [j0, j1) of one (batch row, head): online softmax over its positions, merged across the workgroup.  On return
-// threads tid < D hold (M, L, O) = the chunk's running maximum, its sum of exp(s - M) and channel tid of sum exp(s - M) v.
-// qv: this lane's 8 channels of the (rotated) query; scores are scaling * (q . k) with the products summed in fp32
-// (v_dot2_f32_f16).  `t` holds the wave's first trip (load_trip at jb = j0 + wave * PPW).  The running state is rescaled
-// once per trip (U positions), not once per position.
-// SUBST: position `slot` is taken from registers (knew, vnew: this lane's 8 channels of the new token) instead of the cache.
-template <int D, bool SUBST>
-__device__ __forceinline__ void attn_chunk(const f16x8& qv, float scaling, KvTrip<D>& t, const f16* __restrict__ kbase,
-                                           const f16* __restrict__ vbase, long k_ss, long v_ss, const f16* __restrict__ mrow,
-                                           int j0, int j1, int slot, const f16x8& knew, const f16x8& vnew, float* sm_m,
-                                           float* sm_l, float* sm_o, float& M, float& L, float& O)
+// One trip: the online-softmax update of this lane's running state (m, l, o[8]) with positions [U0, U0 + UN) of the U it holds.
+// scores are scaling * (q . k) (+ mask) with the products summed in fp32 (v_dot2_f32_f16); rows >= Sv count for nothing (they
+// were out of range of the descriptors: k = v = 0).  SUBST: position `slot` is taken from registers (knew, vnew: this lane's 8
+// channels of the new token) instead of the cache -- tested per block (workgroup-uniform), selected per lane inside it.
+template <int D, int U0, int UN, bool SUBST, bool MASK, int U>
+__device__ __forceinline__ void consume_range(KvBlocks<U>& t, int blk0, int dblk, int rib, int Sv, int slot, const f16x8& knew,
+                                              const f16x8& vnew, const f16x2 (&q2)[4], float scaling, float& m, float& l,
+                                              float (&o)[8])
 {
     // every multiply-add below is explicit and contraction is off: the two launch forms instantiate this code separately
     // and must round identically
 #pragma clang fp contract(off)
-    constexpr int LPP  = D / 8;               // lanes per position
-    constexpr int PPW  = 64 / LPP;            // positions per wave instruction
-    constexpr int SETS = (kAttnThreads / 64) * PPW;
-    constexpr int U    = kTripU;
+    static_assert(U0 + UN <= U, "range");
+    constexpr int LPP = AttnGeo<D>::LPP, BLK = AttnGeo<D>::BLK;
+    if ((blk0 + U0 * dblk) * BLK >= Sv) return;  // workgroup-uniform: the trip's first block is beyond the valid rows, so are the others
+    const int     slot_blk = SUBST && slot >= 0 ? slot / BLK : -1;
+    float         sc[U];
+#pragma unroll
+    for (int u = U0; u < U0 + UN; ++u) {
+        const int blk = blk0 + u * dblk, j = blk * BLK + rib;
+        if (SUBST && blk == slot_blk) {  // workgroup-uniform
+            const bool mine = j == slot;
+            t.k[u] = mine ? knew : t.k[u];
+            t.v[u] = mine ? vnew : t.v[u];
+        }
+        float a = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a = __builtin_amdgcn_fdot2(f16x2{t.k[u][2 * i], t.k[u][2 * i + 1]}, q2[i], a, false);
+        a = group_sum<LPP>(a) * scaling;
+        if constexpr (MASK) a += (float)__builtin_bit_cast(f16, t.m[u]);
+        sc[u] = j < Sv ? a : -INFINITY;
+    }
+    float mn = m;
+#pragma unroll
+    for (int u = U0; u < U0 + UN; ++u) mn = fmaxf(mn, sc[u]);
+    if (mn > -INFINITY) {  // group-uniform
+        const float keep = __expf(m - mn);
+        l *= keep;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] *= keep;
+#pragma unroll
+        for (int u = U0; u < U0 + UN; ++u) {
+            const float p = __expf(sc[u] - mn);  // exp(-inf) = 0 for the positions that do not count
+            l += p;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) o[i] = fmaf(p, (float)t.v[u][i], o[i]);
+        }
+        m = mn;
+    }
+}
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>), in order
+template <int N, int I = 0, typename F>
+__device__ __forceinline__ void static_for(F& f)
+{
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
+
+// value of lane ^ OFF (OFF = 8, 16, 32)
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float v)
+{
+    const u32 u = __builtin_bit_cast(u32, v);
+    if constexpr (OFF == 32) {
+        auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __builtin_bit_cast(float, (u32)((threadIdx.x & 32) ? r[0] : r[1]));  // r[0]: the lower half everywhere, r[1]: the upper
+    } else if constexpr (OFF == 16) {
+        auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        return __builtin_bit_cast(float, (u32)((threadIdx.x & 16) ? r[0] : r[1]));  // r[0]: the even 16-lane rows everywhere, r[1]: the odd
+    } else {
+        return __shfl_xor(v, OFF, 64);
+    }
+}
+
+// The consumption of chunk `split` of one (batch row, head) and its merge across the workgroup.  ta: the chunk's first kUA
+// blocks, already requested (load_blocks at blk0 = split, stride splits); tb: registers for the next kUB.  On return
+// threads tid < D hold (M, L, O) = the chunk's running maximum, its sum of exp(s - M) and channel tid of sum exp(s - M) v.
+// qv: this lane's 8 channels of the (rotated) query.
+template <int D, bool SUBST, bool MASK, bool LONG>
+__device__ __forceinline__ void attn_chunk(const f16x8& qv, float scaling, KvBlocks<kUA>& ta, KvBlocks<kUB>& tb, const KvSrc& src,
+                                           int split, int splits, int Sv, int slot, const f16x8& knew, const f16x8& vnew,
+                                           float* sm_m, float* sm_l, float* sm_o, float& M, float& L, float& O)
+{
+#pragma clang fp contract(off)
+    constexpr int LPP = AttnGeo<D>::LPP, PPW = AttnGeo<D>::PPW, BLK = AttnGeo<D>::BLK, NW = kAttnThreads / 64;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int grp = lane / LPP, li = lane % LPP, d0 = li * 8;
+    const int grp = lane / LPP, li = lane % LPP, d0 = li * 8, rib = wave * PPW + grp;
     const f16x2 q2[4] = {{qv[0], qv[1]}, {qv[2], qv[3]}, {qv[4], qv[5]}, {qv[6], qv[7]}};
 
     float m = -INFINITY, l = 0.f, o[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) o[i] = 0.f;
 
-    // Trips are software-pipelined: the next trip's rows are requested (clamped to the chunk: unconditional loads, never
-    // behind a branch) before the current trip is consumed, so a chunk of several trips pays the memory latency once.  The
-    // last iteration's request is wasted (one clamped row).
-    constexpr int STEP = (kAttnThreads / 64) * PPW;
-    KvTrip<D>     nxt;
-    for (int jb = j0 + wave * PPW;;) {
-        const int jn = jb + U * STEP;
-        load_trip<D>(nxt, kbase, vbase, k_ss, v_ss, jn, j1);
-        float sc[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            if (SUBST && t.jj[u] == slot) {
-                t.k[u] = knew;
-                t.v[u] = vnew;
-            }
-            float a = 0.f;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a = __builtin_amdgcn_fdot2(f16x2{t.k[u][2 * i], t.k[u][2 * i + 1]}, q2[i], a, false);
-            a = group_sum<LPP>(a) * scaling;
-            if (mrow) a += (float)mrow[t.jj[u]];
-            sc[u] = t.valid[u] ? a : -INFINITY;
+    // A is on its way (requested by the caller); B is requested here, kUG blocks at a time, between the trips of A: a wave that
+    // asks for more than the memory system takes at once is held AT THE REQUEST until there is room, and a wave held there
+    // consumes nothing -- with all of B requested up front the first trip of A was consumed 4.2 us into the launch although its
+    // rows had landed well before (profiles/r06_attn_stamps.txt).  Trips are kUG blocks each.
+    static_assert(kUA == kUB && kUA % kUG == 0, "trip structure");
+    const int blk_b = split + kUA * splits;
+    auto trips_ab = [&](auto i_tag) {
+        constexpr int I = decltype(i_tag)::value;
+        load_range<D, I * kUG, kUG, MASK>(tb, src, blk_b, splits, rib);
+        __builtin_amdgcn_sched_barrier(0);
+        consume_range<D, I * kUG, kUG, SUBST, MASK>(ta, split, splits, rib, Sv, slot, knew, vnew, q2, scaling, m, l, o);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto trips_b = [&](auto i_tag) {
+        constexpr int I = decltype(i_tag)::value;
+        consume_range<D, I * kUG, kUG, SUBST, MASK>(tb, blk_b, splits, rib, Sv, slot, knew, vnew, q2, scaling, m, l, o);
+    };
+    constexpr int NT = kUA / kUG;  // trips per batch
+    static_for<NT>(trips_ab);
+    if constexpr (LONG) {
+        // further trips of kUL blocks, software-pipelined one ahead; the first is requested before B is consumed
+        const int     nblk = (Sv + BLK - 1) / BLK;
+        int           ub   = kUA + kUB;
+        KvBlocks<kUL> tl, tn;
+        load_blocks<D, kUL, MASK>(tl, src, split + ub * splits, splits, rib);
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<NT>(trips_b);
+        while (split + ub * splits < nblk) {  // workgroup-uniform
+            load_blocks<D, kUL, MASK>(tn, src, split + (ub + kUL) * splits, splits, rib);
+            consume_range<D, 0, kUL, SUBST, MASK>(tl, split + ub * splits, splits, rib, Sv, slot, knew, vnew, q2, scaling, m, l, o);
+            tl = tn;
+            ub += kUL;
         }
-        float mn = m;
+    } else {
+        static_for<NT>(trips_b);
+    }
+
+    // the wave's PPW position groups first (lane swaps, no LDS), then the waves through LDS: NW sets instead of NW * PPW
+    float mw = m;
+    if constexpr (PPW == 8) mw = fmaxf(mw, lane_xor<8>(mw));
+    mw = fmaxf(mw, lane_xor<16>(mw));
+    mw = fmaxf(mw, lane_xor<32>(mw));
+    const float w = mw > -INFINITY ? __expf(m - mw) : 0.f;  // exp(-inf) = 0 for a group without a valid position
+    float       part[9];
+    part[8] = l * w;
 #pragma unroll
-        for (int u = 0; u < U; ++u) mn = fmaxf(mn, sc[u]);
-        if (mn > -INFINITY) {  // group-uniform
-            const float keep = __expf(m - mn);
-            l *= keep;
+    for (int i = 0; i < 8; ++i) part[i] = o[i] * w;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) o[i] *= keep;
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const float p = __expf(sc[u] - mn);  // exp(-inf) = 0 for the positions beyond the chunk
-                l += p;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) o[i] = fmaf(p, (float)t.v[u][i], o[i]);
-            }
-            m = mn;
+    for (int i = 0; i < 9; ++i) {
+        if constexpr (PPW == 8) part[i] += lane_xor<8>(part[i]);
+        part[i] = sum_xor32(sum_xor16(part[i]));
+    }
+    if (lane < LPP) {
+        if (li == 0) {
+            sm_m[wave] = mw;
+            sm_l[wave] = part[8];
         }
-        if (jn >= j1) break;  // wave-uniform
-        t  = nxt;
-        jb = jn;
+        *reinterpret_cast<f32x4*>(sm_o + wave * D + d0)     = f32x4{part[0], part[1], part[2], part[3]};
+        *reinterpret_cast<f32x4*>(sm_o + wave * D + d0 + 4) = f32x4{part[4], part[5], part[6], part[7]};
     }
-    const int set = wave * PPW + grp;
-    if (li == 0) {
-        sm_m[set] = m;
-        sm_l[set] = l;
-    }
-    *reinterpret_cast<f32x4*>(sm_o + set * D + d0)     = f32x4{o[0], o[1], o[2], o[3]};
-    *reinterpret_cast<f32x4*>(sm_o + set * D + d0 + 4) = f32x4{o[4], o[5], o[6], o[7]};
     __syncthreads();
     M = -INFINITY, L = 0.f, O = 0.f;
     if (tid < D) {
 #pragma unroll
-        for (int s2 = 0; s2 < SETS; ++s2) M = fmaxf(M, sm_m[s2]);
+        for (int s2 = 0; s2 < NW; ++s2) M = fmaxf(M, sm_m[s2]);
         if (M > -INFINITY) {
 #pragma unroll
-            for (int s2 = 0; s2 < SETS; ++s2) {
-                const float w = __expf(sm_m[s2] - M);  // exp(-inf) = 0 for empty sets
-                L = fmaf(sm_l[s2], w, L);
-                O = fmaf(sm_o[s2 * D + tid], w, O);
+            for (int s2 = 0; s2 < NW; ++s2) {
+                const float ws = __expf(sm_m[s2] - M);  // exp(-inf) = 0 for empty sets
+                L = fmaf(sm_l[s2], ws, L);
+                O = fmaf(sm_o[s2 * D + tid], ws, O);
             }
         }
     }
+}
+
+// the buffer descriptors of one (batch row, kv head), ending at the valid length Sv
+template <int D, bool MASK>
+__device__ __forceinline__ KvSrc make_kv_src(const f16* kbase, const f16* vbase, long k_ss, long v_ss, int Sv, const f16* mrow)
+{
+    KvSrc s;
+    s.k_row = (unsigned)(k_ss * 2);
+    s.v_row = (unsigned)(v_ss * 2);
+    s.d0b   = (unsigned)(((threadIdx.x & 63) % AttnGeo<D>::LPP) * 16);
+    s.k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(kbase), 0, (int)((unsigned)Sv * s.k_row), 0x00020000);
+    s.v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(vbase), 0, (int)((unsigned)Sv * s.v_row), 0x00020000);
+    s.m = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(MASK ? mrow : kbase), 0, MASK ? Sv * 2 : 0, 0x00020000);
+    return s;
 }
 
 // rows at and beyond the valid length of a pre-allocated (static) cache hold zeros or stale tokens: never attended
@@ -186,30 +311,30 @@ __device__ __forceinline__ int valid_len(int S, const int64_t* kv_len, int kv_le
     return kv_len ? max(0, (int)min((int64_t)S, *kv_len + kv_len_bias)) : S;
 }
 
-template <int D>
+template <int D, bool MASK, bool LONG>
 __global__ __launch_bounds__(kAttnThreads) void attn_decode_partial_kernel(
     const f16* __restrict__ q, const f16* __restrict__ kc, const f16* __restrict__ vc, const f16* __restrict__ mask,
     float* __restrict__ ws, float scaling, int S, int groups, long q_sb, long q_sh, long k_sb, long k_sh,
     long k_ss, long v_sb, long v_sh, long v_ss, long m_sb, const int64_t* __restrict__ kv_len, int kv_len_bias)
 {
-    constexpr int SETS = (kAttnThreads / 64) * (64 / (D / 8));
-    __shared__ float sm_m[SETS], sm_l[SETS];
-    __shared__ __attribute__((aligned(16))) float sm_o[SETS * D];
+    constexpr int NW = kAttnThreads / 64;
+    __shared__ float sm_m[NW], sm_l[NW];
+    __shared__ __attribute__((aligned(16))) float sm_o[NW * D];
 
-    const int split = blockIdx.x, h = blockIdx.y, b = blockIdx.z, hk = h / groups;
+    const int split = blockIdx.x, splits = gridDim.x, h = blockIdx.y, b = blockIdx.z, hk = h / groups;
     const int tid = threadIdx.x, d0 = ((tid & 63) % (D / 8)) * 8;
+    const int rib = (tid >> 6) * AttnGeo<D>::PPW + (tid & 63) / AttnGeo<D>::LPP;
     const int Sv = valid_len(S, kv_len, kv_len_bias);
-    const int chunk = (Sv + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int j0 = split * chunk, j1 = min(Sv, j0 + chunk);
 
-    const f16 *kbase = kc + b * k_sb + hk * k_sh + d0, *vbase = vc + b * v_sb + hk * v_sh + d0;
-    KvTrip<D>  trip;
-    load_trip<D>(trip, kbase, vbase, k_ss, v_ss, j0 + (tid >> 6) * (64 / (D / 8)), j1);
-    const f16x8 qv = *reinterpret_cast<const f16x8*>(q + b * q_sb + h * q_sh + d0);
+    const f16x8 qv  = *reinterpret_cast<const f16x8*>(q + b * q_sb + h * q_sh + d0);
+    const KvSrc src = make_kv_src<D, MASK>(kc + b * k_sb + hk * k_sh, vc + b * v_sb + hk * v_sh, k_ss, v_ss, Sv,
+                                           MASK ? mask + b * m_sb : nullptr);
+    KvBlocks<kUA> ta;
+    KvBlocks<kUB> tb;
+    load_blocks<D, kUA, MASK>(ta, src, split, splits, rib);
     float       M, L, O;
     const f16x8 none = {};
-    attn_chunk<D, false>(qv, scaling, trip, kbase, vbase, k_ss, v_ss, mask ? mask + b * m_sb : nullptr, j0, j1, -1, none, none,
-                         sm_m, sm_l, sm_o, M, L, O);
+    attn_chunk<D, false, MASK, LONG>(qv, scaling, ta, tb, src, split, splits, Sv, -1, none, none, sm_m, sm_l, sm_o, M, L, O);
     if (tid < D) {
         float* out = ws + (((size_t)b * gridDim.x + split) * gridDim.y + h) * (D + kRecPad);  // [batch][split][head][record]
         out[kRecPad + tid] = O;
@@ -366,16 +491,14 @@ struct RopeAttnArgs {
 
 
 // NeoX rotation of this lane's 8 channels [d0, d0 + 8) of one head (rot_dim = D: channel d < D/2 pairs with d + D/2).
-// own / other: the lane's channels and the paired ones; cs: the position's cos|sin row.  fp16 arithmetic, one rounding per
+// own / other: the lane's channels and the paired ones; c / s: the lane's 8 values of the position's cos | sin row.  fp16 arithmetic, one rounding per
 // multiply and add, exactly rotary_neox_kvcache_kernel (norm_rope.hip).
 template <int D>
-__device__ __forceinline__ f16x8 rope8(const f16x8& own, const f16x8& other, const f16* __restrict__ cs, int d0)
+__device__ __forceinline__ f16x8 rope8(const f16x8& own, const f16x8& other, const f16x8& c, const f16x8& s, int d0)
 {
 #pragma clang fp contract(off)
     constexpr int embed = D / 2;
     const bool    low   = d0 < embed;
-    const int     off   = low ? d0 : d0 - embed;
-    const f16x8   c = *reinterpret_cast<const f16x8*>(cs + off), s = *reinterpret_cast<const f16x8*>(cs + embed + off);
     f16x8         r;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -399,16 +522,16 @@ __device__ __forceinline__ void store_sc1(float* p, float v)
 // grid (splits, heads, batch), 256 threads; see the file header.  The five leading pointers are preloaded into SGPRs at
 // launch (-amdgpu-kernarg-preload-count): the three scalar reads the chunk bounds depend on go out with the first
 // instructions, together with the fetch of the argument block, and nothing else stands before the first cache loads.
-template <int D>
+template <int D, bool MASK, bool LONG>
 __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const int64_t* __restrict__ kv_len,
                                                                         const int64_t* __restrict__ slots,
                                                                         const int64_t* __restrict__ positions,
                                                                         f16* __restrict__ kc, f16* __restrict__ vc,
                                                                         const RopeAttnArgs a)
 {
-    constexpr int LPP = D / 8, SETS = (kAttnThreads / 64) * (64 / LPP);
-    __shared__ float    sm_m[SETS], sm_l[SETS];
-    __shared__ __attribute__((aligned(16))) float sm_o[SETS * D];
+    constexpr int LPP = D / 8, NW = kAttnThreads / 64;
+    __shared__ float    sm_m[NW], sm_l[NW];
+    __shared__ __attribute__((aligned(16))) float sm_o[NW * D];
     __shared__ unsigned sm_ticket;
 
     ATTN_STAMP(0);
@@ -419,7 +542,9 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
 
     // three independent scalar reads, every one from a valid address (no branch before the loads): a missing `slots`
     // reads the position instead, a missing `kv_len` reads the position and ignores it
-    // (issued as one batch with one wait: left to itself the compiler waits after each of them)
+    // (issued as one batch with one wait: left to itself the compiler waits after each of them).  They go out with the first
+    // instructions, on a quiet memory system (0.3 - 0.6 us): behind a burst of cache loads the same reads take 1.2 us and
+    // hold back everything that depends on the valid length (measured: profiles/r06_attn_stamps.txt).
     const int64_t* p_pos  = positions + b;
     const int64_t* p_slot = slots ? slots + (long)b * a.slot_stride : positions + b;
     const int64_t* p_len  = kv_len ? kv_len : positions;
@@ -435,34 +560,39 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
     // a full cache (or a bad position) used to be silent: count the dropped steps (eetq_decode_dropped_steps)
     if (!have_new && split == 0 && h == 0 && threadIdx.x == 0) atomicAdd(&g_attn_dropped, 1u);
     const int  Sv = kv_len ? max(0, (int)min((int64_t)a.S, filled + a.kv_len_bias)) : a.S;
-    const int  chunk = (Sv + splits - 1) / splits;
-    const int  j0 = split * chunk, j1 = min(Sv, j0 + chunk);
 
-    // the cache rows of the first trip go in flight before anything else is touched
-    const f16 *kbase = kc + b * a.kc_sb + hk * a.kc_sh + d0, *vbase = vc + b * a.vc_sb + hk * a.vc_sh + d0;
-    KvTrip<D>  trip;
-    load_trip<D>(trip, kbase, vbase, a.kc_ss, a.vc_ss, j0 + (tid >> 6) * (64 / LPP), j1);
-
-    const f16* qp = a.q + b * a.q_sb + (long)h * D;
-    const f16* kp = a.k + b * a.k_sb + (long)hk * D;
-    f16x8      qv = *reinterpret_cast<const f16x8*>(qp + d0);
-    f16x8      knew = *reinterpret_cast<const f16x8*>(kp + d0);
+    // Memory queue order (a wave's loads return in order): the new token and its cos | sin row first, then the chunk's first
+    // kUA blocks; the rotation runs on the former while the latter are on their way; attn_chunk requests the rest.
+    const f16*  qp = a.q + b * a.q_sb + (long)h * D;
+    const f16*  kp = a.k + b * a.k_sb + (long)hk * D;
+    f16x8       qv   = *reinterpret_cast<const f16x8*>(qp + d0);
+    f16x8       knew = *reinterpret_cast<const f16x8*>(kp + d0);
     const f16x8 vnew = *reinterpret_cast<const f16x8*>(a.v + b * a.v_sb + (long)hk * D + d0);
+    const f16x8 qpair = *reinterpret_cast<const f16x8*>(qp + d1), kpair = *reinterpret_cast<const f16x8*>(kp + d1);
+    // (a bad position reads row 0 of the table and is not used)
+    const f16*  cs = a.cos_sin + (have_new ? rpos : 0) * D + (d0 < D / 2 ? d0 : d0 - D / 2);
+    const f16x8 rc = *reinterpret_cast<const f16x8*>(cs), rs = *reinterpret_cast<const f16x8*>(cs + D / 2);
+    __builtin_amdgcn_sched_barrier(0);  // (the scheduler sinks these seven loads below the block loads otherwise)
+    const KvSrc src = make_kv_src<D, MASK>(kc + b * a.kc_sb + hk * a.kc_sh, vc + b * a.vc_sb + hk * a.vc_sh, a.kc_ss, a.vc_ss,
+                                           Sv, MASK ? a.mask + b * a.m_sb : nullptr);
+    const int   rib = (tid >> 6) * AttnGeo<D>::PPW + lane / LPP;
+    KvBlocks<kUA> ta;
+    KvBlocks<kUB> tb;
+    load_blocks<D, kUA, MASK>(ta, src, split, splits, rib);
+    __builtin_amdgcn_sched_barrier(0);
     if (have_new) {
-        const f16x8 q2 = *reinterpret_cast<const f16x8*>(qp + d1), k2 = *reinterpret_cast<const f16x8*>(kp + d1);
-        const f16*  cs = a.cos_sin + rpos * D;
-        qv   = rope8<D>(qv, q2, cs, d0);
-        knew = rope8<D>(knew, k2, cs, d0);
-        // the cache row of the new token: once per kv head, by one position group of the head's first workgroup
-        if (split == 0 && h == hk * a.groups && tid < LPP) {
-            *reinterpret_cast<f16x8*>(kc + b * a.kc_sb + hk * a.kc_sh + (long)slot * a.kc_ss + d0) = knew;
-            *reinterpret_cast<f16x8*>(vc + b * a.vc_sb + hk * a.vc_sh + (long)slot * a.vc_ss + d0) = vnew;
-        }
+        qv   = rope8<D>(qv, qpair, rc, rs, d0);
+        knew = rope8<D>(knew, kpair, rc, rs, d0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the cache row of the new token: once per kv head, by one position group of the head's first workgroup
+    if (have_new && split == 0 && h == hk * a.groups && tid < LPP) {
+        *reinterpret_cast<f16x8*>(kc + b * a.kc_sb + hk * a.kc_sh + (long)slot * a.kc_ss + d0) = knew;
+        *reinterpret_cast<f16x8*>(vc + b * a.vc_sb + hk * a.vc_sh + (long)slot * a.vc_ss + d0) = vnew;
     }
     ATTN_STAMP(2);
     float M, L, O;
-    attn_chunk<D, true>(qv, a.scaling, trip, kbase, vbase, a.kc_ss, a.vc_ss, a.mask ? a.mask + b * a.m_sb : nullptr, j0, j1, slot,
-                        knew, vnew, sm_m, sm_l, sm_o, M, L, O);
+    attn_chunk<D, true, MASK, LONG>(qv, a.scaling, ta, tb, src, split, splits, Sv, slot, knew, vnew, sm_m, sm_l, sm_o, M, L, O);
 
     ATTN_STAMP(3);
     float*     head_ws = a.ws + ((size_t)b * splits * H + h) * (D + kRecPad);  // [batch][split][head][record]
@@ -506,17 +636,60 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
     }
 }
 
+// LONG: some chunk may own more than kUA + kUB blocks (a launch-time fact of the capacity S and the chunk count)
 template <int D>
-int launch_d(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out, float* ws, int B, int H, int Hkv, int S,
-             int splits, float scaling, const long* st, const int64_t* kv_len, int kv_len_bias, int64_t* advance,
-             hipStream_t stream)
+bool long_chunks(int S, int splits)
 {
-    attn_decode_partial_kernel<D><<<dim3(splits, H, B), kAttnThreads, 0, stream>>>(
+    constexpr int BLK = AttnGeo<D>::BLK;
+    return ((S + BLK - 1) / BLK + splits - 1) / splits > kUA + kUB;
+}
+
+template <int D, bool MASK, bool LONG>
+int launch_d2(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out, float* ws, int B, int H, int Hkv, int S,
+              int splits, float scaling, const long* st, const int64_t* kv_len, int kv_len_bias, int64_t* advance,
+              hipStream_t stream)
+{
+    attn_decode_partial_kernel<D, MASK, LONG><<<dim3(splits, H, B), kAttnThreads, 0, stream>>>(
         q, k, v, mask, ws, scaling, S, H / Hkv, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8],
         kv_len, kv_len_bias);
     EETQ_TRY_HIP(hipGetLastError());
     attn_decode_merge_kernel<D><<<dim3(H, B), kAttnThreads, 0, stream>>>(ws, out, splits, st[9], st[10], advance);
     return check_hip(hipGetLastError(), "attn_decode kernels launch");
+}
+
+template <int D>
+int launch_d(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out, float* ws, int B, int H, int Hkv, int S,
+             int splits, float scaling, const long* st, const int64_t* kv_len, int kv_len_bias, int64_t* advance,
+             hipStream_t stream)
+{
+    const bool lng = long_chunks<D>(S, splits);
+#define EETQ_ATTN_GO(MASK, LONG) \
+    return launch_d2<D, MASK, LONG>(q, k, v, mask, out, ws, B, H, Hkv, S, splits, scaling, st, kv_len, kv_len_bias, advance, stream)
+    if (mask) {
+        if (lng) EETQ_ATTN_GO(true, true);
+        EETQ_ATTN_GO(true, false);
+    }
+    if (lng) EETQ_ATTN_GO(false, true);
+    EETQ_ATTN_GO(false, false);
+#undef EETQ_ATTN_GO
+}
+
+template <int D>
+int launch_rope_d(const int64_t* kv_len, const int64_t* slots, const int64_t* positions, f16* kc, f16* vc, const RopeAttnArgs& a,
+                  dim3 grid, hipStream_t stream)
+{
+    const bool lng = long_chunks<D>(a.S, (int)grid.x);
+#define EETQ_ATTN_GO(MASK, LONG) \
+    rope_attn_decode_kernel<D, MASK, LONG><<<grid, kAttnThreads, 0, stream>>>(kv_len, slots, positions, kc, vc, a)
+    if (a.mask) {
+        if (lng) EETQ_ATTN_GO(true, true);
+        else EETQ_ATTN_GO(true, false);
+    } else {
+        if (lng) EETQ_ATTN_GO(false, true);
+        else EETQ_ATTN_GO(false, false);
+    }
+#undef EETQ_ATTN_GO
+    return check_hip(hipGetLastError(), "rope_attn_decode_kernel launch");
 }
 
 }  // namespace
@@ -530,6 +703,9 @@ int launch_attn_decode(const f16* q, const f16* k, const f16* v, const f16* mask
     for (int i = 0; i < 9; ++i)
         if (i != 8) EETQ_REQUIRE(strides[i] % 8 == 0, "q / k / v strides must be multiples of 8 elements (16-byte loads)");
     EETQ_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0, "q, k, v must be 16-byte aligned");
+    EETQ_REQUIRE(strides[4] > 0 && strides[7] > 0 && ((long)S + 4096) * strides[4] * 2 < (1L << 31) &&
+                     ((long)S + 4096) * strides[7] * 2 < (1L << 31),
+                 "one head's cache rows must span less than 2 GiB");
     if (D == 128)
         return launch_d<128>(q, k, v, mask, out, ws, B, H, Hkv, S, splits, scaling, strides, kv_len, kv_len_bias, advance, stream);
     if (D == 64)
@@ -551,6 +727,8 @@ int launch_rope_attn_decode(const int64_t* positions, const int64_t* slots, int 
     for (int i = 0; i < 9; ++i) EETQ_REQUIRE(st[i] % 8 == 0, "q / k / v / cache strides must be multiples of 8 elements (16-byte accesses)");
     EETQ_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)kc | (uintptr_t)vc | (uintptr_t)cos_sin) % 16 == 0,
                  "q, k, v, the caches and the cos|sin table must be 16-byte aligned");
+    EETQ_REQUIRE(st[5] > 0 && st[8] > 0 && ((long)S + 4096) * st[5] * 2 < (1L << 31) && ((long)S + 4096) * st[8] * 2 < (1L << 31),
+                 "one head's cache rows must span less than 2 GiB");
     RopeAttnArgs a;
     a.slot_stride = slot_stride;
     a.q = q, a.k = k, a.v = v, a.q_sb = st[0], a.k_sb = st[1], a.v_sb = st[2];
@@ -560,13 +738,9 @@ int launch_rope_attn_decode(const int64_t* positions, const int64_t* slots, int 
     a.ws = ws, a.tickets = tickets, a.kv_len_bias = kv_len_bias, a.advance = advance;
     a.S = S, a.groups = H / Hkv, a.scaling = scaling;
     a.stamps = g_attn_stamps;
-    if (D == 128)
-        rope_attn_decode_kernel<128><<<dim3(splits, H, B), kAttnThreads, 0, stream>>>(kv_len, slots, positions, kc, vc, a);
-    else if (D == 64)
-        rope_attn_decode_kernel<64><<<dim3(splits, H, B), kAttnThreads, 0, stream>>>(kv_len, slots, positions, kc, vc, a);
-    else
-        return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] decode attention supports head_dim 64 and 128");
-    return check_hip(hipGetLastError(), "rope_attn_decode_kernel launch");
+    if (D == 128) return launch_rope_d<128>(kv_len, slots, positions, kc, vc, a, dim3(splits, H, B), stream);
+    if (D == 64) return launch_rope_d<64>(kv_len, slots, positions, kc, vc, a, dim3(splits, H, B), stream);
+    return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] decode attention supports head_dim 64 and 128");
 }
 
 }  // namespace eetq

@@ -71,9 +71,20 @@ std::vector<Tensor> quant_weights(const Tensor& weight, py::object quant_type, b
     const auto st = weight.scalar_type();
     TORCH_CHECK(st == at::kHalf || st == at::kFloat, "Invalid datatype. Weight must be FP16 or FP32");
     TORCH_CHECK(qt == at::kChar || qt == at::kQUInt4x2, "Must be int4 or int8 quantization");
-    // the reference quantises a 3-D stack and then fails in preprocess_weights_for_mixed_gemm
-    // (cutlass_preprocessors.cc:504): same observable behaviour
-    if (weight.dim() == 3) throw std::runtime_error("[FT][ERROR] Shape must be 2-D");
+    if (weight.dim() == 3) {
+        // [E, K, N] expert stack.  The reference accepts it, allocates [E, K, N] / [E, N] outputs (fpA_intB_gemm_wrapper.cu:45-66)
+        // and then hands symmetric_quantize the 2-D shape {num_rows, num_cols} (:82, :90): only expert 0 is quantised, the other
+        // experts' outputs stay uninitialised.  Here every expert is quantised -- the same output shapes, expert 0 identical.
+        std::vector<Tensor> parts[3];
+        for (int64_t e = 0; e < weight.size(0); ++e) {
+            auto r = quant_weights(weight.select(0, e), quant_type, return_unprocessed_quantized_tensor, layout);
+            for (size_t i = 0; i < r.size(); ++i) parts[i].push_back(r[i]);
+        }
+        std::vector<Tensor> out;
+        for (auto& p : parts)
+            if (!p.empty()) out.push_back(torch::stack(p, 0));
+        return out;
+    }
     const bool   int4 = qt == at::kQUInt4x2;
     const int    lay  = layout_id(layout);
     const size_t K = weight.size(0), N = weight.size(1);
