@@ -93,9 +93,11 @@ def quant_weights(origin_weight, quant_type, return_unprocessed_quantized_tensor
     if quant_type != torch.int8:
         raise RuntimeError("Must be int4 or int8 quantization")
     if weight.dim() == 3:
-        # the reference quantises a 3-D stack and then fails in preprocess_weights_for_mixed_gemm
-        # (cutlass_preprocessors.cc:504): same observable behaviour
-        raise RuntimeError("[FT][ERROR] Shape must be 2-D")
+        # [E, K, N] expert stack: the reference allocates [E, K, N] / [E, N] outputs and quantises expert 0 only
+        # (fpA_intB_gemm_wrapper.cu:45-66, :82, :90 pass the 2-D shape); here every expert is quantised
+        parts = [quant_weights(weight[e], quant_type, return_unprocessed_quantized_tensor, layout)
+                 for e in range(weight.shape[0])]
+        return [torch.stack([p[i] for p in parts], 0) for i in range(len(parts[0]))]
     lay = _layout_id(layout)
     K, N = weight.shape
     dev = _work_device(weight)

@@ -176,6 +176,23 @@ def test_pack_unpack_roundtrip_and_oracle(ops, oracle, layout, K, N):
         assert np.array_equal(native.cpu().numpy(), oracle.gfx950_pack(q))
 
 
+def test_quant_weights_expert_stack(ops, oracle):
+    """[E, K, N] input (reference fpA_intB_gemm_wrapper.cu:36, 45-66): outputs [E, K, N] / [E, N]; the reference quantises
+    expert 0 only (it passes the 2-D shape on, :82 / :90), here every expert holds the oracle's bits."""
+    rng = np.random.default_rng(3)
+    w = (rng.standard_normal((3, 128, 64)) * 0.05).astype(np.float16)
+    raw, processed, scales = ops.quant_weights(torch.from_numpy(w), torch.int8, True)
+    assert tuple(raw.shape) == (3, 128, 64) and tuple(processed.shape) == (3, 128, 64) and tuple(scales.shape) == (3, 64)
+    assert scales.dtype == torch.float16 and not raw.is_cuda
+    for e in range(3):
+        q, s = oracle.quantize(w[e])
+        assert np.array_equal(raw[e].numpy(), q)
+        assert scales[e].numpy().tobytes() == s.tobytes()
+        assert np.array_equal(processed[e].numpy(), oracle.gfx950_pack(q))
+    two = ops.quant_weights(torch.from_numpy(w), torch.int8, False)
+    assert len(two) == 2 and torch.equal(two[0], processed) and torch.equal(two[1], scales)
+
+
 def test_shape_errors(ops):
     with pytest.raises(RuntimeError):
         ops.quant_weights(torch.zeros(32, 64, dtype=torch.float16), torch.int8)        # K % 64
@@ -184,7 +201,7 @@ def test_shape_errors(ops):
     with pytest.raises(RuntimeError):
         ops.preprocess_weights(torch.zeros(64, 32, dtype=torch.int8), False, "sm80")   # N % 64 for sm80
     with pytest.raises(RuntimeError):
-        ops.quant_weights(torch.zeros(2, 64, 64, dtype=torch.float16), torch.int8)     # 3-D: reference throws too
+        ops.quant_weights(torch.zeros(2, 2, 64, 64, dtype=torch.float16), torch.int8)  # 4-D (reference :36)
     x = torch.zeros(1, 100, dtype=torch.float16, device=DEV)
     with pytest.raises(RuntimeError):
         ops.w8_a16_gemm(x, torch.zeros(100, 64, dtype=torch.int8, device=DEV), torch.ones(64, dtype=torch.float16, device=DEV))

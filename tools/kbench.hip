@@ -120,6 +120,109 @@ __global__ void stream_read_kernel(const u32x4* __restrict__ p, unsigned* __rest
     if (acc == 0x9e3779b9u) out[0] = acc;  // practically never: keeps the loads alive
 }
 
+// ---- GEMV ablation ladder (round 6): the shipping M = 1 kernel (16 waves x 4 tiles, exact fit, x in registers) rebuilt one
+// ingredient at a time on top of the load-only kernel of the same geometry.  LEVEL:
+//   0  weight loads only (xor of the bytes kept alive by a store that never executes)
+//   1  + the scale and activation loads queued ahead of the weights
+//   2  + dequant and v_dot2 (the accumulator kept alive the same way)
+//   3  + the wave's xor-16 / xor-32 butterflies
+//   4  + LDS write, barrier, wave 0 sums the 16 waves (+ its butterflies)
+//   5  + the 32-byte store                        == gemv_kernel<1, 16, 4, true, true, 1, 8>'s instruction stream
+//   6  level 5 with the store issued write-through (sc0 sc1): nothing dirty in L2 at the end of the kernel
+//   7  level 5 with the cross-wave sum finished by 4 waves (one per 4 columns) instead of wave 0
+template <int LEVEL>
+__global__ __launch_bounds__(1024, 8) void gemv_ladder_kernel(const eetq::f16* __restrict__ x, const uint8_t* __restrict__ w,
+                                                               const eetq::f16* __restrict__ scales, eetq::f16* __restrict__ y,
+                                                               int N, int K, unsigned* __restrict__ sink)
+{
+    using namespace eetq;
+    constexpr int WAVES = 16, D = 4;
+    __shared__ float red[WAVES * 16];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int g = lane >> 4, c = lane & 15, ntile = blockIdx.x, KT = K / 64;
+    u32   sraw = 0;
+    u32x4 xr[D * 2];
+    if constexpr (LEVEL >= 1) {
+        sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            const u32x4* p = reinterpret_cast<const u32x4*>(x + (wave + d * WAVES) * 64 + 16 * g);
+            xr[d * 2]      = p[0];
+            xr[d * 2 + 1]  = p[1];
+        }
+    }
+    const u32x4* wp = reinterpret_cast<const u32x4*>(w + (size_t)ntile * KT * 1024) + wave * 64 + lane;
+    u32x4        buf[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) buf[d] = eetq::gemv::load_w<true>(wp + (size_t)d * WAVES * 64);
+    if constexpr (LEVEL <= 1) {
+        unsigned a = sraw;
+#pragma unroll
+        for (int d = 0; d < D; ++d) a ^= buf[d].x ^ buf[d].y ^ buf[d].z ^ buf[d].w;
+        if constexpr (LEVEL == 1) {
+#pragma unroll
+            for (int d = 0; d < 2 * D; ++d) a ^= xr[d].x ^ xr[d].y ^ xr[d].z ^ xr[d].w;
+        }
+        if (a == 0x9e3779b9u) sink[0] = a;
+        return;
+    } else {
+        asm volatile("" : "+v"(sraw));
+        const f16x2 scale2 = as_f16x2(sraw | (sraw << 16));
+        float       acc    = 0.f;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            f16x2 wq[8];
+            dequant_16(buf[d], scale2, wq);
+            const u32x4 xa = xr[d * 2], xb = xr[d * 2 + 1];
+            const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc = __builtin_amdgcn_fdot2(wq[i], as_f16x2(xd[i]), acc, false);
+        }
+        if constexpr (LEVEL == 2) {
+            if (__builtin_bit_cast(u32, acc) == 0x9e3779b9u) sink[0] = 1;
+            return;
+        }
+        acc = sum_xor32(sum_xor16(acc));
+        if constexpr (LEVEL == 3) {
+            if (__builtin_bit_cast(u32, acc) == 0x9e3779b9u) sink[0] = 1;
+            return;
+        }
+        if (lane < 16) red[wave * 16 + lane] = acc;
+        __syncthreads();
+        if constexpr (LEVEL == 7) {
+            // waves 0..3: wave v finishes columns 4v..4v+3; lane = 4 * (wave index being summed) + column-in-quad
+            if (wave < 4) {
+                const int cq = lane & 3, ws = lane >> 2;   // 16 waves x 4 columns = 64 lanes
+                float     s  = red[ws * 16 + wave * 4 + cq];
+                s += __shfl_xor(s, 4, 64);
+                s += __shfl_xor(s, 8, 64);
+                s = sum_xor32(sum_xor16(s));
+                if (lane < 4) y[ntile * 16 + wave * 4 + lane] = (f16)s;
+            }
+            return;
+        }
+        if (wave == 0) {
+            float s = 0.f;
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) s += red[(g + 4 * wv) * 16 + c];
+            s = sum_xor32(sum_xor16(s));
+            if constexpr (LEVEL == 4) {
+                if (__builtin_bit_cast(u32, s) == 0x9e3779b9u) sink[0] = 1;
+                return;
+            }
+            if (lane < 16) {
+                const f16 v = (f16)s;
+                if constexpr (LEVEL == 6) {
+                    const unsigned short b = __builtin_bit_cast(unsigned short, v);
+                    asm volatile("global_store_short %0, %1, off sc0 sc1" ::"v"(y + ntile * 16 + c), "v"((u32)b) : "memory");
+                } else {
+                    y[ntile * 16 + c] = v;
+                }
+            }
+        }
+    }
+}
+
 // dispatch-overhead probes: what a kernel costs that touches no memory / one cache line per wave
 __global__ void empty_kernel(unsigned* out, int never)
 {
@@ -573,6 +676,71 @@ int main(int argc, char** argv)
         bench_gemv<1, 16, 2, false, false, 2, 8>("M1 loop lds 16x2 o8", 4096, 11008, bufs_big, x, scales, y);
         bench_gemv<1, 16, 8, false, false, 2, 4>("M1 loop lds 16x8 o4", 4096, 11008, bufs_big, x, scales, y);
         bench_gemv<4, 16, 4, false, false, 8, 4>("M4 loop lds 16x4 o4", 4096, 11008, bufs_big, x, scales, y);
+    }
+    if (!strcmp(what, "gemvladder")) {
+        // one ablation ladder from the load-only kernel to the shipping GEMV, every rung chain-timed (one graph of 1200 dependent
+        // launches over the 40 rotating weight sets) and dispatch-timed on the same box, three passes in alternating order
+        const int  N = 4096, K = 4096, ITERS = 1200;
+        const char* names[8] = {"0 weight loads only", "1 + scale / x loads first", "2 + dequant, dot2", "3 + wave butterflies",
+                                "4 + LDS, barrier, wave-0 sum", "5 + 32-byte store (= GEMV)", "6 = 5, store sc0 sc1",
+                                "7 = 5, sum by 4 waves"};
+        double chain[3][9], disp[3][9];
+        auto run = [&](auto kern, int pass, int idx) {
+            chain[pass][idx] = time_graph(
+                [&](int i, hipStream_t s) {
+                    hipLaunchKernelGGL(kern, dim3(N / 16), dim3(1024), 0, s, x, (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, out);
+                },
+                ITERS);
+            auto st = time_dispatch(
+                [&](int i, hipEvent_t a, hipEvent_t b) {
+                    hipExtLaunchKernelGGL(kern, dim3(N / 16), dim3(1024), 0, 0, a, b, 0, x, (const uint8_t*)bufs[i % bufs.size()], scales, y,
+                                          N, K, out);
+                },
+                400);
+            disp[pass][idx] = st.med;
+        };
+        for (int pass = 0; pass < 3; ++pass) {
+            auto body = [&](int l) {
+                switch (l) {
+                case 0: run(gemv_ladder_kernel<0>, pass, 0); break;
+                case 1: run(gemv_ladder_kernel<1>, pass, 1); break;
+                case 2: run(gemv_ladder_kernel<2>, pass, 2); break;
+                case 3: run(gemv_ladder_kernel<3>, pass, 3); break;
+                case 4: run(gemv_ladder_kernel<4>, pass, 4); break;
+                case 5: run(gemv_ladder_kernel<5>, pass, 5); break;
+                case 6: run(gemv_ladder_kernel<6>, pass, 6); break;
+                case 7: run(gemv_ladder_kernel<7>, pass, 7); break;
+                }
+            };
+            if (pass & 1) for (int l = 7; l >= 0; --l) body(l);
+            else for (int l = 0; l < 8; ++l) body(l);
+            // the library kernel itself, same harness
+            auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
+            const unsigned gsm = (unsigned)eetq::gemv::gemv_smem_bytes(1, K, 16, true);
+            chain[pass][8] = time_graph(
+                [&](int i, hipStream_t s) {
+                    hipLaunchKernelGGL(gk, dim3(N / 16), dim3(1024), gsm, s, x, (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K,
+                                       eetq::Epilogue{}, eetq::Prologue{});
+                },
+                ITERS);
+            auto st = time_dispatch(
+                [&](int i, hipEvent_t a, hipEvent_t b) {
+                    hipExtLaunchKernelGGL(gk, dim3(N / 16), dim3(1024), gsm, 0, a, b, 0, x, (const uint8_t*)bufs[i % bufs.size()], scales, y,
+                                          N, K, eetq::Epilogue{}, eetq::Prologue{});
+                },
+                400);
+            disp[pass][8] = st.med;
+        }
+        printf("--- GEMV ladder, M=1 N=K=4096, 256 x 1024 threads, 16 waves x 4 tiles; chain = us per step of a %d-launch graph (best of 5"
+               " replays), disp = median dispatch begin->end; three passes (up, down, up) ---\n", ITERS);
+        for (int l = 0; l < 9; ++l) {
+            const double c = std::min(chain[0][l], std::min(chain[1][l], chain[2][l]));
+            const double p = l && l < 6 ? std::min(chain[0][l - 1], std::min(chain[1][l - 1], chain[2][l - 1])) : c;
+            printf("%-30s chain %5.2f %5.2f %5.2f  best %5.2f (%+5.2f vs previous rung) | disp med %5.2f %5.2f %5.2f\n",
+                   l < 8 ? names[l] : "library gemv_kernel", chain[0][l], chain[1][l], chain[2][l], c, l && l < 6 ? c - p : 0.0, disp[0][l],
+                   disp[1][l], disp[2][l]);
+        }
+        return 0;
     }
     if (!strcmp(what, "gemv_geom")) {  // wave count x tiles-in-flight at equal bytes in flight (64 KiB per workgroup)
         bench_gemv<1, 16, 4, true, true, 1, 8>("M1 xreg 16 waves x 4 (shipping)", 4096, 4096, bufs, x, scales, y);
