@@ -263,6 +263,98 @@ def load_profile_docs():
     return docs
 
 
+def decode_budget(dec, model, prompt):
+    """Where one decoded token's time goes (batch 1), in microseconds by kernel family:
+      * `step_us`: one replay of the decoder's HIP graph, mean of 20 back-to-back replays (barrier on both sides);
+      * per family: the begin -> end durations of the library's launches of ONE eager step (eetq_prof_begin/_end: start / stop
+        events on the dispatch packets, the quantity rocprofv3 --kernel-trace reports), assigned by launch order -- five launches
+        per decoder layer: norm + q|k|v GEMV, rotary + cache write + attention, o GEMV + residual, norm + gate|up GEMV + SiLU,
+        down GEMV + residual -- with the algorithmic bytes each family streams per token;
+      * `head_us`: embedding, final norm, fp16 lm_head GEMM, argmax and the token hand-over launches timed as their own graph;
+      * `gaps_us` = step - (sum of the above): what lies BETWEEN the dispatches of the graph (the dependent-launch boundaries).
+    The sums reproduce the step by construction; `gap_per_launch_us` says how."""
+    from eetq_amd import _lib
+    L = _lib.lib()
+    base = model.model
+    layers = len(base.layers)
+    cfg = model.config
+    H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+    dev = dec.device
+    if dec.graph is None or not dec._lean():
+        return None
+    with torch.no_grad():
+        dec.generate(prompt, 8)   # the cache back at prompt + 8 rows: the 21 steps below stay inside its capacity
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        dec.graph.replay()
+    torch.cuda.synchronize()
+    step_us = (time.perf_counter() - t0) / 20 * 1e6
+    cap = layers * 8 + 64
+    _lib.check(L.eetq_prof_begin(cap))
+    with torch.no_grad():
+        dec._step()
+    buf = (ctypes.c_float * cap)()
+    cnt = ctypes.c_int(0)
+    _lib.check(L.eetq_prof_end(buf, cap, ctypes.byref(cnt)))
+    us = np.array(buf[:cnt.value], dtype=np.float64)
+    per_layer = 5
+    if cnt.value < layers * per_layer:
+        return {"skipped": "expected %d library launches in an eager step, saw %d" % (layers * per_layer, cnt.value)}
+    body = us[:layers * per_layer].reshape(layers, per_layer)
+    rows = int(dec.s_pos.item()) + 1
+    kv_bytes = 2 * cfg.num_key_value_heads * rows * (H // cfg.num_attention_heads) * 2
+    fam = [("qkv_gemv", H * 3 * H), ("rope_attn_decode", kv_bytes), ("o_gemv", H * H), ("gate_up_gemv", H * 2 * I),
+           ("down_gemv", I * H)]
+    out = {"step_us": round(step_us, 1), "families": {}}
+    total = 0.0
+    for i, (name, nbytes) in enumerate(fam):
+        t = float(body[:, i].sum())
+        total += t
+        out["families"][name] = {"us_per_token": round(t, 1), "us_per_launch": round(t / layers, 2),
+                                 "TBps": round(nbytes / (t / layers) / 1e6, 2)}
+    tail = float(us[layers * per_layer:].sum())   # library launches after the last layer (final norm)
+    # embedding + final norm + lm_head + argmax as their own graph
+    h = torch.zeros(dec.batch, 1, H, dtype=torch.float16, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side), torch.no_grad():
+        sc_out, sc_tok = torch.zeros_like(dec.out_buf), torch.zeros_like(dec.s_tok)
+        sc_pos, sc_idx = torch.zeros_like(dec.s_pos), torch.zeros_like(dec.s_idx)
+
+        def head():
+            e = base.embed_tokens(dec.s_tok)
+            nxt = model.lm_head(base.norm(h + e))[:, -1].argmax(-1, keepdim=True)
+            sc_out.scatter_(1, sc_idx.expand(dec.batch, 1), nxt)   # the step's hand-over launches (GraphDecoder._advance)
+            sc_tok.copy_(nxt)
+            sc_pos.add_(1)
+            sc_idx.add_(0)
+        head()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            head()
+    torch.cuda.current_stream().wait_stream(side)
+    g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g.replay()
+    torch.cuda.synchronize()
+    head_us = (time.perf_counter() - t0) / 20 * 1e6
+    del g
+    launches = layers * per_layer
+    out["head_us"] = round(head_us, 1)
+    out["library_tail_us"] = round(tail, 1)
+    out["kernels_us"] = round(total, 1)
+    out["gaps_us"] = round(step_us - total - head_us, 1)
+    out["gap_per_launch_us"] = round((step_us - total - head_us) / launches, 2)
+    out["weight_floor_us"] = round(layers * (4 * H * H + 3 * H * I) / 8e6, 1)
+    out["note"] = ("step = %d layer launches (begin -> end, one eager step) + head (embedding, norm, fp16 lm_head, argmax, token "
+                   "hand-over as a graph) + gaps (the remainder: dependent-launch boundaries inside the graph); weight_floor = int8 layer "
+                   "weights / 8 TB/s" % launches)
+    return out
+
+
 def config5_leg(grp, prompt_len=1024, new_tokens=50):
     """BASELINE configs[4] on every replica: random-init Llama-2-13B shapes (no checkpoints offline), eet_accelerator with
     W8A16 everywhere, identical prompt fanned out from rank 0, greedy decode of 50 tokens through the HIP-graph decoder.
@@ -296,7 +388,11 @@ def config5_leg(grp, prompt_len=1024, new_tokens=50):
         for B in (1, 2, 4):
             holder = {}
             dec = GraphDecoder(model, B, prompt_len + new_tokens + 8)
-            dec.generate(prompt[:B, :64], 4)   # warm-up (allocations, kernel selection)
+            # warm-up with the SAME prompt and length as the timed call, like the reference's recipe
+            # (examples/models/llama_transformers_example.py:68-79: one generate with the same arguments, then the timed one):
+            # a short warm-up left the first full-length prefill's one-time costs (allocator growth, first use of the M = 1024
+            # kernels) inside the timed region, 6 ms of 180 (tools/decode_timeline.py)
+            dec.generate(prompt[:B], new_tokens)
             torch.cuda.synchronize()
 
             def run():
@@ -307,11 +403,17 @@ def config5_leg(grp, prompt_len=1024, new_tokens=50):
             crcs.append(len(set(c)) == 1)
             batches[str(B)] = {"tokens_per_s": round(grp.world_size * B * new_tokens / secs, 2), "end_to_end_s": round(secs, 4),
                                "prefill_s": round(t_prefill, 4)}
+            budget = None
+            if B == 1 and grp.rank == 0:
+                try:
+                    budget = decode_budget(dec, model, prompt[:B])
+                except Exception as e:  # noqa: BLE001  (diagnostic: never fails the bench line)
+                    budget = {"skipped": str(e)[:120]}
             if B == 1:
                 res = {"workload": "Llama-2-13B shapes (random init), eet_accelerator W8A16, prompt %d + %d new tokens, batch 1 "
                                    "per replica, HIP-graph greedy decode" % (prompt_len, new_tokens),
                        "tokens_per_s": batches["1"]["tokens_per_s"], "end_to_end_s": batches["1"]["end_to_end_s"],
-                       "prefill_s": batches["1"]["prefill_s"], "replicas": grp.world_size}
+                       "prefill_s": batches["1"]["prefill_s"], "replicas": grp.world_size, "decode_budget": budget}
             del dec
             torch.cuda.empty_cache()
     res["replicas_identical_tokens"] = all(crcs)

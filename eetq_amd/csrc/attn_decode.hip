@@ -649,11 +649,11 @@ int launch_d2(const f16* q, const f16* k, const f16* v, const f16* mask, f16* ou
               int splits, float scaling, const long* st, const int64_t* kv_len, int kv_len_bias, int64_t* advance,
               hipStream_t stream)
 {
-    attn_decode_partial_kernel<D, MASK, LONG><<<dim3(splits, H, B), kAttnThreads, 0, stream>>>(
-        q, k, v, mask, ws, scaling, S, H / Hkv, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8],
-        kv_len, kv_len_bias);
+    launch_kernel(attn_decode_partial_kernel<D, MASK, LONG>, dim3(splits, H, B), dim3(kAttnThreads), 0, stream, q, k, v, mask, ws,
+                  scaling, S, H / Hkv, st[0], st[1], st[2], st[3], st[4], st[5], st[6], st[7], st[8], kv_len, kv_len_bias);
     EETQ_TRY_HIP(hipGetLastError());
-    attn_decode_merge_kernel<D><<<dim3(H, B), kAttnThreads, 0, stream>>>(ws, out, splits, st[9], st[10], advance);
+    launch_kernel(attn_decode_merge_kernel<D>, dim3(H, B), dim3(kAttnThreads), 0, stream, (const float*)ws, out, splits, st[9],
+                  st[10], advance);
     return check_hip(hipGetLastError(), "attn_decode kernels launch");
 }
 
@@ -680,7 +680,7 @@ int launch_rope_d(const int64_t* kv_len, const int64_t* slots, const int64_t* po
 {
     const bool lng = long_chunks<D>(a.S, (int)grid.x);
 #define EETQ_ATTN_GO(MASK, LONG) \
-    rope_attn_decode_kernel<D, MASK, LONG><<<grid, kAttnThreads, 0, stream>>>(kv_len, slots, positions, kc, vc, a)
+    launch_kernel(rope_attn_decode_kernel<D, MASK, LONG>, grid, dim3(kAttnThreads), 0, stream, kv_len, slots, positions, kc, vc, a)
     if (a.mask) {
         if (lng) EETQ_ATTN_GO(true, true);
         else EETQ_ATTN_GO(true, false);

@@ -95,6 +95,23 @@ struct Epilogue {
     int        act      = 0;        // EETQ_ACT_*: 0 = identity (the Python-level `output + bias` above); kActGlu8: see below
 };
 
+// The epilogue operands in SGPRs from HERE on.  Kernel arguments beyond the preloaded dwords (14 of the 16 asked for arrive with
+// the wave on this toolchain) are fetched by an s_load that the compiler places where the value is first used -- for an epilogue
+// that is between a kernel's last weight tile and its store, a scalar-cache miss on the critical tail of every launch
+// (0.1 us of the 4.6 us GEMV, profiles/r06_gemv_ladder.txt).  Called right after a kernel has issued its first loads, the
+// fetch overlaps their latency instead; the empty asm makes the values opaque, so they cannot be re-fetched later.
+__device__ __forceinline__ Epilogue pin_epilogue(const Epilogue& ep)
+{
+    unsigned long long b = reinterpret_cast<unsigned long long>(ep.bias), r = reinterpret_cast<unsigned long long>(ep.residual);
+    int                a = ep.act;
+    asm volatile("" : "+s"(b), "+s"(r), "+s"(a));
+    Epilogue e;
+    e.bias     = reinterpret_cast<const f16*>(b);
+    e.residual = reinterpret_cast<const f16*>(r);
+    e.act      = a;
+    return e;
+}
+
 // Gated-MLP epilogue of the M = 1 GEMV (internal value of Epilogue::act, reached through eetq_w8a16_gemv_glu8 only): the
 // weight's columns come in groups of 16 = 8 gate columns followed by the 8 matching up columns, and the kernel writes
 // y[8 t + c] = silu_mul(gate, up) for its tile t -- N/2 outputs, the silu_mul launch saved.

@@ -29,7 +29,7 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         int st = opt_in_large_lds(kern, opted);
         if (st != EETQ_OK) return st;
     }
-    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep, pro);
+    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, pro);
     return check_hip(hipGetLastError(), "gemv_kernel launch");
 }
 
@@ -64,7 +64,7 @@ int launch_half_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue e
         int st = opt_in_large_lds(kern, opted);
         if (st != EETQ_OK) return st;
     }
-    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep, pro);
+    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, pro);
     return check_hip(hipGetLastError(), "gemv_half_kernel launch");
 }
 
@@ -100,7 +100,7 @@ int launch_mixed_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue 
     }
     const int ncu = device_cu_count(), per = N / ncu;
     const int n8 = ncu * (per / 8), n4 = (N - 8 * n8) / 4;
-    launch_kernel(kern, dim3(n8 + n4), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep, pro, n8);
+    launch_kernel(kern, dim3(n8 + n4), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, n8, pro);
     return check_hip(hipGetLastError(), "gemv_mixed_kernel launch");
 }
 
@@ -202,7 +202,7 @@ int launch_inst_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue e
         int st = opt_in_large_lds(kern, opted);
         if (st != EETQ_OK) return st;
     }
-    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep, Prologue{});
+    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, Prologue{});
     return check_hip(hipGetLastError(), "gemv_kernel (int4) launch");
 }
 
@@ -231,7 +231,7 @@ int launch_half_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue e
         int st = opt_in_large_lds(kern, opted);
         if (st != EETQ_OK) return st;
     }
-    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep, Prologue{});
+    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, Prologue{});
     return check_hip(hipGetLastError(), "gemv_half_kernel (int4) launch");
 }
 

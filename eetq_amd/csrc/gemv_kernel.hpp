@@ -194,7 +194,7 @@ __device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, cons
 template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int NORM = 0, int BITS = 8>
 __device__ __forceinline__ void gemv_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, const Epilogue& ep, const Prologue& pro, const int ntile)
+    f16* __restrict__ y, int N, int K, const Epilogue& ep_arg, const Prologue& pro, const int ntile)
 {
     static_assert(!XREG || EXACT, "register-resident activations need the exact-fit shape");
     // NORM: 0 = none, 1 = RMS-norm prologue, 2 = gated-MLP activation prologue
@@ -252,6 +252,7 @@ __device__ __forceinline__ void gemv_body(
     u32x4        buf[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[d] = load_w<true>(wp + d * stride);
+    const Epilogue ep = pin_epilogue(ep_arg);
 
     if constexpr (!XREG) {
         const int xvecs = (M * K) >> 3;
@@ -362,8 +363,13 @@ __device__ __forceinline__ void gemv_body(
 template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
+    f16* __restrict__ y, int N, int K, const f16* bias, const f16* residual, int act, Prologue pro)
 {
+    // the epilogue operands are scalar kernel arguments, not an Epilogue by value: the first 16 argument dwords arrive in SGPRs
+    // with the wave (kernarg preload), an aggregate does not -- its fields were fetched by an s_load where they are first used,
+    // i.e. between the last weight tile and the store, 0.1 us of every launch (profiles/r06_gemv_ladder.txt)
+    Epilogue ep;
+    ep.bias = bias, ep.residual = residual, ep.act = act;
     gemv_body<M, WAVES, D, EXACT, XREG, XV, NORM, BITS>(x, w, scales, y, N, K, ep, pro, blockIdx.x);
 }
 
@@ -416,7 +422,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_grouped_k
 template <int COLS, int WAVES, int D, int XV, int NORM, int BITS = 8>
 __device__ __forceinline__ void gemv_unit_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, const Epilogue& ep, const Prologue& pro, const int col0)
+    f16* __restrict__ y, int N, int K, const Epilogue& ep_arg, const Prologue& pro, const int col0)
 {
     static_assert(COLS == 8 || COLS == 4, "8- or 4-column units");
     constexpr int G = 64 / (4 * COLS);  // k tiles per wave instruction: 2 or 4
@@ -458,6 +464,7 @@ __device__ __forceinline__ void gemv_unit_body(
     u32x4 buf[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[d] = load_w<true>(wptr(wave + d * WAVES));
+    const Epilogue ep = pin_epilogue(ep_arg);
 
     if constexpr (NORM == 1) rmsnorm_staged<XV, WAVES>(xv, gv, tid, xvecs, K, pro.eps, red);
     if constexpr (NORM == 2) silu_mul_staged<XV>(xv, gv);
@@ -514,8 +521,10 @@ __device__ __forceinline__ void gemv_unit_body(
 template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro)
+    f16* __restrict__ y, int N, int K, const f16* bias, const f16* residual, int act, Prologue pro)
 {
+    Epilogue ep;  // (scalar arguments: see gemv_kernel)
+    ep.bias = bias, ep.residual = residual, ep.act = act;
     gemv_unit_body<8, WAVES, D, XV, NORM, BITS>(x, w, scales, y, N, K, ep, pro, blockIdx.x * 8);
 }
 
@@ -526,8 +535,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
 template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_mixed_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, Epilogue ep, Prologue pro, int n8)
+    f16* __restrict__ y, int N, int K, const f16* bias, const f16* residual, int act, int n8, Prologue pro)
 {
+    Epilogue ep;  // (scalar arguments: see gemv_kernel)
+    ep.bias = bias, ep.residual = residual, ep.act = act;
     const int b = blockIdx.x;
     if (b < n8) {
         gemv_unit_body<8, WAVES, D, XV, NORM>(x, w, scales, y, N, K, ep, pro, b * 8);

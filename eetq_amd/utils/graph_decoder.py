@@ -1,4 +1,4 @@
-"""Greedy decode with a static KV cache and ONE captured HIP graph per generated token.
+"""Greedy decode with a static KV cache and captured HIP graphs: one replay per generated token, or per several.
 
 The reference's end-to-end recipe (examples/models/llama_transformers_example.py:68-79) calls transformers'
 ``generate``; with ~360 short kernels per token at Llama-13B shapes that loop is bound by host launch time, not by the
@@ -13,10 +13,15 @@ __all__ = ["GraphDecoder"]
 
 
 class GraphDecoder:
-    def __init__(self, model, batch, max_len, capture=True, lean=True):
+    def __init__(self, model, batch, max_len, capture=True, lean=True, steps_per_graph=7):
         """``max_len``: cache rows (prompt + new tokens).  ``capture=False`` keeps the same static-cache stepping but runs
         every step eagerly (used to check the graph against the launches it was captured from).  ``lean``: step fully
-        accelerated models layer by layer instead of through the stock model forward (see ``_lean``)."""
+        accelerated models layer by layer instead of through the stock model forward (see ``_lean``).
+        ``steps_per_graph``: a second graph holds that many consecutive steps (one replay = that many tokens); the token
+        hand-over between steps (next input id, position, the output row) is done by launches INSIDE the graphs, so a
+        generated token costs the host one ``replay`` per ``steps_per_graph`` tokens and nothing else -- with one graph
+        per token plus three eager bookkeeping launches the host side was 0.125 ms of every 2.96 ms token at 13B shapes
+        (``profiles/r06_bench_*.json``: decode_budget.step_us vs the end-to-end time)."""
         self.lean = bool(lean)
         from transformers import StaticCache
         self.model = model
@@ -31,8 +36,12 @@ class GraphDecoder:
                                      dtype=torch.float16)
         self.s_tok = torch.zeros(self.batch, 1, dtype=torch.long, device=dev)
         self.s_pos = torch.zeros(1, dtype=torch.long, device=dev)
+        # generated tokens: step i of a generate() writes column s_idx (a device counter the graphs advance themselves)
+        self.s_idx = torch.zeros(1, 1, dtype=torch.long, device=dev)
+        self.out_buf = torch.zeros(self.batch, self.max_len + 1, dtype=torch.long, device=dev)
         self.graph = None
-        self.s_out = None
+        self.graph_n = None
+        self.steps_per_graph = max(1, int(steps_per_graph))
         with torch.no_grad():
             # the cache tensors are allocated lazily by the first forward: run one tiny prefill before capturing
             model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True)
@@ -41,11 +50,16 @@ class GraphDecoder:
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     for _ in range(2):
-                        self._step()
+                        self._advance()
                 torch.cuda.current_stream().wait_stream(side)
                 self.graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.graph):
-                    self.s_out = self._step()
+                    self._advance()
+                if self.steps_per_graph > 1:
+                    self.graph_n = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(self.graph_n):
+                        for _ in range(self.steps_per_graph):
+                            self._advance()
         self.cache.reset()
 
     def _lean(self):
@@ -71,6 +85,15 @@ class GraphDecoder:
             lg = self.model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True).logits
         return lg[:, -1].argmax(-1, keepdim=True)
 
+    def _advance(self):
+        """One step and its hand-over, all on the device: the new token goes to its output column and becomes the next
+        input id; position and output column move on."""
+        nxt = self._step()
+        self.out_buf.scatter_(1, self.s_idx.expand(self.batch, 1), nxt)
+        self.s_tok.copy_(nxt)
+        self.s_pos.add_(1)
+        self.s_idx.add_(1)
+
     @torch.no_grad()
     def generate(self, prompt, new_tokens, return_prefill_logits=False):
         """prompt [batch, P] int64 on the model's device -> [batch, P + new_tokens]."""
@@ -81,17 +104,20 @@ class GraphDecoder:
         out = self.model(prompt, past_key_values=self.cache, cache_position=torch.arange(P, device=prompt.device),
                          use_cache=True)
         tok = out.logits[:, -1].argmax(-1, keepdim=True)
-        generated = [tok]
+        self.out_buf[:, :1].copy_(tok)
         self.s_tok.copy_(tok)
         self.s_pos.fill_(P)
-        for _ in range(new_tokens - 1):
-            if self.graph is not None:
+        self.s_idx.fill_(1)
+        left = new_tokens - 1
+        while left > 0:
+            if self.graph_n is not None and left >= self.steps_per_graph:
+                self.graph_n.replay()
+                left -= self.steps_per_graph
+            elif self.graph is not None:
                 self.graph.replay()
-                nxt = self.s_out
+                left -= 1
             else:
-                nxt = self._step()
-            self.s_tok.copy_(nxt)
-            self.s_pos += 1
-            generated.append(nxt.clone())
-        tokens = torch.cat([prompt] + generated, dim=1)
+                self._advance()
+                left -= 1
+        tokens = torch.cat([prompt, self.out_buf[:, :new_tokens]], dim=1)
         return (tokens, out.logits[:, -1]) if return_prefill_logits else tokens

@@ -130,6 +130,10 @@ __global__ void stream_read_kernel(const u32x4* __restrict__ p, unsigned* __rest
 //   5  + the 32-byte store                        == gemv_kernel<1, 16, 4, true, true, 1, 8>'s instruction stream
 //   6  level 5 with the store issued write-through (sc0 sc1): nothing dirty in L2 at the end of the kernel
 //   7  level 5 with the cross-wave sum finished by 4 waves (one per 4 columns) instead of wave 0
+//   8  level 5 with the activations staged per WAVE through LDS: one 16-byte load per lane (the wave's 512 bytes of x, lanes
+//      32..63 duplicate) instead of eight, a ds_write_b128, eight ds_read_b128 -- no workgroup barrier in front of the math
+//   9  level 1 with the scale load only (no activation loads)
+//  10  level 8 with the 512 bytes fetched by lanes 0..31 only (exec-masked load)
 template <int LEVEL>
 __global__ __launch_bounds__(1024, 8) void gemv_ladder_kernel(const eetq::f16* __restrict__ x, const uint8_t* __restrict__ w,
                                                                const eetq::f16* __restrict__ scales, eetq::f16* __restrict__ y,
@@ -142,8 +146,15 @@ __global__ __launch_bounds__(1024, 8) void gemv_ladder_kernel(const eetq::f16* _
     const int g = lane >> 4, c = lane & 15, ntile = blockIdx.x, KT = K / 64;
     u32   sraw = 0;
     u32x4 xr[D * 2];
-    if constexpr (LEVEL >= 1) {
-        sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
+    __shared__ __attribute__((aligned(16))) u32x4 xw[WAVES * 32];  // levels 8 / 10: 512 bytes of x per wave
+    u32x4 xstage = {};
+    if constexpr (LEVEL >= 1) sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
+    if constexpr (LEVEL == 8 || LEVEL == 10) {
+        // lane L (mod 32): 16-byte piece L & 7 of the wave's tile d = (L >> 3) & 3
+        const int L = lane & 31;
+        const u32x4* p = reinterpret_cast<const u32x4*>(x + (wave + (L >> 3) * WAVES) * 64) + (L & 7);
+        if (LEVEL == 8 || lane < 32) xstage = *p;
+    } else if constexpr (LEVEL >= 1 && LEVEL != 9) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const u32x4* p = reinterpret_cast<const u32x4*>(x + (wave + d * WAVES) * 64 + 16 * g);
@@ -155,7 +166,18 @@ __global__ __launch_bounds__(1024, 8) void gemv_ladder_kernel(const eetq::f16* _
     u32x4        buf[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[d] = eetq::gemv::load_w<true>(wp + (size_t)d * WAVES * 64);
-    if constexpr (LEVEL <= 1) {
+    if constexpr (LEVEL == 8 || LEVEL == 10) {
+        // wave-private staging: LDS operations of one wave execute in order, no barrier needed
+        if (lane < 32) xw[wave * 32 + lane] = xstage;
+        __builtin_amdgcn_wave_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            xr[d * 2]     = xw[wave * 32 + d * 8 + 2 * g];
+            xr[d * 2 + 1] = xw[wave * 32 + d * 8 + 2 * g + 1];
+        }
+    }
+    if constexpr (LEVEL <= 1 || LEVEL == 9) {
         unsigned a = sraw;
 #pragma unroll
         for (int d = 0; d < D; ++d) a ^= buf[d].x ^ buf[d].y ^ buf[d].z ^ buf[d].w;
@@ -380,13 +402,13 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
     auto st = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
             hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, eetq::Epilogue{}, eetq::Prologue{});
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
         },
         400);
     double g = time_graph(
         [&](int i, hipStream_t s) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, s, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, eetq::Epilogue{}, eetq::Prologue{});
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
         },
         400);
     printf("%-30s N=%5d K=%5d M=%d | disp mean %6.2f med %6.2f min %6.2f p90 %6.2f us -> %6.0f GB/s(med) | graph %6.2f us/step -> %6.0f GB/s\n",
@@ -681,10 +703,12 @@ int main(int argc, char** argv)
         // one ablation ladder from the load-only kernel to the shipping GEMV, every rung chain-timed (one graph of 1200 dependent
         // launches over the 40 rotating weight sets) and dispatch-timed on the same box, three passes in alternating order
         const int  N = 4096, K = 4096, ITERS = 1200;
-        const char* names[8] = {"0 weight loads only", "1 + scale / x loads first", "2 + dequant, dot2", "3 + wave butterflies",
-                                "4 + LDS, barrier, wave-0 sum", "5 + 32-byte store (= GEMV)", "6 = 5, store sc0 sc1",
-                                "7 = 5, sum by 4 waves"};
-        double chain[3][9], disp[3][9];
+        const char* names[11] = {"0 weight loads only", "1 + scale / x loads first", "2 + dequant, dot2", "3 + wave butterflies",
+                                 "4 + LDS, barrier, wave-0 sum", "5 + 32-byte store (= GEMV)", "6 = 5, store sc0 sc1",
+                                 "7 = 5, sum by 4 waves", "8 = 5, x staged per wave in LDS", "9 = 1, scale load only",
+                                 "10 = 8, 32-lane x load"};
+        constexpr int NL = 11;
+        double chain[3][NL + 1], disp[3][NL + 1];
         auto run = [&](auto kern, int pass, int idx) {
             chain[pass][idx] = time_graph(
                 [&](int i, hipStream_t s) {
@@ -710,34 +734,37 @@ int main(int argc, char** argv)
                 case 5: run(gemv_ladder_kernel<5>, pass, 5); break;
                 case 6: run(gemv_ladder_kernel<6>, pass, 6); break;
                 case 7: run(gemv_ladder_kernel<7>, pass, 7); break;
+                case 8: run(gemv_ladder_kernel<8>, pass, 8); break;
+                case 9: run(gemv_ladder_kernel<9>, pass, 9); break;
+                case 10: run(gemv_ladder_kernel<10>, pass, 10); break;
                 }
             };
-            if (pass & 1) for (int l = 7; l >= 0; --l) body(l);
-            else for (int l = 0; l < 8; ++l) body(l);
+            if (pass & 1) for (int l = NL - 1; l >= 0; --l) body(l);
+            else for (int l = 0; l < NL; ++l) body(l);
             // the library kernel itself, same harness
             auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
             const unsigned gsm = (unsigned)eetq::gemv::gemv_smem_bytes(1, K, 16, true);
-            chain[pass][8] = time_graph(
+            chain[pass][NL] = time_graph(
                 [&](int i, hipStream_t s) {
                     hipLaunchKernelGGL(gk, dim3(N / 16), dim3(1024), gsm, s, x, (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K,
-                                       eetq::Epilogue{}, eetq::Prologue{});
+                                       (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
                 },
                 ITERS);
             auto st = time_dispatch(
                 [&](int i, hipEvent_t a, hipEvent_t b) {
                     hipExtLaunchKernelGGL(gk, dim3(N / 16), dim3(1024), gsm, 0, a, b, 0, x, (const uint8_t*)bufs[i % bufs.size()], scales, y,
-                                          N, K, eetq::Epilogue{}, eetq::Prologue{});
+                                          N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
                 },
                 400);
-            disp[pass][8] = st.med;
+            disp[pass][NL] = st.med;
         }
         printf("--- GEMV ladder, M=1 N=K=4096, 256 x 1024 threads, 16 waves x 4 tiles; chain = us per step of a %d-launch graph (best of 5"
                " replays), disp = median dispatch begin->end; three passes (up, down, up) ---\n", ITERS);
-        for (int l = 0; l < 9; ++l) {
+        for (int l = 0; l <= NL; ++l) {
             const double c = std::min(chain[0][l], std::min(chain[1][l], chain[2][l]));
             const double p = l && l < 6 ? std::min(chain[0][l - 1], std::min(chain[1][l - 1], chain[2][l - 1])) : c;
             printf("%-30s chain %5.2f %5.2f %5.2f  best %5.2f (%+5.2f vs previous rung) | disp med %5.2f %5.2f %5.2f\n",
-                   l < 8 ? names[l] : "library gemv_kernel", chain[0][l], chain[1][l], chain[2][l], c, l && l < 6 ? c - p : 0.0, disp[0][l],
+                   l < NL ? names[l] : "library gemv_kernel", chain[0][l], chain[1][l], chain[2][l], c, l && l < 6 ? c - p : 0.0, disp[0][l],
                    disp[1][l], disp[2][l]);
         }
         return 0;
@@ -832,7 +859,7 @@ int main(int argc, char** argv)
                 auto st = time_dispatch(
                     [&](int i, hipEvent_t a, hipEvent_t b) {
                         hipExtLaunchKernelGGL(kern, dim3(N / 8), dim3(512), (unsigned)smem, 0, a, b, 0, xl,
-                                              (const uint8_t*)b70[i % b70.size()], scales, y, N, K, eetq::Epilogue{}, eetq::Prologue{});
+                                              (const uint8_t*)b70[i % b70.size()], scales, y, N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
                     },
                     400);
                 printf("%-30s N=%5d K=%5d M=1 | disp mean %6.2f med %6.2f min %6.2f us -> %6.0f GB/s(med)\n", name, N, K,
@@ -896,7 +923,7 @@ int main(int argc, char** argv)
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
         for (int i = 0; i < 300; ++i)
             hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{}, eetq::Prologue{});
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
         CK(hipDeviceSynchronize());
     }
     if (!strcmp(what, "gemmcu")) {
@@ -1048,8 +1075,8 @@ int main(int argc, char** argv)
             });
             const uint8_t* wbuf2 = bufs[(r + 33) % bufs.size()];
             float g = timed([&](hipEvent_t s0, hipEvent_t s1) {
-                hipExtLaunchKernelGGL(gk, dim3(256), dim3(1024), gsm, 0, s0, s1, 0, x, wbuf2, scales, y, 4096, 4096, eetq::Epilogue{},
-                                      eetq::Prologue{});
+                hipExtLaunchKernelGGL(gk, dim3(256), dim3(1024), gsm, 0, s0, s1, 0, x, wbuf2, scales, y, 4096, 4096, (const eetq::f16*)nullptr,
+                                      (const eetq::f16*)nullptr, 0, eetq::Prologue{});
             });
             if (r < 0) continue;
             CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
@@ -1137,7 +1164,7 @@ int main(int argc, char** argv)
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
         for (int i = 0; i < 20; ++i)
             hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, eetq::Epilogue{}, eetq::Prologue{});
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
         CK(hipDeviceSynchronize());
     }
     if (!strcmp(what, "splitk")) {
