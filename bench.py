@@ -765,11 +765,21 @@ def main():
                         "`zero_operands` the same instruction stream with nothing toggling, `gaussian_weights_0p02` weights "
                         "~ N(0, 0.02) (bell-shaped int8)" % nl)
         gemm_roofline["power_check"] = diag
+        # the launch in SHADER CYCLES: step x the clock the chip held under this very operand set.  Cycles per launch is what the
+        # code sets (58 - 61 k since round 2, whatever the box); the clock is what the box's power budget sets -- a change in
+        # ms_per_step with unchanged cycles is the box, with changed cycles the code.
+        mhz = diag["uniform_int8_weights"]["effective_clock_mhz"]
+        if mhz:
+            gemm_roofline["cycles_per_launch"] = round(diag["uniform_int8_weights"]["us"] * mhz)
+            gemm_roofline["cycles_per_launch_zero_operands"] = (
+                round(diag["zero_operands"]["us"] * diag["zero_operands"]["effective_clock_mhz"])
+                if diag["zero_operands"]["effective_clock_mhz"] else None)
         del gsets, zeros_w, zeros_x
     roofline["gemm_m1024"] = gemm_roofline
     gemm = {"metric": "dequant-GEMM TFLOPS @ M=1024, N=K=4096", "value": gemm_roofline["whole_job_tflops"],
             "unit": "TFLOP/s", "steps": args.gemm_steps, "timed_steps": gtimed,
-            "ms_per_step": gemm_roofline["ms_per_step"], "roofline": gemm_roofline}
+            "ms_per_step": gemm_roofline["ms_per_step"], "cycles_per_launch": gemm_roofline.get("cycles_per_launch"),
+            "roofline": gemm_roofline}
 
     # ---- CPU baselines (rank 0, N = 1 only; bounded) ----
     cpu_baseline = None

@@ -1,4 +1,5 @@
-// Split-K medium-batch (M <= 128) MFMA dequant-GEMM launcher; kernel and design notes in gemm_splitk_kernel.hpp.
+// Split-K medium-batch MFMA dequant-GEMM launcher (AUTO: 9 <= M <= 128 on some shapes, row-group plans to M = 1024; the forced
+// path takes any M <= 1024); kernel and design notes in gemm_splitk_kernel.hpp.
 // Reference behaviour matched: the small-M preference of the CUTLASS tile heuristic (cutlass_heuristic.cc:123-206) -- the
 // reference never splits K because its wrapper passes no workspace (fpA_intB_gemm_wrapper.cu:169-170); here the workspace
 // is owned by the library so that the operator signature stays workspace-free.
@@ -92,8 +93,8 @@ int region_for(hipStream_t stream, float** slabs, unsigned** tickets)
             static std::atomic<bool> warned{false};
             if (!warned.exchange(true))  // once per process: the fallback is correct but slower, and silent otherwise
                 fprintf(stderr,
-                        "[eetq_amd] all %d split-K scratch regions of device %d are owned by other streams: GEMMs at 17 <= M <= 128 "
-                        "(and K-sliced tiled launches) on further streams run unsplit.  Release a stream's region with "
+                        "[eetq_amd] all %d split-K scratch regions of device %d are owned by other streams: split-K launches (medium-batch GEMMs, "
+                        "9 <= M <= 128 on some shapes, and K-sliced tiled launches) on further streams run unsplit.  Release a stream's region with "
                         "eetq_release_stream_workspace (eetq_amd.ops.release_stream_workspace) before destroying the stream, or raise "
                         "EETQ_AMD_SPLITK_REGIONS.\n", cap, dev);
             return EETQ_ERR_UNSUPPORTED;
@@ -154,7 +155,8 @@ int launch_full(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     // With that fixed both occupancies are exact (tools/deepk_check.py: 812 forced plans, 0 wrong either way;
     // tools/experiments/sk_debug.py) and equally fast (tools/splitk_occupancy.py), so a split launch asks for what it uses.
     const size_t lds = C::kSmem;
-    launch_kernel(kern, dim3(tiles_n * S, R), dim3(C::kThreads), lds, stream, x, w, scales, y, M, N, K, S, slabs,
+    // (grid.x a multiple of 8: see the block-id mapping in the kernel)
+    launch_kernel(kern, dim3((tiles_n * S + 7) & ~7, R), dim3(C::kThreads), lds, stream, x, w, scales, y, M, N, K, S, slabs,
                   tickets, ep);
     return check_hip(hipGetLastError(), "gemm_splitk_kernel launch");
 }
@@ -390,6 +392,10 @@ int launch_gemm_splitk(const f16* x, const uint8_t* w, const f16* scales, Epilog
     }
     EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4) && r >= 1 && r <= 32, "invalid split-K plan");
     EETQ_REQUIRE((M + 32 * r - 1) / (32 * r) <= 4, "split-K plan: a row group holds at most 128 rows");
+    // every K slice must own at least one 256-deep step: the kernel's prologue requests a slice's first stage without a test
+    // (gemm_splitk_kernel.hpp).  The planner never cuts finer (steps / s >= 2); a FORCED plan on a shallow K could
+    // (K = 320, S = 4: two steps, slices 0 and 2 empty) -- such a plan runs with as many slices as there are steps.
+    while (s > 1 && (K / 64 + 3) / 4 < s) s >>= 1;
     // r row groups of 32 * MT rows each (launch_full derives the group count back from MT): MT = ceil(M / (32 r))
     switch ((M + 32 * r - 1) / (32 * r)) {
         case 1: return launch_mt<1>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
@@ -423,6 +429,7 @@ int launch_gemm_splitk_i4(const f16* x, const uint8_t* w, const f16* scales, Epi
         }
     }
     EETQ_REQUIRE((nb == 1 || nb == 2) && (s == 1 || s == 2 || s == 4) && r >= 1 && r <= 4, "invalid split-K plan");
+    while (s > 1 && (K / 128 + 3) / 4 < s) s >>= 1;  // no empty K slice (see launch_gemm_splitk); an int4 tile is 128 deep
     switch ((M + 32 * r - 1) / (32 * r)) {
         case 1: return launch_mt<1, 4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);
         case 2: return launch_mt<2, 4>(x, w, scales, ep, y, M, N, K, nb, s, ring, stream);

@@ -1,5 +1,5 @@
-// Kernel template of the split-K medium-batch (17 <= M <= 128) MFMA dequant-GEMM (included by gemm_splitk.hip and
-// tools/kbench.hip).
+// Kernel template of the split-K medium-batch MFMA dequant-GEMM (AUTO: 9 <= M <= 128 on some shapes, 64-row groups up to
+// M = 1024; the forced path any M <= 1024; included by gemm_splitk.hip and tools/kbench.hip).
 //
 // Why split K.  At these M the time of gemm_mid_kernel is not the weight stream but what ONE compute unit can pull in
 // through its vector memory path (~57 B/clk = ~120 GB/s): a workgroup that owns BN columns re-reads all of x (M x K fp16)
@@ -128,7 +128,11 @@ __global__ __launch_bounds__(W * 64, (W == 4 && Cfg<MT, NB, SA, SB, W, BITS>::kS
         // the same for any tile count (the tiled kernel's formula): tiles_n * S virtual tiles, XCD x takes q or q + 1 consecutive
         // ones (N = 11008 is 172 column tiles; round-robin until the end of round 5: 4096 x 11008 M = 64 17.2 -> 16.8 us,
         // 8192 x 11008 M = 64 30.2 -> 28.6, profiles/r05_ab_xcd_contiguous_any.jsonl)
+        // gridDim.x is padded to a multiple of 8 (the launcher): the hardware deals workgroups by LINEAR id x + gridDim.x * y, so
+        // only then do the row groups y > 0 of a tile land on the XCD its group 0 is on (round-5 ADVICE: N = 11008 with R > 1 had
+        // them rotated across XCDs and lost the shared-L2 weight re-reads the planner prices); the <= 7 surplus ids leave here
         const int TT = tiles_n << sh, q = TT >> 3, r = TT & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+        if (idx >= (xcd < r ? q + 1 : q)) return;
         const int vt = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         slice = vt & (S - 1);
         tile  = vt >> sh;

@@ -70,8 +70,8 @@ def decode_dropped_steps(reset=True, device=None):
 
 
 def release_stream_workspace(stream=None):
-    """Hand the split-K scratch region a stream owns (40 MiB; 17 <= M <= 128 GEMMs and the K-sliced tiled kernel take one per
-    launch stream, at most 16 per device) back to the pool -- the library never reclaims one on its own, so a server that
+    """Hand the split-K scratch region a stream owns (40 MiB; split-K launches -- medium-batch GEMMs, 9 <= M <= 128 on some
+    shapes, and the K-sliced tiled kernel -- take one per launch stream, at most 16 per device) back to the pool -- the library never reclaims one on its own, so a server that
     creates and destroys streams calls this before destroying one (unless HIP graphs captured on it are still replayed).
     Synchronises the stream.  ``stream``: a ``torch.cuda.Stream`` (default: the current one).  eetq_release_stream_workspace."""
     import ctypes

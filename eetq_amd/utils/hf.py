@@ -91,8 +91,10 @@ def use_with_transformers(wire=True):
                 # the layout of the bytes just assigned to the parameters: the checkpoint's own tag (config.json's
                 # quantization_config["layout"], kept on the EetqConfig by the __init__ wrapper below; written by
                 # convert_checkpoint / models.save_quantized / save_pretrained under a non-sm80 wire layout) -- a
-                # reference-written checkpoint has none and is sm80 -- and only without a tag the process-wide wire layout
-                src = getattr(self.quantization_config, "layout", None) or get_wire_layout()
+                # reference-written checkpoint has none and IS sm80, whatever the process-wide wire layout says (the same
+                # default as checkpoint.read_layout / models.from_quantized: an NVIDIA-written checkpoint loaded under
+                # wire_layout("gfx950") was left un-converted before -- garbage weights, silently; round-5 ADVICE)
+                src = getattr(self.quantization_config, "layout", None) or "sm80"
                 if src != "gfx950":
                     convert_model_layout_(model, src, "gfx950")
             return out

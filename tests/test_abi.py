@@ -157,15 +157,8 @@ def test_auto_path_rule_on_a_256_cu_chip(lib):
     assert lib.eetq_diag_auto_path(8, 0, 4096, 4096, ctypes.byref(p), None) == -1
 
 
-def test_splitk_planner_against_the_measured_plan_tables(lib):
-    """The split-K planner (gemm_splitk.hip::splitk_plan through eetq_diag_splitk_plan, host arithmetic) held against the time of
-    EVERY plan measured on the GPU: profiles/r05_splitk_plan_regret*.jsonl hold, per (K, N, M), the chain time of each forced
-    (column blocks, K slices, ring, row groups) plan.  The planner's pick must have been measured in >= 90 % of the rows, be within
-    1 % of the best measured plan on average and miss by more than 5 % on at most 5 % of the points (shipped: 0.56 %, 20 of 653;
-    the round-2 constants scored 1.5 %, 63) -- a change to the cost model that does not hold up against the data fails here."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_splitk_plan_regret*.jsonl")))
-    assert len(files) >= 5
+def _plan_regret(lib, files):
+    """(rows, rows whose planned plan was measured, sum of regrets, rows > 5 %) of splitk_plan over measured plan tables"""
     n = found = bad = 0
     total = 0.0
     for f in files:
@@ -187,8 +180,31 @@ def test_splitk_planner_against_the_measured_plan_tables(lib):
             regret = plans[key] / min(plans.values()) - 1.0
             total += regret
             bad += regret > 0.05
-    assert n >= 600 and found >= 0.9 * n, (n, found)
-    assert total / found <= 0.01 and bad <= 0.05 * found, (n, found, total / found, bad)
+    return n, found, total, bad
+
+
+def test_splitk_planner_against_the_measured_plan_tables(lib):
+    """The split-K planner (gemm_splitk.hip::splitk_plan through eetq_diag_splitk_plan, host arithmetic) held against the time of
+    EVERY plan measured on a 256-CU MI355X: profiles/r05_splitk_plan_regret*.jsonl hold, per (K, N, M), the chain time of each
+    forced (column blocks, K slices, ring, row groups) plan.  Two different claims (round-5 ADVICE):
+      * HELD OUT -- `..._occ3.jsonl` (16 shapes x 7 batch sizes) was measured after the last change to the cost model and never
+        used to fit it: the planner's pick must be within 1 % of the best measured plan on average there, at most 5 % of the
+        points above 5 % (shipped: 0.5 %, 2 of 112).  This is the evidence that the model generalises -- on this chip;
+      * FITTED -- the other tables are the ones the constants were read off (0.56 %, 20 of 653 together with the held-out one;
+        the round-2 constants scored 1.5 %, 63): replaying them only guards against an accidental change of the model, and a
+        deliberate re-fit on new measurements should replace these tables, not fight this test.
+    M > 128 rows are skipped: there the row-group plan (splitk_rows_plan) applies, pinned by test_auto_path_rule_on_a_256_cu_chip."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r05_splitk_plan_regret*.jsonl")))
+    held = [f for f in files if f.endswith("_occ3.jsonl")]
+    fitted = [f for f in files if not f.endswith("_occ3.jsonl")]
+    assert len(held) == 1 and len(fitted) >= 4
+    n, found, total, bad = _plan_regret(lib, held)
+    assert n >= 100 and found >= 0.9 * n, (n, found)
+    assert total / found <= 0.01 and bad <= 0.05 * found, ("held out", n, found, total / found, bad)
+    n, found, total, bad = _plan_regret(lib, fitted)
+    assert n >= 500 and found >= 0.9 * n, (n, found)
+    assert total / found <= 0.01 and bad <= 0.05 * found, ("fitted", n, found, total / found, bad)
     p = ctypes.c_int(0)
     assert lib.eetq_diag_splitk_plan(64, 4096, 4100, ctypes.byref(p), ctypes.byref(p), ctypes.byref(p), ctypes.byref(p)) == -1   # K % 64
     assert lib.eetq_diag_splitk_plan(64, 4096, 4096, None, ctypes.byref(p), ctypes.byref(p), ctypes.byref(p)) == -1

@@ -769,6 +769,32 @@ int main(int argc, char** argv)
         }
         return 0;
     }
+    if (!strcmp(what, "mall")) {
+        // Is a weight stream served from the 256 MB Infinity Cache faster than from HBM?  A load-only kernel over a 128 MiB region:
+        // the same region every launch (cache-resident after the first) vs four rotating regions (512 MiB), nt and plain loads.
+        const size_t REG = 128ull << 20;
+        uint8_t*     big;
+        CK(hipMalloc(&big, 4 * REG));
+        CK(hipMemset(big, 1, 4 * REG));
+        auto run = [&](const char* name, auto kern, int nreg, int threads, int loads) {
+            const int grid = (int)(REG / 16 / threads / loads);
+            double    g    = time_graph(
+                [&](int i, hipStream_t s) {
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, (const u32x4*)(big + (size_t)(i % nreg) * REG), out);
+                },
+                200);
+            printf("%-44s regions %d | %7.2f us per 128 MiB launch -> %6.0f GB/s\n", name, nreg, g, (double)REG / g / 1e3);
+        };
+        for (int rep = 0; rep < 2; ++rep) {
+            run("nt loads, 1024 thr x 4", stream_read_kernel<4, true>, 4, 1024, 4);
+            run("nt loads, 1024 thr x 4", stream_read_kernel<4, true>, 1, 1024, 4);
+            run("plain loads, 1024 thr x 4", stream_read_kernel<4, false>, 4, 1024, 4);
+            run("plain loads, 1024 thr x 4", stream_read_kernel<4, false>, 1, 1024, 4);
+            run("plain loads, 256 thr x 16", stream_read_kernel<16, false>, 4, 256, 16);
+            run("plain loads, 256 thr x 16", stream_read_kernel<16, false>, 1, 256, 16);
+        }
+        return 0;
+    }
     if (!strcmp(what, "gemv_geom")) {  // wave count x tiles-in-flight at equal bytes in flight (64 KiB per workgroup)
         bench_gemv<1, 16, 4, true, true, 1, 8>("M1 xreg 16 waves x 4 (shipping)", 4096, 4096, bufs, x, scales, y);
         bench_gemv<1, 8, 8, true, true, 1, 2>("M1 xreg  8 waves x 8", 4096, 4096, bufs, x, scales, y);
