@@ -18,7 +18,7 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
     auto         kern = streamk::streamk_kernel<MT, NT, WAVES, D, OCC, BITS, XM>;
     const size_t smem = streamk::streamk_smem_bytes(MT, NT, WAVES) +
                         (XM == 1 ? (((size_t)M * K * 2 + 1023) & ~(size_t)1023)
-                                 : XM >= 2 ? (size_t)WAVES * (2 * D - 1) * (XM == 4 ? (BITS == 4 ? 4096 : 2048) : (BITS == 4 && XM == 2) ? 2048 : 1024) : 0);
+                                 : XM >= 2 ? (size_t)WAVES * (2 * D - 1) * (XM == 5 ? 4096 : XM == 4 ? (BITS == 4 ? 4096 : 2048) : (BITS == 4 && XM == 2) ? 2048 : 1024) : 0);
     if (smem > 64 * 1024) {
         static std::atomic<unsigned long long> opted{0};
         int st = opt_in_large_lds(kern, opted);
@@ -182,6 +182,19 @@ inline StreamPlan pick_plan_i4(int M, int N, int K, int ncu, int nt0, bool eight
     return p;
 }
 
+// 17 <= M <= 32: which form the explicit stream path takes (AUTO sends these batch sizes to the split-K tile; abi.hip)
+// Measured on the 14 seam shapes x M in {17, 24, 32} (tools/experiments/stream_ring32_seam.py -> profiles/r06_stream_ring32_seam.jsonl):
+// the 32-row ring runs at 0.55 - 0.8 of the register form's time everywhere (4096^2 M = 32 10.1 -> 7.9 us, 5120 x 13824 M = 32
+// 45 -> 22), one tile row per workgroup up to one workgroup per CU (N = 4096: 4096^2, 11008 x 4096, 14336 x 4096), two beyond.
+// Against the split-K plans AUTO runs at these batch sizes it is ahead by >= 5 % on three points only, all at M = 17 (4096^2
+// 7.05 -> 6.43, 4096 x 6144 8.67 -> 8.19, 8192^2 16.5 -> 15.0) and 15 - 37 % behind on the wide / deep shapes: AUTO keeps the
+// split-K tile from M = 17 (verdict item 5: fewer than five shapes, shelved as an AUTO choice).
+inline StreamPlan ring32_plan(int M, int N, int K, int ncu)
+{
+    (void)M, (void)K;
+    return StreamPlan{2, N / kTileN <= ncu ? 1 : 2, 8};
+}
+
 template <int MT>
 int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                 hipStream_t stream)
@@ -248,6 +261,27 @@ int launch_mt(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f1
                           : launch_inst<MT, 2, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
             return e8 ? launch_inst<MT, 1, 8, 2, 4>(x, w, scales, ep, y, M, N, K, stream)
                       : launch_inst<MT, 1, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
+        }
+        if constexpr (MT == 2) {
+            // 17 <= M <= 32 (round 6): the 32-row per-wave ring -- four LDS-DMAs per k tile and wave, two MFMA row tiles per weight
+            // register tile, 8-wave workgroups (4 KiB slots: 16 waves would need 192 KiB of LDS) -- next to the register form
+            // (16 clamped rows x 128 B of activations from L2 per row tile and weight tile).  Same fragments into the same MFMAs at
+            // equal wave count.  EETQ_AMD_I8_STREAM_PLAN=ring|regs,nt,waves picks for A/B runs; the default: see the ring32 rule.
+            static const StreamPlan forced = plan_from_env("EETQ_AMD_I8_STREAM_PLAN");
+            const int ncu = device_cu_count();
+            StreamPlan plan = ring32_plan(M, N, K, ncu);
+            if (forced.form >= 0) plan.form = forced.form;
+            if (forced.nt) plan.nt = forced.nt;
+            if (forced.waves) plan.waves = forced.waves;
+            if (plan.nt == 2 && N % (2 * kTileN) != 0) plan.nt = 1;
+            if (plan.form == 2) {
+                if (plan.nt == 2) return launch_inst<MT, 2, 8, 2, 2, 8, 5>(x, w, scales, ep, y, M, N, K, stream);
+                return launch_inst<MT, 1, 8, 2, 2, 8, 5>(x, w, scales, ep, y, M, N, K, stream);
+            }
+            if (plan.waves == 8) {
+                if (plan.nt == 2) return launch_inst<MT, 2, 8, 2, 2>(x, w, scales, ep, y, M, N, K, stream);
+                return launch_inst<MT, 1, 8, 2, 2>(x, w, scales, ep, y, M, N, K, stream);
+            }
         }
         return launch_inst<MT, 1, 16, 2, 4>(x, w, scales, ep, y, M, N, K, stream);
     }

@@ -7,6 +7,7 @@
 //   XM = 0  registers: straight from global memory (L2), 16 clamped rows x 128 B per weight tile and wave (any MT)
 //   XM = 1  block copy: the M rows once per workgroup into LDS (MT = 1, K % 128 == 0, M*K*2 bytes must fit)
 //   XM = 2  per-wave ring of 8 rows (M <= 8), XM = 3 of 4 rows (int4, M <= 4), XM = 4 of 16 rows (M <= 16): LDS-DMA per k tile
+//   XM = 5  (round 6, int8) per-wave ring of 32 rows, MT = 2: four DMAs per k tile, two MFMA row tiles per weight register tile
 // All forms feed the same fragments to the same MFMAs in the same order: bit-identical results at equal WAVES.
 // Included by streamk.hip and tools/kbench.hip.
 #pragma once
@@ -41,10 +42,11 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     constexpr bool XLDS = XM == 1, XRING = XM >= 2;
     constexpr int  kRing     = 2 * D - 1;
     constexpr int  kRowBytes = BITS == 8 ? 128 : 256;          // activation bytes per row and k tile
-    constexpr int  kRingRows = XM == 3 ? 4 : XM == 4 ? 16 : 8;    // XM = 4: 9 <= M <= 16, two DMAs per int8 tile, four per int4 tile
+    constexpr int  kRingRows = XM == 3 ? 4 : XM == 4 ? 16 : XM == 5 ? 32 : 8;  // XM = 4: 9 <= M <= 16, two DMAs per int8 tile, four per int4 tile; XM = 5: 17 <= M <= 32
     constexpr int  kSlot     = kRingRows * kRowBytes;          // 1 KiB; int4 with 8 rows: 2 KiB
     constexpr int  kDma      = kSlot / 1024;
-    static_assert(XM == 0 || MT == 1, "LDS-staged activations: one row tile");
+    static_assert(XM == 0 || MT == 1 || (XM == 5 && MT == 2 && BITS == 8), "LDS-staged activations: one row tile (two in the 32-row ring)");
+    constexpr int  kRT       = XM == 5 ? 2 : 1;                 // row tiles whose fragments come from the ring
     static_assert(XM != 3 || BITS == 4, "the 4-row ring is the int4 form for M <= 4");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int xs_bytes = XLDS ? ((M * K * 2 + 1023) & ~1023) : XRING ? WAVES * kRing * kSlot : 0;
@@ -106,10 +108,12 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
     }
 
     __amdgpu_buffer_rsrc_t ring_rs;
-    int                    ring_voff[4] = {0, 0, 0, 0}, ring_rd[XQ];
+    int                    ring_voff[4] = {0, 0, 0, 0}, ring_rd[kRT][XQ];
     uint8_t*               ring_wr      = smem;
 #pragma unroll
-    for (int q = 0; q < XQ; ++q) ring_rd[q] = 0;
+    for (int rt = 0; rt < kRT; ++rt)
+#pragma unroll
+        for (int q = 0; q < XQ; ++q) ring_rd[rt][q] = 0;
     if constexpr (XRING) {
         constexpr int kChunks = kRowBytes / 16;
         ring_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16*>(x), 0, M * K * 2, 0x00020000);
@@ -120,10 +124,13 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
             ring_voff[j]  = rr * K * 2 + (((lane & (kChunks - 1)) ^ (rr & (kChunks - 1))) << 4);
         }
         ring_wr        = smem + wave * (kRing * kSlot);
-        const int rc   = c < M ? c : M - 1;  // fragment lane (g, c): row rc, chunks XQ*g .. XQ*g + XQ - 1
         const int lds0 = (int)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)smem + wave * (kRing * kSlot);
 #pragma unroll
-        for (int q = 0; q < XQ; ++q) ring_rd[q] = lds0 + rc * kRowBytes + (((XQ * g + q) ^ (rc & (kChunks - 1))) << 4);
+        for (int rt = 0; rt < kRT; ++rt) {
+            const int rc = 16 * rt + c < M ? 16 * rt + c : M - 1;  // fragment lane (g, c): row rc, chunks XQ*g .. XQ*g + XQ - 1
+#pragma unroll
+            for (int q = 0; q < XQ; ++q) ring_rd[rt][q] = lds0 + rc * kRowBytes + (((XQ * g + q) ^ (rc & (kChunks - 1))) << 4);
+        }
     }
 
     struct Stage {
@@ -165,7 +172,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
 
     f16x2 scale2[NT];
     auto  consume = [&](const Stage& s) {
-        u32x4 xa[XQ];
+        u32x4 xa[XQ], xb[XQ];  // xb: the second row tile of the 32-row ring
         if constexpr (XLDS) {
             const int ko = BITS == 8 ? (s.kt ^ xl_hi) << 7 : s.kt << 8;
 #pragma unroll
@@ -177,16 +184,24 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
             // among the inputs makes the compiler wait for this stage's weights first -- the DMA was issued before them and returns
             // are in order, so the slot is complete.
             const int ko = s.kt * kSlot;
-            if constexpr (BITS == 8) {
+            if constexpr (XM == 5) {
+                asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
+                             "s_waitcnt lgkmcnt(0)"
+                             : "=&v"(xa[0]), "=&v"(xa[1]), "=&v"(xb[0]), "=&v"(xb[1])
+                             : "v"(ring_rd[0][0] + ko), "v"(ring_rd[0][1] + ko), "v"(ring_rd[1][0] + ko), "v"(ring_rd[1][1] + ko),
+                               "v"(s.wq[NT - 1].x)
+                             : "memory");
+            } else if constexpr (BITS == 8) {
                 asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %3\n\ts_waitcnt lgkmcnt(0)"
                              : "=&v"(xa[0]), "=&v"(xa[1])
-                             : "v"(ring_rd[0] + ko), "v"(ring_rd[1] + ko), "v"(s.wq[NT - 1].x)
+                             : "v"(ring_rd[0][0] + ko), "v"(ring_rd[0][1] + ko), "v"(s.wq[NT - 1].x)
                              : "memory");
             } else {
                 asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\t"
                              "s_waitcnt lgkmcnt(0)"
                              : "=&v"(xa[0]), "=&v"(xa[1]), "=&v"(xa[2]), "=&v"(xa[3])
-                             : "v"(ring_rd[0] + ko), "v"(ring_rd[1] + ko), "v"(ring_rd[2] + ko), "v"(ring_rd[3] + ko), "v"(s.wq[NT - 1].x)
+                             : "v"(ring_rd[0][0] + ko), "v"(ring_rd[0][1] + ko), "v"(ring_rd[0][2] + ko), "v"(ring_rd[0][3] + ko),
+                               "v"(s.wq[NT - 1].x)
                              : "memory");
             }
         }
@@ -199,6 +214,10 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void streamk_kernel
                 const f16x8 b1 = {wq[4].x, wq[4].y, wq[5].x, wq[5].y, wq[6].x, wq[6].y, wq[7].x, wq[7].y};
                 acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xa[0]), b0, acc[0][t], 0, 0, 0);
                 acc[0][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xa[1]), b1, acc[0][t], 0, 0, 0);
+                if constexpr (XM == 5) {
+                    acc[MT - 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xb[0]), b0, acc[MT - 1][t], 0, 0, 0);
+                    acc[MT - 1][t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, xb[1]), b1, acc[MT - 1][t], 0, 0, 0);
+                }
             } else if constexpr (BITS == 8) {
                 f16x2 wq[8];
                 dequant_16(s.wq[t], scale2[t], wq);

@@ -229,12 +229,14 @@ def test_gemv_vs_oracle(ops, oracle, M, K, N):
                                           np.argwhere(~ok)[:4])
 
 
-@pytest.mark.parametrize("M", [2, 8, 13, 16])
+@pytest.mark.parametrize("M", [2, 8, 13, 16, 17, 24, 32])
 @pytest.mark.parametrize("K,N", [(2048, 8192), (2112, 8256), (2048, 8208), (2048, 5120), (2048, 6144)])
 def test_stream_wide_n_vs_oracle(ops, oracle, M, K, N):
     """Shapes where the launcher's cost model puts two 16-column tile rows into one workgroup (they share the activation
     fragments): N = 8192 / 8256, and N = 5120 / 6144 where one tile row per workgroup would leave a second, mostly empty
-    round of workgroups; 8208 is the N % 32 != 0 fallback to one tile row."""
+    round of workgroups; 8208 is the N % 32 != 0 fallback to one tile row.  M = 17 / 24 / 32 (round 6): the 32-row per-wave
+    ring with two MFMA row tiles per weight tile (streamk_kernel<..., XM = 5>), two tile rows per workgroup beyond one
+    workgroup per CU."""
     w, x = _rand_case(K, N, M, seed=7 * K + N + M)
     x[:, 1::2] *= -1
     y, q, s = _run_gemm(ops, oracle, w, x, path="stream")

@@ -37,7 +37,7 @@ def ring_params(fn):
     if not m:
         return None
     mt, nt, waves, depth, occ, bits, xm = (int(g) for g in m.groups())
-    rows = 4 if xm == 3 else 16 if xm == 4 else 8
+    rows = 4 if xm == 3 else 16 if xm == 4 else 32 if xm == 5 else 8
     kdma = rows * (128 if bits == 8 else 256) // 1024
     return {"nt": nt, "depth": depth, "kdma": kdma}
 
