@@ -21,6 +21,8 @@ ap.add_argument("--kv-heads", type=int, default=40)
 ap.add_argument("--layers", type=int, default=20)
 ap.add_argument("--splits", default="default,4,8,12,17,25,34")
 ap.add_argument("--stamps", action="store_true", help="per-phase device-clock decomposition of the one-launch form")
+ap.add_argument("--pair", action="store_true", help="attention + the o projection behind it (H*D x H*D int8), with and without "
+                                                    "the L2 prefetch of the projection's weight inside the attention launch")
 args = ap.parse_args()
 dev = "cuda:0"
 B, H, Hkv, D, S, L = args.batch, args.heads, args.kv_heads, 128, args.rows, args.layers
@@ -72,6 +74,42 @@ def timed(fn, splits, reps=30):
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 1e3 / (reps * L)
 
+
+if args.pair:
+    C = H * D
+    gw = torch.Generator(device=dev).manual_seed(3)
+    ow = [torch.randint(-128, 127, (C, C), dtype=torch.int8, device=dev, generator=gw) for _ in range(L)]
+    osc = [(torch.rand(C, dtype=torch.float16, device=dev, generator=gw) * 0.01 + 0.001) for _ in range(L)]
+    res = torch.zeros(B, C, dtype=torch.float16, device=dev)
+
+    def pair(i, hint):
+        att = ops.rope_decode_attention(pos, q, k, v, table, kc[i], vc[i], tickets[i], slots=counters[i], kv_len=counters[i],
+                                        kv_len_bias=1, next_weight=ow[i] if hint else None)
+        return ops.w8_a16_gemm(att.view(B, C), ow[i], osc[i], residual=res)
+
+    def attn_only(i, _):
+        return ops.rope_decode_attention(pos, q, k, v, table, kc[i], vc[i], tickets[i], slots=counters[i], kv_len=counters[i], kv_len_bias=1)
+
+    def attn_hint_only(i, _):
+        return ops.rope_decode_attention(pos, q, k, v, table, kc[i], vc[i], tickets[i], slots=counters[i], kv_len=counters[i], kv_len_bias=1,
+                                         next_weight=ow[i])
+
+    def proj_only(i, _):
+        return ops.w8_a16_gemm(res, ow[i], osc[i], residual=res)
+
+    y0 = pair(0, False).clone()
+    y1 = pair(0, True).clone()
+    same = bool(torch.equal(y0, y1))
+    out = {"form": "attention + o projection", "batch": B, "heads": H, "filled": args.filled, "rows": S, "o_proj": "%dx%d" % (C, C),
+           "same_bits_with_hint": same}
+    for rep in range(2):
+        out["attention_us"] = round(timed(attn_only, None), 2)
+        out["attention_with_prefetch_us"] = round(timed(attn_hint_only, None), 2)
+        out["o_proj_us"] = round(timed(proj_only, None), 2)
+        out["pair_us"] = round(timed(pair, False), 2)
+        out["pair_with_prefetch_us"] = round(timed(pair, True), 2)
+        print(json.dumps(out), flush=True)
+    sys.exit(0)
 
 if args.stamps:
     import ctypes

@@ -245,6 +245,20 @@ __global__ __launch_bounds__(1024, 8) void gemv_ladder_kernel(const eetq::f16* _
     }
 }
 
+// L2 prefetch probe (round 6): every lane touches ONE dword of its own 64-byte sector (STRIDE = 64) or 128-byte line (STRIDE = 128)
+// with a plain load; 256 threads, grid sized by the caller
+template <int STRIDE>
+__global__ void touch_lines_kernel(const uint8_t* __restrict__ p, size_t bytes, unsigned* __restrict__ out)
+{
+    // workgroup b touches the b-th 1 / gridDim of the bytes: with as many workgroups as the reader has, a toucher and the reader
+    // of the same bytes have the same block id, i.e. (as the dispatcher deals blocks today) the same XCD and the same L2
+    unsigned     acc   = 0;
+    const size_t chunk = bytes / gridDim.x, base = (size_t)blockIdx.x * chunk;
+    for (size_t off = (size_t)threadIdx.x * STRIDE; off < chunk; off += (size_t)blockDim.x * STRIDE)
+        acc ^= *reinterpret_cast<const unsigned*>(p + base + off);
+    if (acc == 0x9e3779b9u) out[0] = acc;
+}
+
 // dispatch-overhead probes: what a kernel costs that touches no memory / one cache line per wave
 __global__ void empty_kernel(unsigned* out, int never)
 {
@@ -785,6 +799,46 @@ int main(int argc, char** argv)
                 200);
             printf("%-44s regions %d | %7.2f us per 128 MiB launch -> %6.0f GB/s\n", name, nreg, g, (double)REG / g / 1e3);
         };
+        // ... and from the per-XCD L2s (32 MiB in all)?  The same 16 MiB / 24 MiB every launch: does L2 content survive a kernel boundary?
+        auto run_small = [&](const char* name, auto kern, size_t bytes, int nreg, int threads, int loads) {
+            const int grid = (int)(bytes / 16 / threads / loads);
+            double    g    = time_graph(
+                [&](int i, hipStream_t s) {
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(threads), 0, s, (const u32x4*)(big + (size_t)(i % nreg) * REG), out);
+                },
+                400);
+            printf("%-44s %2zu MiB, regions %d | %7.2f us per launch -> %6.0f GB/s\n", name, bytes >> 20, nreg, g, (double)bytes / g / 1e3);
+        };
+        for (int rep = 0; rep < 2; ++rep) {
+            run_small("plain loads, 1024 thr x 4", stream_read_kernel<4, false>, 16ull << 20, 1, 1024, 4);
+            run_small("plain loads, 1024 thr x 4", stream_read_kernel<4, false>, 16ull << 20, 4, 1024, 4);
+            run_small("nt loads, 1024 thr x 4", stream_read_kernel<4, true>, 16ull << 20, 1, 1024, 4);
+            run_small("plain loads, 1024 thr x 4", stream_read_kernel<4, false>, 24ull << 20, 1, 1024, 4);
+            run_small("plain loads, 1024 thr x 4", stream_read_kernel<4, false>, 24ull << 20, 4, 1024, 4);
+            run_small("plain loads, 1024 thr x 4", stream_read_kernel<4, false>, 8ull << 20, 1, 1024, 4);
+            run_small("plain loads, 1024 thr x 4", stream_read_kernel<4, false>, 8ull << 20, 4, 1024, 4);
+        }
+        // ... and can a CHEAP kernel put them there for the next one?  Pairs (touch one dword per sector / line of region i, then read
+        // region i with the GEMV's load pattern, nt or plain), four rotating 16 / 24 MiB regions; the touch kernel alone for its cost
+        auto run_pair = [&](const char* name, auto touch, auto kern, size_t bytes, bool with_read) {
+            const int grid = (int)(bytes / 16 / 1024 / 4);
+            double    g    = time_graph(
+                [&](int i, hipStream_t s) {
+                    const uint8_t* reg = big + (size_t)(i % 4) * REG;
+                    hipLaunchKernelGGL(touch, dim3(grid), dim3(256), 0, s, reg, bytes, out);
+                    if (with_read) hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), 0, s, (const u32x4*)reg, out);
+                },
+                400);
+            printf("%-62s %2zu MiB | %7.2f us per %s\n", name, bytes >> 20, g, with_read ? "pair" : "touch launch");
+        };
+        for (size_t mb : {16, 24}) {
+            run_pair("touch 1 dword / 64 B alone", touch_lines_kernel<64>, stream_read_kernel<4, true>, mb << 20, false);
+            run_pair("touch 1 dword / 128 B alone", touch_lines_kernel<128>, stream_read_kernel<4, true>, mb << 20, false);
+            run_pair("touch / 64 B, then nt read", touch_lines_kernel<64>, stream_read_kernel<4, true>, mb << 20, true);
+            run_pair("touch / 64 B, then plain read", touch_lines_kernel<64>, stream_read_kernel<4, false>, mb << 20, true);
+            run_pair("touch / 128 B, then nt read", touch_lines_kernel<128>, stream_read_kernel<4, true>, mb << 20, true);
+            run_pair("touch / 128 B, then plain read", touch_lines_kernel<128>, stream_read_kernel<4, false>, mb << 20, true);
+        }
         for (int rep = 0; rep < 2; ++rep) {
             run("nt loads, 1024 thr x 4", stream_read_kernel<4, true>, 4, 1024, 4);
             run("nt loads, 1024 thr x 4", stream_read_kernel<4, true>, 1, 1024, 4);
