@@ -56,6 +56,9 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 // branch, no clamped duplicate rows, no select on the way in.  An out-of-range load is not free, though (0.5 us per launch for
 // one per block, same probe): the mask loads exist only in the MASK instantiation, the further trips only in the LONG one.
 // The running softmax state is rescaled once per trip (A, B, then each further trip), not once per position.
+// Measured and shelved (tools/experiments/attn_loader_consumer.patch, profiles/r06_attn_forms.txt): eight waves per workgroup, four
+// LOADERS moving the chunk into LDS by LDS-DMA and four consumers taking it from there trip by trip (bit-identical) -- the
+// consumers start at 1.6 us instead of 3.4, but the rows arrive later than through registers: 9.9 - 10.7 us per step against 9.4.
 constexpr int kUA = 8, kUB = 8, kUL = 4, kUG = 4;
 constexpr int kNt = 2;  // aux bits of a buffer load: nt
 
@@ -196,6 +199,53 @@ __device__ __forceinline__ float lane_xor(float v)
     }
 }
 
+// The position groups of a wave (lane swaps, no LDS), then the waves through LDS (NW sets): (m, l, o[8]) per lane -> threads
+// tid < D hold (M, L, O) of the chunk.  One barrier; only the consuming waves (kAttnThreads threads) call it.
+template <int D>
+__device__ __forceinline__ void chunk_merge(float m, float l, const float (&o)[8], float* sm_m, float* sm_l, float* sm_o, float& M,
+                                            float& L, float& O)
+{
+#pragma clang fp contract(off)
+    constexpr int LPP = AttnGeo<D>::LPP, PPW = AttnGeo<D>::PPW, NW = kAttnThreads / 64;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, li = lane % LPP, d0 = li * 8;
+    float mw = m;
+    if constexpr (PPW == 8) mw = fmaxf(mw, lane_xor<8>(mw));
+    mw = fmaxf(mw, lane_xor<16>(mw));
+    mw = fmaxf(mw, lane_xor<32>(mw));
+    const float w = mw > -INFINITY ? __expf(m - mw) : 0.f;  // exp(-inf) = 0 for a group without a valid position
+    float       part[9];
+    part[8] = l * w;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) part[i] = o[i] * w;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        if constexpr (PPW == 8) part[i] += lane_xor<8>(part[i]);
+        part[i] = sum_xor32(sum_xor16(part[i]));
+    }
+    if (lane < LPP) {
+        if (li == 0) {
+            sm_m[wave] = mw;
+            sm_l[wave] = part[8];
+        }
+        *reinterpret_cast<f32x4*>(sm_o + wave * D + d0)     = f32x4{part[0], part[1], part[2], part[3]};
+        *reinterpret_cast<f32x4*>(sm_o + wave * D + d0 + 4) = f32x4{part[4], part[5], part[6], part[7]};
+    }
+    __syncthreads();
+    M = -INFINITY, L = 0.f, O = 0.f;
+    if (tid < D) {
+#pragma unroll
+        for (int s2 = 0; s2 < NW; ++s2) M = fmaxf(M, sm_m[s2]);
+        if (M > -INFINITY) {
+#pragma unroll
+            for (int s2 = 0; s2 < NW; ++s2) {
+                const float ws = __expf(sm_m[s2] - M);  // exp(-inf) = 0 for empty sets
+                L = fmaf(sm_l[s2], ws, L);
+                O = fmaf(sm_o[s2 * D + tid], ws, O);
+            }
+        }
+    }
+}
+
 // The consumption of chunk `split` of one (batch row, head) and its merge across the workgroup.  ta: the chunk's first kUA
 // blocks, already requested (load_blocks at blk0 = split, stride splits); tb: registers for the next kUB.  On return
 // threads tid < D hold (M, L, O) = the chunk's running maximum, its sum of exp(s - M) and channel tid of sum exp(s - M) v.
@@ -206,9 +256,9 @@ __device__ __forceinline__ void attn_chunk(const f16x8& qv, float scaling, KvBlo
                                            float* sm_m, float* sm_l, float* sm_o, float& M, float& L, float& O)
 {
 #pragma clang fp contract(off)
-    constexpr int LPP = AttnGeo<D>::LPP, PPW = AttnGeo<D>::PPW, BLK = AttnGeo<D>::BLK, NW = kAttnThreads / 64;
+    constexpr int LPP = AttnGeo<D>::LPP, PPW = AttnGeo<D>::PPW, BLK = AttnGeo<D>::BLK;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int grp = lane / LPP, li = lane % LPP, d0 = li * 8, rib = wave * PPW + grp;
+    const int grp = lane / LPP, rib = wave * PPW + grp;
     const f16x2 q2[4] = {{qv[0], qv[1]}, {qv[2], qv[3]}, {qv[4], qv[5]}, {qv[6], qv[7]}};
 
     float m = -INFINITY, l = 0.f, o[8];
@@ -252,43 +302,7 @@ __device__ __forceinline__ void attn_chunk(const f16x8& qv, float scaling, KvBlo
         static_for<NT>(trips_b);
     }
 
-    // the wave's PPW position groups first (lane swaps, no LDS), then the waves through LDS: NW sets instead of NW * PPW
-    float mw = m;
-    if constexpr (PPW == 8) mw = fmaxf(mw, lane_xor<8>(mw));
-    mw = fmaxf(mw, lane_xor<16>(mw));
-    mw = fmaxf(mw, lane_xor<32>(mw));
-    const float w = mw > -INFINITY ? __expf(m - mw) : 0.f;  // exp(-inf) = 0 for a group without a valid position
-    float       part[9];
-    part[8] = l * w;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) part[i] = o[i] * w;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) {
-        if constexpr (PPW == 8) part[i] += lane_xor<8>(part[i]);
-        part[i] = sum_xor32(sum_xor16(part[i]));
-    }
-    if (lane < LPP) {
-        if (li == 0) {
-            sm_m[wave] = mw;
-            sm_l[wave] = part[8];
-        }
-        *reinterpret_cast<f32x4*>(sm_o + wave * D + d0)     = f32x4{part[0], part[1], part[2], part[3]};
-        *reinterpret_cast<f32x4*>(sm_o + wave * D + d0 + 4) = f32x4{part[4], part[5], part[6], part[7]};
-    }
-    __syncthreads();
-    M = -INFINITY, L = 0.f, O = 0.f;
-    if (tid < D) {
-#pragma unroll
-        for (int s2 = 0; s2 < NW; ++s2) M = fmaxf(M, sm_m[s2]);
-        if (M > -INFINITY) {
-#pragma unroll
-            for (int s2 = 0; s2 < NW; ++s2) {
-                const float ws = __expf(sm_m[s2] - M);  // exp(-inf) = 0 for empty sets
-                L = fmaf(sm_l[s2], ws, L);
-                O = fmaf(sm_o[s2 * D + tid], ws, O);
-            }
-        }
-    }
+    chunk_merge<D>(m, l, o, sm_m, sm_l, sm_o, M, L, O);
 }
 
 // the buffer descriptors of one (batch row, kv head), ending at the valid length Sv
@@ -519,6 +533,54 @@ __device__ __forceinline__ void store_sc1(float* p, float v)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // write-through
 }
 
+// Publish the chunk record, take the head's ticket; the last arriver merges the head's chunks and stores the output, and the last
+// head advances the cache's token counter.  Threads tid < D hold the chunk's (M, L, O); kAttnThreads threads call (barriers inside).
+template <int D>
+__device__ __forceinline__ void head_handoff(const RopeAttnArgs& a, int split, int splits, int h, int b, int H, float M, float L,
+                                             float O, float* sm_o, unsigned* sm_ticket)
+{
+    const int tid = threadIdx.x;
+    float*     head_ws = a.ws + ((size_t)b * splits * H + h) * (D + kRecPad);  // [batch][split][head][record]
+    const long rec_stride = (long)H * (D + kRecPad);
+    if (splits > 1) {
+        // ---- publish the chunk record (write-through), take a ticket; every storing wave drains its own stores ----
+        if (tid < D) {
+            float* rec = head_ws + (size_t)split * rec_stride;
+            store_sc1(rec + kRecPad + tid, O);
+            if (tid == 0) {
+                store_sc1(rec, M);
+                store_sc1(rec + 1, L);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        ATTN_STAMP(4);
+        if (tid == 0)
+            *sm_ticket = __hip_atomic_fetch_add(a.tickets + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        ATTN_STAMP(5);
+        if (*sm_ticket != (unsigned)(splits - 1)) return;  // not the head's last chunk
+        if (tid == 0) __hip_atomic_store(a.tickets + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- last arriver: merge all chunk records of the head (its own one read back like the others) ----
+        const CoherentRecords recs{__builtin_amdgcn_make_buffer_rsrc(head_ws, 0, 0x7fffffff, 0x00020000)};
+        O = attn_merge<D, kAttnThreads>(recs, rec_stride, splits, tid, sm_o);  // sm_o is free again: reused for the exchange
+    } else if (tid < D) {
+        O = L > 0.f ? O / L : 0.f;
+    }
+    ATTN_STAMP(6);
+    if (tid < D) a.out[b * a.o_sb + h * a.o_sh + tid] = (f16)O;
+    ATTN_STAMP(7);
+    // ---- the last head to finish advances the token counter: by then every workgroup of the launch has read it ----
+    if (a.advance && tid == 0) {
+        const unsigned heads_total = (unsigned)(H * gridDim.z);
+        unsigned*      done = a.tickets + heads_total;
+        if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == heads_total - 1) {
+            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *a.advance += 1;
+        }
+    }
+}
+
 // grid (splits, heads, batch), 256 threads; see the file header.  The five leading pointers are preloaded into SGPRs at
 // launch (-amdgpu-kernarg-preload-count): the three scalar reads the chunk bounds depend on go out with the first
 // instructions, together with the fetch of the argument block, and nothing else stands before the first cache loads.
@@ -595,45 +657,7 @@ __global__ __launch_bounds__(kAttnThreads) void rope_attn_decode_kernel(const in
     attn_chunk<D, true, MASK, LONG>(qv, a.scaling, ta, tb, src, split, splits, Sv, slot, knew, vnew, sm_m, sm_l, sm_o, M, L, O);
 
     ATTN_STAMP(3);
-    float*     head_ws = a.ws + ((size_t)b * splits * H + h) * (D + kRecPad);  // [batch][split][head][record]
-    const long rec_stride = (long)H * (D + kRecPad);
-    if (splits > 1) {
-        // ---- publish the chunk record (write-through), take a ticket; every storing wave drains its own stores ----
-        if (tid < D) {
-            float* rec = head_ws + (size_t)split * rec_stride;
-            store_sc1(rec + kRecPad + tid, O);
-            if (tid == 0) {
-                store_sc1(rec, M);
-                store_sc1(rec + 1, L);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        ATTN_STAMP(4);
-        if (tid == 0)
-            sm_ticket = __hip_atomic_fetch_add(a.tickets + b * H + h, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        ATTN_STAMP(5);
-        if (sm_ticket != (unsigned)(splits - 1)) return;  // not the head's last chunk
-        if (tid == 0) __hip_atomic_store(a.tickets + b * H + h, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // ---- last arriver: merge all chunk records of the head (its own one read back like the others) ----
-        const CoherentRecords recs{__builtin_amdgcn_make_buffer_rsrc(head_ws, 0, 0x7fffffff, 0x00020000)};
-        O = attn_merge<D, kAttnThreads>(recs, rec_stride, splits, tid, sm_o);  // sm_o is free again: reused for the exchange
-    } else if (tid < D) {
-        O = L > 0.f ? O / L : 0.f;
-    }
-    ATTN_STAMP(6);
-    if (tid < D) a.out[b * a.o_sb + h * a.o_sh + tid] = (f16)O;
-    ATTN_STAMP(7);
-    // ---- the last head to finish advances the token counter: by then every workgroup of the launch has read it ----
-    if (a.advance && tid == 0) {
-        const unsigned heads_total = (unsigned)(H * gridDim.z);
-        unsigned*      done = a.tickets + heads_total;
-        if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == heads_total - 1) {
-            __hip_atomic_store(done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            *a.advance += 1;
-        }
-    }
+    head_handoff<D>(a, split, splits, h, b, H, M, L, O, sm_o, &sm_ticket);
 }
 
 // LONG: some chunk may own more than kUA + kUB blocks (a launch-time fact of the capacity S and the chunk count)
