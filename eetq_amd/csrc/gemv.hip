@@ -22,15 +22,25 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
         if (pro.gamma) return launch_inst<M, WAVES, D, EXACT, XREG, XV, OCC, 1>(x, w, scales, ep, y, N, K, stream, pro);
         if (pro.up) return launch_inst<M, WAVES, D, EXACT, XREG, XV, OCC, 2>(x, w, scales, ep, y, N, K, stream, pro);
     }
-    auto         kern = gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC, NORM>;
     const size_t smem = gemv::gemv_smem_bytes(M, K, WAVES, XREG);
-    if (smem > 64 * 1024) {
-        static std::atomic<unsigned long long> opted{0};
-        int st = opt_in_large_lds(kern, opted);
-        if (st != EETQ_OK) return st;
+    auto go = [&](auto kern, std::atomic<unsigned long long>& opted) {
+        if (smem > 64 * 1024) {
+            int st = opt_in_large_lds(kern, opted);
+            if (st != EETQ_OK) return st;
+        }
+        launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, pro);
+        return check_hip(hipGetLastError(), "gemv_kernel launch");
+    };
+    if constexpr (M == 1 && !NORM) {
+        // the plain projection (no bias, residual or activation) has its own instantiation of every M = 1 kernel form: same
+        // arithmetic, same bits, no run-time epilogue (gemv_kernel.hpp: PLAIN)
+        if (!ep.bias && !ep.residual && ep.act == 0) {
+            static std::atomic<unsigned long long> opted_plain{0};
+            return go(gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC, NORM, 8, true>, opted_plain);
+        }
     }
-    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, pro);
-    return check_hip(hipGetLastError(), "gemv_kernel launch");
+    static std::atomic<unsigned long long> opted{0};
+    return go(gemv_kernel<M, WAVES, D, EXACT, XREG, XV, OCC, NORM>, opted);
 }
 
 // LDS-staged activations: pick the number of 16-byte x loads per thread at compile time (no conditional loads)

@@ -191,7 +191,10 @@ __device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, cons
 // Dynamic LDS: [M*K fp16 activations unless XREG] + WAVES*M*16 floats (cross-wave reduction).
 // The body is a device function of the tile row `ntile` so that the grouped launch (one dispatch over the tile rows of
 // several problems, gemv_grouped_kernel below) runs exactly the same code as the single-problem kernel.
-template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int NORM = 0, int BITS = 8>
+// PLAIN: y = fp16(acc), no bias / residual / activation -- the reference's own GEMV instantiates its no-bias form at compile time
+// too (weightOnlyBatchedGemv/kernelLauncher.cu:165-192: Zero = 0, Bias = 0); the run-time epilogue (argument fetch, three
+// branches) is 0.1 us of the 4.6 us launch (profiles/r06_gemv_ladder.txt: ladder rung 5 vs the library kernel).
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int NORM = 0, int BITS = 8, bool PLAIN = false>
 __device__ __forceinline__ void gemv_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int N, int K, const Epilogue& ep_arg, const Prologue& pro, const int ntile)
@@ -252,7 +255,7 @@ __device__ __forceinline__ void gemv_body(
     u32x4        buf[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) buf[d] = load_w<true>(wp + d * stride);
-    const Epilogue ep = pin_epilogue(ep_arg);
+    const Epilogue ep = PLAIN ? Epilogue{} : pin_epilogue(ep_arg);
 
     if constexpr (!XREG) {
         const int xvecs = (M * K) >> 3;
@@ -341,7 +344,9 @@ __device__ __forceinline__ void gemv_body(
                 if (ww < WAVES) s += red[(ww * M + m) * 16 + c];
             }
             s = sum_xor32(sum_xor16(s));
-            if (lane < 16) {
+            if constexpr (PLAIN) {
+                if (lane < 16) y[(size_t)m * N + ntile * 16 + c] = (f16)s;
+            } else if (lane < 16) {
                 if (ep.act == kActGlu8) {
                     // columns 0..7 of the tile are gate, 8..15 the matching up columns: N/2 outputs per row
                     Epilogue lin = ep;
@@ -360,7 +365,7 @@ __device__ __forceinline__ void gemv_body(
     EETQ_STAMP(2);
 }
 
-template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8>
+template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8, bool PLAIN = false>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int N, int K, const f16* bias, const f16* residual, int act, Prologue pro)
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     // i.e. between the last weight tile and the store, 0.1 us of every launch (profiles/r06_gemv_ladder.txt)
     Epilogue ep;
     ep.bias = bias, ep.residual = residual, ep.act = act;
-    gemv_body<M, WAVES, D, EXACT, XREG, XV, NORM, BITS>(x, w, scales, y, N, K, ep, pro, blockIdx.x);
+    gemv_body<M, WAVES, D, EXACT, XREG, XV, NORM, BITS, PLAIN>(x, w, scales, y, N, K, ep, pro, blockIdx.x);
 }
 
 // ---- grouped launch: ONE dispatch over the tile rows of up to kMaxGroup independent M = 1 problems of equal K ----------

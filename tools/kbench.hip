@@ -722,7 +722,7 @@ int main(int argc, char** argv)
                                  "7 = 5, sum by 4 waves", "8 = 5, x staged per wave in LDS", "9 = 1, scale load only",
                                  "10 = 8, 32-lane x load"};
         constexpr int NL = 11;
-        double chain[3][NL + 1], disp[3][NL + 1];
+        double chain[3][NL + 1], disp[3][NL + 1], plain_chain[3];
         auto run = [&](auto kern, int pass, int idx) {
             chain[pass][idx] = time_graph(
                 [&](int i, hipStream_t s) {
@@ -771,6 +771,13 @@ int main(int argc, char** argv)
                 },
                 400);
             disp[pass][NL] = st.med;
+            auto gp = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8, 0, 8, true>;
+            plain_chain[pass] = time_graph(
+                [&](int i, hipStream_t s) {
+                    hipLaunchKernelGGL(gp, dim3(N / 16), dim3(1024), gsm, s, x, (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K,
+                                       (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                },
+                ITERS);
         }
         printf("--- GEMV ladder, M=1 N=K=4096, 256 x 1024 threads, 16 waves x 4 tiles; chain = us per step of a %d-launch graph (best of 5"
                " replays), disp = median dispatch begin->end; three passes (up, down, up) ---\n", ITERS);
@@ -781,6 +788,8 @@ int main(int argc, char** argv)
                    l < NL ? names[l] : "library gemv_kernel", chain[0][l], chain[1][l], chain[2][l], c, l && l < 6 ? c - p : 0.0, disp[0][l],
                    disp[1][l], disp[2][l]);
         }
+        printf("%-30s chain %5.2f %5.2f %5.2f  (no run-time epilogue: what a plain projection launches)\n", "library gemv_kernel, PLAIN", plain_chain[0],
+               plain_chain[1], plain_chain[2]);
         return 0;
     }
     if (!strcmp(what, "mall")) {
