@@ -660,7 +660,7 @@ int eetq_w8a16_gemm_glu8(const void* x, const int8_t* w_packed, const void* scal
 {
     int st = check_gemm_args(x, w_packed, scales, y, M, N, K);
     if (st != EETQ_OK) return st;
-    EETQ_REQUIRE(M >= 1 && M <= 16, "the gated epilogue is implemented for 1 <= M <= 16 rows");
+    EETQ_REQUIRE(!bias || (uintptr_t)bias % 8 == 0, "bias must be 8-byte aligned");
     Epilogue ep;
     ep.bias = static_cast<const f16*>(bias);
     ep.act  = kActGlu8;
@@ -668,7 +668,17 @@ int eetq_w8a16_gemm_glu8(const void* x, const int8_t* w_packed, const void* scal
     const auto wp = reinterpret_cast<const uint8_t*>(w_packed);
     const auto sp = static_cast<const f16*>(scales);
     if (M == 1) return launch_gemv(xp, wp, sp, ep, static_cast<f16*>(y), 1, N, K, static_cast<hipStream_t>(stream));
-    return launch_streamk(xp, wp, sp, ep, static_cast<f16*>(y), M, N, K, static_cast<hipStream_t>(stream));
+    if (M <= 16) return launch_streamk(xp, wp, sp, ep, static_cast<f16*>(y), M, N, K, static_cast<hipStream_t>(stream));
+    // larger batches (prompts): where AUTO runs the plain projection on the tiled MFMA kernel, that kernel writes the activation
+    // out of its fp16 tile image; the other kernels have no gated write-out
+    st = EETQ_ERR_UNSUPPORTED;
+    const AutoChoice c = auto_path_i8(M, N, K, 0);
+    if ((c.path == EETQ_PATH_MFMA || (c.path == EETQ_PATH_TILESPLIT && c.detail == 1)) && (uintptr_t)y % 16 == 0)
+        st = launch_gemm_mfma(xp, wp, sp, ep, static_cast<f16*>(y), M, N, K, static_cast<hipStream_t>(stream));
+    if (st == EETQ_ERR_UNSUPPORTED)
+        return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] eetq_w8a16_gemm_glu8: no gated write-out for this shape (M > 16 off the tiled MFMA "
+                                          "kernel); run eetq_w8a16_gemm_act, then eetq_silu_mul_glu8_f16");
+    return st;
 }
 
 int eetq_silu_mul_glu8_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream)
@@ -695,6 +705,22 @@ int eetq_rotary_neox_kvcache_f16(const int64_t* positions, const int64_t* slots,
                                  static_cast<f16*>(k_cache), static_cast<f16*>(v_cache), batch, q_heads, k_heads, head_size,
                                  rot_dim, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5],
                                  max_positions, static_cast<hipStream_t>(stream));
+}
+
+int eetq_rotary_neox_kvcache_prefill_f16(const int64_t* positions, void* query, const void* key, const void* value,
+                                         const void* cos_sin_cache, void* k_cache, void* v_cache, int batch, int tokens,
+                                         const int64_t* first_row_dev, int first_row, int q_heads, int k_heads, int head_size,
+                                         int rot_dim, const long* strides, int max_positions, void* stream)
+{
+    EETQ_REQUIRE(strides, "null pointer");
+    EETQ_REQUIRE(batch >= 0 && tokens >= 0, "invalid shape");
+    if (batch == 0 || tokens == 0) return EETQ_OK;
+    EETQ_REQUIRE((long)batch * tokens < (1L << 31), "too many tokens for one launch");
+    return launch_rotary_kvcache(positions, first_row_dev, 0, static_cast<f16*>(query), static_cast<const f16*>(key),
+                                 static_cast<const f16*>(value), static_cast<const f16*>(cos_sin_cache),
+                                 static_cast<f16*>(k_cache), static_cast<f16*>(v_cache), batch, q_heads, k_heads, head_size,
+                                 rot_dim, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5],
+                                 max_positions, static_cast<hipStream_t>(stream), tokens, first_row);
 }
 
 int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slots, int slot_stride, const void* query,

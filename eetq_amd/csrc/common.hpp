@@ -282,7 +282,8 @@ int launch_attn_decode(const f16* q, const f16* k, const f16* v, const f16* mask
 
 int launch_rotary_kvcache(const int64_t* pos, const int64_t* slots, int slot_stride, f16* q, const f16* k, const f16* v,
                           const f16* cache, f16* kcache, f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,
-                          long k_stride, long v_stride, long c_sb, long c_sh, long c_ss, int max_pos, hipStream_t stream);
+                          long k_stride, long v_stride, long c_sb, long c_sh, long c_ss, int max_pos, hipStream_t stream, int tokens = 0,
+                          int first_row = 0);  // tokens > 0: the prefill form (batch * tokens blocks, rows first_row + t)
 
 int launch_silu_mul(const f16* gu, f16* out, int rows, int inter, hipStream_t stream, bool glu8 = false);
 

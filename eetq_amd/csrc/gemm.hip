@@ -67,6 +67,9 @@ int launch_tile_splitk_cols(const f16* x, const uint8_t* w, const f16* scales, E
 int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, f16* y, int M, int N, int K,
                      hipStream_t stream)
 {
+    // kActGlu8: the weight's columns are gate / up groups of 8 + 8 and y is [M][N / 2] (gemm_kernel.hpp, GLU); no residual
+    const bool glu = ep.act == kActGlu8;
+    if (glu && (K / BK < kMinKSteps || N % 16 != 0 || ep.residual)) return EETQ_ERR_UNSUPPORTED;  // quiet: the caller runs two launches
     if (K / BK < kMinKSteps) {
         // K < 320: a few KiB of weights per column tile; run the stream kernel over 64-row chunks instead of carrying a
         // second tiled kernel for it (the weights are re-read from L2, the activations are read once)
@@ -80,9 +83,12 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         return EETQ_OK;
     }
     {   // > 64 KiB of dynamic LDS: one opt-in per kernel and device (common.hpp)
-        static std::atomic<unsigned long long> opted2{0}, opted1{0}, opted2a{0}, opted1a{0};
+        static std::atomic<unsigned long long> opted2{0}, opted1{0}, opted2a{0}, opted1a{0}, opted2g{0}, opted1g{0};
         int st = EETQ_OK;
-        if (ep.act == 0) {
+        if (glu) {
+            st = opt_in_large_lds(gemm_tile_kernel<0, 2, false, 2, true>, opted2g);
+            if (st == EETQ_OK) st = opt_in_large_lds(gemm_tile_kernel<0, 1, false, 2, true>, opted1g);
+        } else if (ep.act == 0) {
             st = opt_in_large_lds(gemm_tile_kernel<0, 2>, opted2);
             if (st == EETQ_OK) st = opt_in_large_lds(gemm_tile_kernel<0, 1>, opted1);
         } else {  // the activation epilogues are their own instantiation (gemm_kernel.hpp)
@@ -115,10 +121,13 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         const uint8_t* wc = w + (size_t)(c0 / kTileN) * (K / kTileK) * kTileBytes;
         const bool     narrow = force_j == 1 || (force_j == 0 && cost1 < cost2);
         auto go = [&](auto kern, int tiles, size_t smem) {
-            launch_kernel(kern, dim3(tiles), dim3(256), smem, stream, x + (size_t)m * K, wc, scales + c0, y + (size_t)m * N + c0,
-                          rows, cols, K, N, e);
+            const int ldc = glu ? N / 2 : N;
+            launch_kernel(kern, dim3(tiles), dim3(256), smem, stream, x + (size_t)m * K, wc, scales + c0,
+                          y + (size_t)m * ldc + (glu ? c0 / 2 : c0), rows, cols, K, ldc, e);
         };
-        if (narrow && e.act == 0) go(gemm_tile_kernel<0, 1>, tiles1, TileCfg<1>::SMEM_BYTES);
+        if (glu && narrow) go(gemm_tile_kernel<0, 1, false, 2, true>, tiles1, TileCfg<1>::SMEM_BYTES);
+        else if (glu) go(gemm_tile_kernel<0, 2, false, 2, true>, tiles2, TileCfg<2>::SMEM_BYTES);
+        else if (narrow && e.act == 0) go(gemm_tile_kernel<0, 1>, tiles1, TileCfg<1>::SMEM_BYTES);
         else if (narrow) go(gemm_tile_kernel<0, 1, true>, tiles1, TileCfg<1>::SMEM_BYTES);
         else if (e.act == 0) go(gemm_tile_kernel<0, 2>, tiles2, TileCfg<2>::SMEM_BYTES);
         else go(gemm_tile_kernel<0, 2, true>, tiles2, TileCfg<2>::SMEM_BYTES);

@@ -95,7 +95,10 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // tiles meet in `slabs` ([tile][slice][BM * BN] floats, accumulator order) and the workgroup that draws the last of the tile's
 // S tickets adds them IN SLICE ORDER (replicas stay bit-identical) and runs the ordinary epilogue.  Same hand-over as
 // gemm_splitk_kernel.hpp: write-through stores, every wave drains them, barrier, one relaxed agent-scope ticket.
-template <int ABLATE, int J, bool ACT, int CW, bool SPLIT>
+// GLU (its own instantiation, identity rounding): the weight is in "glu8" column order (groups of 16 = 8 gate + the 8 matching up
+// columns); the fp16 image of the tile is written out as silu_mul(gate, up) -- y is [M][N / 2] with row stride ldc, what
+// eetq_silu_mul_glu8_f16 makes of the plain projection's output, without the [M][N] round trip through HBM.
+template <int ABLATE, int J, bool ACT, int CW, bool SPLIT, bool GLU = false>
 __device__ __forceinline__ void gemm_tile_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep, int S, float* __restrict__ slabs,
@@ -561,7 +564,24 @@ __device__ __forceinline__ void gemm_tile_body(
         }
     }
     __syncthreads();
-    {
+    if constexpr (GLU) {
+        static_assert(!GLU || (!ACT && !SPLIT), "the gated write-out exists for the unsplit identity tile");
+        constexpr int kLanesPerRow = BN / 16, kRowsPerWave = 64 / kLanesPerRow, kRowsPerRound = NW * kRowsPerWave;
+        const int     c            = (lane % kLanesPerRow) * 16;  // one group per lane: 8 gate + 8 up halfs -> 8 outputs
+#pragma unroll
+        for (int r0 = 0; r0 < BM; r0 += kRowsPerRound) {
+            const int r = r0 + wave * kRowsPerWave + lane / kLanesPerRow;
+            const int m = m0 + r;
+            if (m < M && n0 + c < N) {
+                const f16x8 g = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(image + r * kRowHalfs + c));
+                const f16x8 u = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(image + r * kRowHalfs + c + 8));
+                f16x8       o;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = silu_mul_f16(g[j], u[j]);
+                *reinterpret_cast<f16x8*>(y + (size_t)m * ldc + ((n0 + c) >> 1)) = o;
+            }
+        }
+    } else {
         constexpr int kLanesPerRow = BN / 8, kRowsPerWave = 64 / kLanesPerRow, kRowsPerRound = NW * kRowsPerWave;
         const int     c            = (lane % kLanesPerRow) * 8;
 #pragma unroll
@@ -585,12 +605,12 @@ __device__ __forceinline__ void gemm_tile_body(
     EETQ_GEMM_STAMP(5);
 }
 
-template <int ABLATE, int J, bool ACT = false, int CW = 2>
+template <int ABLATE, int J, bool ACT = false, int CW = 2, bool GLU = false>
 __global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
 {
-    gemm_tile_body<ABLATE, J, ACT, CW, false>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
+    gemm_tile_body<ABLATE, J, ACT, CW, false, GLU>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
 }
 
 // Round 5, measured and shelved with their patch (tools/experiments/tile_ring_depth_and_persistent.patch): the

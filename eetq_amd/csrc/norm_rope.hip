@@ -135,18 +135,22 @@ __global__ void silu_mul_glu8_kernel(const f16* __restrict__ gu, f16* __restrict
 // Decode-step form: one token per batch row.  blockIdx.y = 0 rotates q in place; 1 rotates k and writes it into the KV
 // cache at [b][head][pos]; 2 copies v there.  Replaces, for a static cache, the stock sequence arange + add + two index_copy
 // launches + the rotary launch by one.
+// Prefill form (tokens > 0): blockIdx.x = token b * tokens + t of batch row b (uniform token stride in q / k / v), rotated by
+// positions[token], cached at row base + t of cache batch b, base = *slots (a static cache's token counter) or first_row.
 __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions, const int64_t* __restrict__ slots,
                                            int slot_stride, f16* __restrict__ query,
                                            const f16* __restrict__ key, const f16* __restrict__ value,
                                            const f16* __restrict__ cache, f16* __restrict__ kcache,
                                            f16* __restrict__ vcache, int rot_dim, long q_stride, long k_stride,
                                            long v_stride, long c_sb, long c_sh, long c_ss, int q_heads, int k_heads,
-                                           int head_size, int max_pos)
+                                           int head_size, int max_pos, int tokens, int first_row)
 {
 #pragma clang fp contract(off)
     const int     b    = blockIdx.x;
+    const int     cb   = tokens > 0 ? b / tokens : b;                // batch row of the cache
     const int64_t rpos = positions[b];                               // index into the cos|sin table
-    const int64_t pos  = slots ? slots[(long)b * slot_stride] : rpos;  // cache row the new token is written to
+    const int64_t pos  = tokens > 0 ? (slots ? slots[0] : (int64_t)first_row) + (b - cb * tokens)
+                                    : slots ? slots[(long)b * slot_stride] : rpos;  // cache row the new token is written to
     if (pos < 0 || pos >= max_pos || rpos < 0) {  // never write outside the cache; counted (eetq_decode_dropped_steps)
         if (blockIdx.y == 0 && threadIdx.x == 0) atomicAdd(&g_rope_dropped, 1u);
         return;
@@ -166,7 +170,7 @@ __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions
         for (int i = threadIdx.x; i < k_heads * embed; i += blockDim.x) {
             const int  head = i / embed, off = i - head * embed;
             const f16* p = key + b * k_stride + (long)head * head_size;
-            f16*       d = kcache + b * c_sb + head * c_sh + pos * c_ss;
+            f16*       d = kcache + cb * c_sb + head * c_sh + pos * c_ss;
             const f16  c = cp[off], s = cp[embed + off], vx = p[off], vy = p[embed + off];
             const f16  xc = vx * c, ys = vy * s, yc = vy * c, xs = vx * s;
             d[off]         = xc - ys;
@@ -175,12 +179,12 @@ __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions
         const int tail = head_size - rot_dim;  // channels beyond the rotated ones are cached as they are
         for (int i = threadIdx.x; i < k_heads * tail; i += blockDim.x) {
             const int head = i / tail, off = rot_dim + (i - head * tail);
-            kcache[b * c_sb + head * c_sh + pos * c_ss + off] = key[b * k_stride + (long)head * head_size + off];
+            kcache[cb * c_sb + head * c_sh + pos * c_ss + off] = key[b * k_stride + (long)head * head_size + off];
         }
     } else {
         for (int i = threadIdx.x; i < k_heads * head_size; i += blockDim.x) {
             const int head = i / head_size, off = i - head * head_size;
-            vcache[b * c_sb + head * c_sh + pos * c_ss + off] = value[b * v_stride + (long)head * head_size + off];
+            vcache[cb * c_sb + head * c_sh + pos * c_ss + off] = value[b * v_stride + (long)head * head_size + off];
         }
     }
 }
@@ -189,16 +193,19 @@ __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions
 
 int launch_rotary_kvcache(const int64_t* pos, const int64_t* slots, int slot_stride, f16* q, const f16* k, const f16* v,
                           const f16* cache, f16* kcache, f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,
-                          long k_stride, long v_stride, long c_sb, long c_sh, long c_ss, int max_pos, hipStream_t stream)
+                          long k_stride, long v_stride, long c_sb, long c_sh, long c_ss, int max_pos, hipStream_t stream, int tokens,
+                          int first_row)
 {
     EETQ_REQUIRE(pos && q && k && v && cache && kcache && vcache, "null pointer");
+    EETQ_REQUIRE(tokens >= 0 && first_row >= 0 && (slots || (long)first_row + tokens <= max_pos), "the prefill rows must lie inside the cache");
     EETQ_REQUIRE(batch >= 0 && q_heads > 0 && k_heads > 0 && head_size > 0 && rot_dim > 0 && rot_dim % 2 == 0 &&
                      rot_dim <= head_size && max_pos > 0,
                  "invalid rotary shape");
     if (batch == 0) return EETQ_OK;
-    rotary_neox_kvcache_kernel<<<dim3(batch, 3), 512, 0, stream>>>(pos, slots, slot_stride, q, k, v, cache, kcache, vcache, rot_dim, q_stride,
-                                                                     k_stride, v_stride, c_sb, c_sh, c_ss, q_heads,
-                                                                     k_heads, head_size, max_pos);
+    const int blocks = tokens > 0 ? batch * tokens : batch;
+    rotary_neox_kvcache_kernel<<<dim3(blocks, 3), 512, 0, stream>>>(pos, slots, slot_stride, q, k, v, cache, kcache, vcache, rot_dim, q_stride,
+                                                                      k_stride, v_stride, c_sb, c_sh, c_ss, q_heads,
+                                                                      k_heads, head_size, max_pos, tokens, first_row);
     return check_hip(hipGetLastError(), "rotary_neox_kvcache_kernel launch");
 }
 

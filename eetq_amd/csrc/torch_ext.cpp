@@ -332,6 +332,28 @@ Tensor w8_a16_gemm(const Tensor& input_in, const Tensor& weight, const Tensor& s
                                        stream_of(input)));
             return output;
         }
+        if (rows > 16 && path == "auto" && input.size(-1) == kw && input.is_cuda() && input.scalar_type() == at::kHalf &&
+            weight.scalar_type() == at::kChar && scale.scalar_type() == at::kHalf && weight.is_contiguous() &&
+            weight.device() == input.device() && scale.device() == input.device()) {
+            // prompts: the tiled MFMA kernel writes the activation out of its fp16 tile image where AUTO runs the shape on it
+            Tensor xin = input.contiguous();
+            if (norm) {
+                Tensor normed = torch::empty_like(xin);
+                layernorm_forward(xin, std::get<0>(*norm), normed, std::get<1>(*norm));
+                xin = normed;
+            }
+            check_epilogue(input, bias, residual, rows, n);
+            Tensor           output = torch::empty(out_shape(input, n / 2), input.options());
+            c10::DeviceGuard guard(input.device());
+            const int        st = eetq_w8a16_gemm_glu8(xin.data_ptr(), weight.data_ptr<int8_t>(), scale.data_ptr(),
+                                                       bias ? bias->data_ptr() : nullptr, output.data_ptr(), (int)rows, (int)n,
+                                                       (int)kw, stream_of(input));
+            if (st != EETQ_ERR_UNSUPPORTED) {
+                check(st);
+                return output;
+            }
+            return silu_mul(w8_a16_gemm(xin, weight, scale, path, bias, residual, std::nullopt, false, std::string()), true);
+        }
         return silu_mul(w8_a16_gemm(input_in, weight, scale, path, bias, residual, norm, false, std::string()), true);
     }
     if (gated) {
@@ -502,6 +524,46 @@ void rotary_embedding_neox_kvcache(const Tensor& positions, Tensor& query, const
                                        cos_sin_cache.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)B, (int)H,
                                        (int)Hkv, (int)head_size, (int)cos_sin_cache.size(1), strides, (int)key_cache.size(2),
                                        stream_of(query)));
+}
+
+// Prefill on a pre-allocated KV cache (extension): query [B, T, H, D] rotated in place, key [B, T, Hkv, D] rotated into
+// key_cache[b, :, base + t], value copied to value_cache[b, :, base + t], base = first_row_dev (device int64) or first_row:
+// eetq_rotary_neox_kvcache_prefill_f16
+void rotary_embedding_neox_kvcache_prefill(const Tensor& positions, Tensor& query, const Tensor& key, const Tensor& value,
+                                           int64_t head_size, const Tensor& cos_sin_cache, Tensor& key_cache,
+                                           Tensor& value_cache, int64_t first_row, const OptTensor& first_row_dev)
+{
+    const char* name = "rotary_embedding_neox_kvcache_prefill: ";
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&query, &key, &value, &cos_sin_cache, &key_cache, &value_cache}) {
+        TORCH_CHECK(t->scalar_type() == at::kHalf, name, "float16 tensors expected");
+        TORCH_CHECK(t->is_cuda() && t->device() == query.device(), name, "all tensors must be on one CUDA device");
+    }
+    TORCH_CHECK(positions.scalar_type() == at::kLong && positions.is_contiguous() && positions.device() == query.device(),
+                name, "positions must be contiguous int64 on the device");
+    TORCH_CHECK(query.dim() == 4 && key.dim() == 4 && value.dim() == 4 && key_cache.dim() == 4, name, "shape mismatch");
+    const int64_t B = query.size(0), T = query.size(1), H = query.size(2), D = query.size(3), Hkv = key.size(2);
+    TORCH_CHECK(key.size(0) == B && key.size(1) == T && key.size(3) == D && value.sizes() == key.sizes() && D == head_size &&
+                    key_cache.size(0) == B && key_cache.size(1) == Hkv && key_cache.size(3) == D &&
+                    value_cache.sizes() == key_cache.sizes() && value_cache.strides() == key_cache.strides() &&
+                    positions.numel() == B * T && first_row >= 0 && (first_row_dev || first_row + T <= key_cache.size(2)),
+                name, "shape mismatch");
+    if (first_row_dev)
+        TORCH_CHECK(first_row_dev->scalar_type() == at::kLong && first_row_dev->numel() == 1 &&
+                        first_row_dev->device() == query.device(),
+                    name, "first_row_dev must be one int64 on the device");
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&query, &key, &value})
+        TORCH_CHECK(t->stride(-1) == 1 && t->stride(-2) == D && (B == 1 || T == 1 || t->stride(0) == T * t->stride(1)), name,
+                    "[heads, head_size] must be dense and the tokens of all rows one stride apart");
+    const int tdim = T == 1 ? 0 : 1;  // (a size-1 dimension's stride is arbitrary)
+    TORCH_CHECK(key_cache.stride(-1) == 1 && cos_sin_cache.is_contiguous(), name, "cache rows must be dense");
+    const long strides[6] = {(long)query.stride(tdim), (long)key.stride(tdim), (long)value.stride(tdim), (long)key_cache.stride(0),
+                             (long)key_cache.stride(1), (long)key_cache.stride(2)};
+    c10::DeviceGuard guard(query.device());
+    check(eetq_rotary_neox_kvcache_prefill_f16(positions.data_ptr<int64_t>(), query.data_ptr(), key.data_ptr(), value.data_ptr(),
+                                               cos_sin_cache.data_ptr(), key_cache.data_ptr(), value_cache.data_ptr(), (int)B,
+                                               (int)T, first_row_dev ? first_row_dev->data_ptr<int64_t>() : nullptr,
+                                               (int)first_row, (int)H, (int)Hkv, (int)head_size,
+                                               (int)cos_sin_cache.size(1), strides, (int)key_cache.size(2), stream_of(query)));
 }
 
 Tensor decode_attention(const Tensor& query, const Tensor& key_cache, const Tensor& value_cache, const OptTensor& mask,
@@ -746,6 +808,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
     m.def("rotary_embedding_neox_kvcache", &rotary_embedding_neox_kvcache, "decode-step rotary + KV-cache write",
           py::arg("positions"), py::arg("query"), py::arg("key"), py::arg("value"), py::arg("head_size"),
           py::arg("cos_sin_cache"), py::arg("key_cache"), py::arg("value_cache"), py::arg("slots") = py::none());
+    m.def("rotary_embedding_neox_kvcache_prefill", &rotary_embedding_neox_kvcache_prefill, "prompt rotary + KV-cache write",
+          py::arg("positions"), py::arg("query"), py::arg("key"), py::arg("value"), py::arg("head_size"),
+          py::arg("cos_sin_cache"), py::arg("key_cache"), py::arg("value_cache"), py::arg("first_row") = 0,
+          py::arg("first_row_dev") = py::none());
     m.def("decode_attention", &decode_attention, "single-query attention over a KV cache", py::arg("query"),
           py::arg("key_cache"), py::arg("value_cache"), py::arg("mask") = py::none(), py::arg("scaling") = py::none(),
           py::arg("splits") = py::none(), py::arg("kv_len") = py::none(), py::arg("kv_len_bias") = 0,

@@ -10,6 +10,7 @@ projections as ONE launch over concatenated channels (bit-identical to three lau
 ``EETLlamaMLP`` (gate/up as one launch) has no counterpart in llama_modules.py; the reference fuses gate/up only in its
 offline export layer (python/eetq/models/llama.py:39-77).
 """
+import contextlib
 import threading
 
 import torch
@@ -17,7 +18,26 @@ import torch.nn as nn
 
 from .. import ops
 
-__all__ = ["EETRotaryEmbedding", "EETLlamaAttention", "EETQuantLlamaAttention", "EETLlamaMLP"]
+__all__ = ["EETRotaryEmbedding", "EETLlamaAttention", "EETQuantLlamaAttention", "EETLlamaMLP", "fresh_static_prefill"]
+
+_prefill_promise = threading.local()
+
+
+@contextlib.contextmanager
+def fresh_static_prefill():
+    """The caller's promise for the forwards run inside (per thread): the static KV cache holds NO tokens yet and the prompt is
+    unpadded, so a prompt's attention is plain causal attention over its own T tokens.  The attention blocks then write cache
+    rows 0 .. T - 1 and SET the token counter to T (the rows need no reset first; the counters do where the model derives the
+    prompt's positions from them), attend those T rows with the causal
+    flag of the library attention (half the work of a masked pass over the whole pre-allocated cache) and ignore the
+    model-level mask.  ``GraphDecoder.generate`` makes this promise; without it a prompt
+    on a static cache is attended as transformers does it: every cache row, under the model's mask."""
+    prev = getattr(_prefill_promise, "fresh", False)
+    _prefill_promise.fresh = True
+    try:
+        yield
+    finally:
+        _prefill_promise.fresh = prev
 
 
 class EETRotaryEmbedding(nn.Module):
@@ -76,6 +96,7 @@ class _EETAttentionBase(nn.Module):
         self.is_causal = True
         self.decode_math_attention = True
         self.fused_decode_step = True   # rotary + cache write + attention of a static-cache decode step as one launch
+        self.static_prefill = True      # rotary + cache write of a PROMPT on an initialised static cache as one launch
         self._tickets = None            # that launch's arrival counters (zero between launches)
         self.rotary_emb = EETRotaryEmbedding(self.head_dim, max_position_embeddings=max_position_embeddings,
                                              base=rope_theta, device=dev)
@@ -187,11 +208,23 @@ class _EETAttentionBase(nn.Module):
             return None
         return positions, table, layer, self._step_tickets(bsz, hidden_states.device), add
 
-    def _attend(self, q, k, v, attention_mask, past_key_values, input_shape, kwargs):
-        """q [B, T, H, D], k/v [B, T, Hkv, D] (views into the projection output) -> [B, T, H*D]"""
-        q, k, v = q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)
-        if past_key_values is not None:
-            k, v = past_key_values.update(k, v, self.layer_idx)
+    def _attend(self, q, k, v, attention_mask, past_key_values, input_shape, kwargs, cached=None):
+        """q [B, T, H, D], k/v [B, T, Hkv, D] (views into the projection output) -> [B, T, H*D].  ``cached``: the (keys, values)
+        of a static cache that already hold this call's rotated k and v (then k, v and past_key_values are unused)."""
+        q = q.transpose(1, 2)
+        if cached is not None:
+            k, v = cached
+            if (getattr(_prefill_promise, "fresh", False) and q.shape[2] > 1 and not kwargs.get("output_attentions", False)):
+                # promised: the cache was empty and the prompt is unpadded -> causal attention over the T rows just written
+                t_len = q.shape[2]
+                out = torch.nn.functional.scaled_dot_product_attention(
+                    q, k[:, :, :t_len], v[:, :, :t_len], is_causal=True, scale=self.scaling,
+                    enable_gqa=self.num_key_value_groups > 1).transpose(1, 2)
+                return out.reshape(*input_shape, -1).contiguous(), None
+        else:
+            k, v = k.transpose(1, 2), v.transpose(1, 2)
+            if past_key_values is not None:
+                k, v = past_key_values.update(k, v, self.layer_idx)
         # One query token.  The library attention kernels launch one workgroup per head (40 workgroups streaming the whole
         # KV cache: 68 us per layer at Llama-13B shapes, S = 1.2 k).  decode_math_attention: True -> the library's own
         # split-KV kernel (ops.decode_attention, ~10 us) whenever it applies, and a batched matrix-vector fallback while
@@ -318,8 +351,34 @@ class EETLlamaAttention(_EETAttentionBase):
                                            kv_len=counter, kv_len_bias=1, advance=counter).reshape(bsz, q_len, -1)
             weights = None
         else:
-            self.rotary_emb(q, k, positions)
-            out, weights = self._attend(q, k, v, attention_mask, past_key_values, (bsz, q_len), kwargs)
+            player = self._static_cache_layer(past_key_values) if (q_len > 1 and q.is_cuda and self.static_prefill) else None
+            if (player is not None and not getattr(past_key_values, "offloading", False) and player.keys.shape[0] == bsz
+                    and player.keys.shape[1] == hkv and q_len <= player.keys.shape[2]
+                    and player.cumulative_length.device == q.device):
+                # a prompt on an initialised static cache: ONE launch rotates q in place and writes the rotated k and v into
+                # the cache rows counter .. counter + T - 1, one more advances the counter -- the stock update() is arange +
+                # add + counter add + two index_copy launches, behind the separate rotary launch.  Same bits in the cache.
+                self._grow_table(player.keys.shape[2])
+                table = self.rotary_emb.cos_sin_cache
+                if table.shape[-1] == d:
+                    counter = player.cumulative_length
+                    if getattr(_prefill_promise, "fresh", False):   # promised empty: rows 0 .. T - 1, whatever the counter held
+                        ops.rotary_embedding_neox_kvcache_prefill(positions, q, k, v, d, table, player.keys, player.values)
+                        counter.fill_(q_len)
+                    else:
+                        ops.rotary_embedding_neox_kvcache_prefill(positions, q, k, v, d, table, player.keys, player.values,
+                                                                  first_row_dev=counter)
+                        counter.add_(q_len)
+                else:
+                    player = None
+            else:
+                player = None
+            if player is None:
+                self.rotary_emb(q, k, positions)
+                out, weights = self._attend(q, k, v, attention_mask, past_key_values, (bsz, q_len), kwargs)
+            else:
+                out, weights = self._attend(q, None, None, attention_mask, None, (bsz, q_len), kwargs,
+                                            cached=(player.keys, player.values))
         if residual is None:
             return self.o_proj(out), weights
         if hasattr(self.o_proj, "qweight"):

@@ -36,6 +36,7 @@ if _C is not None:
     rotary_embedding_neox = _C.rotary_embedding_neox
     rotary_embedding_neox_strided = _C.rotary_embedding_neox_strided
     rotary_embedding_neox_kvcache = _C.rotary_embedding_neox_kvcache
+    rotary_embedding_neox_kvcache_prefill = _C.rotary_embedding_neox_kvcache_prefill
     decode_attention = _C.decode_attention
     rope_decode_attention = _C.rope_decode_attention
     silu_mul = _C.silu_mul
@@ -45,13 +46,13 @@ else:
     BOUNDARY = "ctypes"
     from .ops_ctypes import (decode_attention, layernorm_forward, preprocess_weights, quant_weights,  # noqa: F401
                              rope_decode_attention, rotary_embedding_neox, rotary_embedding_neox_kvcache,
-                             rotary_embedding_neox_strided, silu_mul,
+                             rotary_embedding_neox_kvcache_prefill, rotary_embedding_neox_strided, silu_mul,
                              unprocess_weights, w8_a16_gemm, w8_a16_gemm_, w8_a16_gemv_grouped)
     llama_decode_layer = None
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_", "layernorm_forward",
-           "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention",
-           "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped", "decode_dropped_steps",
+           "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "rotary_embedding_neox_kvcache_prefill",
+           "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped", "decode_dropped_steps",
            "release_stream_workspace", "release_workspace", "BOUNDARY"]
 
 

@@ -25,7 +25,7 @@ from ._lib import (ACT_GELU, ACT_IDENTITY, ACT_RELU, ACT_SILU, DTYPE_F16, DTYPE_
                    LAYOUT_SM80, PATH_AUTO, PATH_GEMV, PATH_MFMA, check)
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_",
-           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped"]
+           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "rotary_embedding_neox_kvcache_prefill", "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped"]
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
@@ -214,8 +214,12 @@ def w8_a16_gemm(input, weight, scale, path="auto", bias=None, residual=None, nor
                 and (gamma is None or (gamma.dtype == torch.float16 and gamma.is_contiguous() and gamma.numel() == k
                                        and gamma.device == input.device))):
             return _gemv_glu8_launch(input, gamma, norm[1] if norm is not None else 0.0, weight, scale, bias, n, k)
-        if (2 <= rows <= 16 and path == "auto" and input.shape[-1] == k and input.is_cuda and input.dtype == torch.float16):
-            return _gemm_glu8_launch(input, norm, weight, scale, bias, rows, n, k)
+        if (rows >= 2 and path == "auto" and input.shape[-1] == k and input.is_cuda and input.dtype == torch.float16):
+            # batched decode: the small-batch kernel's epilogue; prompts: the tiled MFMA kernel's gated write-out where AUTO
+            # runs the shape on it (None: no such form, two launches)
+            out = _gemm_glu8_launch(input, norm, weight, scale, bias, rows, n, k)
+            if out is not None:
+                return out
         return silu_mul(w8_a16_gemm(input, weight, scale, path, bias, None, norm), glu8=True)
     if activation not in _ACTS:
         raise RuntimeError("unknown activation %r (identity, relu, gelu, silu; silu_glu8 for gated weights)" % (activation,))
@@ -267,8 +271,11 @@ def _gemm_glu8_launch(input, norm, weight, scale, bias, rows, n, k):
         x = normed
     output = torch.empty(tuple(input.shape[:-1]) + (n // 2,), dtype=input.dtype, device=input.device)
     with torch.cuda.device(input.device):
-        check(_lib.lib().eetq_w8a16_gemm_glu8(_ptr(x), _ptr(weight), _ptr(scale), _ptr(bias) if bias is not None else None,
-                                              _ptr(output), rows, n, k, _stream_ptr()))
+        st = _lib.lib().eetq_w8a16_gemm_glu8(_ptr(x), _ptr(weight), _ptr(scale), _ptr(bias) if bias is not None else None,
+                                             _ptr(output), rows, n, k, _stream_ptr())
+    if st == _lib.ERR_UNSUPPORTED and rows > 16:
+        return None
+    check(st)
     return output
 
 
@@ -622,6 +629,50 @@ def rotary_embedding_neox_kvcache(positions, query, key, value, head_size, cos_s
                                                       _ptr(cos_sin_cache), _ptr(key_cache), _ptr(value_cache), B, H, Hkv,
                                                       int(head_size), cos_sin_cache.shape[1], strides,
                                                       key_cache.shape[2], _stream_ptr()))
+    return None
+
+
+@_eager_only
+def rotary_embedding_neox_kvcache_prefill(positions, query, key, value, head_size, cos_sin_cache, key_cache, value_cache,
+                                          first_row=0, first_row_dev=None):
+    """Prefill on a pre-allocated KV cache: rotate ``query`` [B, T, H, D] in place by ``positions`` [B, T] (int64), write the
+    rotated ``key`` [B, T, Hkv, D] and ``value`` into the caches [B, Hkv, S, D] at rows ``base + t``, base = ``first_row_dev``
+    (one int64 on the device, e.g. a static cache's token counter; read, not advanced) or ``first_row``.  One launch instead
+    of rotary + two index_copy launches and their index arithmetic (eetq_rotary_neox_kvcache_prefill_f16)."""
+    name = "rotary_embedding_neox_kvcache_prefill: "
+    for t in (query, key, value, cos_sin_cache, key_cache, value_cache):
+        if t.dtype != torch.float16:
+            raise RuntimeError(name + "float16 tensors expected")
+        if not t.is_cuda or t.device != query.device:
+            raise RuntimeError(name + "all tensors must be on one CUDA device")
+    if positions.dtype != torch.int64 or not positions.is_contiguous() or positions.device != query.device:
+        raise RuntimeError(name + "positions must be contiguous int64 on the device")
+    if query.dim() != 4 or key.dim() != 4 or value.dim() != 4 or key_cache.dim() != 4:
+        raise RuntimeError(name + "shape mismatch")
+    B, T, H, D = query.shape
+    Hkv = key.shape[2]
+    if (key.shape != (B, T, Hkv, D) or value.shape != key.shape or D != head_size or key_cache.shape[0] != B
+            or key_cache.shape[1] != Hkv or key_cache.shape[3] != D or value_cache.shape != key_cache.shape
+            or value_cache.stride() != key_cache.stride() or positions.numel() != B * T or first_row < 0
+            or (first_row_dev is None and first_row + T > key_cache.shape[2])):
+        raise RuntimeError(name + "shape mismatch")
+    if first_row_dev is not None and (first_row_dev.dtype != torch.int64 or first_row_dev.numel() != 1
+                                      or first_row_dev.device != query.device):
+        raise RuntimeError(name + "first_row_dev must be one int64 on the device")
+    for t in (query, key, value):
+        if t.stride(-1) != 1 or t.stride(-2) != D or (B != 1 and T != 1 and t.stride(0) != T * t.stride(1)):
+            raise RuntimeError(name + "[heads, head_size] must be dense and the tokens of all rows one stride apart")
+    tdim = 0 if T == 1 else 1   # (a size-1 dimension's stride is arbitrary)
+    if key_cache.stride(-1) != 1 or not cos_sin_cache.is_contiguous():
+        raise RuntimeError(name + "cache rows must be dense")
+    strides = (ctypes.c_long * 6)(query.stride(tdim), key.stride(tdim), value.stride(tdim), key_cache.stride(0),
+                                  key_cache.stride(1), key_cache.stride(2))
+    with torch.cuda.device(query.device):
+        check(_lib.lib().eetq_rotary_neox_kvcache_prefill_f16(_ptr(positions), _ptr(query), _ptr(key), _ptr(value),
+                                                              _ptr(cos_sin_cache), _ptr(key_cache), _ptr(value_cache), B, T,
+                                                              _ptr(first_row_dev) if first_row_dev is not None else None,
+                                                              int(first_row), H, Hkv, int(head_size), cos_sin_cache.shape[1],
+                                                              strides, key_cache.shape[2], _stream_ptr()))
     return None
 
 

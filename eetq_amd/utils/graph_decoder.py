@@ -7,6 +7,9 @@ tensors; the static cache's own token counter is advanced on the device by the a
 Prefill stays eager.  Works with any transformers causal LM whose forward accepts ``past_key_values`` / ``cache_position``
 (stock Llama, ``eet_quantize``-d or ``eet_accelerator``-ed).
 """
+import contextlib
+import inspect
+
 import torch
 
 __all__ = ["GraphDecoder"]
@@ -41,6 +44,9 @@ class GraphDecoder:
         self.out_buf = torch.zeros(self.batch, self.max_len + 1, dtype=torch.long, device=dev)
         self.graph = None
         self.graph_n = None
+        # the prompt pass needs the LAST position's logits only (the stock forward projects all of them onto the vocabulary)
+        params = inspect.signature(model.forward).parameters
+        self._last_logits_only = {"logits_to_keep": 1} if "logits_to_keep" in params else {}
         self.steps_per_graph = max(1, int(steps_per_graph))
         with torch.no_grad():
             # the cache tensors are allocated lazily by the first forward: run one tiny prefill before capturing
@@ -61,6 +67,18 @@ class GraphDecoder:
                         for _ in range(self.steps_per_graph):
                             self._advance()
         self.cache.reset()
+
+    def _fresh_prefill_ok(self):
+        """True when the prompt may run under ``fresh_static_prefill``: the lean layer-by-layer model, every attention block
+        able to take its static-cache prompt path (initialised cache layer, supported head size)."""
+        if not self._lean():
+            return False
+        for layer in self.model.model.layers:
+            attn = getattr(layer, "self_attn", None)
+            if (attn is None or not getattr(attn, "static_prefill", False) or not hasattr(attn, "_static_cache_layer")
+                    or attn._static_cache_layer(self.cache) is None):
+                return False
+        return True
 
     def _lean(self):
         """True when every decoder layer is an accelerated one (eet_accelerator with fused_attn / fused_mlp / fused_residual):
@@ -100,9 +118,7 @@ class GraphDecoder:
         B, P = prompt.shape
         if B != self.batch or P + new_tokens > self.max_len:
             raise ValueError("GraphDecoder: built for batch %d and %d cache rows" % (self.batch, self.max_len))
-        self.cache.reset()
-        out = self.model(prompt, past_key_values=self.cache, cache_position=torch.arange(P, device=prompt.device),
-                         use_cache=True)
+        out = self.prefill(prompt)
         tok = out.logits[:, -1].argmax(-1, keepdim=True)
         self.out_buf[:, :1].copy_(tok)
         self.s_tok.copy_(tok)
@@ -121,3 +137,25 @@ class GraphDecoder:
                 left -= 1
         tokens = torch.cat([prompt, self.out_buf[:, :new_tokens]], dim=1)
         return (tokens, out.logits[:, -1]) if return_prefill_logits else tokens
+
+    def prefill(self, prompt):
+        """Empty the cache and run the (unpadded) prompt [batch, P] eagerly; returns the model output, whose logits hold the LAST
+        position only where the model's forward can be told so."""
+        P = prompt.shape[1]
+        fresh = self._fresh_prefill_ok()
+        if fresh:
+            # every layer is an accelerated block on an initialised static cache: only the token counters are reset (the model
+            # derives the prompt's positions from them; the blocks never read a row at or beyond the counter, so the stock
+            # reset's zero-fill of 2 x layers cache tensors buys nothing), and the prompt is attended causally over its own
+            # rows (llama_modules.fresh_static_prefill)
+            for layer in self.cache.layers:
+                layer.cumulative_length.zero_()
+            from ..modules.llama_modules import fresh_static_prefill
+            ctx = fresh_static_prefill()
+        else:
+            self.cache.reset()
+            ctx = contextlib.nullcontext()
+        with ctx:
+            out = self.model(prompt, past_key_values=self.cache, cache_position=torch.arange(P, device=prompt.device),
+                             use_cache=True, **self._last_logits_only)
+        return out

@@ -77,9 +77,9 @@ enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SIL
  *   caller-provided workspace is therefore treated as exactly N floats (the atomicMax route); NULL as above.  Callers that
  *   allocate eetq_quantize_workspace_floats() floats should move to eetq_quantize_i8_ws to get the faster route. */
 /* Revision history: 1 = round 1-2; 2 = eetq_quantize_i8_ws (sized workspace), eetq_release_stream_workspace, eetq_w4a16_gemm_ex;
- * 3 = eetq_diag_auto_path, EETQ_PATH_SPLITK accepts M <= 1024 (row groups); 4 = eetq_diag_splitk_plan.  Revisions only ADD entry points: a caller built
- * against an older header keeps working. */
-#define EETQ_AMD_ABI_VERSION 4
+ * 3 = eetq_diag_auto_path, EETQ_PATH_SPLITK accepts M <= 1024 (row groups); 4 = eetq_diag_splitk_plan; 5 =
+ * eetq_rotary_neox_kvcache_prefill_f16.  Revisions only ADD entry points: a caller built against an older header keeps working. */
+#define EETQ_AMD_ABI_VERSION 5
 int eetq_abi_version(void);   /* EETQ_AMD_ABI_VERSION of the loaded library */
 int eetq_quantize_i8_ws(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
                         int layout, void* scales, float* workspace, size_t workspace_floats, void* stream);
@@ -237,7 +237,12 @@ int eetq_silu_mul_f16(const void* gate_up, void* out, int rows, int intermediate
  *     such a weight; gate_up [rows][2 * intermediate] dense, intermediate % 8 == 0. */
 int eetq_w8a16_gemv_glu8(const void* x, const void* gamma, float eps, const int8_t* w_packed, const void* scales,
                          const void* bias, void* y, int N, int K, void* stream);
-/*   eetq_w8a16_gemm_glu8: the same for 1 <= M <= 16 rows (batched decode; no norm prologue): y [M][N / 2]. */
+/*   eetq_w8a16_gemm_glu8: the same for M > 1 rows (no norm prologue): y [M][N / 2].  2 <= M <= 16 (batched decode): the small-
+ *     batch kernel's epilogue.  M > 16 (prompts; since ABI 5): where EETQ_PATH_AUTO runs the plain projection on the unsplit tiled
+ *     MFMA kernel (eetq_diag_auto_path: EETQ_PATH_MFMA, or EETQ_PATH_TILESPLIT with one slice), that kernel writes silu_mul of its
+ *     fp16 tile image -- the same bits as eetq_w8a16_gemm_act
+ *     (+ bias) followed by eetq_silu_mul_glu8_f16, without the [M][N] round trip; any other shape returns EETQ_ERR_UNSUPPORTED
+ *     and launches nothing (the caller runs those two). */
 int eetq_w8a16_gemm_glu8(const void* x, const int8_t* w_packed, const void* scales, const void* bias, void* y, int M, int N,
                          int K, void* stream);
 int eetq_silu_mul_glu8_f16(const void* gate_up, void* out, int rows, int intermediate, void* stream);
@@ -254,6 +259,20 @@ int eetq_rotary_neox_kvcache_f16(const int64_t* positions, const int64_t* slots,
                                  const void* key, const void* value, const void* cos_sin_cache, void* k_cache,
                                  void* v_cache, int batch, int q_heads, int k_heads, int head_size, int rot_dim,
                                  const long* strides, int max_positions, void* stream);
+
+/* Prefill form of the above (extension, ABI 5): `tokens` new tokens per batch row.  Token t of row b -- element b * tokens + t
+ * of positions and of query / key / value, which advance by ONE stride per token (a fused QKV projection output [batch][tokens]
+ * [(q_heads + 2 k_heads) * head_size]) -- is rotated by cos_sin_cache[positions[b * tokens + t]]; q in place, k into
+ * k_cache[b][head][base + t][:], v copied to v_cache[b][head][base + t][:], base = *first_row_dev (DEVICE int64, e.g. a static
+ * cache's token counter -- read, not advanced) or, with first_row_dev == NULL, first_row.  Replaces the rotary launch plus
+ * the two index_copy launches (and their index arithmetic) of a static cache's update on a prompt.  Same fp16 arithmetic as
+ * eetq_rotary_neox_f16.  strides (elements): {q_token, k_token, v_token, cache_b, cache_head, cache_pos}.  Host-known rows
+ * must satisfy first_row + tokens <= max_positions (EETQ_ERR_INVALID, nothing launched); tokens whose device-side row falls
+ * outside [0, max_positions) are left untouched and counted (eetq_decode_dropped_steps). */
+int eetq_rotary_neox_kvcache_prefill_f16(const int64_t* positions, void* query, const void* key, const void* value,
+                                         const void* cos_sin_cache, void* k_cache, void* v_cache, int batch, int tokens,
+                                         const int64_t* first_row_dev, int first_row, int q_heads, int k_heads, int head_size,
+                                         int rot_dim, const long* strides, int max_positions, void* stream);
 
 /* Single-query (decode) attention over a KV cache; extension used by the EET attention blocks' decode step (the
  * reference delegates the attention product to flash-attn, python/eetq/modules/llama_modules.py:131-143).

@@ -1108,6 +1108,114 @@ def test_rotary_kvcache_write(ops, oracle):
     assert ops.decode_dropped_steps() == 0
 
 
+@pytest.mark.parametrize("B,T,H,Hkv,D", [(1, 33, 8, 8, 128), (2, 17, 8, 2, 64), (3, 1, 4, 4, 64), (1, 200, 4, 1, 128)])
+def test_rotary_kvcache_prefill(ops, oracle, B, T, H, Hkv, D):
+    """Prompt form of the rotary + cache write: q [B, T, H, D] rotated in place (bit-exact vs the oracle), rotated k and v in cache
+    rows base .. base + T - 1 of their batch row -- base a host integer or a device counter (read, not advanced) -- every other
+    cache element and the k / v parts of the projection untouched; rows beyond the cache are refused (host base) or skipped
+    and counted (device base).  The cache must hold what rotary_embedding_neox_strided + index_copy_ put there."""
+    torch.manual_seed(B * 100 + T)
+    S = T + 11
+    row = (H + 2 * Hkv) * D
+    qkv = torch.randn(B, T, row).half()
+    inv = 1.0 / (10000 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.einsum("i,j->ij", torch.arange(S + 40).float(), inv)
+    table = torch.cat([fr.cos(), fr.sin()], -1).half()
+    pos = (torch.arange(T)[None, :] + torch.arange(B)[:, None] * 3 + 2).contiguous()     # per-row offsets: positions != cache rows
+    q0 = qkv[..., : H * D].reshape(B * T, H, D).numpy()
+    k0 = qkv[..., H * D: (H + Hkv) * D].reshape(B * T, Hkv, D).numpy()
+    qo, _ = oracle.rotary_neox_f16(pos.reshape(-1).numpy(), q0, q0.copy(), table.numpy(), D)
+    ko, _ = oracle.rotary_neox_f16(pos.reshape(-1).numpy(), k0, k0.copy(), table.numpy(), D)
+    for base, dev_base in ((0, False), (7, False), (5, True)):
+        d = qkv.to(DEV)
+        q = d[..., : H * D].unflatten(-1, (H, D))
+        k = d[..., H * D: (H + Hkv) * D].unflatten(-1, (Hkv, D))
+        v = d[..., (H + Hkv) * D:].unflatten(-1, (Hkv, D))
+        kc = torch.full((B, Hkv, S, D), 7.0, dtype=torch.float16, device=DEV)
+        vc = torch.full((B, Hkv, S, D), -3.0, dtype=torch.float16, device=DEV)
+        counter = torch.tensor(base, dtype=torch.int64, device=DEV)
+        if dev_base:
+            ops.rotary_embedding_neox_kvcache_prefill(pos.to(DEV), q, k, v, D, table.to(DEV), kc, vc, first_row_dev=counter)
+            assert int(counter) == base
+        else:
+            ops.rotary_embedding_neox_kvcache_prefill(pos.to(DEV), q, k, v, D, table.to(DEV), kc, vc, first_row=base)
+        got = d.cpu()
+        assert np.array_equal(got[..., : H * D].reshape(B * T, H, D).numpy(), qo)
+        assert torch.equal(got[..., H * D:], qkv[..., H * D:])
+        kc, vc = kc.cpu(), vc.cpu()
+        assert np.array_equal(kc[:, :, base: base + T].transpose(1, 2).reshape(B * T, Hkv, D).numpy(), ko)
+        assert torch.equal(vc[:, :, base: base + T].transpose(1, 2), qkv[..., (H + Hkv) * D:].reshape(B, T, Hkv, D))
+        assert (kc[:, :, :base] == 7.0).all() and (kc[:, :, base + T:] == 7.0).all()
+        assert (vc[:, :, :base] == -3.0).all() and (vc[:, :, base + T:] == -3.0).all()
+    # ... the same cache contents as the two-step stock sequence
+    d = qkv.to(DEV)
+    q = d[..., : H * D].unflatten(-1, (H, D))
+    k = d[..., H * D: (H + Hkv) * D].unflatten(-1, (Hkv, D))
+    ops.rotary_embedding_neox_strided(pos.to(DEV), q, k, D, table.to(DEV))
+    kc2 = torch.full((B, Hkv, S, D), 7.0, dtype=torch.float16, device=DEV)
+    kc2.index_copy_(2, torch.arange(T, device=DEV) + 5, k.transpose(1, 2))
+    assert torch.equal(kc2.cpu(), kc)
+    # rows beyond the cache: a host base is refused, a device base skips the tokens that do not fit and counts them
+    d = qkv.to(DEV)
+    q = d[..., : H * D].unflatten(-1, (H, D))
+    k = d[..., H * D: (H + Hkv) * D].unflatten(-1, (Hkv, D))
+    v = d[..., (H + Hkv) * D:].unflatten(-1, (Hkv, D))
+    kz = torch.zeros(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.rotary_embedding_neox_kvcache_prefill(pos.to(DEV), q, k, v, D, table.to(DEV), kz, kz.clone(), first_row=12)
+    assert ops.decode_dropped_steps(reset=True) == 0
+    ops.rotary_embedding_neox_kvcache_prefill(pos.to(DEV), q, k, v, D, table.to(DEV), kz, kz.clone(),
+                                              first_row_dev=torch.tensor(S - 1, dtype=torch.int64, device=DEV))
+    assert torch.count_nonzero(kz[:, :, : S - 1]) == 0 and torch.count_nonzero(kz[:, :, S - 1]) > 0
+    assert ops.decode_dropped_steps(reset=True) == B * (T - 1)
+
+
+def test_eet_attention_static_cache_prompt_matches_stock_path(ops):
+    """A prompt on an INITIALISED transformers StaticCache: the one-launch rotary + cache write (+ counter add) must leave the
+    cache and the counter exactly as the stock rotary + StaticLayer.update leave them, and give the same logits (same attention
+    call on the same cache and mask); under fresh_static_prefill (cache empty, prompt unpadded) the causal attention over the
+    prompt's own rows must agree within fp16 attention tolerance; a second chunk of prompt appends behind the first."""
+    transformers = pytest.importorskip("transformers")
+    import copy
+    from eetq_amd.utils import eet_accelerator
+    from eetq_amd.modules.llama_modules import fresh_static_prefill
+    cfg = transformers.LlamaConfig(hidden_size=256, intermediate_size=704, num_hidden_layers=2, num_attention_heads=4,
+                                   num_key_value_heads=2, vocab_size=512, max_position_embeddings=128)
+    torch.manual_seed(0)
+    stock = transformers.LlamaForCausalLM(cfg).half().to(DEV).eval()
+    model = eet_accelerator(copy.deepcopy(stock), quantize=True, fused_attn=True, fused_mlp=True, fused_norm=True,
+                            fused_residual=True)
+    prompt = torch.randint(0, 512, (2, 19), device=DEV)
+    more = torch.randint(0, 512, (2, 5), device=DEV)
+
+    def run(fast, fresh=False):
+        for layer in model.model.layers:
+            layer.self_attn.static_prefill = fast
+        cache = transformers.StaticCache(config=cfg, max_cache_len=40)
+        with torch.no_grad():
+            model(prompt[:, :1], past_key_values=cache, use_cache=True)     # allocates the cache tensors
+            if fresh:      # counters only: the model derives positions from them; the rows keep the stale token
+                for l in cache.layers:
+                    l.cumulative_length.zero_()
+                with fresh_static_prefill():
+                    a = model(prompt, past_key_values=cache, use_cache=True).logits.float()
+            else:
+                cache.reset()
+                a = model(prompt, past_key_values=cache, use_cache=True).logits.float()
+            b = model(more, past_key_values=cache, use_cache=True).logits.float()    # appended behind the prompt, never "fresh"
+        return a, b, [(l.keys.clone(), l.values.clone(), int(l.cumulative_length)) for l in cache.layers]
+
+    ra, rb, rc = run(False)
+    ga, gb, gc = run(True)
+    assert torch.equal(ga, ra) and torch.equal(gb, rb)
+    for (k0, v0, n0), (k1, v1, n1) in zip(rc, gc):
+        assert n0 == n1 == 24 and torch.equal(k0, k1) and torch.equal(v0, v1)
+    fa, fb, fc = run(True, fresh=True)
+    spread = ra.abs().max().item()
+    assert (fa - ra).abs().max().item() < 4e-3 * spread + 4e-3 and (fb - rb).abs().max().item() < 4e-3 * spread + 4e-3
+    assert fc[0][2] == 24 and torch.equal(fc[0][0], rc[0][0])             # layer 0's cache does not depend on any attention
+
+
 def test_eet_attention_static_cache_decode_matches_stock_path(ops):
     """Token-by-token decode on a transformers StaticCache: the fused path (rotary + cache write in one launch, split-KV
     attention) must track the same model running its stock cache update and attention call."""
