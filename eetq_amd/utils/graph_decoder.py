@@ -148,8 +148,7 @@ class GraphDecoder:
             # derives the prompt's positions from them; the blocks never read a row at or beyond the counter, so the stock
             # reset's zero-fill of 2 x layers cache tensors buys nothing), and the prompt is attended causally over its own
             # rows (llama_modules.fresh_static_prefill)
-            for layer in self.cache.layers:
-                layer.cumulative_length.zero_()
+            torch._foreach_zero_([layer.cumulative_length for layer in self.cache.layers])   # one launch for all layers
             from ..modules.llama_modules import fresh_static_prefill
             ctx = fresh_static_prefill()
         else:

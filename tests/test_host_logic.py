@@ -87,8 +87,12 @@ def test_ops_validate_before_touching_the_gpu():
         ops.quant_weights(torch.zeros(0, 64, dtype=torch.float16), torch.int8)
     with pytest.raises(RuntimeError, match="dim"):
         ops.quant_weights(torch.zeros(64, dtype=torch.float16), torch.int8)
-    with pytest.raises(RuntimeError, match="2-D"):
-        ops.quant_weights(torch.zeros(2, 64, 64, dtype=torch.float16), torch.int8)
+    with pytest.raises(RuntimeError, match="dim"):
+        ops.quant_weights(torch.zeros(2, 2, 64, 64, dtype=torch.float16), torch.int8)
+    if not torch.cuda.is_available():
+        # a 3-D expert stack [E, K, N] is a valid request (every expert is quantised): it reaches the device check
+        with pytest.raises(RuntimeError, match="no HIP device"):
+            ops.quant_weights(torch.zeros(2, 64, 64, dtype=torch.float16), torch.int8)
     with pytest.raises(RuntimeError):
         ops.preprocess_weights(torch.zeros(64, 64, dtype=torch.int8), True)
     with pytest.raises(RuntimeError, match="unknown weight layout"):
