@@ -83,8 +83,9 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         return EETQ_OK;
     }
     {   // > 64 KiB of dynamic LDS: one opt-in per kernel and device (common.hpp)
-        static std::atomic<unsigned long long> opted2{0}, opted1{0}, opted2a{0}, opted1a{0}, opted2g{0}, opted1g{0};
-        int st = EETQ_OK;
+        static std::atomic<unsigned long long> opted2{0}, opted1{0}, opted2a{0}, opted1a{0}, opted2g{0}, opted1g{0}, opted_tall{0};
+        int st = opt_in_large_lds(gemm_tile_kernel<0, 2, false, 2, false, 2>, opted_tall);
+        if (st != EETQ_OK) return st;
         if (glu) {
             st = opt_in_large_lds(gemm_tile_kernel<0, 2, false, 2, true>, opted2g);
             if (st == EETQ_OK) st = opt_in_large_lds(gemm_tile_kernel<0, 1, false, 2, true>, opted1g);
@@ -120,11 +121,22 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
         if (e.residual) e.residual += (size_t)m * N + c0;
         const uint8_t* wc = w + (size_t)(c0 / kTileN) * (K / kTileK) * kTileBytes;
         const bool     narrow = force_j == 1 || (force_j == 0 && cost1 < cost2);
-        auto go = [&](auto kern, int tiles, size_t smem) {
+        auto go = [&](auto kern, int tiles, size_t smem, int threads = 256) {
             const int ldc = glu ? N / 2 : N;
-            launch_kernel(kern, dim3(tiles), dim3(256), smem, stream, x + (size_t)m * K, wc, scales + c0,
+            launch_kernel(kern, dim3(tiles), dim3(threads), smem, stream, x + (size_t)m * K, wc, scales + c0,
                           y + (size_t)m * ldc + (glu ? c0 / 2 : c0), rows, cols, K, ldc, e);
         };
+        // the tall tile (256 x 128 on eight waves, gemm_kernel.hpp): EETQ_AMD_TILE_TALL=1 (behind EETQ_AMD_TUNING) for A/B runs
+        static const int tall_env = [] {
+            const char* t = tuning_env("EETQ_AMD_TILE_TALL");
+            return t ? atoi(t) : 0;
+        }();
+        if (tall_env == 1 && !glu && e.act == 0 && rows >= 256) {
+            using Tall = TileCfg<2, 2, 2>;
+            const int tiles_t = ((rows + Tall::ROWS - 1) / Tall::ROWS) * ((cols + Tall::BN - 1) / Tall::BN);
+            go(gemm_tile_kernel<0, 2, false, 2, false, 2>, tiles_t, Tall::SMEM_BYTES, 512);
+            return check_hip(hipGetLastError(), "gemm_tile_kernel (tall) launch");
+        }
         if (glu && narrow) go(gemm_tile_kernel<0, 1, false, 2, true>, tiles1, TileCfg<1>::SMEM_BYTES);
         else if (glu) go(gemm_tile_kernel<0, 2, false, 2, true>, tiles2, TileCfg<2>::SMEM_BYTES);
         else if (narrow && e.act == 0) go(gemm_tile_kernel<0, 1>, tiles1, TileCfg<1>::SMEM_BYTES);

@@ -31,13 +31,19 @@ constexpr int kMinKSteps    = STAGES - 1;   // the statically unrolled drain nee
 // CW = waves across the tile's columns (each owns 32*J of them); 2*CW waves per workgroup.  CW = 2: the round-1 geometry,
 // one wave per SIMD.  (J, CW) = (1, 4): the 128 x 128 tile on EIGHT waves, two per SIMD -- half the accumulators and half the
 // DMA pieces per wave, and a second wave on every SIMD to issue MFMAs while the first sits in an LDS-DMA issue or a barrier.
-template <int J, int CW = 2>
+// RH = row halves: RH = 2 is the TALL tile, 256 x 128 on eight waves (round 6) -- waves 0..3 own rows 0..127 exactly as the four
+// waves of the 128 x 128 tile do, waves 4..7 rows 128..255, both halves read the SAME weight stage (one weight DMA and 8 KiB of LDS
+// per K step and 256 rows instead of two), 40 KiB stages in a 4-slot ring (all 160 KiB of LDS), the epilogue in two phases.
+template <int J, int CW = 2, int RH = 1>
 struct TileCfg {
     static constexpr int BN            = 32 * J * CW;
-    static constexpr int WAVES         = 2 * CW;
+    static constexpr int WAVES         = 2 * CW * RH;
+    static constexpr int ROWS          = BM * RH;
+    static constexpr int RING          = RH == 2 ? 4 : STAGES;
+    static constexpr int A_BYTES       = A_STAGE_BYTES * RH;
     static constexpr int B_STAGE_BYTES = BN * BK;  // BN/16 native 1 KiB tiles per K step
-    static constexpr int STAGE_BYTES   = A_STAGE_BYTES + B_STAGE_BYTES;
-    static constexpr int SMEM_BYTES    = STAGES * STAGE_BYTES;  // 144 / 120 KiB (also covers the end-of-kernel reduction)
+    static constexpr int STAGE_BYTES   = A_BYTES + B_STAGE_BYTES;
+    static constexpr int SMEM_BYTES    = RING * STAGE_BYTES;  // 144 / 120 / 160 KiB (also covers the end-of-kernel reduction)
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -98,7 +104,7 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // GLU (its own instantiation, identity rounding): the weight is in "glu8" column order (groups of 16 = 8 gate + the 8 matching up
 // columns); the fp16 image of the tile is written out as silu_mul(gate, up) -- y is [M][N / 2] with row stride ldc, what
 // eetq_silu_mul_glu8_f16 makes of the plain projection's output, without the [M][N] round trip through HBM.
-template <int ABLATE, int J, bool ACT, int CW, bool SPLIT, bool GLU = false>
+template <int ABLATE, int J, bool ACT, int CW, bool SPLIT, bool GLU = false, int RH = 1>
 __device__ __forceinline__ void gemm_tile_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep, int S, float* __restrict__ slabs,
@@ -106,21 +112,25 @@ __device__ __forceinline__ void gemm_tile_body(
 {
     // N = columns of THIS launch (w, scales, y, ep.* already point at its first column); ldc = row stride of y / residual
     EETQ_GEMM_STAMP(0);
-    using Cfg = TileCfg<J, CW>;
+    using Cfg = TileCfg<J, CW, RH>;
     constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES, NW = Cfg::WAVES;
-    constexpr int APW = 16 / NW;  // activation DMA pieces (8 rows each) per wave and stage: 4 or 2
-    constexpr int WN_COLS = 32 * J, PIECES = APW + J, NMFMA = 8 * J;
+    constexpr int ST = Cfg::RING, BMT = Cfg::ROWS, A_BYTES = Cfg::A_BYTES;
+    constexpr int APW = 16 * RH / NW;         // activation DMA pieces (8 rows each) per wave and stage: 4 or 2
+    constexpr int BPW = (BN / 16) / NW;       // weight tiles per wave and stage: J, or 1 in the tall tile
+    constexpr int WN_COLS = 32 * J, PIECES = APW + BPW, NMFMA = 8 * J;
     static_assert(J == 1 || J == 2, "slot tables exist for J = 1 and J = 2");
     static_assert(CW == 2 || (CW == 4 && J == 1), "geometries with slot tables: 4 waves (J = 1, 2) and 8 waves (J = 1)");
+    static_assert(RH == 1 || (RH == 2 && J == 2 && CW == 2 && !SPLIT), "the tall tile is 256 x 128, unsplit");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lane = tid & 63;
-    const int grp  = wave / CW;  // which 32-deep half of each K step
-    const int wn   = wave % CW;  // which 32*J-column part of the tile
+    const int rh   = wave / (2 * CW);         // which 128-row half of the tile (0 unless RH = 2)
+    const int grp  = (wave % (2 * CW)) / CW;  // which 32-deep half of each K step
+    const int wn   = wave % CW;               // which 32*J-column part of the tile
     const int KT   = K >> 6;
 
-    const int tiles_m = (M + BM - 1) / BM;
+    const int tiles_m = (M + BMT - 1) / BMT;
     const int tiles_n = (N + BN - 1) / BN;
     const int T       = tiles_m * tiles_n;
     int       tile, slice = 0, k0 = 0, ksteps = KT;  // this workgroup's K steps: [k0, k0 + ksteps)
@@ -146,7 +156,7 @@ __device__ __forceinline__ void gemm_tile_body(
     const int chunk   = tile / (kGroupM * tiles_n);
     const int in_ch   = tile - chunk * (kGroupM * tiles_n);
     const int ch_rows = tiles_m - chunk * kGroupM < kGroupM ? tiles_m - chunk * kGroupM : kGroupM;
-    const int m0 = (chunk * kGroupM + in_ch % ch_rows) * BM;
+    const int m0 = (chunk * kGroupM + in_ch % ch_rows) * BMT;
     const int n0 = (in_ch / ch_rows) * BN;
 
     // descriptors start kShift bytes below the operands: a piece's voff is pre-compensated by -(its instruction
@@ -171,20 +181,20 @@ __device__ __forceinline__ void gemm_tile_body(
     }
 #pragma unroll
     for (int i = APW; i < PIECES; ++i) {
-        int nt      = (n0 >> 4) + wave * J + (i - APW);
+        int nt      = (n0 >> 4) + wave * BPW + (i - APW);
         nt          = nt < n_tiles_total ? nt : n_tiles_total - 1;
         dma_voff[i] = nt * KT * kTileBytes + lane * 16 + kShift - (i - APW) * 1024;
     }
     const int dma_lds_a = wave * APW * 1024;                  // + i * 1024
-    const int dma_lds_b = A_STAGE_BYTES + wave * J * 1024;    // + (i - APW) * 1024
+    const int dma_lds_b = A_BYTES + wave * BPW * 1024;        // + (i - APW) * 1024
 
     const int fn = lane & 31, fh = lane >> 5;
     const int a_key = (fn >> 1) & 7;
     // per-lane constants of the LDS fragment reads (added to the stage offset)
     const int lds0 = (int)(uint32_t)(uintptr_t)(lds_void*)smem;
-    const int c_a0 = lds0 + fn * 128 + (((4 * grp + 2 * fh + 0) ^ a_key) << 4);
-    const int c_a1 = lds0 + fn * 128 + (((4 * grp + 2 * fh + 1) ^ a_key) << 4);
-    const int c_b0 = lds0 + A_STAGE_BYTES + ((wn * WN_COLS + fn) >> 4) * 1024 + (fn & 15) * 16 + fh * 256 + grp * 512;
+    const int c_a0 = lds0 + rh * A_STAGE_BYTES + fn * 128 + (((4 * grp + 2 * fh + 0) ^ a_key) << 4);
+    const int c_a1 = lds0 + rh * A_STAGE_BYTES + fn * 128 + (((4 * grp + 2 * fh + 1) ^ a_key) << 4);
+    const int c_b0 = lds0 + A_BYTES + ((wn * WN_COLS + fn) >> 4) * 1024 + (fn & 15) * 16 + fh * 256 + grp * 512;
     const int c_b1 = c_b0 + 2048;
 
     f16x2 scale2[J];
@@ -213,7 +223,7 @@ __device__ __forceinline__ void gemm_tile_body(
 
     // ring state of the step about to run (wave-uniform): rd = LDS offset of the stage whose fragments it reads
     // (stage kt+1), wr = LDS offset its DMA fills (stage kt+5), ka / kb = source offsets of that stage
-    int rd = STAGE_BYTES, wr = (STAGES - 1) * STAGE_BYTES, ka = (k0 + STAGES - 1) * BK * 2, kb = (k0 + STAGES - 1) * kTileBytes;
+    int rd = STAGE_BYTES, wr = (ST - 1) * STAGE_BYTES, ka = (k0 + ST - 1) * BK * 2, kb = (k0 + ST - 1) * kTileBytes;
     int ra0 = rd + c_a0, ra1 = rd + c_a1, rb0 = rd + c_b0, rb1 = rd + c_b1;
 
     auto dma_piece = [&](auto itag) {
@@ -293,7 +303,8 @@ __device__ __forceinline__ void gemm_tile_body(
                     if (i == 3) dma_piece(std::integral_constant<int, 2>{});
                     if (i == 5) dma_piece(std::integral_constant<int, 3>{});
                     if (i == 8) dma_piece(std::integral_constant<int, 4>{});
-                    if (i == 11) dma_piece(std::integral_constant<int, 5>{});
+                    if constexpr (PIECES > 5)
+                        if (i == 11) dma_piece(std::integral_constant<int, 5>{});
                 } else if constexpr (CW == 2) {
                     if (i == 0) dma_piece(std::integral_constant<int, 0>{});
                     if (i == 1) dma_piece(std::integral_constant<int, 1>{});
@@ -344,12 +355,100 @@ __device__ __forceinline__ void gemm_tile_body(
         }
     };
 
+    // ---- the tall tile's K step (RH = 2).  Two waves per SIMD leave 256 registers each: the schedule above keeps two full fragment
+    // sets next to 128 accumulators (1 373 spilled registers when compiled for eight waves: 1.2 - 1.3 x the 128 x 128 tile's time,
+    // tools/experiments/tall_tile_ab.py).  Here only the WEIGHTS are double-buffered (raw + dequantised, as above); an activation
+    // fragment is requested two MFMA pairs ahead of its use into a four-deep window -- pair p = (K half e = p / 4, row block mt = p % 4)
+    // feeds the two column blocks back to back -- and the window carries the next step's first two pairs across the barrier.  Every
+    // accumulator still adds its K halves in the order e = 0, 1: the same bits as the 128 x 128 tile.
+    f16x8 xw[4];
+    int   ca0 = c_a0, ca1 = c_a1;  // fragment addresses of the CURRENT stage (ra0 / ra1: the next one's)
+    auto  step_tall = [&](const WFrag& wcur, auto read_tag, Frags& fnext, WFrag& wnext, auto dma_tag) {
+        constexpr bool READ = decltype(read_tag)::value;
+        constexpr bool DMA  = decltype(dma_tag)::value;
+        u32            wd[J][8];
+        const f16x2    bias1152 = {(f16)1152.0f, (f16)1152.0f};
+#pragma unroll
+        for (int i = 0; i < NMFMA; ++i) {
+            const int p = i >> 1, j = i & 1, e = p >> 2, mt = p & 3;
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur.f[j][e], xw[p & 3], acc[mt][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if ((i & 1) == 0) {  // the pair's first MFMA is issued: request pair p + 2 (its slot of the window was pair p - 2's)
+                const int q = p + 2;
+                if (q < 8) {
+                    xw[q & 3] = __builtin_bit_cast(f16x8, lds_read16(((q >> 2) ? ca1 : ca0) + (q & 3) * 32 * 128));
+                } else if constexpr (READ) {
+                    xw[q & 3] = __builtin_bit_cast(f16x8, lds_read16(ra0 + (q - 8) * 32 * 128));
+                }
+            }
+            if constexpr (READ) {
+                if (i == 0) {
+                    fnext.wq[0] = lds_read16(rb0);
+                    fnext.wq[1] = lds_read16(rb1);
+                }
+                if (i >= 4) {  // dequant micro-ops, as in the 128 x 128 schedule: one kind of op on four half-dwords per gap
+                    const int jj = (i - 4) / 6, dp = ((i - 4) / 3) & 1, kind = (i - 4) % 3;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int h = 4 * dp + u, d = h >> 1;
+                        if (kind == 0) {
+                            const u32 wdw = d == 0 ? fnext.wq[jj].x : d == 1 ? fnext.wq[jj].y : d == 2 ? fnext.wq[jj].z : fnext.wq[jj].w;
+                            wd[jj][h] = __builtin_amdgcn_perm(wdw, 0x64646464u, (h & 1) ? 0x00070005u : 0x00060004u);
+                        } else if (kind == 1) {
+                            wd[jj][h] = as_u32(as_f16x2(wd[jj][h]) - bias1152);
+                        } else {
+                            wd[jj][h] = as_u32(as_f16x2(wd[jj][h]) * scale2[jj]);
+                        }
+                    }
+                    asm volatile("" ::"v"(wd[jj][4 * dp]), "v"(wd[jj][4 * dp + 1]), "v"(wd[jj][4 * dp + 2]), "v"(wd[jj][4 * dp + 3]));
+                }
+            }
+            if constexpr (DMA) {
+                if (i == 0) dma_piece(std::integral_constant<int, 0>{});
+                if (i == 1) dma_piece(std::integral_constant<int, 1>{});
+                if (i == 3) dma_piece(std::integral_constant<int, 2>{});
+                if (i == 5) dma_piece(std::integral_constant<int, 3>{});
+                if (i == 8) dma_piece(std::integral_constant<int, 4>{});
+            }
+            if constexpr (READ) {
+                if (i == 12) {
+                    rd = rd + STAGE_BYTES == SMEM_BYTES ? 0 : rd + STAGE_BYTES;
+                    asm volatile("" : "+s"(rd));
+                }
+                if (i == 13) {
+                    wr = wr + STAGE_BYTES == SMEM_BYTES ? 0 : wr + STAGE_BYTES;
+                    ka += BK * 2;
+                    kb += kTileBytes;
+                    asm volatile("" : "+s"(wr), "+s"(ka), "+s"(kb));
+                }
+                if (i == 15) {  // behind the step's last fragment request
+                    ca0 = ra0;
+                    ca1 = ra1;
+                    ra0 = rd + c_a0;
+                    ra1 = rd + c_a1;
+                    rb0 = rd + c_b0;
+                    rb1 = rd + c_b1;
+                    asm volatile("" : "+v"(ca0), "+v"(ca1), "+v"(ra0), "+v"(ra1), "+v"(rb0), "+v"(rb1));
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if constexpr (READ) {
+#pragma unroll
+            for (int jj = 0; jj < J; ++jj) {
+                wnext.f[jj][0] = make_frag(as_f16x2(wd[jj][0]), as_f16x2(wd[jj][1]), as_f16x2(wd[jj][2]), as_f16x2(wd[jj][3]));
+                wnext.f[jj][1] = make_frag(as_f16x2(wd[jj][4]), as_f16x2(wd[jj][5]), as_f16x2(wd[jj][6]), as_f16x2(wd[jj][7]));
+            }
+            __builtin_amdgcn_s_waitcnt(0xC07F);
+        }
+    };
+
     // ---- prologue: STAGES-1 stages in flight; stage 0 -> fragments ----
     asm volatile("" ::"v"(scale2[0]));
     {
         int pwr = 0, pka = k0 * BK * 2, pkb = k0 * kTileBytes;
 #pragma unroll
-        for (int s = 0; s < STAGES - 1; ++s) {  // KT >= STAGES - 1 by launch contract
+        for (int s = 0; s < ST - 1; ++s) {  // KT >= STAGES - 1 by launch contract
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {  // plain form: voff carries -IMM, so the LDS address gets it back here
                 if (i < APW)
@@ -362,7 +461,7 @@ __device__ __forceinline__ void gemm_tile_body(
             pkb += kTileBytes;
         }
     }
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * PIECES) : "memory");  // stage 0 landed
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((ST - 2) * PIECES) : "memory");  // stage 0 landed
     __builtin_amdgcn_s_barrier();
     EETQ_GEMM_STAMP(1);
     Frags f0, f1;
@@ -370,10 +469,15 @@ __device__ __forceinline__ void gemm_tile_body(
     {
         f0.wq[0] = lds_read16(c_b0);
         if constexpr (J == 2) f0.wq[1] = lds_read16(c_b1);
+        if constexpr (RH == 2) {  // the window's first two pairs
+            xw[0] = __builtin_bit_cast(f16x8, lds_read16(c_a0));
+            xw[1] = __builtin_bit_cast(f16x8, lds_read16(c_a0 + 32 * 128));
+        } else {
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            f0.xa[0][mt] = __builtin_bit_cast(f16x8, lds_read16(c_a0 + mt * 32 * 128));
-            f0.xa[1][mt] = __builtin_bit_cast(f16x8, lds_read16(c_a1 + mt * 32 * 128));
+            for (int mt = 0; mt < 4; ++mt) {
+                f0.xa[0][mt] = __builtin_bit_cast(f16x8, lds_read16(c_a0 + mt * 32 * 128));
+                f0.xa[1][mt] = __builtin_bit_cast(f16x8, lds_read16(c_a1 + mt * 32 * 128));
+            }
         }
 #pragma unroll
         for (int j = 0; j < J; ++j) {
@@ -389,15 +493,17 @@ __device__ __forceinline__ void gemm_tile_body(
     auto k_step = [&](auto rem_tag, const WFrag& wcur, const Frags& fcur, WFrag& wnext, Frags& fnext) {
         constexpr int REM = decltype(rem_tag)::value;
         if constexpr (REM >= 1) {
-            constexpr int younger = (REM - 1) < (STAGES - 3) ? (REM - 1) : (STAGES - 3);
+            constexpr int younger = (REM - 1) < (ST - 3) ? (REM - 1) : (ST - 3);
             if constexpr (!(ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger * PIECES) : "memory");
             if constexpr (!(ABLATE & 16)) __builtin_amdgcn_s_barrier();
-            step(wcur, fcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= STAGES - 1)>{});
+            if constexpr (RH == 2) step_tall(wcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= ST - 1)>{});
+            else step(wcur, fcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= ST - 1)>{});
         } else {
-            step(wcur, fcur, std::false_type{}, fnext, wnext, std::false_type{});
+            if constexpr (RH == 2) step_tall(wcur, std::false_type{}, fnext, wnext, std::false_type{});
+            else step(wcur, fcur, std::false_type{}, fnext, wnext, std::false_type{});
         }
     };
-    using Steady = std::integral_constant<int, STAGES - 1>;
+    using Steady = std::integral_constant<int, ST - 1>;
     const int tail = (ksteps & 1) ? 5 : 6;
     int       kt   = 0;
     for (; kt < ksteps - tail; kt += 2) {
@@ -426,9 +532,13 @@ __device__ __forceinline__ void gemm_tile_body(
     // group 0 rounds to fp16 (+ bias / activation) into a row-major LDS image of the tile, and all four waves write it out 16
     // bytes per lane, whole 256-byte rows (4 rows per wave instruction), adding the residual on the way. ----
     EETQ_GEMM_STAMP(3);
+    // (tall tile: one 128-row half after the other -- the parked K half (64 KiB) and the fp16 image (34 KiB) of both do not fit)
+#pragma unroll
+    for (int ph = 0; ph < RH; ++ph) {
+    const bool mine = RH == 1 || rh == ph;  // this wave's rows are the phase's
     __builtin_amdgcn_s_barrier();
     f32x4* red4 = reinterpret_cast<f32x4*>(smem) + (size_t)wn * (16 * J) * 64;  // [block][quad][lane]
-    if (grp == 1) {
+    if (grp == 1 && mine) {
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -531,7 +641,7 @@ __device__ __forceinline__ void gemm_tile_body(
     // who rounds which row blocks into the image: the K-half-0 waves all four -- or, after a split read-back, every wave the two
     // it summed (held in acc[0], acc[1])
     const bool summed = SPLIT && S > 1;
-    if (grp == 0 || summed) {
+    if ((grp == 0 && mine) || summed) {
 #pragma unroll
         for (int mt_ = 0; mt_ < 4; ++mt_) {
             if (summed && mt_ >= 2) break;
@@ -571,7 +681,7 @@ __device__ __forceinline__ void gemm_tile_body(
 #pragma unroll
         for (int r0 = 0; r0 < BM; r0 += kRowsPerRound) {
             const int r = r0 + wave * kRowsPerWave + lane / kLanesPerRow;
-            const int m = m0 + r;
+            const int m = m0 + ph * BM + r;
             if (m < M && n0 + c < N) {
                 const f16x8 g = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(image + r * kRowHalfs + c));
                 const f16x8 u = __builtin_bit_cast(f16x8, *reinterpret_cast<const u32x4*>(image + r * kRowHalfs + c + 8));
@@ -587,7 +697,7 @@ __device__ __forceinline__ void gemm_tile_body(
 #pragma unroll
         for (int r0 = 0; r0 < BM; r0 += kRowsPerRound) {
             const int r = r0 + wave * kRowsPerWave + lane / kLanesPerRow;
-            const int m = m0 + r;
+            const int m = m0 + ph * BM + r;
             if (m < M && n0 + c < N) {
                 u32x4 v = *reinterpret_cast<const u32x4*>(image + r * kRowHalfs + c);
                 if (ep.residual) {
@@ -601,16 +711,18 @@ __device__ __forceinline__ void gemm_tile_body(
             }
         }
     }
+    if constexpr (RH > 1) __syncthreads();  // the next phase reuses the parked area and the image
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     EETQ_GEMM_STAMP(5);
 }
 
-template <int ABLATE, int J, bool ACT = false, int CW = 2, bool GLU = false>
-__global__ __launch_bounds__(128 * CW, 1) void gemm_tile_kernel(
+template <int ABLATE, int J, bool ACT = false, int CW = 2, bool GLU = false, int RH = 1>
+__global__ __launch_bounds__(128 * CW * RH, 1) void gemm_tile_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
 {
-    gemm_tile_body<ABLATE, J, ACT, CW, false, GLU>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
+    gemm_tile_body<ABLATE, J, ACT, CW, false, GLU, RH>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
 }
 
 // Round 5, measured and shelved with their patch (tools/experiments/tile_ring_depth_and_persistent.patch): the

@@ -1,5 +1,6 @@
 """The two bindings of the C ABI -- the compiled module ``EETQ`` (product boundary) and the ctypes twin -- must give
 bit-identical results and the same error behaviour: they are two doors to the same kernels."""
+import numpy as np
 import pytest
 import torch
 
@@ -137,3 +138,42 @@ print("AUTO_IS_MID", int(torch.equal(auto, mid)), "AUTO_IS_SPLIT", int(torch.equ
         outs[flag] = res.stdout.strip().splitlines()[-1].split()
     assert outs["0"][1] == "1" and outs["0"][5] == "1", outs        # opted out: AUTO == mid
     assert outs["1"][3] == "1", outs                                # default: AUTO == split-K
+
+
+_TALL_CHILD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+import eetq_amd.ops as ops
+out = {{}}
+for K, N, M in {cases!r}:
+    g = torch.Generator(device="cuda:0").manual_seed(K + N + M)
+    w = torch.randint(-128, 127, (K, N), dtype=torch.int8, device="cuda:0", generator=g)
+    s = torch.rand(N, dtype=torch.float16, device="cuda:0", generator=g) * 0.01
+    x = torch.randn(M, K, dtype=torch.float16, device="cuda:0", generator=g)
+    b = torch.randn(N, dtype=torch.float16, device="cuda:0", generator=g)
+    r = torch.randn(M, N, dtype=torch.float16, device="cuda:0", generator=g)
+    out["%d_%d_%d" % (K, N, M)] = ops.w8_a16_gemm(x, w, s, path="mfma", bias=b, residual=r).cpu().numpy()
+np.savez({dst!r}, **out)
+"""
+
+
+def test_tall_tile_equals_the_128_row_tile(tmp_path):
+    """The 256 x 128 tile on eight waves (gemm_tile_kernel<..., RH = 2>: both row halves read one weight stage, activation fragments
+    through a four-deep window, two-phase epilogue; measured 5 - 23 % behind the 128 x 128 tile and therefore only reachable through
+    the A/B hook EETQ_AMD_TILE_TALL) must give the 128-row tile's BITS: whole and ragged row tiles, ragged column edge, bias and
+    residual, an odd and an even number of K steps."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = [(4096, 4096, 2048), (1024, 640, 300), (704, 4096, 1000), (2048, 1008, 513)]
+    got = {}
+    for name, hook in (("tile128", None), ("tall256", "1")):
+        dst = str(tmp_path / (name + ".npz"))
+        env = dict(os.environ)
+        if hook:
+            env.update(EETQ_AMD_TUNING="1", EETQ_AMD_TILE_TALL=hook)
+        r = subprocess.run([sys.executable, "-c", _TALL_CHILD.format(root=root, cases=cases, dst=dst)], env=env, capture_output=True,
+                           text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        got[name] = np.load(dst)
+    for key in got["tile128"].files:
+        assert np.array_equal(got["tile128"][key], got["tall256"][key]), key
