@@ -84,7 +84,9 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
     }
     {   // > 64 KiB of dynamic LDS: one opt-in per kernel and device (common.hpp)
         static std::atomic<unsigned long long> opted2{0}, opted1{0}, opted2a{0}, opted1a{0}, opted2g{0}, opted1g{0}, opted_tall{0};
+        static std::atomic<unsigned long long> opted_deep{0};
         int st = opt_in_large_lds(gemm_tile_kernel<0, 2, false, 2, false, 2>, opted_tall);
+        if (st == EETQ_OK) st = opt_in_large_lds(gemm_tile_kernel<0, 2, false, 2, false, 1, 2>, opted_deep);
         if (st != EETQ_OK) return st;
         if (glu) {
             st = opt_in_large_lds(gemm_tile_kernel<0, 2, false, 2, true>, opted2g);
@@ -131,6 +133,12 @@ int launch_gemm_mfma(const f16* x, const uint8_t* w, const f16* scales, Epilogue
             const char* t = tuning_env("EETQ_AMD_TILE_TALL");
             return t ? atoi(t) : 0;
         }();
+        if (tall_env == 2 && !glu && e.act == 0 && rows >= 256) {  // the deep tile: 256 x 128 on four waves
+            using Deep = TileCfg<2, 2, 1, 2>;
+            const int tiles_d = ((rows + Deep::ROWS - 1) / Deep::ROWS) * ((cols + Deep::BN - 1) / Deep::BN);
+            go(gemm_tile_kernel<0, 2, false, 2, false, 1, 2>, tiles_d, Deep::SMEM_BYTES, 256);
+            return check_hip(hipGetLastError(), "gemm_tile_kernel (deep) launch");
+        }
         if (tall_env == 1 && !glu && e.act == 0 && rows >= 256) {
             using Tall = TileCfg<2, 2, 2>;
             const int tiles_t = ((rows + Tall::ROWS - 1) / Tall::ROWS) * ((cols + Tall::BN - 1) / Tall::BN);

@@ -34,13 +34,16 @@ constexpr int kMinKSteps    = STAGES - 1;   // the statically unrolled drain nee
 // RH = row halves: RH = 2 is the TALL tile, 256 x 128 on eight waves (round 6) -- waves 0..3 own rows 0..127 exactly as the four
 // waves of the 128 x 128 tile do, waves 4..7 rows 128..255, both halves read the SAME weight stage (one weight DMA and 8 KiB of LDS
 // per K step and 256 rows instead of two), 40 KiB stages in a 4-slot ring (all 160 KiB of LDS), the epilogue in two phases.
-template <int J, int CW = 2, int RH = 1>
+// RB = 32-row-block multiplier per wave: RB = 2 is the DEEP tile, 256 x 128 on FOUR waves -- a wave owns 256 rows x 64 columns of
+// one K half (256 accumulators per lane, one wave per SIMD): every dequantised weight fragment feeds 8 MFMAs instead of 4, so the
+// dequant work and the weight reads per MFMA halve as well as the weight DMA.  Same stages, ring and epilogue phases as the tall tile.
+template <int J, int CW = 2, int RH = 1, int RB = 1>
 struct TileCfg {
     static constexpr int BN            = 32 * J * CW;
     static constexpr int WAVES         = 2 * CW * RH;
-    static constexpr int ROWS          = BM * RH;
-    static constexpr int RING          = RH == 2 ? 4 : STAGES;
-    static constexpr int A_BYTES       = A_STAGE_BYTES * RH;
+    static constexpr int ROWS          = BM * RH * RB;
+    static constexpr int RING          = RH * RB == 2 ? 4 : STAGES;
+    static constexpr int A_BYTES       = A_STAGE_BYTES * RH * RB;
     static constexpr int B_STAGE_BYTES = BN * BK;  // BN/16 native 1 KiB tiles per K step
     static constexpr int STAGE_BYTES   = A_BYTES + B_STAGE_BYTES;
     static constexpr int SMEM_BYTES    = RING * STAGE_BYTES;  // 144 / 120 / 160 KiB (also covers the end-of-kernel reduction)
@@ -104,7 +107,7 @@ __device__ __forceinline__ f16x8 make_frag(f16x2 a, f16x2 b, f16x2 c, f16x2 d)
 // GLU (its own instantiation, identity rounding): the weight is in "glu8" column order (groups of 16 = 8 gate + the 8 matching up
 // columns); the fp16 image of the tile is written out as silu_mul(gate, up) -- y is [M][N / 2] with row stride ldc, what
 // eetq_silu_mul_glu8_f16 makes of the plain projection's output, without the [M][N] round trip through HBM.
-template <int ABLATE, int J, bool ACT, int CW, bool SPLIT, bool GLU = false, int RH = 1>
+template <int ABLATE, int J, bool ACT, int CW, bool SPLIT, bool GLU = false, int RH = 1, int RB = 1>
 __device__ __forceinline__ void gemm_tile_body(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep, int S, float* __restrict__ slabs,
@@ -112,15 +115,17 @@ __device__ __forceinline__ void gemm_tile_body(
 {
     // N = columns of THIS launch (w, scales, y, ep.* already point at its first column); ldc = row stride of y / residual
     EETQ_GEMM_STAMP(0);
-    using Cfg = TileCfg<J, CW, RH>;
+    using Cfg = TileCfg<J, CW, RH, RB>;
     constexpr int BN = Cfg::BN, STAGE_BYTES = Cfg::STAGE_BYTES, SMEM_BYTES = Cfg::SMEM_BYTES, NW = Cfg::WAVES;
     constexpr int ST = Cfg::RING, BMT = Cfg::ROWS, A_BYTES = Cfg::A_BYTES;
-    constexpr int APW = 16 * RH / NW;         // activation DMA pieces (8 rows each) per wave and stage: 4 or 2
+    constexpr int APW = 16 * RH * RB / NW;    // activation DMA pieces (8 rows each) per wave and stage: 4 or 2; 8 in the deep tile
     constexpr int BPW = (BN / 16) / NW;       // weight tiles per wave and stage: J, or 1 in the tall tile
-    constexpr int WN_COLS = 32 * J, PIECES = APW + BPW, NMFMA = 8 * J;
+    constexpr int WN_COLS = 32 * J, PIECES = APW + BPW, NMFMA = 8 * J * RB;
+    constexpr int MT = 4 * RB;                // 32-row blocks per wave
     static_assert(J == 1 || J == 2, "slot tables exist for J = 1 and J = 2");
     static_assert(CW == 2 || (CW == 4 && J == 1), "geometries with slot tables: 4 waves (J = 1, 2) and 8 waves (J = 1)");
     static_assert(RH == 1 || (RH == 2 && J == 2 && CW == 2 && !SPLIT), "the tall tile is 256 x 128, unsplit");
+    static_assert(RB == 1 || (RB == 2 && RH == 1 && J == 2 && CW == 2 && !SPLIT && ABLATE == 0), "the deep tile is 256 x 128 on four waves, unsplit");
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int tid  = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -177,7 +182,7 @@ __device__ __forceinline__ void gemm_tile_body(
         const int slot = (lane & 7) ^ ((row >> 1) & 7);
         int       gm   = m0 + row;
         gm             = gm < M ? gm : M - 1;
-        dma_voff[i]    = (gm * K + slot * 8) * 2 + kShift - i * 1024;
+        dma_voff[i]    = (gm * K + slot * 8) * 2 + kShift - (i & 3) * 1024;  // the instruction offset: at most 3 KiB
     }
 #pragma unroll
     for (int i = APW; i < PIECES; ++i) {
@@ -205,9 +210,9 @@ __device__ __forceinline__ void gemm_tile_body(
         scale2[j]      = f16x2{sc, sc};
     }
 
-    f32x16 acc[4][J];
+    f32x16 acc[MT][J];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int j = 0; j < J; ++j)
 #pragma unroll
@@ -229,7 +234,7 @@ __device__ __forceinline__ void gemm_tile_body(
     auto dma_piece = [&](auto itag) {
         constexpr int i = decltype(itag)::value;
         if constexpr (i < APW)
-            dma16_imm<i * 1024>(x_rsrc, dma_voff[i], ka, smem + wr + dma_lds_a);
+            dma16_imm<(i & 3) * 1024>(x_rsrc, dma_voff[i], ka, smem + wr + dma_lds_a + (i >> 2) * 4096);
         else
             dma16_imm<(i - APW) * 1024>(w_rsrc, dma_voff[i], kb, smem + wr + dma_lds_b);
     };
@@ -361,7 +366,11 @@ __device__ __forceinline__ void gemm_tile_body(
     // fragment is requested two MFMA pairs ahead of its use into a four-deep window -- pair p = (K half e = p / 4, row block mt = p % 4)
     // feeds the two column blocks back to back -- and the window carries the next step's first two pairs across the barrier.  Every
     // accumulator still adds its K halves in the order e = 0, 1: the same bits as the 128 x 128 tile.
-    f16x8 xw[4];
+    // The deep tile (RB = 2) runs the same K step on ONE wave per SIMD with 16 pairs, an eight-deep window and requests four pairs
+    // ahead (128+ cycles of MFMA between request and use), 32 MFMA gaps: fragment requests in the even gaps, the dequant micro-ops in
+    // the odd gaps 5..27, the wave's ten DMA pieces in gaps 1, 3, 4, 8, ..., 28, ring bookkeeping in gaps 29..31.
+    constexpr int NP = 8 * RB, WIN = 4 * RB, DIST = 2 * RB;  // pairs per step, window depth, request distance
+    f16x8 xw[WIN];
     int   ca0 = c_a0, ca1 = c_a1;  // fragment addresses of the CURRENT stage (ra0 / ra1: the next one's)
     auto  step_tall = [&](const WFrag& wcur, auto read_tag, Frags& fnext, WFrag& wnext, auto dma_tag) {
         constexpr bool READ = decltype(read_tag)::value;
@@ -370,15 +379,15 @@ __device__ __forceinline__ void gemm_tile_body(
         const f16x2    bias1152 = {(f16)1152.0f, (f16)1152.0f};
 #pragma unroll
         for (int i = 0; i < NMFMA; ++i) {
-            const int p = i >> 1, j = i & 1, e = p >> 2, mt = p & 3;
-            acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur.f[j][e], xw[p & 3], acc[mt][j], 0, 0, 0);
+            const int p = i >> 1, j = i & 1, e = p / (NP / 2), mt = p % (NP / 2);
+            acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur.f[j][e], xw[p % WIN], acc[mt][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            if ((i & 1) == 0) {  // the pair's first MFMA is issued: request pair p + 2 (its slot of the window was pair p - 2's)
-                const int q = p + 2;
-                if (q < 8) {
-                    xw[q & 3] = __builtin_bit_cast(f16x8, lds_read16(((q >> 2) ? ca1 : ca0) + (q & 3) * 32 * 128));
+            if ((i & 1) == 0) {  // the pair's first MFMA is issued: request pair p + DIST (its slot of the window was pair p + DIST - WIN's)
+                const int q = p + DIST;
+                if (q < NP) {
+                    xw[q % WIN] = __builtin_bit_cast(f16x8, lds_read16((q >= NP / 2 ? ca1 : ca0) + (q % (NP / 2)) * 32 * 128));
                 } else if constexpr (READ) {
-                    xw[q & 3] = __builtin_bit_cast(f16x8, lds_read16(ra0 + (q - 8) * 32 * 128));
+                    xw[q % WIN] = __builtin_bit_cast(f16x8, lds_read16(ra0 + (q - NP) * 32 * 128));
                 }
             }
             if constexpr (READ) {
@@ -386,8 +395,11 @@ __device__ __forceinline__ void gemm_tile_body(
                     fnext.wq[0] = lds_read16(rb0);
                     fnext.wq[1] = lds_read16(rb1);
                 }
-                if (i >= 4) {  // dequant micro-ops, as in the 128 x 128 schedule: one kind of op on four half-dwords per gap
-                    const int jj = (i - 4) / 6, dp = ((i - 4) / 3) & 1, kind = (i - 4) % 3;
+                // dequant micro-ops, as in the 128 x 128 schedule: one kind of op on four half-dwords per gap, dependent ops a gap
+                // (deep tile: two gaps) apart; g = which of the 12 groups this gap carries, -1 = none
+                const int g = RB == 2 ? ((i >= 5 && i <= 27 && (i & 1)) ? (i - 5) / 2 : -1) : (i >= 4 ? i - 4 : -1);
+                if (g >= 0) {
+                    const int jj = g / 6, dp = (g / 3) & 1, kind = g % 3;
 #pragma unroll
                     for (int u = 0; u < 4; ++u) {
                         const int h = 4 * dp + u, d = h >> 1;
@@ -404,24 +416,37 @@ __device__ __forceinline__ void gemm_tile_body(
                 }
             }
             if constexpr (DMA) {
-                if (i == 0) dma_piece(std::integral_constant<int, 0>{});
-                if (i == 1) dma_piece(std::integral_constant<int, 1>{});
-                if (i == 3) dma_piece(std::integral_constant<int, 2>{});
-                if (i == 5) dma_piece(std::integral_constant<int, 3>{});
-                if (i == 8) dma_piece(std::integral_constant<int, 4>{});
+                if constexpr (RB == 2) {
+                    if (i == 1) dma_piece(std::integral_constant<int, 0>{});
+                    if (i == 3) dma_piece(std::integral_constant<int, 1>{});
+                    if (i == 4) dma_piece(std::integral_constant<int, 2>{});
+                    if (i == 8) dma_piece(std::integral_constant<int, 3>{});
+                    if (i == 12) dma_piece(std::integral_constant<int, 4>{});
+                    if (i == 16) dma_piece(std::integral_constant<int, 5>{});
+                    if (i == 20) dma_piece(std::integral_constant<int, 6>{});
+                    if (i == 24) dma_piece(std::integral_constant<int, 7>{});
+                    if (i == 26) dma_piece(std::integral_constant<int, 8>{});
+                    if (i == 28) dma_piece(std::integral_constant<int, 9>{});
+                } else {
+                    if (i == 0) dma_piece(std::integral_constant<int, 0>{});
+                    if (i == 1) dma_piece(std::integral_constant<int, 1>{});
+                    if (i == 3) dma_piece(std::integral_constant<int, 2>{});
+                    if (i == 5) dma_piece(std::integral_constant<int, 3>{});
+                    if (i == 8) dma_piece(std::integral_constant<int, 4>{});
+                }
             }
             if constexpr (READ) {
-                if (i == 12) {
+                if (i == NMFMA - 4 + (RB == 2 ? 1 : 0)) {  // gap 12 / 29
                     rd = rd + STAGE_BYTES == SMEM_BYTES ? 0 : rd + STAGE_BYTES;
                     asm volatile("" : "+s"(rd));
                 }
-                if (i == 13) {
+                if (i == NMFMA - 3 + (RB == 2 ? 1 : 0)) {  // gap 13 / 30: behind the step's last DMA piece
                     wr = wr + STAGE_BYTES == SMEM_BYTES ? 0 : wr + STAGE_BYTES;
                     ka += BK * 2;
                     kb += kTileBytes;
                     asm volatile("" : "+s"(wr), "+s"(ka), "+s"(kb));
                 }
-                if (i == 15) {  // behind the step's last fragment request
+                if (i == NMFMA - 1) {  // behind the step's last fragment request
                     ca0 = ra0;
                     ca1 = ra1;
                     ra0 = rd + c_a0;
@@ -452,7 +477,7 @@ __device__ __forceinline__ void gemm_tile_body(
 #pragma unroll
             for (int i = 0; i < PIECES; ++i) {  // plain form: voff carries -IMM, so the LDS address gets it back here
                 if (i < APW)
-                    dma16(x_rsrc, dma_voff[i] + i * 1024, pka, smem + pwr + dma_lds_a + i * 1024);
+                    dma16(x_rsrc, dma_voff[i] + (i & 3) * 1024, pka, smem + pwr + dma_lds_a + i * 1024);
                 else
                     dma16(w_rsrc, dma_voff[i] + (i - APW) * 1024, pkb, smem + pwr + dma_lds_b + (i - APW) * 1024);
             }
@@ -469,9 +494,9 @@ __device__ __forceinline__ void gemm_tile_body(
     {
         f0.wq[0] = lds_read16(c_b0);
         if constexpr (J == 2) f0.wq[1] = lds_read16(c_b1);
-        if constexpr (RH == 2) {  // the window's first two pairs
-            xw[0] = __builtin_bit_cast(f16x8, lds_read16(c_a0));
-            xw[1] = __builtin_bit_cast(f16x8, lds_read16(c_a0 + 32 * 128));
+        if constexpr (RH * RB == 2) {  // the window's first pairs
+#pragma unroll
+            for (int q = 0; q < DIST; ++q) xw[q] = __builtin_bit_cast(f16x8, lds_read16(c_a0 + q * 32 * 128));
         } else {
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {
@@ -496,10 +521,10 @@ __device__ __forceinline__ void gemm_tile_body(
             constexpr int younger = (REM - 1) < (ST - 3) ? (REM - 1) : (ST - 3);
             if constexpr (!(ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(younger * PIECES) : "memory");
             if constexpr (!(ABLATE & 16)) __builtin_amdgcn_s_barrier();
-            if constexpr (RH == 2) step_tall(wcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= ST - 1)>{});
+            if constexpr (RH * RB == 2) step_tall(wcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= ST - 1)>{});
             else step(wcur, fcur, std::true_type{}, fnext, wnext, std::integral_constant<bool, (REM >= ST - 1)>{});
         } else {
-            if constexpr (RH == 2) step_tall(wcur, std::false_type{}, fnext, wnext, std::false_type{});
+            if constexpr (RH * RB == 2) step_tall(wcur, std::false_type{}, fnext, wnext, std::false_type{});
             else step(wcur, fcur, std::false_type{}, fnext, wnext, std::false_type{});
         }
     };
@@ -534,8 +559,9 @@ __device__ __forceinline__ void gemm_tile_body(
     EETQ_GEMM_STAMP(3);
     // (tall tile: one 128-row half after the other -- the parked K half (64 KiB) and the fp16 image (34 KiB) of both do not fit)
 #pragma unroll
-    for (int ph = 0; ph < RH; ++ph) {
+    for (int ph = 0; ph < RH * RB; ++ph) {
     const bool mine = RH == 1 || rh == ph;  // this wave's rows are the phase's
+    const int  ab   = RB == 2 ? 4 * ph : 0; // deep tile: the phase's four row blocks of this wave's eight
     __builtin_amdgcn_s_barrier();
     f32x4* red4 = reinterpret_cast<f32x4*>(smem) + (size_t)wn * (16 * J) * 64;  // [block][quad][lane]
     if (grp == 1 && mine) {
@@ -546,7 +572,7 @@ __device__ __forceinline__ void gemm_tile_body(
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
                     red4[((mt * J + j) * 4 + q) * 64 + lane] =
-                        f32x4{acc[mt][j][4 * q], acc[mt][j][4 * q + 1], acc[mt][j][4 * q + 2], acc[mt][j][4 * q + 3]};
+                        f32x4{acc[ab + mt][j][4 * q], acc[ab + mt][j][4 * q + 1], acc[ab + mt][j][4 * q + 2], acc[ab + mt][j][4 * q + 3]};
     }
     __syncthreads();
     EETQ_GEMM_STAMP(4);
@@ -653,8 +679,8 @@ __device__ __forceinline__ void gemm_tile_body(
                 for (int q = 0; q < 4; ++q) {
                     // (SPLIT: the other K half -- and the other slices -- were added above)
                     const f32x4 o  = SPLIT ? f32x4{0.f, 0.f, 0.f, 0.f} : red4[((mt * J + j) * 4 + q) * 64 + lane];
-                    const float a4[4] = {acc[mt_][j][4 * q + 0] + o.x, acc[mt_][j][4 * q + 1] + o.y, acc[mt_][j][4 * q + 2] + o.z,
-                                         acc[mt_][j][4 * q + 3] + o.w};
+                    const float a4[4] = {acc[ab + mt_][j][4 * q + 0] + o.x, acc[ab + mt_][j][4 * q + 1] + o.y, acc[ab + mt_][j][4 * q + 2] + o.z,
+                                         acc[ab + mt_][j][4 * q + 3] + o.w};
                     f16x2      lo = {}, hi = {};
                     const bool in_n = n0 + ncol + 8 * q < N;  // columns beyond a ragged launch edge: nothing to read or keep
                     if constexpr (ACT) {
@@ -711,18 +737,18 @@ __device__ __forceinline__ void gemm_tile_body(
             }
         }
     }
-    if constexpr (RH > 1) __syncthreads();  // the next phase reuses the parked area and the image
+    if constexpr (RH * RB > 1) __syncthreads();  // the next phase reuses the parked area and the image
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     EETQ_GEMM_STAMP(5);
 }
 
-template <int ABLATE, int J, bool ACT = false, int CW = 2, bool GLU = false, int RH = 1>
+template <int ABLATE, int J, bool ACT = false, int CW = 2, bool GLU = false, int RH = 1, int RB = 1>
 __global__ __launch_bounds__(128 * CW * RH, 1) void gemm_tile_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
     f16* __restrict__ y, int M, int N, int K, int ldc, Epilogue ep)
 {
-    gemm_tile_body<ABLATE, J, ACT, CW, false, GLU, RH>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
+    gemm_tile_body<ABLATE, J, ACT, CW, false, GLU, RH, RB>(x, w, scales, y, M, N, K, ldc, ep, 1, nullptr, nullptr);
 }
 
 // Round 5, measured and shelved with their patch (tools/experiments/tile_ring_depth_and_persistent.patch): the

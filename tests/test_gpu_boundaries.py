@@ -158,7 +158,7 @@ np.savez({dst!r}, **out)
 
 
 def test_tall_tile_equals_the_128_row_tile(tmp_path):
-    """The 256 x 128 tile on eight waves (gemm_tile_kernel<..., RH = 2>: both row halves read one weight stage, activation fragments
+    """(and the deep tile, RB = 2: 256 x 128 on FOUR waves with 256 accumulators per lane, hook value 2)  The 256 x 128 tile on eight waves (gemm_tile_kernel<..., RH = 2>: both row halves read one weight stage, activation fragments
     through a four-deep window, two-phase epilogue; measured 5 - 23 % behind the 128 x 128 tile and therefore only reachable through
     the A/B hook EETQ_AMD_TILE_TALL) must give the 128-row tile's BITS: whole and ragged row tiles, ragged column edge, bias and
     residual, an odd and an even number of K steps."""
@@ -166,7 +166,7 @@ def test_tall_tile_equals_the_128_row_tile(tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cases = [(4096, 4096, 2048), (1024, 640, 300), (704, 4096, 1000), (2048, 1008, 513)]
     got = {}
-    for name, hook in (("tile128", None), ("tall256", "1")):
+    for name, hook in (("tile128", None), ("tall256", "1"), ("deep256", "2")):
         dst = str(tmp_path / (name + ".npz"))
         env = dict(os.environ)
         if hook:
@@ -177,3 +177,4 @@ def test_tall_tile_equals_the_128_row_tile(tmp_path):
         got[name] = np.load(dst)
     for key in got["tile128"].files:
         assert np.array_equal(got["tile128"][key], got["tall256"][key]), key
+        assert np.array_equal(got["tile128"][key], got["deep256"][key]), key

@@ -1,4 +1,5 @@
-"""Round 6: the tall tile (256 x 128 on eight waves, gemm_tile_kernel<..., RH = 2>) against the shipping 128 x 128 tile on the explicit
+"""Round 6: the tall tile (256 x 128 on eight waves, gemm_tile_kernel<..., RH = 2>; hook value 1) and the deep tile (256 x 128 on four
+waves with 256 accumulators per lane, RB = 2; hook value 2) against the shipping 128 x 128 tile on the explicit
 MFMA path at M >= 1024: bit-identity of the two outputs and graph-replayed chain times.  One child process per arm (the hook
 EETQ_AMD_TILE_TALL is read once per process, behind EETQ_AMD_TUNING=1)."""
 import json, os, subprocess, sys
@@ -33,7 +34,7 @@ if __name__ == "__main__":
         child()
         sys.exit(0)
     res = {}
-    for name, tall in (("tile128", None), ("tall256", "1")):
+    for name, tall in (("tile128", None), ("tall256", "1"), ("deep256", "2")):
         env = dict(os.environ)
         if tall:
             env["EETQ_AMD_TUNING"] = "1"
@@ -45,6 +46,12 @@ if __name__ == "__main__":
         else:
             print(name, "FAILED", r.stderr[-1500:], file=sys.stderr)
     for key in res.get("tile128", {}):
-        a, b = res["tile128"][key], res.get("tall256", {}).get(key, [None, None])
-        print(json.dumps({"point": key, "tile128_us": a[0], "tall256_us": b[0], "ratio": round(b[0] / a[0], 3) if b[0] else None,
-                          "bit_identical": a[1] == b[1]}), flush=True)
+        a = res["tile128"][key]
+        row = {"point": key, "tile128_us": a[0]}
+        for arm in ("tall256", "deep256"):
+            b = res.get(arm, {}).get(key)
+            if b:
+                row[arm + "_us"] = b[0]
+                row[arm + "_ratio"] = round(b[0] / a[0], 3)
+                row[arm + "_bit_identical"] = a[1] == b[1]
+        print(json.dumps(row), flush=True)
