@@ -79,13 +79,19 @@ for bits, M, K, N in ((8, 2, 4096, 11008), (8, 6, 4096, 11008), (8, 4, 4096, 409
     w = torch.randint(-128, 127, (K, N if bits == 8 else N // 2), dtype=torch.int8, device=dev)
     s = torch.rand(N, dtype=torch.float16, device=dev) * 0.01
     x = torch.randn(M, K, dtype=torch.float16, device=dev)
-    scases.append((x, w, s, ops.w8_a16_gemm(x, w, s).clone()))
+    scases.append((x, w, s, ops.w8_a16_gemm(x, w, s).clone(), "auto"))
+# round 6: the 32-row ring (17 <= M <= 32 on the explicit stream path: four LDS-DMAs per k tile and wave, two MFMA row tiles)
+for M, K, N in ((17, 4096, 4096), (32, 4096, 11008), (24, 5120, 5120)):
+    w = torch.randint(-128, 127, (K, N), dtype=torch.int8, device=dev)
+    s = torch.rand(N, dtype=torch.float16, device=dev) * 0.01
+    x = torch.randn(M, K, dtype=torch.float16, device=dev)
+    scases.append((x, w, s, ops.w8_a16_gemm(x, w, s, path="stream").clone(), "stream"))
 for it in range(n_s):
-    x, w, s, ref = scases[it % len(scases)]
+    x, w, s, ref, pth = scases[it % len(scases)]
     st = streams[it % 3] if it % 4 == 0 else torch.cuda.current_stream()
     st.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(st):
-        y = ops.w8_a16_gemm(x, w, s)
+        y = ops.w8_a16_gemm(x, w, s, path=pth)
     torch.cuda.current_stream().wait_stream(st)
     if it % 7 == 0:
         junk.add_(1)
@@ -124,5 +130,35 @@ for it in range(iters):
     if it % 97 == 0 and (int(counter.item()) != 501 or int(tickets.abs().sum().item()) != 0):
         bad2 += 1000
 print("decode attention: %d launches, %d mismatches; tickets zero: %s" % (iters, bad2, int(tickets.abs().sum().item()) == 0))
+
+# ---- the same launch on a long cache (round 6: chunks of more than 16 blocks take the kernel's second-batch trips), 13B head count
+B, H, Hkv, S = 1, 40, 40, 2300
+fr = torch.einsum("i,j->ij", torch.arange(S + 8).float(), inv)
+table = torch.cat([fr.cos(), fr.sin()], -1).half().to(dev)
+kc = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=dev)
+vc = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=dev)
+qkv = torch.randn(B, 1, (H + 2 * Hkv) * D, dtype=torch.float16, device=dev)
+q = qkv[..., : H * D].unflatten(-1, (H, D))[:, 0]
+k = qkv[..., H * D: (H + Hkv) * D].unflatten(-1, (Hkv, D))[:, 0]
+v = qkv[..., (H + Hkv) * D:].unflatten(-1, (Hkv, D))[:, 0]
+pos = torch.tensor([2200], device=dev)
+tickets = torch.zeros(B * H + 1, dtype=torch.int32, device=dev)
+counter = torch.tensor(2200, dtype=torch.int64, device=dev)
+refs, bad3, n3 = {}, 0, max(1, iters // 2)
+for it in range(n3):
+    splits = (None, 4, 16)[it % 3]
+    counter.fill_(2200)
+    out = ops.rope_decode_attention(pos, q, k, v, table, kc, vc, tickets, slots=counter, splits=splits, kv_len=counter,
+                                    kv_len_bias=1, advance=counter)
+    if it % 7 == 0:
+        junk.add_(1)
+    if splits not in refs:
+        refs[splits] = out.clone()
+    elif not torch.equal(out, refs[splits]):
+        bad3 += 1
+    if it % 97 == 0 and (int(counter.item()) != 2201 or int(tickets.abs().sum().item()) != 0):
+        bad3 += 1000
+print("decode attention, long cache: %d launches, %d mismatches; tickets zero: %s" % (n3, bad3, int(tickets.abs().sum().item()) == 0))
+bad2 += bad3
 print("elapsed %.1f s" % (time.time() - t0))
 sys.exit(1 if bad or bad2 else 0)
