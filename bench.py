@@ -270,7 +270,7 @@ def decode_budget(dec, model, prompt):
         events on the dispatch packets, the quantity rocprofv3 --kernel-trace reports), assigned by launch order -- five launches
         per decoder layer: norm + q|k|v GEMV, rotary + cache write + attention, o GEMV + residual, norm + gate|up GEMV + SiLU,
         down GEMV + residual -- with the algorithmic bytes each family streams per token;
-      * `head_us`: embedding, final norm, fp16 lm_head GEMM, argmax and the token hand-over launches timed as their own graph;
+      * `head_us`: embedding, final norm, fp16 lm_head GEMM and the argmax + token hand-over launch timed as their own graph;
       * `gaps_us` = step - (sum of the above): what lies BETWEEN the dispatches of the graph (the dependent-launch boundaries).
     The sums reproduce the step by construction; `gap_per_launch_us` says how."""
     from eetq_amd import _lib
@@ -322,13 +322,12 @@ def decode_budget(dec, model, prompt):
         sc_out, sc_tok = torch.zeros_like(dec.out_buf), torch.zeros_like(dec.s_tok)
         sc_pos, sc_idx = torch.zeros_like(dec.s_pos), torch.zeros_like(dec.s_idx)
 
-        def head():
+        def head():   # embedding, final norm, lm_head and the step's hand-over exactly as GraphDecoder._advance runs them
             e = base.embed_tokens(dec.s_tok)
-            nxt = model.lm_head(base.norm(h + e))[:, -1].argmax(-1, keepdim=True)
-            sc_out.scatter_(1, sc_idx.expand(dec.batch, 1), nxt)   # the step's hand-over launches (GraphDecoder._advance)
-            sc_tok.copy_(nxt)
-            sc_pos.add_(1)
-            sc_idx.add_(0)
+            lg = model.lm_head(base.norm(h + e))[:, -1]
+            import eetq_amd.ops as _ops
+            _ops.greedy_handover(lg, sc_out, sc_idx, sc_tok, sc_pos)   # argmax + hand-over, one launch (a column beyond the
+            #                                                             scratch buffer is skipped by the kernel)
         head()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g, stream=side):

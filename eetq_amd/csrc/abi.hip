@@ -118,6 +118,11 @@ int eetq::device_cu_count()
     return c;
 }
 
+namespace eetq {
+int launch_greedy_handover(const f16* logits, long row_stride, int vocab, int batch, int64_t* out_buf, long out_stride, int out_cols,
+                           int64_t* s_idx, int64_t* s_tok, int64_t* s_pos, hipStream_t stream);  // norm_rope.hip
+}
+
 extern "C" {
 
 const char* eetq_last_error(void) { return g_last_error.c_str(); }
@@ -721,6 +726,13 @@ int eetq_rotary_neox_kvcache_prefill_f16(const int64_t* positions, void* query, 
                                  static_cast<f16*>(k_cache), static_cast<f16*>(v_cache), batch, q_heads, k_heads, head_size,
                                  rot_dim, strides[0], strides[1], strides[2], strides[3], strides[4], strides[5],
                                  max_positions, static_cast<hipStream_t>(stream), tokens, first_row);
+}
+
+int eetq_greedy_handover_f16(const void* logits, long row_stride, int vocab, int batch, int64_t* out_tokens, long out_stride,
+                             int out_cols, int64_t* column, int64_t* next_token, int64_t* position, void* stream)
+{
+    return eetq::launch_greedy_handover(static_cast<const f16*>(logits), row_stride, vocab, batch, out_tokens, out_stride, out_cols,
+                                        column, next_token, position, static_cast<hipStream_t>(stream));
 }
 
 int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slots, int slot_stride, const void* query,

@@ -189,7 +189,75 @@ __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions
     }
 }
 
+// Greedy decode hand-over (extension for the HIP-graph decoder, utils/graph_decoder.py): per batch row the index of the row's
+// maximum logit -- the FIRST one on ties, a NaN counts as the maximum, like torch.argmax -- written to out_buf[b][*s_idx] and to
+// s_tok[b]; then *s_pos += 1 and *s_idx += 1.  ONE workgroup walks the rows (batch is small), so the column is read before anyone
+// advances it.  Replaces argmax + scatter_ + copy_ + two add_ launches of every decoded token (~25 us of launches -> ~5).
+__global__ __launch_bounds__(1024) void greedy_handover_kernel(const f16* __restrict__ logits, long row_stride, int vocab, int batch,
+                                                               int64_t* __restrict__ out_buf, long out_stride, int out_cols,
+                                                               int64_t* __restrict__ s_idx, int64_t* __restrict__ s_tok,
+                                                               int64_t* __restrict__ s_pos)
+{
+    __shared__ unsigned long long best_of_wave[16];
+    const int     tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t col = *s_idx;
+    auto key_of = [](f16 v, int idx) -> unsigned long long {
+        const unsigned short u = __builtin_bit_cast(unsigned short, v);
+        // monotone 16-bit key of the fp16 value, every NaN above +inf; the low word prefers the smaller index
+        // (-0 and +0 share one key: they compare equal)
+        const unsigned k = ((u & 0x7FFF) > 0x7C00) ? 0xFFFFu : ((u & 0x7FFF) == 0) ? 0x8000u : (u & 0x8000) ? (unsigned)(unsigned short)~u : (unsigned)(u | 0x8000);
+        return ((unsigned long long)k << 32) | (unsigned)(0xFFFFFFFFu - (unsigned)idx);
+    };
+    for (int b = 0; b < batch; ++b) {
+        const f16*         row  = logits + b * row_stride;
+        unsigned long long best = 0;
+        const int          vec  = ((uintptr_t)row % 16 == 0) ? (vocab & ~7) : 0;
+        for (int i = tid * 8; i < vec; i += 1024 * 8) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(row + i);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long k = key_of(v[j], i + j);
+                best = k > best ? k : best;
+            }
+        }
+        for (int i = vec + tid; i < vocab; i += 1024) {
+            const unsigned long long k = key_of(row[i], i);
+            best = k > best ? k : best;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned long long o = __shfl_xor(best, m, 64);
+            best = o > best ? o : best;
+        }
+        if (lane == 0) best_of_wave[wave] = best;
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long t = best_of_wave[0];
+#pragma unroll
+            for (int w = 1; w < 16; ++w) t = best_of_wave[w] > t ? best_of_wave[w] : t;
+            const int64_t tok = (int64_t)(0xFFFFFFFFu - (unsigned)(t & 0xFFFFFFFFu));
+            if (col >= 0 && col < out_cols) out_buf[b * out_stride + col] = tok;
+            s_tok[b] = tok;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        *s_pos += 1;
+        *s_idx = col + 1;
+    }
+}
+
 }  // namespace
+
+int launch_greedy_handover(const f16* logits, long row_stride, int vocab, int batch, int64_t* out_buf, long out_stride, int out_cols,
+                           int64_t* s_idx, int64_t* s_tok, int64_t* s_pos, hipStream_t stream)
+{
+    EETQ_REQUIRE(logits && out_buf && s_idx && s_tok && s_pos, "null pointer");
+    EETQ_REQUIRE(vocab > 0 && batch >= 0 && out_cols > 0 && row_stride >= vocab && out_stride >= out_cols, "invalid shape");
+    if (batch == 0) return EETQ_OK;
+    greedy_handover_kernel<<<1, 1024, 0, stream>>>(logits, row_stride, vocab, batch, out_buf, out_stride, out_cols, s_idx, s_tok, s_pos);
+    return check_hip(hipGetLastError(), "greedy_handover_kernel launch");
+}
 
 int launch_rotary_kvcache(const int64_t* pos, const int64_t* slots, int slot_stride, f16* q, const f16* k, const f16* v,
                           const f16* cache, f16* kcache, f16* vcache, int batch, int q_heads, int k_heads, int head_size, int rot_dim, long q_stride,

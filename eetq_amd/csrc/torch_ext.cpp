@@ -566,6 +566,25 @@ void rotary_embedding_neox_kvcache_prefill(const Tensor& positions, Tensor& quer
                                                (int)cos_sin_cache.size(1), strides, (int)key_cache.size(2), stream_of(query)));
 }
 
+// Greedy decode hand-over (extension): argmax of logits [B, V] (fp16, dense rows) -> out_tokens[:, column] and next_token, then
+// position += 1, column += 1, all on the device in one launch (eetq_greedy_handover_f16)
+void greedy_handover(const Tensor& logits, Tensor& out_tokens, Tensor& column, Tensor& next_token, Tensor& position)
+{
+    const char* name = "greedy_handover: ";
+    TORCH_CHECK(logits.is_cuda() && logits.scalar_type() == at::kHalf && logits.dim() == 2 && logits.stride(1) == 1, name,
+                "logits must be a float16 CUDA tensor [B, V] with dense rows");
+    const int64_t B = logits.size(0), V = logits.size(1);
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&out_tokens, &column, &next_token, &position})
+        TORCH_CHECK(t->scalar_type() == at::kLong && t->device() == logits.device(), name, "int64 tensors on the logits' device expected");
+    TORCH_CHECK(out_tokens.dim() == 2 && out_tokens.size(0) == B && out_tokens.stride(1) == 1 && next_token.numel() == B &&
+                    next_token.is_contiguous() && column.numel() == 1 && position.numel() == 1 && V > 0,
+                name, "shape mismatch");
+    c10::DeviceGuard guard(logits.device());
+    check(eetq_greedy_handover_f16(logits.data_ptr(), (long)logits.stride(0), (int)V, (int)B, out_tokens.data_ptr<int64_t>(),
+                                   (long)out_tokens.stride(0), (int)out_tokens.size(1), column.data_ptr<int64_t>(),
+                                   next_token.data_ptr<int64_t>(), position.data_ptr<int64_t>(), stream_of(logits)));
+}
+
 Tensor decode_attention(const Tensor& query, const Tensor& key_cache, const Tensor& value_cache, const OptTensor& mask,
                         std::optional<double> scaling, std::optional<int64_t> splits_in, const OptTensor& kv_len,
                         int64_t kv_len_bias, const OptTensor& advance)
@@ -812,6 +831,8 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("positions"), py::arg("query"), py::arg("key"), py::arg("value"), py::arg("head_size"),
           py::arg("cos_sin_cache"), py::arg("key_cache"), py::arg("value_cache"), py::arg("first_row") = 0,
           py::arg("first_row_dev") = py::none());
+    m.def("greedy_handover", &greedy_handover, "argmax + token hand-over of a greedy decode step", py::arg("logits"),
+          py::arg("out_tokens"), py::arg("column"), py::arg("next_token"), py::arg("position"));
     m.def("decode_attention", &decode_attention, "single-query attention over a KV cache", py::arg("query"),
           py::arg("key_cache"), py::arg("value_cache"), py::arg("mask") = py::none(), py::arg("scaling") = py::none(),
           py::arg("splits") = py::none(), py::arg("kv_len") = py::none(), py::arg("kv_len_bias") = 0,

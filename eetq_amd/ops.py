@@ -37,6 +37,7 @@ if _C is not None:
     rotary_embedding_neox_strided = _C.rotary_embedding_neox_strided
     rotary_embedding_neox_kvcache = _C.rotary_embedding_neox_kvcache
     rotary_embedding_neox_kvcache_prefill = _C.rotary_embedding_neox_kvcache_prefill
+    greedy_handover = _C.greedy_handover
     decode_attention = _C.decode_attention
     rope_decode_attention = _C.rope_decode_attention
     silu_mul = _C.silu_mul
@@ -44,7 +45,7 @@ if _C is not None:
     llama_decode_layer = _C.llama_decode_layer   # compiled boundary only: its point is the interpreter time it saves
 else:
     BOUNDARY = "ctypes"
-    from .ops_ctypes import (decode_attention, layernorm_forward, preprocess_weights, quant_weights,  # noqa: F401
+    from .ops_ctypes import (decode_attention, greedy_handover, layernorm_forward, preprocess_weights, quant_weights,  # noqa: F401
                              rope_decode_attention, rotary_embedding_neox, rotary_embedding_neox_kvcache,
                              rotary_embedding_neox_kvcache_prefill, rotary_embedding_neox_strided, silu_mul,
                              unprocess_weights, w8_a16_gemm, w8_a16_gemm_, w8_a16_gemv_grouped)
@@ -52,7 +53,7 @@ else:
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_", "layernorm_forward",
            "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "rotary_embedding_neox_kvcache_prefill",
-           "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped", "decode_dropped_steps",
+           "greedy_handover", "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped", "decode_dropped_steps",
            "release_stream_workspace", "release_workspace", "BOUNDARY"]
 
 

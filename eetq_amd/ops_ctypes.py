@@ -25,7 +25,7 @@ from ._lib import (ACT_GELU, ACT_IDENTITY, ACT_RELU, ACT_SILU, DTYPE_F16, DTYPE_
                    LAYOUT_SM80, PATH_AUTO, PATH_GEMV, PATH_MFMA, check)
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_",
-           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "rotary_embedding_neox_kvcache_prefill", "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped"]
+           "layernorm_forward", "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "rotary_embedding_neox_kvcache_prefill", "greedy_handover", "decode_attention", "rope_decode_attention", "silu_mul", "convert_layout", "w8_a16_gemv_grouped"]
 
 _LAYOUTS = {"gfx950": LAYOUT_GFX950, "native": LAYOUT_GFX950, "sm80": LAYOUT_SM80, "row_major": LAYOUT_ROW_MAJOR,
             LAYOUT_GFX950: LAYOUT_GFX950, LAYOUT_SM80: LAYOUT_SM80, LAYOUT_ROW_MAJOR: LAYOUT_ROW_MAJOR}
@@ -673,6 +673,28 @@ def rotary_embedding_neox_kvcache_prefill(positions, query, key, value, head_siz
                                                               _ptr(first_row_dev) if first_row_dev is not None else None,
                                                               int(first_row), H, Hkv, int(head_size), cos_sin_cache.shape[1],
                                                               strides, key_cache.shape[2], _stream_ptr()))
+    return None
+
+
+@_eager_only
+def greedy_handover(logits, out_tokens, column, next_token, position):
+    """Greedy decode hand-over in one launch: ``argmax`` of ``logits`` [B, V] (fp16; first index on ties, NaN = maximum, like
+    ``torch.argmax``) goes to ``out_tokens[:, column]`` and ``next_token`` [B]; then ``position += 1`` and ``column += 1``
+    (int64 device scalars).  (eetq_greedy_handover_f16)"""
+    name = "greedy_handover: "
+    if not logits.is_cuda or logits.dtype != torch.float16 or logits.dim() != 2 or logits.stride(1) != 1:
+        raise RuntimeError(name + "logits must be a float16 CUDA tensor [B, V] with dense rows")
+    B, V = logits.shape
+    for t in (out_tokens, column, next_token, position):
+        if t.dtype != torch.int64 or t.device != logits.device:
+            raise RuntimeError(name + "int64 tensors on the logits' device expected")
+    if (out_tokens.dim() != 2 or out_tokens.shape[0] != B or out_tokens.stride(1) != 1 or next_token.numel() != B
+            or not next_token.is_contiguous() or column.numel() != 1 or position.numel() != 1 or V <= 0):
+        raise RuntimeError(name + "shape mismatch")
+    with torch.cuda.device(logits.device):
+        check(_lib.lib().eetq_greedy_handover_f16(_ptr(logits), logits.stride(0), V, B, _ptr(out_tokens), out_tokens.stride(0),
+                                                  out_tokens.shape[1], _ptr(column), _ptr(next_token), _ptr(position),
+                                                  _stream_ptr()))
     return None
 
 

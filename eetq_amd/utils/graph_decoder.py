@@ -89,7 +89,8 @@ class GraphDecoder:
         return (self.lean and layers is not None and len(layers) > 0 and hasattr(base, "embed_tokens") and hasattr(base, "norm")
                 and hasattr(self.model, "lm_head") and all(getattr(l, "fused_layer_step", False) for l in layers))
 
-    def _step(self):
+    def _logits(self):
+        """The last position's logits [batch, vocab] of one decode step on the static tensors."""
         if self._lean():
             base = self.model.model
             h = base.embed_tokens(self.s_tok)
@@ -101,12 +102,21 @@ class GraphDecoder:
             lg = self.model.lm_head(base.norm(h))
         else:
             lg = self.model(self.s_tok, past_key_values=self.cache, cache_position=self.s_pos, use_cache=True).logits
-        return lg[:, -1].argmax(-1, keepdim=True)
+        return lg[:, -1]
+
+    def _step(self):
+        return self._logits().argmax(-1, keepdim=True)
 
     def _advance(self):
         """One step and its hand-over, all on the device: the new token goes to its output column and becomes the next
-        input id; position and output column move on."""
-        nxt = self._step()
+        input id; position and output column move on -- one library launch (``ops.greedy_handover``: torch.argmax's answer)
+        where the logits are fp16 on the GPU, otherwise argmax + scatter_ + copy_ + two add_."""
+        lg = self._logits()
+        if lg.is_cuda and lg.dtype == torch.float16 and lg.stride(-1) == 1:
+            from .. import ops
+            ops.greedy_handover(lg, self.out_buf, self.s_idx, self.s_tok, self.s_pos)
+            return
+        nxt = lg.argmax(-1, keepdim=True)
         self.out_buf.scatter_(1, self.s_idx.expand(self.batch, 1), nxt)
         self.s_tok.copy_(nxt)
         self.s_pos.add_(1)

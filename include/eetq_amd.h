@@ -78,7 +78,7 @@ enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SIL
  *   allocate eetq_quantize_workspace_floats() floats should move to eetq_quantize_i8_ws to get the faster route. */
 /* Revision history: 1 = round 1-2; 2 = eetq_quantize_i8_ws (sized workspace), eetq_release_stream_workspace, eetq_w4a16_gemm_ex;
  * 3 = eetq_diag_auto_path, EETQ_PATH_SPLITK accepts M <= 1024 (row groups); 4 = eetq_diag_splitk_plan; 5 =
- * eetq_rotary_neox_kvcache_prefill_f16.  Revisions only ADD entry points: a caller built against an older header keeps working. */
+ * eetq_rotary_neox_kvcache_prefill_f16, eetq_greedy_handover_f16, eetq_w8a16_gemm_glu8 at M > 16.  Revisions only ADD entry points: a caller built against an older header keeps working. */
 #define EETQ_AMD_ABI_VERSION 5
 int eetq_abi_version(void);   /* EETQ_AMD_ABI_VERSION of the loaded library */
 int eetq_quantize_i8_ws(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
@@ -273,6 +273,15 @@ int eetq_rotary_neox_kvcache_prefill_f16(const int64_t* positions, void* query, 
                                          const void* cos_sin_cache, void* k_cache, void* v_cache, int batch, int tokens,
                                          const int64_t* first_row_dev, int first_row, int q_heads, int k_heads, int head_size,
                                          int rot_dim, const long* strides, int max_positions, void* stream);
+
+/* Greedy decode hand-over (extension, ABI 5; the reference's recipe leaves this to transformers' generate loop,
+ * examples/models/llama_transformers_example.py:68-79): for each of `batch` rows of fp16 logits [batch][vocab] (row_stride
+ * elements apart) the index of the maximum -- the first one on ties, a NaN counts as the maximum: torch.argmax's answer -- is
+ * written to out_tokens[b][*column] ([batch][out_cols] int64, out_stride elements apart; skipped when *column is outside
+ * [0, out_cols)) and to next_token[b]; then *position += 1 and *column += 1 (DEVICE int64 scalars).  One launch, capturable:
+ * what a HIP-graph decode loop does between two model steps. */
+int eetq_greedy_handover_f16(const void* logits, long row_stride, int vocab, int batch, int64_t* out_tokens, long out_stride,
+                             int out_cols, int64_t* column, int64_t* next_token, int64_t* position, void* stream);
 
 /* Single-query (decode) attention over a KV cache; extension used by the EET attention blocks' decode step (the
  * reference delegates the attention product to flash-attn, python/eetq/modules/llama_modules.py:131-143).

@@ -158,3 +158,40 @@ def test_many_steps_under_graph_replay(ops):
         assert torch.equal(out_a, out_b), step
         assert int(cnt_b.item()) == 101 + step
     assert torch.equal(kc_a, kc_b) and torch.equal(vc_a, vc_b) and torch.count_nonzero(tickets) == 0
+
+
+def test_greedy_handover_is_torch_argmax_plus_bookkeeping():
+    """eetq_greedy_handover_f16: argmax (first index on ties, NaN = maximum, -0 == +0, all -inf rows, unaligned and odd-length rows)
+    written to the output column and the next-token tensor, position and column advanced -- against torch.argmax + the four
+    torch launches it replaces; a column outside the output buffer writes nothing there but still hands the token on."""
+    import eetq_amd.ops as ops
+    torch.manual_seed(5)
+    for B, V in ((1, 32000), (4, 32000), (3, 1001), (2, 7), (1, 128256)):
+        lg = (torch.randn(B, V, device=DEV) * 3).half()
+        if V > 100:
+            lg[0, 17] = lg[0, 90] = lg[0].max() + 1          # a tie: the first index wins
+            if B > 1:
+                lg[1, 5] = float("nan")                       # NaN is the maximum ...
+                lg[1, 3] = float("inf")                       # ... even next to +inf
+            if B > 2:
+                lg[2] = float("-inf")                         # nothing but -inf: index 0
+        else:
+            lg[0] = 0.0
+            lg[0, 2] = -0.0                                   # -0 == +0: index 0
+        ref = lg.argmax(-1)
+        out = torch.full((B, 6), -7, dtype=torch.int64, device=DEV)
+        col = torch.tensor([[2]], dtype=torch.int64, device=DEV)
+        tok = torch.full((B, 1), -1, dtype=torch.int64, device=DEV)
+        pos = torch.tensor([40], dtype=torch.int64, device=DEV)
+        ops.greedy_handover(lg, out, col, tok, pos)
+        assert torch.equal(tok[:, 0], ref) and torch.equal(out[:, 2], ref)
+        assert (out[:, [0, 1, 3, 4, 5]] == -7).all() and int(col) == 3 and int(pos) == 41
+        view = lg[:, 1:]                                       # rows that are not 16-byte aligned
+        ops.greedy_handover(view, out, col, tok, pos)
+        assert torch.equal(tok[:, 0], view.argmax(-1)) and torch.equal(out[:, 3], view.argmax(-1)) and int(col) == 4
+        col.fill_(6)                                           # beyond the buffer: no write, the token is still handed on
+        before = out.clone()
+        ops.greedy_handover(lg, out, col, tok, pos)
+        assert torch.equal(out, before) and torch.equal(tok[:, 0], ref) and int(col) == 7 and int(pos) == 43
+    with pytest.raises(RuntimeError):
+        ops.greedy_handover(lg.float(), out, col, tok, pos)
