@@ -150,6 +150,30 @@ __device__ __forceinline__ float dot_lane(const u32x4& wv, f16x2 scale2, const u
     return acc;
 }
 
+// acc += wq . (one dword of x read from lane SRC of this lane's 16-lane row): DPP row broadcast on the dot product's own operand
+// -- no LDS, no extra instruction.  In the native tile a 16-lane row is one k-group: its lanes all need the same 16 k of x.
+template <int SRC>
+__device__ __forceinline__ float dot2_row_bcast(f16x2 wq, u32 xreg, float acc)
+{
+    asm("v_dot2c_f32_f16_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(xreg), "v"(wq), "n"(SRC));
+    return acc;
+}
+// Tile d (0..3) of a wave's four: the row's 32 dwords of x ([tile][dword]) sit two per lane, lane c holding 2c and 2c + 1
+// (xp0, xp1); pair i of the tile is dword 8d + i.  Same products, same order as the sixteen-bytes-per-lane form: same bits.
+template <int DT>
+__device__ __forceinline__ float dot_tile_row_bcast(const f16x2 (&wq)[8], u32 xp0, u32 xp1, float acc)
+{
+    acc = dot2_row_bcast<DT * 4 + 0>(wq[0], xp0, acc);
+    acc = dot2_row_bcast<DT * 4 + 0>(wq[1], xp1, acc);
+    acc = dot2_row_bcast<DT * 4 + 1>(wq[2], xp0, acc);
+    acc = dot2_row_bcast<DT * 4 + 1>(wq[3], xp1, acc);
+    acc = dot2_row_bcast<DT * 4 + 2>(wq[4], xp0, acc);
+    acc = dot2_row_bcast<DT * 4 + 2>(wq[5], xp1, acc);
+    acc = dot2_row_bcast<DT * 4 + 3>(wq[6], xp0, acc);
+    acc = dot2_row_bcast<DT * 4 + 3>(wq[7], xp1, acc);
+    return acc;
+}
+
 // One 1 KiB tile: this lane's k values of column c against the matching activations of every batch row.
 // xs = this lane's window of the LDS copy of x (row m at xs + m*K halfs).
 template <int M, int BITS = 8>
@@ -186,7 +210,10 @@ __device__ __forceinline__ void consume_tile(const u32x4& wv, f16x2 scale2, cons
 //   else  : every wave owns >= D tiles; software-pipelined loop with unconditional refills, then a clamped
 //           (possibly redundant, L2-resident) tail batch whose *use* is predicated.
 //   XREG  : (EXACT only) activations go straight to registers, issued ahead of the weight stream so they
-//           retire at L2 latency; no LDS, no barrier before the math.
+//           retire at L2 latency; no LDS, no barrier before the math.  M = 1, int8, D = 4 (the K = 4096 form): ONE 8-byte load
+//           per lane -- the 16 lanes of a k-group hold the group's 32 dwords of x between them, two each -- and the dot
+//           products take their operand from the owning lane by DPP row broadcast (round 6: 128 KiB of lane data per
+//           workgroup became 8; profiles/r06_gemv_ladder3.txt rung 11, -0.07 us, same bits).
 //   else  : activations are staged once per workgroup in LDS (XV 16-byte loads per thread, clamped).
 // Dynamic LDS: [M*K fp16 activations unless XREG] + WAVES*M*16 floats (cross-wave reduction).
 // The body is a device function of the tile row `ntile` so that the grouped launch (one dispatch over the tile rows of
@@ -219,9 +246,16 @@ __device__ __forceinline__ void gemv_body(
     // retire at L2 latency while the weight stream is already queued right behind them.
     u32 sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
 
-    u32x4 xr[XREG ? M * D * XQ : 1];  // XREG: this lane's activations for each of its D tiles, per batch row
+    constexpr bool XBC = XREG && M == 1 && BITS == 8 && D == 4;  // activations by row broadcast (see XREG above)
+    u32x4 xr[XREG && !XBC ? M * D * XQ : 1];  // XREG: this lane's activations for each of its D tiles, per batch row
     u32x4 xv[XREG ? 1 : XV];
-    if constexpr (XREG) {
+    u32   xp0 = 0, xp1 = 0;
+    if constexpr (XBC) {
+        // lane (g, c): dwords 2c, 2c + 1 of row g's list [tile d][dword i] -> tile c >> 2, dwords 2 (c & 3), + 1
+        using u32x2 = __attribute__((ext_vector_type(2))) u32;
+        const u32x2 v = *reinterpret_cast<const u32x2*>(x + (wave + (c >> 2) * WAVES) * TK + LK * g + 4 * (c & 3));
+        xp0 = v.x, xp1 = v.y;
+    } else if constexpr (XREG) {
 #pragma unroll
         for (int m = 0; m < M; ++m)
 #pragma unroll
@@ -275,7 +309,17 @@ __device__ __forceinline__ void gemv_body(
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[m] = 0.f;
 
-    if constexpr (XREG) {
+    if constexpr (XBC) {
+        f16x2 wq[8];
+        dequant_16(buf[0], scale2, wq);
+        acc[0] = dot_tile_row_bcast<0>(wq, xp0, xp1, acc[0]);
+        dequant_16(buf[1], scale2, wq);
+        acc[0] = dot_tile_row_bcast<1>(wq, xp0, xp1, acc[0]);
+        dequant_16(buf[2], scale2, wq);
+        acc[0] = dot_tile_row_bcast<2>(wq, xp0, xp1, acc[0]);
+        dequant_16(buf[3], scale2, wq);
+        acc[0] = dot_tile_row_bcast<3>(wq, xp0, xp1, acc[0]);
+    } else if constexpr (XREG) {
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             if constexpr (BITS == 8) {

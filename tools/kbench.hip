@@ -134,6 +134,32 @@ __global__ void stream_read_kernel(const u32x4* __restrict__ p, unsigned* __rest
 //      32..63 duplicate) instead of eight, a ds_write_b128, eight ds_read_b128 -- no workgroup barrier in front of the math
 //   9  level 1 with the scale load only (no activation loads)
 //  10  level 8 with the 512 bytes fetched by lanes 0..31 only (exec-masked load)
+//  11  level 5 with the activations fetched ONCE per wave (8 bytes per lane: the 16 lanes of a k-group hold the group's 32 dwords
+//      of x, two each) and handed to the dot products by DPP row broadcast on the v_dot2c operand: no LDS, no extra instruction
+// acc += wq[i] . x dword (tile d, i), the x dword read from lane d * 4 + (i >> 1) of this lane's 16-lane row (row_newbcast)
+template <int SRC>
+__device__ __forceinline__ float dot2_bcast(eetq::f16x2 wq, eetq::u32 xreg, float acc)
+{
+    asm volatile("v_dot2c_f32_f16_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(xreg), "v"(wq), "n"(SRC));
+    return acc;
+}
+__device__ __forceinline__ void ladder_dot_bcast(const eetq::f16x2 (&wq)[8], eetq::u32 xp0, eetq::u32 xp1, int d, float& acc)
+{
+#define EETQ_LD(dd)                                                  \
+    case dd:                                                         \
+        acc = dot2_bcast<dd * 4 + 0>(wq[0], xp0, acc);               \
+        acc = dot2_bcast<dd * 4 + 0>(wq[1], xp1, acc);               \
+        acc = dot2_bcast<dd * 4 + 1>(wq[2], xp0, acc);               \
+        acc = dot2_bcast<dd * 4 + 1>(wq[3], xp1, acc);               \
+        acc = dot2_bcast<dd * 4 + 2>(wq[4], xp0, acc);               \
+        acc = dot2_bcast<dd * 4 + 2>(wq[5], xp1, acc);               \
+        acc = dot2_bcast<dd * 4 + 3>(wq[6], xp0, acc);               \
+        acc = dot2_bcast<dd * 4 + 3>(wq[7], xp1, acc);               \
+        break;
+    switch (d) { EETQ_LD(0) EETQ_LD(1) EETQ_LD(2) EETQ_LD(3) }
+#undef EETQ_LD
+}
+
 template <int LEVEL>
 __global__ __launch_bounds__(1024, 8) void gemv_ladder_kernel(const eetq::f16* __restrict__ x, const uint8_t* __restrict__ w,
                                                                const eetq::f16* __restrict__ scales, eetq::f16* __restrict__ y,
@@ -149,7 +175,14 @@ __global__ __launch_bounds__(1024, 8) void gemv_ladder_kernel(const eetq::f16* _
     __shared__ __attribute__((aligned(16))) u32x4 xw[WAVES * 32];  // levels 8 / 10: 512 bytes of x per wave
     u32x4 xstage = {};
     if constexpr (LEVEL >= 1) sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
-    if constexpr (LEVEL == 8 || LEVEL == 10) {
+    u32 xp0 = 0, xp1 = 0;
+    if constexpr (LEVEL == 11 || LEVEL == 12) {
+        // lane (g, c): dwords 2c, 2c + 1 of row g's list [tile d][dword i] = [d * 8 + i]
+        const u32* p = reinterpret_cast<const u32*>(x + (wave + (c >> 2) * WAVES) * 64 + 16 * g + 4 * (c & 3));
+        const auto v = *reinterpret_cast<const __attribute__((ext_vector_type(2))) u32*>(p);
+        xp0 = v.x, xp1 = v.y;
+        if constexpr (LEVEL == 12) __builtin_amdgcn_sched_barrier(0);  // the activation load stays ahead of the weight stream
+    } else if constexpr (LEVEL == 8 || LEVEL == 10) {
         // lane L (mod 32): 16-byte piece L & 7 of the wave's tile d = (L >> 3) & 3
         const int L = lane & 31;
         const u32x4* p = reinterpret_cast<const u32x4*>(x + (wave + (L >> 3) * WAVES) * 64) + (L & 7);
@@ -195,6 +228,10 @@ __global__ __launch_bounds__(1024, 8) void gemv_ladder_kernel(const eetq::f16* _
         for (int d = 0; d < D; ++d) {
             f16x2 wq[8];
             dequant_16(buf[d], scale2, wq);
+            if constexpr (LEVEL == 11 || LEVEL == 12) {
+                ladder_dot_bcast(wq, xp0, xp1, d, acc);
+                continue;
+            }
             const u32x4 xa = xr[d * 2], xb = xr[d * 2 + 1];
             const u32   xd[8] = {xa.x, xa.y, xa.z, xa.w, xb.x, xb.y, xb.z, xb.w};
 #pragma unroll
@@ -717,11 +754,22 @@ int main(int argc, char** argv)
         // one ablation ladder from the load-only kernel to the shipping GEMV, every rung chain-timed (one graph of 1200 dependent
         // launches over the 40 rotating weight sets) and dispatch-timed on the same box, three passes in alternating order
         const int  N = 4096, K = 4096, ITERS = 1200;
-        const char* names[11] = {"0 weight loads only", "1 + scale / x loads first", "2 + dequant, dot2", "3 + wave butterflies",
+        const char* names[13] = {"0 weight loads only", "1 + scale / x loads first", "2 + dequant, dot2", "3 + wave butterflies",
                                  "4 + LDS, barrier, wave-0 sum", "5 + 32-byte store (= GEMV)", "6 = 5, store sc0 sc1",
                                  "7 = 5, sum by 4 waves", "8 = 5, x staged per wave in LDS", "9 = 1, scale load only",
-                                 "10 = 8, 32-lane x load"};
-        constexpr int NL = 11;
+                                 "10 = 8, 32-lane x load", "11 = 5, x by DPP row broadcast", "12 = 11, x load pinned first"};
+        constexpr int NL = 13;
+        {   // level 11 must give level 5's bits
+            std::vector<uint16_t> y5(N), y11(N);
+            hipLaunchKernelGGL(gemv_ladder_kernel<5>, dim3(N / 16), dim3(1024), 0, 0, x, (const uint8_t*)bufs[3], scales, y, N, K, out);
+            CK(hipMemcpy(y5.data(), y, N * 2, hipMemcpyDeviceToHost));
+            CK(hipMemset(y, 0, N * 2));
+            hipLaunchKernelGGL(gemv_ladder_kernel<11>, dim3(N / 16), dim3(1024), 0, 0, x, (const uint8_t*)bufs[3], scales, y, N, K, out);
+            CK(hipMemcpy(y11.data(), y, N * 2, hipMemcpyDeviceToHost));
+            int bad = 0;
+            for (int i = 0; i < N; ++i) bad += y5[i] != y11[i];
+            printf("level 11 vs level 5: %d of %d outputs differ (y[0] = 0x%04x / 0x%04x)\n", bad, N, y5[0], y11[0]);
+        }
         double chain[3][NL + 1], disp[3][NL + 1], plain_chain[3];
         auto run = [&](auto kern, int pass, int idx) {
             chain[pass][idx] = time_graph(
@@ -751,6 +799,8 @@ int main(int argc, char** argv)
                 case 8: run(gemv_ladder_kernel<8>, pass, 8); break;
                 case 9: run(gemv_ladder_kernel<9>, pass, 9); break;
                 case 10: run(gemv_ladder_kernel<10>, pass, 10); break;
+                case 11: run(gemv_ladder_kernel<11>, pass, 11); break;
+                case 12: run(gemv_ladder_kernel<12>, pass, 12); break;
                 }
             };
             if (pass & 1) for (int l = NL - 1; l >= 0; --l) body(l);
