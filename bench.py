@@ -855,6 +855,7 @@ def main():
             "config": {"workload": "w8a16 GEMV M=1, N=K=4096 (BASELINE configs[1]); %d distinct weight sets rotated (%d MiB)"
                                    % (nbuf, nbuf * K * N // (1 << 20)), "M": M, "N": N, "K": K,
                        "parallelism": "replicas x%d (no data-path collective)" % grp.world_size,
+                       "fan_out_backend": grp.backend_note or (grp.backend if grp.world_size > 1 else "none (one replica)"),
                        "launch": "one HIP graph of %d dependent launches (= %d x the %d-step sequence, whole passes over the "
                                  "weight sets; its length does not depend on --steps), replayed %d times (%d timed steps, "
                                  "%.1f ms)" % (graph_len, graph_len // steps, steps, replays, timed_steps, seconds * 1e3),

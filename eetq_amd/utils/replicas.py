@@ -32,14 +32,39 @@ class ReplicaGroup:
         # whole N > 1 path of bench.py, with gloo carrying the three latency-bound collectives
         self.backend = backend or os.environ.get("EETQ_REPLICA_BACKEND") or ("nccl" if self.device.type == "cuda" else "gloo")
         self._own_pg = False
+        self.backend_note = None  # set when RCCL could not be brought up and gloo carries the collectives instead
         if self.world_size > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29500")
-            kw = {}
-            if self.backend == "nccl":
-                kw["device_id"] = self.device
-            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world_size, **kw)
+            self._init_group()
             self._own_pg = True
+
+    def _init_group(self):
+        """RCCL first (device_id makes the communicator come up inside init_process_group, on every rank at once, so a
+        failure shows here and on all of them); if that raises, the three collectives -- all of them latency-bound and outside
+        the kernels -- are carried by gloo through host memory and `backend_note` says so: N replicas still produce a number.
+        EETQ_REPLICA_STRICT=1 keeps the exception."""
+        if self.backend != "nccl":
+            dist.init_process_group(self.backend, rank=self.rank, world_size=self.world_size)
+            return
+        try:
+            dist.init_process_group("nccl", rank=self.rank, world_size=self.world_size, device_id=self.device)
+            probe = torch.ones(1, device=self.device)
+            dist.all_reduce(probe)  # first collective on the communicator: a broken xGMI / IPC setup fails here, not mid-bench
+            torch.cuda.synchronize(self.device)
+            if int(probe.item()) != self.world_size:
+                raise RuntimeError("RCCL all_reduce probe returned %r for %d ranks" % (probe.item(), self.world_size))
+        except Exception as e:  # noqa: BLE001 -- whatever RCCL raised, the replicas themselves do not need it
+            if os.environ.get("EETQ_REPLICA_STRICT") == "1":
+                raise
+            import sys
+            print("[eetq_amd] rank %d: RCCL process group failed (%s: %s); fan-out falls back to gloo" %
+                  (self.rank, type(e).__name__, str(e).splitlines()[0] if str(e) else ""), file=sys.stderr)
+            if dist.is_initialized():
+                dist.destroy_process_group()
+            self.backend = "gloo"
+            self.backend_note = "gloo (RCCL init failed: %s)" % type(e).__name__
+            dist.init_process_group("gloo", rank=self.rank, world_size=self.world_size)
 
     @property
     def collective_device(self):

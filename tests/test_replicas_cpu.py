@@ -175,3 +175,41 @@ def test_collectives_use_device_tensors_under_rccl():
         os.environ.update(env)
     src = open(os.path.join(ROOT, "eetq_amd", "utils", "replicas.py")).read()
     assert src.count("device=self.collective_device") == 2        # both collective inputs are built there
+
+
+# RCCL that cannot come up (a broken IPC / xGMI setup on the node) must not cost the run its number: the group falls back to
+# gloo on every rank, says so, and the three collectives still work.  "nccl" does not exist on this CPU box, which is exactly
+# the failure: init_process_group("nccl", device_id=...) raises on both ranks.
+WORKER_FALLBACK = textwrap.dedent("""
+    import sys, torch
+    sys.path.insert(0, %r)
+    torch.cuda.set_device = lambda d: None
+    torch.cuda.synchronize = lambda *a, **k: None
+    from eetq_amd.utils.replicas import ReplicaGroup
+    g = ReplicaGroup(backend="nccl", device="cuda:0")
+    assert g.backend == "gloo" and g.backend_note.startswith("gloo (RCCL init failed"), (g.backend, g.backend_note)
+    assert g.collective_device.type == "cpu"
+    x = torch.full((3,), float(g.rank + 5))
+    g.fan_out(x)
+    assert torch.equal(x, torch.full((3,), 5.0))
+    assert g.max_over_ranks(float(g.rank)) == 1.0
+    g.close()
+    print("rank", g.rank, "ok")
+""")
+
+
+def test_rccl_failure_falls_back_to_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_FALLBACK % ROOT)
+    port = str(_free_port())
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=port)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=180)[0] for p in procs]
+    for rank, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0, out
+        assert "rank %d ok" % rank in out
+        assert "falls back to gloo" in out
