@@ -21,6 +21,7 @@ ap.add_argument("--kv-heads", type=int, default=40)
 ap.add_argument("--layers", type=int, default=20)
 ap.add_argument("--splits", default="default,4,8,12,17,25,34")
 ap.add_argument("--stamps", action="store_true", help="per-phase device-clock decomposition of the one-launch form")
+ap.add_argument("--stamps-fused", action="store_true", help="device-clock decomposition of the fused attention + o projection launch")
 ap.add_argument("--pair", action="store_true", help="attention + the o projection behind it (H*D x H*D int8), with and without "
                                                     "the L2 prefetch of the projection's weight inside the attention launch")
 args = ap.parse_args()
@@ -104,10 +105,25 @@ if args.pair:
     def proj_only(i, _):
         return ops.w8_a16_gemm(res, ow[i], osc[i], residual=res)
 
+    tickets2 = [torch.zeros(ops.rope_decode_attention_oproj_tickets(H) if getattr(ops, 'rope_decode_attention_oproj_tickets', None) else B * H + 2, dtype=torch.int32, device=dev) for _ in range(L)]
+    have_fused = (getattr(ops, "rope_decode_attention_oproj", None) is not None and B == 1
+                  and ops.rope_decode_attention_oproj_supported(1, H, D, C, False))
+
+    def fused(i, _):
+        return ops.rope_decode_attention_oproj(pos, q, k, v, table, kc[i], vc[i], tickets2[i], ow[i], osc[i], None, res.view(-1),
+                                               slots=counters[i], kv_len=counters[i], kv_len_bias=1)
+
     y0 = pair(0, False).clone()
     same = bool(torch.equal(y0, pair(0, True).clone())) if have_hint else None
     out = {"form": "attention + o projection", "batch": B, "heads": H, "filled": args.filled, "rows": S, "o_proj": "%dx%d" % (C, C),
            "same_bits_with_hint": same}
+    if have_fused:
+        yf = fused(0, None).clone().view(B, C)
+        torch.cuda.synchronize()
+        err = (yf.float() - y0.float()).abs().max().item()
+        out["fused_vs_pair_max_abs"] = err
+        out["fused_vs_pair_tier_a"] = bool(((yf.float() - y0.float()).abs() <= 1e-3 * y0.float().abs().max() + 2e-3 * y0.float().abs()).all())
+        out["fused_timeouts"] = ops.attn_oproj_timeouts()
     for rep in range(2):
         out["attention_us"] = round(timed(attn_only, None), 2)
         if have_hint:
@@ -116,7 +132,66 @@ if args.pair:
         out["pair_us"] = round(timed(pair, False), 2)
         if have_hint:
             out["pair_with_prefetch_us"] = round(timed(pair, True), 2)
+        if have_fused:
+            out["fused_us"] = round(timed(fused, None), 2)
+            out["fused_timeouts_after"] = ops.attn_oproj_timeouts()
         print(json.dumps(out), flush=True)
+    sys.exit(0)
+
+if args.stamps_fused:
+    import ctypes
+    from eetq_amd import _lib
+    lib = _lib.lib()
+    C = H * D
+    gw = torch.Generator(device=dev).manual_seed(3)
+    ow = [torch.randint(-128, 127, (C, C), dtype=torch.int8, device=dev, generator=gw) for _ in range(L)]
+    osc = [(torch.rand(C, dtype=torch.float16, device=dev, generator=gw) * 0.01 + 0.001) for _ in range(L)]
+    res = torch.zeros(B, C, dtype=torch.float16, device=dev)
+    tk = [torch.zeros(ops.rope_decode_attention_oproj_tickets(H), dtype=torch.int32, device=dev) for _ in range(L)]
+    splits = lib.eetq_decode_attention_splits(B, H, S)
+    A, R = H * splits, C // 16
+    buf = torch.zeros((A + R) * 8, dtype=torch.int64, device=dev)
+
+    def fused(i):
+        return ops.rope_decode_attention_oproj(pos, q, k, v, table, kc[i], vc[i], tk[i], ow[i], osc[i], None, res.view(-1),
+                                               slots=counters[i], kv_len=counters[i], kv_len_bias=1)
+
+    lib.eetq_diag_attn_stamps(ctypes.c_void_p(buf.data_ptr()))
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(L):
+            fused(i)
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            for i in range(L):
+                fused(i)
+    torch.cuda.current_stream().wait_stream(side)
+    lib.eetq_diag_attn_stamps(None)
+    rows = []
+    for it in range(12):
+        g.replay()
+        g.replay()
+        torch.cuda.synchronize()
+        st = buf.view(A + R, 8).cpu().double()
+        t0 = st[:, 0][st[:, 0] > 0].min()
+        rel = (st - t0) / 100.0
+        rel[st == 0] = float("nan")
+        rows.append(rel)
+    allr = torch.stack(rows[2:])
+    an = ["entry", "scalar reads", "q rotated + first trip landed", "chunk done", "record published", "ticket drawn",
+          "merge done (last of head)", "output stored (last of head)"]
+    pn = ["entry", "weights requested", "weights landed (wave 0)", "flag seen", "dot products done", "output stored"]
+    print("fused attention + o projection, %d attention + %d projection workgroups; us since the first workgroup entered (mean / min / max)" % (A, R))
+    for title, sl, names in (("attention workgroups", slice(0, A), an), ("projection workgroups", slice(A, A + R), pn)):
+        print(title + ":")
+        for i, n in enumerate(names):
+            col = allr[:, sl, i]
+            col = col[~col.isnan()]
+            if col.numel():
+                print("  %-34s mean %6.2f   min %6.2f   max %6.2f   (n=%d)" % (n, col.mean(), col.min(), col.max(), col.numel()))
+    print("launch span (first entry -> last projection output stored): %.2f us" %
+          torch.nan_to_num(allr[:, A:, 5], nan=0.0).amax(1).mean())
     sys.exit(0)
 
 if args.stamps:
