@@ -1,5 +1,7 @@
 // Kernel templates of the W8A16 decode GEMV (included by gemv.hip and by tools/kbench.hip).
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 
 namespace eetq {
@@ -174,6 +176,39 @@ __device__ __forceinline__ float dot_tile_row_bcast(const f16x2 (&wq)[8], u32 xp
     return acc;
 }
 
+// int4 tiles (128 k per tile, 32 k = 16 dwords of x per lane and tile): tile DT of the wave's D, the row's 16 D dwords of x spread
+// over its sixteen lanes, DPL = D per lane (lane c holds dwords DPL c ... DPL c + DPL - 1 of the list [tile][dword]).  Dword d of
+// the lane's weights meets x dwords 4 d ... 4 d + 3 of the tile: same products, same order as dot_lane<4>.
+template <int DT, int DPL>
+__device__ __forceinline__ float dot_tile_row_bcast_i4(const u32x4& wv, f16x2 scale2, const u32 (&xp)[DPL], float acc)
+{
+    static_assert(DPL == 2 || DPL == 4, "two tiles (K = 4096) or four (K = 8192) per wave");
+    const u32 wd[4] = {wv.x, wv.y, wv.z, wv.w};
+    auto one = [&](auto d_tag) {
+        constexpr int d = decltype(d_tag)::value;
+        f16x2         wq[4];
+        dequant_dword_i4(wd[d], scale2, wq);
+        if constexpr (DPL == 2) {
+            constexpr int L = DT * 8 + 2 * d;
+            acc = dot2_row_bcast<L>(wq[0], xp[0], acc);
+            acc = dot2_row_bcast<L>(wq[1], xp[1], acc);
+            acc = dot2_row_bcast<L + 1>(wq[2], xp[0], acc);
+            acc = dot2_row_bcast<L + 1>(wq[3], xp[1], acc);
+        } else {
+            constexpr int L = DT * 4 + d;
+            acc = dot2_row_bcast<L>(wq[0], xp[0], acc);
+            acc = dot2_row_bcast<L>(wq[1], xp[1], acc);
+            acc = dot2_row_bcast<L>(wq[2], xp[2], acc);
+            acc = dot2_row_bcast<L>(wq[3], xp[3], acc);
+        }
+    };
+    one(std::integral_constant<int, 0>{});
+    one(std::integral_constant<int, 1>{});
+    one(std::integral_constant<int, 2>{});
+    one(std::integral_constant<int, 3>{});
+    return acc;
+}
+
 // One 1 KiB tile: this lane's k values of column c against the matching activations of every batch row.
 // xs = this lane's window of the LDS copy of x (row m at xs + m*K halfs).
 template <int M, int BITS = 8>
@@ -246,11 +281,25 @@ __device__ __forceinline__ void gemv_body(
     // retire at L2 latency while the weight stream is already queued right behind them.
     u32 sraw = reinterpret_cast<const uint16_t*>(scales)[ntile * 16 + c];
 
-    constexpr bool XBC = XREG && M == 1 && BITS == 8 && D == 4;  // activations by row broadcast (see XREG above)
-    u32x4 xr[XREG && !XBC ? M * D * XQ : 1];  // XREG: this lane's activations for each of its D tiles, per batch row
+    constexpr bool XBC  = XREG && M == 1 && BITS == 8 && D == 4;  // activations by row broadcast (see XREG above)
+    constexpr bool XBC4 = XREG && M == 1 && BITS == 4 && (D == 2 || D == 4);  // the same on int4 tiles: 16 D dwords per row
+    constexpr int  DPL4 = XBC4 ? D : 2;
+    u32x4 xr[XREG && !XBC && !XBC4 ? M * D * XQ : 1];  // XREG: this lane's activations for each of its D tiles, per batch row
     u32x4 xv[XREG ? 1 : XV];
     u32   xp0 = 0, xp1 = 0;
-    if constexpr (XBC) {
+    u32   xp4[DPL4] = {};
+    if constexpr (XBC4) {
+        // lane (g, c): dwords DPL c ... of row g's list [tile][16 dwords]: tile (DPL c) / 16, dword (DPL c) % 16
+        const f16* px = x + (wave + ((DPL4 * c) >> 4) * WAVES) * TK + LK * g + 2 * ((DPL4 * c) & 15);
+        if constexpr (DPL4 == 2) {
+            using u32x2v = __attribute__((ext_vector_type(2))) u32;
+            const u32x2v v = *reinterpret_cast<const u32x2v*>(px);
+            xp4[0] = v.x, xp4[1] = v.y;
+        } else {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(px);
+            xp4[0] = v.x, xp4[1] = v.y, xp4[2] = v.z, xp4[3] = v.w;
+        }
+    } else if constexpr (XBC) {
         // lane (g, c): dwords 2c, 2c + 1 of row g's list [tile d][dword i] -> tile c >> 2, dwords 2 (c & 3), + 1
         using u32x2 = __attribute__((ext_vector_type(2))) u32;
         const u32x2 v = *reinterpret_cast<const u32x2*>(x + (wave + (c >> 2) * WAVES) * TK + LK * g + 4 * (c & 3));
@@ -309,7 +358,14 @@ __device__ __forceinline__ void gemv_body(
 #pragma unroll
     for (int m = 0; m < M; ++m) acc[m] = 0.f;
 
-    if constexpr (XBC) {
+    if constexpr (XBC4) {
+        acc[0] = dot_tile_row_bcast_i4<0, DPL4>(buf[0], scale2, xp4, acc[0]);
+        acc[0] = dot_tile_row_bcast_i4<1, DPL4>(buf[1], scale2, xp4, acc[0]);
+        if constexpr (D == 4) {
+            acc[0] = dot_tile_row_bcast_i4<2, DPL4>(buf[2], scale2, xp4, acc[0]);
+            acc[0] = dot_tile_row_bcast_i4<3, DPL4>(buf[3], scale2, xp4, acc[0]);
+        }
+    } else if constexpr (XBC) {
         f16x2 wq[8];
         dequant_16(buf[0], scale2, wq);
         acc[0] = dot_tile_row_bcast<0>(wq, xp0, xp1, acc[0]);
