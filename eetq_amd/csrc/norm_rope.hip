@@ -137,6 +137,10 @@ __global__ void silu_mul_glu8_kernel(const f16* __restrict__ gu, f16* __restrict
 // launches + the rotary launch by one.
 // Prefill form (tokens > 0): blockIdx.x = token b * tokens + t of batch row b (uniform token stride in q / k / v), rotated by
 // positions[token], cached at row base + t of cache batch b, base = *slots (a static cache's token counter) or first_row.
+// VEC (round 6): rot_dim == head_size, head_size % 16 == 0 and every pointer / stride a multiple of 8 elements -> eight channels per
+// thread through 16-byte loads and stores (the scalar form moved a prompt's 62 MB per layer at 3.1 TB/s: 20 us at 1 024 tokens).
+// The same fp16 products and sums per channel, contraction off: the same bits.
+template <bool VEC>
 __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions, const int64_t* __restrict__ slots,
                                            int slot_stride, f16* __restrict__ query,
                                            const f16* __restrict__ key, const f16* __restrict__ value,
@@ -157,6 +161,42 @@ __global__ void rotary_neox_kvcache_kernel(const int64_t* __restrict__ positions
     }
     const f16* cp    = cache + rpos * rot_dim;
     const int  embed = rot_dim / 2;
+    if constexpr (VEC) {
+        const int e8 = embed >> 3;  // 8-channel vectors per half head
+        auto rot8 = [&](const f16* src, f16* dst, int off) {
+            const f16x8 c = *reinterpret_cast<const f16x8*>(cp + off), sn = *reinterpret_cast<const f16x8*>(cp + embed + off);
+            const f16x8 vx = *reinterpret_cast<const f16x8*>(src + off), vy = *reinterpret_cast<const f16x8*>(src + embed + off);
+            f16x8       lo, hi;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const f16 xc = vx[j] * c[j], ys = vy[j] * sn[j], yc = vy[j] * c[j], xs = vx[j] * sn[j];
+                lo[j] = xc - ys;
+                hi[j] = yc + xs;
+            }
+            *reinterpret_cast<f16x8*>(dst + off)         = lo;
+            *reinterpret_cast<f16x8*>(dst + embed + off) = hi;
+        };
+        if (blockIdx.y == 0) {
+            for (int i = threadIdx.x; i < q_heads * e8; i += blockDim.x) {
+                const int head = i / e8, off = (i - head * e8) * 8;
+                f16*      p = query + b * q_stride + (long)head * head_size;
+                rot8(p, p, off);
+            }
+        } else if (blockIdx.y == 1) {
+            for (int i = threadIdx.x; i < k_heads * e8; i += blockDim.x) {
+                const int head = i / e8, off = (i - head * e8) * 8;
+                rot8(key + b * k_stride + (long)head * head_size, kcache + cb * c_sb + head * c_sh + pos * c_ss, off);
+            }
+        } else {
+            const int h8 = head_size >> 3;
+            for (int i = threadIdx.x; i < k_heads * h8; i += blockDim.x) {
+                const int head = i / h8, off = (i - head * h8) * 8;
+                *reinterpret_cast<f16x8*>(vcache + cb * c_sb + head * c_sh + pos * c_ss + off) =
+                    *reinterpret_cast<const f16x8*>(value + b * v_stride + (long)head * head_size + off);
+            }
+        }
+        return;
+    }
     if (blockIdx.y == 0) {
         for (int i = threadIdx.x; i < q_heads * embed; i += blockDim.x) {
             const int head = i / embed, off = i - head * embed;
@@ -270,10 +310,18 @@ int launch_rotary_kvcache(const int64_t* pos, const int64_t* slots, int slot_str
                      rot_dim <= head_size && max_pos > 0,
                  "invalid rotary shape");
     if (batch == 0) return EETQ_OK;
-    const int blocks = tokens > 0 ? batch * tokens : batch;
-    rotary_neox_kvcache_kernel<<<dim3(blocks, 3), 512, 0, stream>>>(pos, slots, slot_stride, q, k, v, cache, kcache, vcache, rot_dim, q_stride,
-                                                                      k_stride, v_stride, c_sb, c_sh, c_ss, q_heads,
-                                                                      k_heads, head_size, max_pos, tokens, first_row);
+    const int  blocks = tokens > 0 ? batch * tokens : batch;
+    const bool vec    = rot_dim == head_size && head_size % 16 == 0 &&
+                     (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)cache | (uintptr_t)kcache | (uintptr_t)vcache) & 15) == 0 &&
+                     ((q_stride | k_stride | v_stride | c_sb | c_sh | c_ss) & 7) == 0;
+    if (vec)
+        rotary_neox_kvcache_kernel<true><<<dim3(blocks, 3), 256, 0, stream>>>(pos, slots, slot_stride, q, k, v, cache, kcache, vcache,
+                                                                               rot_dim, q_stride, k_stride, v_stride, c_sb, c_sh, c_ss,
+                                                                               q_heads, k_heads, head_size, max_pos, tokens, first_row);
+    else
+        rotary_neox_kvcache_kernel<false><<<dim3(blocks, 3), 512, 0, stream>>>(pos, slots, slot_stride, q, k, v, cache, kcache, vcache,
+                                                                                rot_dim, q_stride, k_stride, v_stride, c_sb, c_sh, c_ss,
+                                                                                q_heads, k_heads, head_size, max_pos, tokens, first_row);
     return check_hip(hipGetLastError(), "rotary_neox_kvcache_kernel launch");
 }
 
