@@ -89,6 +89,8 @@ def _declare(L):
                                       vp],
         "eetq_rope_decode_attention_f16": [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32,
                                            ctypes.c_float, vp, vp, i32, vp, vp],
+        "eetq_prefill_attention_f16": [vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, ctypes.c_float, vp, vp],
+        "eetq_prefill_attention_supported": [i32],
         "eetq_decode_attention_splits": [i32, i32, i32],
         "eetq_prof_begin": [i32],
         "eetq_prof_end": [vp, i32, vp],
@@ -120,7 +122,7 @@ def _declare(L):
 EXPORTED_SYMBOLS = (
     "eetq_quantize_i8", "eetq_quantize_i8_ws", "eetq_abi_version", "eetq_quantize_i8_host", "eetq_pack_i8", "eetq_unpack_i8", "eetq_pack_i8_host",
     "eetq_unpack_i8_host", "eetq_w8a16_gemm", "eetq_w8a16_gemm_ex", "eetq_w8a16_gemm_bias", "eetq_w8a16_gemm_fused", "eetq_w8a16_gemm_act", "eetq_quantize_i4", "eetq_pack_i4", "eetq_unpack_i4", "eetq_w4a16_gemm", "eetq_w4a16_gemm_ex", "eetq_rmsnorm_f16",
-    "eetq_rotary_neox_f16", "eetq_rotary_neox_strided_f16", "eetq_w8a16_gemv_rmsnorm", "eetq_w8a16_gemv_silu_gated", "eetq_silu_mul_f16", "eetq_silu_mul_glu8_f16", "eetq_w8a16_gemv_glu8", "eetq_w8a16_gemm_glu8", "eetq_rotary_neox_kvcache_f16", "eetq_rotary_neox_kvcache_prefill_f16", "eetq_greedy_handover_f16", "eetq_decode_attention_f16", "eetq_decode_attention_splits", "eetq_rope_decode_attention_f16", "eetq_prof_begin", "eetq_prof_end", "eetq_diag_stream_read", "eetq_diag_empty", "eetq_diag_clock_stamp", "eetq_diag_attn_stamps", "eetq_diag_stream_plan", "eetq_diag_auto_path", "eetq_diag_splitk_plan", "eetq_last_error", "eetq_version", "eetq_device_supported",
+    "eetq_rotary_neox_f16", "eetq_rotary_neox_strided_f16", "eetq_w8a16_gemv_rmsnorm", "eetq_w8a16_gemv_silu_gated", "eetq_silu_mul_f16", "eetq_silu_mul_glu8_f16", "eetq_w8a16_gemv_glu8", "eetq_w8a16_gemm_glu8", "eetq_rotary_neox_kvcache_f16", "eetq_rotary_neox_kvcache_prefill_f16", "eetq_greedy_handover_f16", "eetq_decode_attention_f16", "eetq_decode_attention_splits", "eetq_rope_decode_attention_f16", "eetq_prefill_attention_f16", "eetq_prefill_attention_supported", "eetq_prof_begin", "eetq_prof_end", "eetq_diag_stream_read", "eetq_diag_empty", "eetq_diag_clock_stamp", "eetq_diag_attn_stamps", "eetq_diag_stream_plan", "eetq_diag_auto_path", "eetq_diag_splitk_plan", "eetq_last_error", "eetq_version", "eetq_device_supported",
     "eetq_quantize_workspace_floats", "eetq_release_workspace", "eetq_release_stream_workspace", "eetq_rotary_neox", "eetq_w8a16_gemv_grouped", "eetq_decode_dropped_steps",
 )
 

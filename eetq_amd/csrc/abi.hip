@@ -750,6 +750,16 @@ int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slot
                                    strides, kv_len, kv_len_bias, advance, static_cast<hipStream_t>(stream));
 }
 
+int eetq_prefill_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads, int kv_heads, int q_tokens,
+                               int keys, int head_dim, int causal_offset, float scaling, const long* strides, void* stream)
+{
+    return launch_prefill_attention(static_cast<const f16*>(q), static_cast<const f16*>(k), static_cast<const f16*>(v),
+                                    static_cast<f16*>(out), batch, heads, kv_heads, q_tokens, keys, head_dim, causal_offset, scaling,
+                                    strides, static_cast<hipStream_t>(stream));
+}
+
+int eetq_prefill_attention_supported(int head_dim) { return prefill_attention_supports(head_dim) ? 1 : 0; }
+
 int eetq_decode_dropped_steps(unsigned long long* count, int reset)
 {
     EETQ_REQUIRE(count, "null pointer");

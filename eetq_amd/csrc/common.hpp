@@ -276,6 +276,11 @@ int launch_rope_attn_decode(const int64_t* positions, const int64_t* slots, int 
                             unsigned* tickets, int B, int H, int Hkv, int S, int D, int splits, float scaling,
                             const long* strides, const int64_t* kv_len, int kv_len_bias, int64_t* advance,
                             hipStream_t stream);
+// causal attention over a prompt on MFMA (attn_prefill.hip); st: {q_b, q_token, q_head, k_b, k_head, k_row, v_b, v_head, v_row, out_b,
+// out_token, out_head} in elements
+bool prefill_attention_supports(int D);
+int launch_prefill_attention(const f16* q, const f16* k, const f16* v, f16* out, int B, int H, int Hkv, int Tq, int Tk, int D,
+                             int causal_offset, float scaling, const long* st, hipStream_t stream);
 int launch_attn_decode(const f16* q, const f16* k, const f16* v, const f16* mask, f16* out, float* ws, int B, int H, int Hkv,
                        int S, int D, int splits, float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
                        int64_t* advance, hipStream_t stream);

@@ -221,6 +221,33 @@ Tensor rope_decode_attention(const Tensor& positions, const Tensor& query, const
     return out;
 }
 
+// causal attention over a prompt on the matrix cores (eetq_prefill_attention_f16): query [B, T, H, D] (any token / head strides, D
+// dense), key / value cache views [B, Hkv, rows >= keys, D]; returns [B, T, H, D] contiguous
+bool prefill_attention_supported(int64_t head_dim) { return eetq_prefill_attention_supported((int)head_dim) != 0; }
+
+Tensor prefill_attention(const Tensor& query, const Tensor& key, const Tensor& value, int64_t keys, std::optional<double> scaling,
+                         std::optional<int64_t> causal_offset)
+{
+    for (const Tensor* t : std::initializer_list<const Tensor*>{&query, &key, &value})
+        TORCH_CHECK(t->scalar_type() == at::kHalf && t->is_cuda() && t->dim() == 4 && t->stride(-1) == 1 && t->device() == query.device(),
+                    "prefill_attention: float16 CUDA tensors [B, T, H, D] / [B, Hkv, S, D] with a dense last dimension expected");
+    const int64_t B = query.size(0), T = query.size(1), H = query.size(2), D = query.size(3), Hkv = key.size(1);
+    TORCH_CHECK(key.size(0) == B && key.size(3) == D && value.sizes() == key.sizes() && Hkv > 0 && H % Hkv == 0 && keys > 0 &&
+                    keys <= key.size(2) && T > 0,
+                "prefill_attention: shape mismatch");
+    TORCH_CHECK(prefill_attention_supported(D), "prefill_attention: unsupported head_dim");
+    const double sc  = scaling ? *scaling : 1.0 / std::sqrt((double)D);
+    const int64_t off = causal_offset ? *causal_offset : keys - T;
+    Tensor       out = torch::empty({B, T, H, D}, query.options());
+    const long   st[12] = {(long)query.stride(0), (long)query.stride(1), (long)query.stride(2), (long)key.stride(0), (long)key.stride(1),
+                           (long)key.stride(2),   (long)value.stride(0), (long)value.stride(1), (long)value.stride(2),
+                           (long)out.stride(0),   (long)out.stride(1),   (long)out.stride(2)};
+    c10::DeviceGuard guard(query.device());
+    check(eetq_prefill_attention_f16(query.data_ptr(), key.data_ptr(), value.data_ptr(), out.data_ptr(), (int)B, (int)H, (int)Hkv, (int)T,
+                                     (int)keys, (int)D, (int)off, (float)sc, st, stream_of(query)));
+    return out;
+}
+
 Tensor silu_mul(const Tensor& gate_up, bool glu8 = false);
 
 void check_epilogue(const Tensor& input, const OptTensor& bias, const OptTensor& residual, int64_t m, int64_t n)
@@ -842,6 +869,10 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m)
           py::arg("slots") = py::none(), py::arg("mask") = py::none(), py::arg("scaling") = py::none(),
           py::arg("splits") = py::none(), py::arg("kv_len") = py::none(), py::arg("kv_len_bias") = 0,
           py::arg("advance") = py::none());
+    m.def("prefill_attention", &prefill_attention, py::arg("query"), py::arg("key"), py::arg("value"), py::arg("keys"),
+          py::arg("scaling") = py::none(), py::arg("causal_offset") = py::none(),
+          "causal attention of a prompt's query rows [B, T, H, D] over the first `keys` rows of a KV cache [B, Hkv, S, D] (MFMA)");
+    m.def("prefill_attention_supported", &prefill_attention_supported, py::arg("head_dim"));
     m.def("llama_decode_layer", &llama_decode_layer, "one decode step of an accelerated Llama decoder layer (six launches, one call)",
           py::arg("hidden"), py::arg("input_norm"), py::arg("qkv_weight"), py::arg("qkv_scale"), py::arg("qkv_bias"),
           py::arg("positions"), py::arg("cos_sin_cache"), py::arg("key_cache"), py::arg("value_cache"), py::arg("tickets"),

@@ -41,6 +41,8 @@ if _C is not None:
     decode_attention = _C.decode_attention
     rope_decode_attention = _C.rope_decode_attention
     silu_mul = _C.silu_mul
+    prefill_attention = _C.prefill_attention                        # compiled boundary only (None -> torch's attention)
+    prefill_attention_supported = _C.prefill_attention_supported
     w8_a16_gemv_grouped = _C.w8_a16_gemv_grouped
     llama_decode_layer = _C.llama_decode_layer   # compiled boundary only: its point is the interpreter time it saves
 else:
@@ -50,6 +52,8 @@ else:
                              rotary_embedding_neox_kvcache_prefill, rotary_embedding_neox_strided, silu_mul,
                              unprocess_weights, w8_a16_gemm, w8_a16_gemm_, w8_a16_gemv_grouped)
     llama_decode_layer = None
+    prefill_attention = None
+    prefill_attention_supported = None
 
 __all__ = ["quant_weights", "preprocess_weights", "unprocess_weights", "w8_a16_gemm", "w8_a16_gemm_", "layernorm_forward",
            "rotary_embedding_neox", "rotary_embedding_neox_strided", "rotary_embedding_neox_kvcache", "rotary_embedding_neox_kvcache_prefill",

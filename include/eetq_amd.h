@@ -78,8 +78,9 @@ enum { EETQ_ACT_IDENTITY = 0, EETQ_ACT_RELU = 1, EETQ_ACT_GELU = 2, EETQ_ACT_SIL
  *   allocate eetq_quantize_workspace_floats() floats should move to eetq_quantize_i8_ws to get the faster route. */
 /* Revision history: 1 = round 1-2; 2 = eetq_quantize_i8_ws (sized workspace), eetq_release_stream_workspace, eetq_w4a16_gemm_ex;
  * 3 = eetq_diag_auto_path, EETQ_PATH_SPLITK accepts M <= 1024 (row groups); 4 = eetq_diag_splitk_plan; 5 =
- * eetq_rotary_neox_kvcache_prefill_f16, eetq_greedy_handover_f16, eetq_w8a16_gemm_glu8 at M > 16.  Revisions only ADD entry points: a caller built against an older header keeps working. */
-#define EETQ_AMD_ABI_VERSION 5
+ * eetq_rotary_neox_kvcache_prefill_f16, eetq_greedy_handover_f16, eetq_w8a16_gemm_glu8 at M > 16; 6 = eetq_prefill_attention_f16
+ * (+ _supported).  Revisions only ADD entry points: a caller built against an older header keeps working. */
+#define EETQ_AMD_ABI_VERSION 6
 int eetq_abi_version(void);   /* EETQ_AMD_ABI_VERSION of the loaded library */
 int eetq_quantize_i8_ws(const void* w, int w_dtype, size_t K, size_t N, int8_t* q_raw, int8_t* q_packed,
                         int layout, void* scales, float* workspace, size_t workspace_floats, void* stream);
@@ -319,6 +320,18 @@ int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slot
                                    int batch, int heads, int kv_heads, int max_positions, int head_dim, int splits,
                                    float scaling, const long* strides, const int64_t* kv_len, int kv_len_bias,
                                    int64_t* advance, void* stream);
+
+/* Causal attention over a PROMPT on the matrix cores (extension, ABI revision 6): out[b][t][h] = softmax_j<=t+causal_offset(scaling
+ * q[b][t][h] . k[b][h / groups][j]) v[b][h / groups][j] over the first `keys` rows of a KV cache, fp16 in / out, fp32 scores, softmax
+ * state and accumulation (probabilities rounded to fp16 for the second product, like flash-attn, which the reference's block calls
+ * here: python/eetq/modules/llama_modules.py:131-143).  q: the rotated query rows, e.g. a view into the fused QKV projection's
+ * output; k, v: cache tensors [batch][kv_heads][rows][head_dim].  strides (elements): {q_b, q_token, q_head, k_b, k_head, k_row,
+ * v_b, v_head, v_row, out_b, out_token, out_head}, head_dim contiguous, q / k / v strides multiples of 8, out strides of 4.
+ * causal_offset = keys - q_tokens for a prompt appended to `keys - q_tokens` cached rows (0 on an empty cache).  head_dim 128
+ * (eetq_prefill_attention_supported); EETQ_ERR_UNSUPPORTED otherwise. */
+int eetq_prefill_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads, int kv_heads, int q_tokens,
+                               int keys, int head_dim, int causal_offset, float scaling, const long* strides, void* stream);
+int eetq_prefill_attention_supported(int head_dim);
 
 /* Diagnostics: while `stamps` (DEVICE, batch * heads * splits * 8 uint64) is set, every eetq_rope_decode_attention_f16
  * launch of this process records per workgroup the 100 MHz device clock at: 0 entry, 1 scalar reads done, 2 new token

@@ -1548,3 +1548,39 @@ def test_gemv_gated_activation_prologue(ops, oracle, K, N):
                        ops.w8_a16_gemm(ops.silu_mul(gu3), processed, scales))
     with pytest.raises(RuntimeError):
         ops.w8_a16_gemm(gu[:, : K], processed, scales, gated=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,T,H,Hkv,S,base", [(1, 128, 2, 2, 160, 0), (1, 200, 4, 2, 256, 0), (2, 130, 4, 4, 300, 37), (1, 64, 2, 1, 64, 0),
+                                               (1, 1, 2, 2, 16, 5), (2, 515, 8, 2, 600, 0)])
+def test_prefill_attention_vs_torch(ops, B, T, H, Hkv, S, base):
+    """The prompt's causal attention on the matrix cores (eetq_prefill_attention_f16) against a float32 softmax(q k^T) v of the same
+    fp16 inputs: strided query view of a fused QKV row, grouped-query heads, ragged token counts, a prompt appended behind `base`
+    cached rows.  fp16 flash tolerance: 3e-3 absolute on outputs of order 1 (probabilities are rounded to fp16 for the second
+    product, as in flash-attn, which the reference's block calls here: python/eetq/modules/llama_modules.py:131-143)."""
+    if ops.BOUNDARY != "ext":
+        pytest.skip("prefill_attention lives in the compiled module")
+    D = 128
+    torch.manual_seed(B * 1000 + T)
+    qkv = torch.randn(B, T, (H + 2 * Hkv) * D, dtype=torch.float16, device=DEV)
+    q = qkv[..., :H * D].unflatten(-1, (H, D))
+    kc = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+    vc = torch.randn(B, Hkv, S, D, dtype=torch.float16, device=DEV)
+    keys = base + T
+    out = ops.prefill_attention(q, kc, vc, keys)
+    assert out.shape == (B, T, H, D) and out.is_contiguous()
+    qq = q.transpose(1, 2).float()
+    k, v = kc[:, :, :keys].float(), vc[:, :, :keys].float()
+    if Hkv != H:
+        k, v = k.repeat_interleave(H // Hkv, 1), v.repeat_interleave(H // Hkv, 1)
+    sc = torch.matmul(qq, k.transpose(2, 3)) / D ** 0.5
+    mask = torch.arange(keys, device=DEV)[None, :] > (torch.arange(T, device=DEV)[:, None] + base)
+    ref = torch.matmul(torch.softmax(sc.masked_fill(mask, float("-inf")), -1), v).transpose(1, 2)
+    assert not out.isnan().any()
+    assert (out.float() - ref).abs().max().item() < 3e-3
+    # rows beyond `keys` must not matter: poison them
+    kc[:, :, keys:] = float("nan")
+    vc[:, :, keys:] = float("nan")
+    assert torch.equal(ops.prefill_attention(q, kc, vc, keys), out)
+    with pytest.raises(RuntimeError):
+        ops.prefill_attention(q[..., :64], kc[..., :64], vc[..., :64], keys)   # head_dim 64: unsupported, loudly
