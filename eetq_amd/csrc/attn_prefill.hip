@@ -10,12 +10,14 @@
 //   S^T = K Q^T   (v_mfma_f32_32x32x16_f16, K rows as the A operand, the wave's Q rows as B: a lane owns ONE query column and 32 of
 //                  the block's 64 keys, its partner lane ^ 32 the others -- the row maximum and sum are 31 local operations and one
 //                  lane swap; the probabilities, rounded to fp16, ARE the B operand of the next product, no data movement)
-//   O^T += V^T P^T (V^T rows = channels as the A operand: V is transposed on its way into LDS -- 2-byte stores into a [D][64 keys]
-//                  image with a 136-byte pitch -- so that a lane's 8 k-slots are two 8-byte reads; the k-slot <-> key assignment
+//   O^T += V^T P^T (V^T rows = channels as the A operand: V is transposed on its way into LDS -- a thread holds one 16-byte chunk of four
+//                  consecutive rows and stores four keys of one channel at a time into a [D][64 keys] image with a 136-byte pitch --
+//                  so that a lane's 8 k-slots are two 8-byte reads; the k-slot <-> key assignment
 //                  follows what the S^T accumulator layout hands out: slots 0..3 = keys base + 4 hi + j, 4..7 = base + 8 + 4 hi + j)
 // K rows sit in LDS as 256-byte rows with their 16-byte chunks XOR-swizzled by (row & 15) (conflict-free 16-byte fragment reads).
 // Two LDS buffers, one barrier per block: block j + 1 goes from registers into the free buffer at the top of block j, block j + 2 is
-// fetched then and has a whole block of arithmetic to land.  Two workgroups per CU (<= 256 registers: everything in the
+// fetched then and has a whole block of arithmetic to land.  (Issuing block j + 1's score product between block j's softmax and its
+// second product -- two barriers per block -- measured the same: the waves of the two resident workgroups run their phases in step.)  Two workgroups per CU (<= 256 registers: everything in the
 // architectural file, no accumulator copies).    Blocks beyond a wave's last query row are skipped by that wave; heavy query blocks are
 // dispatched first (1-D grid ordered by weight).
 #include <type_traits>
@@ -86,33 +88,35 @@ __global__ __launch_bounds__(kPfThreads, 2) void prefill_attn_kernel(const Prefi
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging registers (thread t: chunks t + 256 r of a tile: key (chunk >> 4), 16-byte chunk (chunk & 15))
+    // staging registers: thread t holds 16-byte chunk t % 16 of the FOUR rows 4 (t / 16) .. + 3 of a tile -- so that the transposed V
+    // image is written as 8-byte pieces (four keys of one channel: 8 LDS writes per thread and tile; 2-byte writes, 64 of them, kept
+    // the LDS pipe busy for ~4 000 cycles per tile and workgroup and bounded the kernel)
+    static_assert(NLD == 4 && CH == 16, "four rows per thread");
     u32x4 kreg[NLD], vreg[NLD];
-    // per-thread byte offset inside a tile (constant: chunk r of a thread is kPfThreads / CH rows further down, which rides in the
-    // scalar operand together with the tile's own offset)
+    const int c16 = tid % CH, p4 = 4 * (tid / CH);
     const int krow_b = (int)(a.k_ss * 2), vrow_b = (int)(a.v_ss * 2);
-    const int kvo = (tid / CH) * krow_b + (tid % CH) * 16, vvo = (tid / CH) * vrow_b + (tid % CH) * 16;
+    const int kvo = p4 * krow_b + c16 * 16, vvo = p4 * vrow_b + c16 * 16;  // constant; tile and row offsets ride in the scalar operand
     auto fetch = [&](int j) {
 #pragma unroll
         for (int r = 0; r < NLD; ++r) {
-            const int rows = j * kPfBN + r * (kPfThreads / CH);
-            kreg[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvo, rows * krow_b, 0));
-            vreg[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, rows * vrow_b, 0));
+            kreg[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, kvo, (j * kPfBN + r) * krow_b, 0));
+            vreg[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, (j * kPfBN + r) * vrow_b, 0));
         }
     };
-    // K rows: 16-byte chunks XOR-swizzled by (row & 15).  V^T image: channel row d, key column key ^ (((d >> 5) & 3) << 3) -- the
-    // sixteen chunks of a wave's 2-byte stores land in sixteen banks.
+    // K rows: 16-byte chunks XOR-swizzled by (row & 15).  V^T image: channel row d, key column key ^ (((d >> 5) & 3) << 3): a wave's
+    // sixty-four 8-byte stores (16 chunks x 4 row groups) land in sixty-four different banks.
     auto stage = [&](int buf) {
         f16* kl = k_lds2[buf];
         f16* vl = vt_lds2[buf];
 #pragma unroll
-        for (int r = 0; r < NLD; ++r) {
-            const int chunk = tid + kPfThreads * r, key = chunk / CH, c16 = chunk % CH;
-            *reinterpret_cast<u32x4*>(kl + key * D + 8 * (c16 ^ (key & 15))) = kreg[r];
-            const int   col = key ^ (((c16 >> 2) & 3) << 3);
-            const f16x8 vv  = __builtin_bit_cast(f16x8, vreg[r]);
+        for (int r = 0; r < NLD; ++r) *reinterpret_cast<u32x4*>(kl + (p4 + r) * D + 8 * (c16 ^ ((p4 + r) & 15))) = kreg[r];
+        const f16x8 v0 = __builtin_bit_cast(f16x8, vreg[0]), v1 = __builtin_bit_cast(f16x8, vreg[1]);
+        const f16x8 v2 = __builtin_bit_cast(f16x8, vreg[2]), v3 = __builtin_bit_cast(f16x8, vreg[3]);
+        f16*        vp = vl + 8 * c16 * VT_PITCH + (p4 ^ (((c16 >> 2) & 3) << 3));
 #pragma unroll
-            for (int e = 0; e < 8; ++e) vl[(8 * c16 + e) * VT_PITCH + col] = vv[e];
+        for (int e = 0; e < 8; ++e) {
+            const f16x2 lo = {v0[e], v1[e]}, hh = {v2[e], v3[e]};
+            *reinterpret_cast<u32x2*>(vp + e * VT_PITCH) = u32x2{as_u32(lo), as_u32(hh)};
         }
     };
 
@@ -131,22 +135,23 @@ __global__ __launch_bounds__(kPfThreads, 2) void prefill_attn_kernel(const Prefi
         const f16* k_lds  = k_lds2[j & 1];
         const f16* vt_lds = vt_lds2[j & 1];
         if (active) {
-            // ---- S^T = K Q^T: two 32-key halves ----
+            // ---- S^T = K Q^T: two 32-key halves (alternating: back-to-back MFMAs on one accumulator wait out each other's latency) ----
             f32x16 s[2];
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int i = 0; i < 16; ++i) s[kb][i] = 0.f;
-                const int krow = 32 * kb + ln;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int   krow = 32 * kb + ln;
                     const f16x8 kf = *reinterpret_cast<const f16x8*>(k_lds + krow * D + 8 * ((2 * ks + hi) ^ (krow & 15)));
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
                 }
-            }
-            // ---- mask (where the block touches the wave's diagonal or the end of the keys; the optimiser turns the test into selects:
-            // a second copy of the code behind a branch was tried and spilled), running maximum (scaled domain) ----
-            const bool edge = key0 + kPfBN - 1 > q0 + wave * 32 + a.koff || key0 + kPfBN > a.Tk;  // wave-uniform
+            // ---- mask (only where the block touches the wave's diagonal or the end of the keys: a wave-uniform branch), running maximum
+            // (scaled domain) ----
+            const bool edge = key0 + kPfBN - 1 > q0 + wave * 32 + a.koff || key0 + kPfBN > a.Tk;
             float mloc = -INFINITY;
             if (edge) {
 #pragma unroll
@@ -155,7 +160,9 @@ __global__ __launch_bounds__(kPfThreads, 2) void prefill_attn_kernel(const Prefi
                     for (int r = 0; r < 16; ++r) {
                         const int  key   = key0 + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
                         const bool valid = key < a.Tk && key <= qrow + a.koff;
-                        s[kb][r]         = valid ? s[kb][r] : -INFINITY;
+                        float      t     = valid ? s[kb][r] : -INFINITY;
+                        asm volatile("" : "+v"(t));  // pins the select inside the branch (else: 170 select instructions on EVERY block)
+                        s[kb][r] = t;
                     }
             }
 #pragma unroll
