@@ -44,7 +44,7 @@ struct PrefillArgs {
 template <int D>
 __global__ __launch_bounds__(kPfThreads, 2) void prefill_attn_kernel(const PrefillArgs a)
 {
-    static_assert(D == 128, "head_dim 128");
+    static_assert(D == 128 || D == 64, "head_dim 128 or 64");
     constexpr int KS = D / 16;            // k-steps of the score product
     constexpr int DT = D / 32;            // 32-channel blocks of the output
     constexpr int VT_PITCH = kPfBN + 4;   // halfs per channel row of the transposed V image (136 bytes)
@@ -88,12 +88,12 @@ __global__ __launch_bounds__(kPfThreads, 2) void prefill_attn_kernel(const Prefi
         for (int i = 0; i < 16; ++i) o[dt][i] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
 
-    // staging registers: thread t holds 16-byte chunk t % 16 of the FOUR rows 4 (t / 16) .. + 3 of a tile -- so that the transposed V
-    // image is written as 8-byte pieces (four keys of one channel: 8 LDS writes per thread and tile; 2-byte writes, 64 of them, kept
-    // the LDS pipe busy for ~4 000 cycles per tile and workgroup and bounded the kernel)
-    static_assert(NLD == 4 && CH == 16, "four rows per thread");
+    // staging registers: thread t holds 16-byte chunk t % CH of the NLD consecutive rows NLD (t / CH) .. of a tile (four rows at D = 128,
+    // two at D = 64) -- so that the transposed V image is written as 8- / 4-byte pieces (NLD keys of one channel: 8 LDS writes per
+    // thread and tile; 2-byte writes, 64 of them, kept the LDS pipe busy for ~4 000 cycles per tile and workgroup)
+    static_assert((NLD == 4 && CH == 16) || (NLD == 2 && CH == 8), "rows per thread");
     u32x4 kreg[NLD], vreg[NLD];
-    const int c16 = tid % CH, p4 = 4 * (tid / CH);
+    const int c16 = tid % CH, p4 = NLD * (tid / CH);
     const int krow_b = (int)(a.k_ss * 2), vrow_b = (int)(a.v_ss * 2);
     const int kvo = p4 * krow_b + c16 * 16, vvo = p4 * vrow_b + c16 * 16;  // constant; tile and row offsets ride in the scalar operand
     auto fetch = [&](int j) {
@@ -103,20 +103,28 @@ __global__ __launch_bounds__(kPfThreads, 2) void prefill_attn_kernel(const Prefi
             vreg[r] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(vrs, vvo, (j * kPfBN + r) * vrow_b, 0));
         }
     };
-    // K rows: 16-byte chunks XOR-swizzled by (row & 15).  V^T image: channel row d, key column key ^ (((d >> 5) & 3) << 3): a wave's
-    // sixty-four 8-byte stores (16 chunks x 4 row groups) land in sixty-four different banks.
+    // K rows: 16-byte chunks XOR-swizzled by (row & (CH - 1)).  V^T image: channel row d, key column key ^ (((d >> 5) & 3) << 3): a
+    // wave's stores land in different banks.
     auto stage = [&](int buf) {
         f16* kl = k_lds2[buf];
         f16* vl = vt_lds2[buf];
 #pragma unroll
-        for (int r = 0; r < NLD; ++r) *reinterpret_cast<u32x4*>(kl + (p4 + r) * D + 8 * (c16 ^ ((p4 + r) & 15))) = kreg[r];
+        for (int r = 0; r < NLD; ++r) *reinterpret_cast<u32x4*>(kl + (p4 + r) * D + 8 * (c16 ^ ((p4 + r) & (CH - 1)))) = kreg[r];
+        f16* vp = vl + 8 * c16 * VT_PITCH + (p4 ^ (((c16 >> 2) & 3) << 3));
         const f16x8 v0 = __builtin_bit_cast(f16x8, vreg[0]), v1 = __builtin_bit_cast(f16x8, vreg[1]);
-        const f16x8 v2 = __builtin_bit_cast(f16x8, vreg[2]), v3 = __builtin_bit_cast(f16x8, vreg[3]);
-        f16*        vp = vl + 8 * c16 * VT_PITCH + (p4 ^ (((c16 >> 2) & 3) << 3));
+        if constexpr (NLD == 4) {
+            const f16x8 v2 = __builtin_bit_cast(f16x8, vreg[2]), v3 = __builtin_bit_cast(f16x8, vreg[3]);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const f16x2 lo = {v0[e], v1[e]}, hh = {v2[e], v3[e]};
-            *reinterpret_cast<u32x2*>(vp + e * VT_PITCH) = u32x2{as_u32(lo), as_u32(hh)};
+            for (int e = 0; e < 8; ++e) {
+                const f16x2 lo = {v0[e], v1[e]}, hh = {v2[e], v3[e]};
+                *reinterpret_cast<u32x2*>(vp + e * VT_PITCH) = u32x2{as_u32(lo), as_u32(hh)};
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const f16x2 lo = {v0[e], v1[e]};
+                *reinterpret_cast<u32*>(vp + e * VT_PITCH) = as_u32(lo);
+            }
         }
     };
 
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void prefill_attn_kernel(const Prefi
 #pragma unroll
                 for (int kb = 0; kb < 2; ++kb) {
                     const int   krow = 32 * kb + ln;
-                    const f16x8 kf = *reinterpret_cast<const f16x8*>(k_lds + krow * D + 8 * ((2 * ks + hi) ^ (krow & 15)));
+                    const f16x8 kf = *reinterpret_cast<const f16x8*>(k_lds + krow * D + 8 * ((2 * ks + hi) ^ (krow & (CH - 1))));
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[ks], s[kb], 0, 0, 0);
                 }
             // ---- mask (only where the block touches the wave's diagonal or the end of the keys: a wave-uniform branch), running maximum
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(kPfThreads, 2) void prefill_attn_kernel(const Prefi
 
 }  // namespace
 
-bool prefill_attention_supports(int D) { return D == 128; }
+bool prefill_attention_supports(int D) { return D == 128 || D == 64; }
 
 // strides (elements): {q_b, q_token, q_head, k_b, k_head, k_row, v_b, v_head, v_row, out_b, out_token, out_head}
 int launch_prefill_attention(const f16* q, const f16* k, const f16* v, f16* out, int B, int H, int Hkv, int Tq, int Tk, int D,
@@ -235,7 +243,7 @@ int launch_prefill_attention(const f16* q, const f16* k, const f16* v, f16* out,
 {
     EETQ_REQUIRE(q && k && v && out && st, "null pointer");
     EETQ_REQUIRE(B > 0 && H > 0 && Hkv > 0 && H % Hkv == 0 && Tq > 0 && Tk > 0, "invalid attention shape");
-    if (!prefill_attention_supports(D)) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] prompt attention supports head_dim 128");
+    if (!prefill_attention_supports(D)) return fail(EETQ_ERR_UNSUPPORTED, "[eetq_amd] prompt attention supports head_dim 64 and 128");
     for (int i = 0; i < 12; ++i) EETQ_REQUIRE(st[i] % 4 == 0, "strides must be multiples of 4 elements");
     for (int i = 0; i < 9; ++i) EETQ_REQUIRE(st[i] % 8 == 0, "q / k / v strides must be multiples of 8 elements (16-byte loads)");
     EETQ_REQUIRE(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 == 0 && (uintptr_t)out % 8 == 0, "q, k, v must be 16-byte aligned, out 8-byte");
@@ -248,7 +256,10 @@ int launch_prefill_attention(const f16* q, const f16* k, const f16* v, f16* out,
     EETQ_REQUIRE((long)Tk * st[5] * 2 < (1L << 31) && (long)Tk * st[8] * 2 < (1L << 31), "one head's cache rows must span less than 2 GiB");
     a.H = H, a.B = B, a.nqb = (Tq + kPfBM - 1) / kPfBM;
     EETQ_REQUIRE((long)a.nqb * H * B < (1L << 31), "too many workgroups");
-    launch_kernel(prefill_attn_kernel<128>, dim3((unsigned)(a.nqb * H * B)), dim3(kPfThreads), 0, stream, a);
+    if (D == 128)
+        launch_kernel(prefill_attn_kernel<128>, dim3((unsigned)(a.nqb * H * B)), dim3(kPfThreads), 0, stream, a);
+    else
+        launch_kernel(prefill_attn_kernel<64>, dim3((unsigned)(a.nqb * H * B)), dim3(kPfThreads), 0, stream, a);
     return check_hip(hipGetLastError(), "prefill_attn_kernel launch");
 }
 

@@ -327,7 +327,7 @@ int eetq_rope_decode_attention_f16(const int64_t* positions, const int64_t* slot
  * here: python/eetq/modules/llama_modules.py:131-143).  q: the rotated query rows, e.g. a view into the fused QKV projection's
  * output; k, v: cache tensors [batch][kv_heads][rows][head_dim].  strides (elements): {q_b, q_token, q_head, k_b, k_head, k_row,
  * v_b, v_head, v_row, out_b, out_token, out_head}, head_dim contiguous, q / k / v strides multiples of 8, out strides of 4.
- * causal_offset = keys - q_tokens for a prompt appended to `keys - q_tokens` cached rows (0 on an empty cache).  head_dim 128
+ * causal_offset = keys - q_tokens for a prompt appended to `keys - q_tokens` cached rows (0 on an empty cache).  head_dim 64 or 128
  * (eetq_prefill_attention_supported); EETQ_ERR_UNSUPPORTED otherwise. */
 int eetq_prefill_attention_f16(const void* q, const void* k, const void* v, void* out, int batch, int heads, int kv_heads, int q_tokens,
                                int keys, int head_dim, int causal_offset, float scaling, const long* strides, void* stream);

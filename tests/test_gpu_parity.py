@@ -1551,16 +1551,16 @@ def test_gemv_gated_activation_prologue(ops, oracle, K, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("D", [128, 64])
 @pytest.mark.parametrize("B,T,H,Hkv,S,base", [(1, 128, 2, 2, 160, 0), (1, 200, 4, 2, 256, 0), (2, 130, 4, 4, 300, 37), (1, 64, 2, 1, 64, 0),
                                                (1, 1, 2, 2, 16, 5), (2, 515, 8, 2, 600, 0)])
-def test_prefill_attention_vs_torch(ops, B, T, H, Hkv, S, base):
+def test_prefill_attention_vs_torch(ops, B, T, H, Hkv, S, base, D):
     """The prompt's causal attention on the matrix cores (eetq_prefill_attention_f16) against a float32 softmax(q k^T) v of the same
     fp16 inputs: strided query view of a fused QKV row, grouped-query heads, ragged token counts, a prompt appended behind `base`
     cached rows.  fp16 flash tolerance: 3e-3 absolute on outputs of order 1 (probabilities are rounded to fp16 for the second
     product, as in flash-attn, which the reference's block calls here: python/eetq/modules/llama_modules.py:131-143)."""
     if ops.BOUNDARY != "ext":
         pytest.skip("prefill_attention lives in the compiled module")
-    D = 128
     torch.manual_seed(B * 1000 + T)
     qkv = torch.randn(B, T, (H + 2 * Hkv) * D, dtype=torch.float16, device=DEV)
     q = qkv[..., :H * D].unflatten(-1, (H, D))
@@ -1583,4 +1583,4 @@ def test_prefill_attention_vs_torch(ops, B, T, H, Hkv, S, base):
     vc[:, :, keys:] = float("nan")
     assert torch.equal(ops.prefill_attention(q, kc, vc, keys), out)
     with pytest.raises(RuntimeError):
-        ops.prefill_attention(q[..., :64], kc[..., :64], vc[..., :64], keys)   # head_dim 64: unsupported, loudly
+        ops.prefill_attention(q[..., :32], kc[..., :32], vc[..., :32], keys)   # head_dim 32: unsupported, loudly
