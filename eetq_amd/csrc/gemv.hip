@@ -28,7 +28,8 @@ int launch_inst(const f16* x, const uint8_t* w, const f16* scales, Epilogue ep, 
             int st = opt_in_large_lds(kern, opted);
             if (st != EETQ_OK) return st;
         }
-        launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, pro);
+        launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, pro.gamma ? pro.gamma : pro.up, ep.bias,
+                      ep.residual, ep.act, pro.eps);
         return check_hip(hipGetLastError(), "gemv_kernel launch");
     };
     if constexpr (M == 1 && !NORM) {
@@ -74,7 +75,8 @@ int launch_half_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue e
         int st = opt_in_large_lds(kern, opted);
         if (st != EETQ_OK) return st;
     }
-    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, pro);
+    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, pro.gamma ? pro.gamma : pro.up, ep.bias, ep.residual,
+                  ep.act, pro.eps);
     return check_hip(hipGetLastError(), "gemv_half_kernel launch");
 }
 
@@ -110,7 +112,8 @@ int launch_mixed_xv(const f16* x, const uint8_t* w, const f16* scales, Epilogue 
     }
     const int ncu = device_cu_count(), per = N / ncu;
     const int n8 = ncu * (per / 8), n4 = (N - 8 * n8) / 4;
-    launch_kernel(kern, dim3(n8 + n4), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, n8, pro);
+    launch_kernel(kern, dim3(n8 + n4), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, pro.gamma ? pro.gamma : pro.up, ep.bias, ep.residual,
+                  ep.act, pro.eps);  // (the kernel derives n8 from N and the grid)
     return check_hip(hipGetLastError(), "gemv_mixed_kernel launch");
 }
 
@@ -212,7 +215,7 @@ int launch_inst_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue e
         int st = opt_in_large_lds(kern, opted);
         if (st != EETQ_OK) return st;
     }
-    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, Prologue{});
+    launch_kernel(kern, dim3(N / kTileN), dim3(WAVES * 64), smem, stream, x, w, scales, y, N, K, (const f16*)nullptr, ep.bias, ep.residual, ep.act, 0.f);
     return check_hip(hipGetLastError(), "gemv_kernel (int4) launch");
 }
 
@@ -241,7 +244,7 @@ int launch_half_i4(const f16* x, const uint8_t* w, const f16* scales, Epilogue e
         int st = opt_in_large_lds(kern, opted);
         if (st != EETQ_OK) return st;
     }
-    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, ep.bias, ep.residual, ep.act, Prologue{});
+    launch_kernel(kern, dim3(N / 8), dim3(8 * 64), smem, stream, x, w, scales, y, N, K, (const f16*)nullptr, ep.bias, ep.residual, ep.act, 0.f);
     return check_hip(hipGetLastError(), "gemv_half_kernel (int4) launch");
 }
 

@@ -468,13 +468,17 @@ __device__ __forceinline__ void gemv_body(
 template <int M, int WAVES, int D, bool EXACT, bool XREG, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8, bool PLAIN = false>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, const f16* bias, const f16* residual, int act, Prologue pro)
+    f16* __restrict__ y, int N, int K, const f16* aux, const f16* bias, const f16* residual, int act, float eps)
 {
     // the epilogue operands are scalar kernel arguments, not an Epilogue by value: the first 16 argument dwords arrive in SGPRs
     // with the wave (kernarg preload), an aggregate does not -- its fields were fetched by an s_load where they are first used,
-    // i.e. between the last weight tile and the store, 0.1 us of every launch (profiles/r06_gemv_ladder.txt)
+    // i.e. between the last weight tile and the store, 0.1 us of every launch (profiles/r06_gemv_ladder.txt).  The prologue's
+    // pointer (aux: gamma of the RMS-norm or the `up` half of the gated activation) sits inside those 16 dwords too: behind them
+    // (round 5: a Prologue by value at dword 16) its s_load and the wait for it stood in front of the first weight load.
     Epilogue ep;
     ep.bias = bias, ep.residual = residual, ep.act = act;
+    Prologue pro;
+    pro.gamma = NORM == 1 ? aux : nullptr, pro.up = NORM == 2 ? aux : nullptr, pro.eps = eps;
     gemv_body<M, WAVES, D, EXACT, XREG, XV, NORM, BITS, PLAIN>(x, w, scales, y, N, K, ep, pro, blockIdx.x);
 }
 
@@ -626,10 +630,12 @@ __device__ __forceinline__ void gemv_unit_body(
 template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0, int BITS = 8>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, const f16* bias, const f16* residual, int act, Prologue pro)
+    f16* __restrict__ y, int N, int K, const f16* aux, const f16* bias, const f16* residual, int act, float eps)
 {
     Epilogue ep;  // (scalar arguments: see gemv_kernel)
     ep.bias = bias, ep.residual = residual, ep.act = act;
+    Prologue pro;
+    pro.gamma = NORM == 1 ? aux : nullptr, pro.up = NORM == 2 ? aux : nullptr, pro.eps = eps;
     gemv_unit_body<8, WAVES, D, XV, NORM, BITS>(x, w, scales, y, N, K, ep, pro, blockIdx.x * 8);
 }
 
@@ -640,10 +646,13 @@ __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_half_kern
 template <int WAVES, int D, int XV, int MIN_WAVES_PER_SIMD, int NORM = 0>
 __global__ __launch_bounds__(WAVES * 64, MIN_WAVES_PER_SIMD) void gemv_mixed_kernel(
     const f16* __restrict__ x, const uint8_t* __restrict__ w, const f16* __restrict__ scales,
-    f16* __restrict__ y, int N, int K, const f16* bias, const f16* residual, int act, int n8, Prologue pro)
+    f16* __restrict__ y, int N, int K, const f16* aux, const f16* bias, const f16* residual, int act, float eps)
 {
     Epilogue ep;  // (scalar arguments: see gemv_kernel)
     ep.bias = bias, ep.residual = residual, ep.act = act;
+    Prologue pro;
+    pro.gamma = NORM == 1 ? aux : nullptr, pro.up = NORM == 2 ? aux : nullptr, pro.eps = eps;
+    const int n8 = N / 4 - (int)gridDim.x;  // 8 n8 + 4 n4 = N and n8 + n4 = gridDim.x (no argument: it would be the seventeenth dword)
     const int b = blockIdx.x;
     if (b < n8) {
         gemv_unit_body<8, WAVES, D, XV, NORM>(x, w, scales, y, N, K, ep, pro, b * 8);

@@ -337,7 +337,7 @@ int main(int argc, char** argv)
             const StepIO io = io_of(e, yref);
             if (form == 0)
                 hipLaunchKernelGGL((gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>), dim3(N / 16), dim3(1024), 16 * 16 * 4, s0,
-                                   io.x, io.w, io.scales, io.y, N, K, (const f16*)nullptr, (const f16*)nullptr, 0, Prologue{});
+                                   io.x, io.w, io.scales, io.y, N, K, (const f16*)nullptr, (const f16*)nullptr, (const f16*)nullptr, 0, 0.f);
             else
                 hipLaunchKernelGGL(chain_step_kernel<false>, dim3(N / 16), dim3(1024), 0, s0, io, nullptr, 0u, nullptr, err);
         }
@@ -400,7 +400,7 @@ int main(int argc, char** argv)
             for (int e = 0; e < S; ++e) {
                 const StepIO io = io_of(e, yref);
                 hipLaunchKernelGGL((gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>), dim3(N / 16), dim3(1024), 16 * 16 * 4, s0,
-                                   io.x, wsel(e), io.scales, io.y, N, K, (const f16*)nullptr, (const f16*)nullptr, 0, Prologue{});
+                                   io.x, wsel(e), io.scales, io.y, N, K, (const f16*)nullptr, (const f16*)nullptr, (const f16*)nullptr, 0, 0.f);
             }
             CK(hipStreamEndCapture(s0, &g));
             CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));

@@ -453,13 +453,13 @@ static void bench_gemv(const char* name, int N, int K, const std::vector<uint8_t
     auto st = time_dispatch(
         [&](int i, hipEvent_t a, hipEvent_t b) {
             hipExtLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, 0, a, b, 0, x,
-                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                                  (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, 0.f);
         },
         400);
     double g = time_graph(
         [&](int i, hipStream_t s) {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(WAVES * 64), (unsigned)smem, s, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, 0.f);
         },
         400);
     printf("%-30s N=%5d K=%5d M=%d | disp mean %6.2f med %6.2f min %6.2f p90 %6.2f us -> %6.0f GB/s(med) | graph %6.2f us/step -> %6.0f GB/s\n",
@@ -811,13 +811,13 @@ int main(int argc, char** argv)
             chain[pass][NL] = time_graph(
                 [&](int i, hipStream_t s) {
                     hipLaunchKernelGGL(gk, dim3(N / 16), dim3(1024), gsm, s, x, (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K,
-                                       (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                                       (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, 0.f);
                 },
                 ITERS);
             auto st = time_dispatch(
                 [&](int i, hipEvent_t a, hipEvent_t b) {
                     hipExtLaunchKernelGGL(gk, dim3(N / 16), dim3(1024), gsm, 0, a, b, 0, x, (const uint8_t*)bufs[i % bufs.size()], scales, y,
-                                          N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                                          N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, 0.f);
                 },
                 400);
             disp[pass][NL] = st.med;
@@ -825,7 +825,7 @@ int main(int argc, char** argv)
             plain_chain[pass] = time_graph(
                 [&](int i, hipStream_t s) {
                     hipLaunchKernelGGL(gp, dim3(N / 16), dim3(1024), gsm, s, x, (const uint8_t*)bufs[i % bufs.size()], scales, y, N, K,
-                                       (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                                       (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, 0.f);
                 },
                 ITERS);
         }
@@ -998,7 +998,7 @@ int main(int argc, char** argv)
                 auto st = time_dispatch(
                     [&](int i, hipEvent_t a, hipEvent_t b) {
                         hipExtLaunchKernelGGL(kern, dim3(N / 8), dim3(512), (unsigned)smem, 0, a, b, 0, xl,
-                                              (const uint8_t*)b70[i % b70.size()], scales, y, N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                                              (const uint8_t*)b70[i % b70.size()], scales, y, N, K, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, 0.f);
                     },
                     400);
                 printf("%-30s N=%5d K=%5d M=1 | disp mean %6.2f med %6.2f min %6.2f us -> %6.0f GB/s(med)\n", name, N, K,
@@ -1062,7 +1062,7 @@ int main(int argc, char** argv)
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
         for (int i = 0; i < 300; ++i)
             hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, 0.f);
         CK(hipDeviceSynchronize());
     }
     if (!strcmp(what, "gemmcu")) {
@@ -1214,8 +1214,7 @@ int main(int argc, char** argv)
             });
             const uint8_t* wbuf2 = bufs[(r + 33) % bufs.size()];
             float g = timed([&](hipEvent_t s0, hipEvent_t s1) {
-                hipExtLaunchKernelGGL(gk, dim3(256), dim3(1024), gsm, 0, s0, s1, 0, x, wbuf2, scales, y, 4096, 4096, (const eetq::f16*)nullptr,
-                                      (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                hipExtLaunchKernelGGL(gk, dim3(256), dim3(1024), gsm, 0, s0, s1, 0, x, wbuf2, scales, y, 4096, 4096, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, 0.f);
             });
             if (r < 0) continue;
             CK(hipMemcpy(h.data(), stamps, h.size() * 8, hipMemcpyDeviceToHost));
@@ -1303,7 +1302,7 @@ int main(int argc, char** argv)
         auto gk = eetq::gemv::gemv_kernel<1, 16, 4, true, true, 1, 8>;
         for (int i = 0; i < 20; ++i)
             hipLaunchKernelGGL(gk, dim3(256), dim3(1024), (unsigned)eetq::gemv::gemv_smem_bytes(1, 4096, 16, true), 0, x,
-                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, eetq::Prologue{});
+                               (const uint8_t*)bufs[i % bufs.size()], scales, y, 4096, 4096, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, (const eetq::f16*)nullptr, 0, 0.f);
         CK(hipDeviceSynchronize());
     }
     if (!strcmp(what, "splitk")) {
