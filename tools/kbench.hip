@@ -297,6 +297,27 @@ __global__ void touch_lines_kernel(const uint8_t* __restrict__ p, size_t bytes, 
 }
 
 // dispatch-overhead probes: what a kernel costs that touches no memory / one cache line per wave
+__global__ void empty_kernel_b(unsigned* out, int never)
+{
+    if (never == 7) out[1] = 2;
+}
+// the same with ~200 live registers (accumulators that are never stored unless `never` says so)
+__global__ __launch_bounds__(256) void fat_kernel(unsigned* out, int never)
+{
+    float acc[192];
+#pragma unroll
+    for (int i = 0; i < 192; ++i) acc[i] = (float)(threadIdx.x + i);
+    if (never == 7) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r)
+#pragma unroll
+            for (int i = 0; i < 192; ++i) acc[i] = acc[i] * acc[(i + 1) % 192] + (float)r;
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 192; ++i) t += acc[i];
+        out[2] = (unsigned)t;
+    }
+}
 __global__ void empty_kernel(unsigned* out, int never)
 {
     if (never == 12345) out[0] = threadIdx.x;
@@ -749,6 +770,46 @@ int main(int argc, char** argv)
         bench_gemv<1, 16, 2, false, false, 2, 8>("M1 loop lds 16x2 o8", 4096, 11008, bufs_big, x, scales, y);
         bench_gemv<1, 16, 8, false, false, 2, 4>("M1 loop lds 16x8 o4", 4096, 11008, bufs_big, x, scales, y);
         bench_gemv<4, 16, 4, false, false, 8, 4>("M4 loop lds 16x4 o4", 4096, 11008, bufs_big, x, scales, y);
+    }
+    if (!strcmp(what, "gaps")) {
+        // What does a dependent dispatch cost when CONSECUTIVE launches differ?  Graph chains of 1 000 empty launches (256 workgroups):
+        // one kernel repeated / two kernels alternating / one kernel alternating its dynamic LDS size / its workgroup size / its
+        // register footprint (a decode step alternates five kernels of different LDS and register needs)
+        auto chain = [&](const char* name, std::function<void(int, hipStream_t)> f) {
+            printf("%-64s %6.3f us per launch\n", name, time_graph(f, 1000));
+        };
+        CK(hipFuncSetAttribute((const void*)empty_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        CK(hipFuncSetAttribute((const void*)empty_kernel_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        for (int pass = 0; pass < 2; ++pass) {
+            chain("same kernel, 256 x 256 threads, no LDS", [&](int, hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, s, out, 0); });
+            chain("two kernels alternating", [&](int i, hipStream_t s) {
+                if (i & 1) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, s, out, 0);
+                else hipLaunchKernelGGL(empty_kernel_b, dim3(256), dim3(256), 0, s, out, 0);
+            });
+            chain("same kernel, LDS 0 / 64 KiB alternating", [&](int i, hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), (i & 1) ? 65536 : 0, s, out, 0); });
+            chain("same kernel, LDS 64 KiB always", [&](int, hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 65536, s, out, 0); });
+            chain("same kernel, 256 / 1024 threads alternating", [&](int i, hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3((i & 1) ? 1024 : 256), 0, s, out, 0); });
+            chain("same kernel, 1024 threads always", [&](int, hipStream_t s) { hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(1024), 0, s, out, 0); });
+            chain("small / big register footprint alternating", [&](int i, hipStream_t s) {
+                if (i & 1) hipLaunchKernelGGL(empty_kernel, dim3(256), dim3(256), 0, s, out, 0);
+                else hipLaunchKernelGGL(fat_kernel, dim3(256), dim3(256), 0, s, out, 0);
+            });
+            chain("big register footprint always", [&](int, hipStream_t s) { hipLaunchKernelGGL(fat_kernel, dim3(256), dim3(256), 0, s, out, 0); });
+            chain("five kernels of different LDS / threads / registers", [&](int i, hipStream_t s) {
+                switch (i % 5) {
+                case 0: hipLaunchKernelGGL(empty_kernel, dim3(960), dim3(512), 20480, s, out, 0); break;
+                case 1: hipLaunchKernelGGL(fat_kernel, dim3(200), dim3(256), 0, s, out, 0); break;
+                case 2: hipLaunchKernelGGL(empty_kernel_b, dim3(768), dim3(512), 10240, s, out, 0); break;
+                case 3: hipLaunchKernelGGL(empty_kernel, dim3(1728), dim3(512), 10240, s, out, 0); break;
+                default: hipLaunchKernelGGL(empty_kernel_b, dim3(768), dim3(512), 27648, s, out, 0); break;
+                }
+            });
+            chain("... the same five shapes, one kernel, one LDS size", [&](int i, hipStream_t s) {
+                const int grids[5] = {960, 200, 768, 1728, 768};
+                hipLaunchKernelGGL(empty_kernel, dim3(grids[i % 5]), dim3(512), 27648, s, out, 0);
+            });
+        }
+        return 0;
     }
     if (!strcmp(what, "gemvladder")) {
         // one ablation ladder from the load-only kernel to the shipping GEMV, every rung chain-timed (one graph of 1200 dependent
